@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Headline benchmark: M lattice-cell updates / s of one RK4 step incl. the 4 Poisson projections,
+3-D Taylor-Green vortex, fp64 (BASELINE.json `metric`).
+
+  python bench.py --gpus 1 --steps K --warmup W          (N = 1: TGV3D 256^3 = BASELINE configs[1])
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (z-slab decomposition)
+
+Prints ONE JSON line on rank 0.  `roofline` is the fused momentum-RHS stencil (48 algorithmic B/cell,
+SURVEY.md §8d) timed live with HIP events on the step's stream; `cpu_baseline` is the CPU oracle (a numpy
+restatement, NOT Julia) timed on a bounded sample on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+K1_BYTES_PER_CELL = 48.0  # read u (3 x 8 B) + write F (3 x 8 B)                       SURVEY.md §8d
+
+
+def tgv3d(al, x, y, z):
+    """examples/TaylorGreenVortex3D.jl:30-37"""
+    if al == 0:
+        return np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y) * np.sin(2 * np.pi * z) / 2
+    if al == 1:
+        return -np.cos(2 * np.pi * x) * np.sin(2 * np.pi * y) * np.sin(2 * np.pi * z) / 2
+    return 0 * (x + y + z)
+
+
+def cpu_baseline(budget_s=20.0):
+    """Time the CPU oracle (numpy port of the reference's pass structure) on TGV3D at a size that fits
+    the time budget; returns the dict for the JSON line."""
+    from oracle import ins_oracle as o
+
+    n = 64
+    x = (np.linspace(0.0, 1.0, n + 1),) * 3
+    so = o.make_setup(x, Re=1000.0)
+    ps = o.psolver_spectral(so)
+    u = o.velocityfield(so, o.tgv3d_ufunc, 0.0, psolver=ps)
+    m = o.RK44()
+    cache = o.ode_method_cache(m, so)
+    st = dict(setup=so, psolver=ps, u=u, t=0.0, n=0)
+    st = o.timestep_(m, st, 1e-3, cache)  # warm-up
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < budget_s and steps < 50:
+        st = o.timestep_(m, st, 1e-3, cache)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {
+        "value": n**3 * steps / dt / 1e6,
+        "unit": "M cell-updates/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"numpy CPU restatement (not Julia), TGV3D {n}^3 fp64, {steps} RK4 steps in {dt:.1f} s on 1 core",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=256, help="cells per direction on one GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import ins_amd as ins
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    if world > 1:
+        from bench_dist import run_distributed  # z-slab path
+
+        return run_distributed(args, ins)
+
+    n = args.n
+    x = (np.linspace(0.0, 1.0, n + 1),) * 3
+    setup = ins.Setup(x=x, Re=1000.0, device=dev)
+    ps = ins.psolver_spectral(setup)
+    u = ins.velocityfield(setup, tgv3d, 0.0, psolver=ps)
+    method = ins.RKMethods.RK44()
+    cache = ins.ode_method_cache(method, setup, ps)
+    stepper = ins.create_stepper(method, setup=setup, psolver=ps, u=u, t=0.0)
+    dt = 1e-3
+    for _ in range(args.warmup):
+        stepper = ins.timestep_(method, stepper, dt, cache=cache)
+    ins._lib.call("ins_rk_profile_enable", cache.handle, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stepper = ins.timestep_(method, stepper, dt, cache=cache)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    import ctypes as C
+
+    k1_ms, k1_n = C.c_double(), C.c_int64()
+    ins._lib.call("ins_rk_profile_read", cache.handle, C.byref(k1_ms), C.byref(k1_n))
+    ins._lib.call("ins_rk_profile_enable", cache.handle, 0)
+
+    ms_per_step = (t1 - t0) * 1e3 / args.steps
+    cells = float(n) ** 3
+    value = cells / (ms_per_step * 1e-3) / 1e6
+    k1_avg_ms = k1_ms.value / max(k1_n.value, 1)
+    k1_gbs = K1_BYTES_PER_CELL * cells / (k1_avg_ms * 1e-3) / 1e9
+    div = ins.max_abs_divergence(stepper.u, setup)
+    energy = ins.total_kinetic_energy(stepper.u, setup)
+    assert np.isfinite(energy) and div / n < 1e-10, f"bench state is not a valid flow: div={div}, E={energy}"
+
+    out = {
+        "metric": "M lattice-cell updates/sec (RK4 step incl. Poisson), 3D TGV fp64",
+        "value": value,
+        "unit": "M cell-updates/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"TaylorGreenVortex3D {n}^3 periodic fp64, RK44 + spectral Poisson, dt=1e-3, Re=1e3",
+                   "grid": [n, n, n], "decomposition": "single GPU"},
+        "roofline": {
+            "kernel": "momentum-RHS stencil (convection+diffusion, fill fused)",
+            "bound": "hbm",
+            "achieved": k1_gbs,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": k1_gbs / HBM_PEAK_GBS,
+            "traffic": None,
+            "bytes_per_cell": K1_BYTES_PER_CELL,
+            "avg_launch_ms": k1_avg_ms,
+            "launches": k1_n.value,
+        },
+        "step_bandwidth": {"design_bytes_per_cell": 1104, "achieved_GBs": 1104 * cells / (ms_per_step * 1e-3) / 1e9},
+        "check": {"max_abs_div_times_dx": div / n, "kinetic_energy": energy},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

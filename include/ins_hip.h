@@ -1,0 +1,157 @@
+/*
+ * ins_hip.h — C ABI of libinship.so: the MI355X (gfx950) hot path of IncompressibleNavierStokes.jl.
+ *
+ * The reference has no FFI; its extension seam is Julia multiple dispatch on `setup.backend` and on the
+ * array type of `setup.grid.x[1]` (precedent: ext/IncompressibleNavierStokesCUDSSExt.jl:18).
+ * Every entry point below replaces the body of one reference function and is what a Julia `ccall`
+ * (julia/INSHip.jl) or the Python ctypes host (incompressiblenavierstokes.jl_amd/_lib.py) binds.
+ *
+ * Conventions
+ *   - Plain C types only.  Field pointers are DEVICE pointers owned by the caller, laid out exactly as
+ *     the reference's arrays: vector field `u` = Float64 (N1,N2[,N3],D) column-major, x fastest, component
+ *     slowest (initializers.jl:5-6); scalar field `p` = Float64 (N1,N2[,N3]) (initializers.jl:2).
+ *     N includes the ghost volumes (grid.jl:121).
+ *   - Index ranges are 0-based half-open [lo, hi):  Julia `a:b`  ->  lo = a-1, hi = b.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All work is enqueued on it and
+ *     the call returns immediately; only the functions documented as "blocking" synchronise — the same
+ *     contract as the reference, which blocks only when a scalar is read (solver.jl:112, pressure.jl:244).
+ *   - Return value: 0 on success, negative on failure (INS_ERR_*).  No exceptions cross the boundary.
+ *     `ins_last_error()` returns a thread-local human-readable message for the last failure.
+ *   - The library owns only the handles it creates.
+ */
+#ifndef INS_HIP_H
+#define INS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INS_OK 0
+#define INS_ERR_INVALID (-1)     /* bad argument (NULL handle, unsupported D, shape mismatch) */
+#define INS_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define INS_ERR_FFT (-3)         /* a hipFFT/rocFFT call failed */
+#define INS_ERR_UNSUPPORTED (-4) /* valid request that this build does not implement */
+#define INS_ERR_NOCONV (-5)      /* iterative solver hit maxiter */
+
+/* Boundary-condition codes, boundary_conditions.jl:2-36.  INS_BC_HALO marks a side whose ghost plane is
+ * filled by the caller (the z-faces of a slab in the multi-GPU decomposition). */
+#define INS_BC_PERIODIC 0
+#define INS_BC_DIRICHLET 1
+#define INS_BC_SYMMETRIC 2
+#define INS_BC_PRESSURE 3
+#define INS_BC_HALO 4
+
+typedef struct ins_grid ins_grid_t;       /* device copy of `setup.grid` metrics   (grid.jl:100-276)   */
+typedef struct ins_poisson ins_poisson_t; /* a `psolver` closure                   (pressure.jl:85-351) */
+typedef struct ins_rk ins_rk_t;           /* `ode_method_cache` + stepper state    (time_stepper_caches.jl:34-49) */
+
+/* Host-side description of `setup.grid` + `setup.boundary_conditions`; all pointers are HOST pointers
+ * to the reference's 1-D metric vectors, copied (and turned into reciprocal tables) by ins_grid_create. */
+typedef struct ins_grid_desc {
+  int32_t D;                /* 2 or 3                                           grid.jl:105          */
+  int32_t N[3];             /* volumes per direction incl. ghosts               grid.jl:121          */
+  const double* dx[3];      /* Δ[α],  length N[α]                               grid.jl:177-181      */
+  const double* dxu[3];     /* Δu[α], length N[α]                               grid.jl:183-187      */
+  const double* A1[3][3];   /* A[α][β][1], length N[β]                          grid.jl:227-248      */
+  const double* A2[3][3];   /* A[α][β][2], length N[β]                                               */
+  int32_t iu_lo[3][3];      /* Iu[α] range in direction β, 0-based half-open    grid.jl:145-152      */
+  int32_t iu_hi[3][3];
+  int32_t ip_lo[3];         /* Ip                                               grid.jl:155-159      */
+  int32_t ip_hi[3];
+  int32_t bc[3][2];         /* INS_BC_* per direction and side                  setup.jl:16          */
+  double bc_u[3][2][3];     /* DirichletBC constants u[β][side][α]; 0 for no-slip  boundary_conditions.jl:347-350 */
+} ins_grid_desc_t;
+
+/* ---------------------------------------------------------------------------------- library / errors */
+int ins_version(void);
+const char* ins_last_error(void);
+/* Device the calling thread's handles live on (hipSetDevice).  Blocking. */
+int ins_set_device(int device);
+/* Blocking: wait for all work on `stream`. */
+int ins_sync(void* stream);
+
+/* ---------------------------------------------------------------------------------- Grid  (grid.jl:100) */
+int ins_grid_create(const ins_grid_desc_t* desc, ins_grid_t** out);
+int ins_grid_destroy(ins_grid_t* grid);
+
+/* ---------------------------------------------------------------------------------- ghost fill */
+/* apply_bc_u!(u, t, setup; dudt)   boundary_conditions.jl:159-167 (+276-288, 344-375, 414-428, 472-482).
+ * Dirichlet values are the constants in the grid descriptor, or, when `planes` is non-NULL, per-(β,side,α)
+ * DEVICE plane buffers planes[(β*2+side)*3+α] (NULL entries fall back to the constant); a plane spans the
+ * full padded extent of the other directions in memory order — this is how time-dependent closures
+ * `bc.u(α, x..., t)` cross the ABI: the host evaluates them into plane buffers. */
+int ins_apply_bc_u_f64(const ins_grid_t* grid, double* u, int dudt, const double* const* planes, void* stream);
+/* apply_bc_p!(p, t, setup)         boundary_conditions.jl:197-206 (+306-318, 388, 445-453, 497-502) */
+int ins_apply_bc_p_f64(const ins_grid_t* grid, double* p, void* stream);
+
+/* ---------------------------------------------------------------------------------- operators.jl */
+/* scalewithvolume!(p, setup)               operators.jl:81-95   (whole padded array) */
+int ins_scalewithvolume_f64(const ins_grid_t* grid, double* p, void* stream);
+/* divergence!(div, u, setup)               operators.jl:106-125 (writes Ip only) */
+int ins_divergence_f64(const ins_grid_t* grid, const double* u, double* div, void* stream);
+/* pressuregradient!(G, p, setup)           operators.jl:159-178 (writes Iu[α] only) */
+int ins_pressuregradient_f64(const ins_grid_t* grid, const double* p, double* G, void* stream);
+/* applypressure!(u, p, setup)              operators.jl:214-233 */
+int ins_applypressure_f64(const ins_grid_t* grid, double* u, const double* p, void* stream);
+/* laplacian!(L, p, setup)                  operators.jl:297-364 (zeroes L, then writes Ip) */
+int ins_laplacian_f64(const ins_grid_t* grid, const double* p, double* L, void* stream);
+/* convection!(F, u, setup)                 operators.jl:378-415 (F += ...) */
+int ins_convection_f64(const ins_grid_t* grid, const double* u, double* F, void* stream);
+/* diffusion!(F, u, setup; use_viscosity)   operators.jl:537-573 (F += visc * ...); pass visc = 1/Re or 1 */
+int ins_diffusion_f64(const ins_grid_t* grid, double visc, const double* u, double* F, void* stream);
+/* convectiondiffusion!(F, u, setup)        operators.jl:634-690 (F += ...); visc = 1/Re */
+int ins_convectiondiffusion_f64(const ins_grid_t* grid, double visc, const double* u, double* F, void* stream);
+/* momentum!(F, u, nothing, t, setup)       operators.jl:967-976 with bodyforce = temp = nothing:
+ * fill!(F, 0) + convectiondiffusion! fused into one write-only pass over F. */
+int ins_momentum_f64(const ins_grid_t* grid, double visc, const double* u, double* F, void* stream);
+/* kinetic_energy!(ke, u, setup; interpolate_first)   operators.jl:1516-1545 */
+int ins_kinetic_energy_f64(const ins_grid_t* grid, const double* u, double* ke, int interpolate_first, void* stream);
+/* total_kinetic_energy(u, setup; interpolate_first)  operators.jl:1551-1556.  Blocking (returns a scalar). */
+int ins_total_kinetic_energy_f64(const ins_grid_t* grid, const double* u, int interpolate_first, double* out, void* stream);
+/* get_cfl_timestep!(buf, u, setup)         solver.jl:101-125.  Blocking.  `Re` as in setup.Re. */
+int ins_cfl_timestep_f64(const ins_grid_t* grid, double Re, const double* u, double* out, void* stream);
+/* maximum(abs, divergence(u)[Ip]) — the reference's implied invariant (methods.jl:177-182).  Blocking. */
+int ins_max_abs_divergence_f64(const ins_grid_t* grid, const double* u, double* out, void* stream);
+
+/* ---------------------------------------------------------------------------------- pressure.jl */
+/* psolver_spectral(setup)                  pressure.jl:289-351: rocFFT (hipFFT API) D2Z/Z2D plans, symbol
+ * vectors ahat, work buffers pI / phat.  Requires all-periodic, uniform, even N (utils.jl:1-13). */
+int ins_poisson_spectral_create(const ins_grid_t* grid, ins_poisson_t** out);
+/* psolver_cg(setup; abstol, reltol, maxiter)   pressure.jl:209-286 with the Jacobi preconditioner of
+ * pressure.jl:188-206.  maxiter <= 0 selects prod(Np) as the reference does. */
+int ins_poisson_cg_create(const ins_grid_t* grid, double abstol, double reltol, int64_t maxiter, ins_poisson_t** out);
+int ins_poisson_destroy(ins_poisson_t* ps);
+/* poisson!(psolver, p) = psolver(p)        pressure.jl:22: solves L p = f in place on the padded array.
+ * Spectral: asynchronous.  CG: blocking (the reference reads residuals on the host, pressure.jl:244,275). */
+int ins_poisson_solve_f64(ins_poisson_t* ps, double* p, void* stream);
+/* Iterations / final residual of the last CG solve (0 / 0 for spectral). */
+int ins_poisson_last_info(const ins_poisson_t* ps, int64_t* iterations, double* residual);
+/* project!(u, setup; psolver, p)           pressure.jl:69-82.  `p` is left ghost-filled as the reference
+ * leaves it.  Spectral solver: fused divergence*Ω -> FFT -> symbol -> iFFT -> gradient-subtract path. */
+int ins_project_f64(const ins_grid_t* grid, ins_poisson_t* ps, double* u, double* p, void* stream);
+
+/* ---------------------------------------------------------------------------------- explicit Runge-Kutta */
+/* ode_method_cache(method, setup) + create_stepper     time_stepper_caches.jl:34-49, step_explicit_runge_kutta.jl:1-2.
+ * `A` is the SHIFTED nstage x nstage tableau of methods.jl:231-236, row-major; `c` the shifted nodes. */
+int ins_rk_create(const ins_grid_t* grid, ins_poisson_t* ps, int nstage, const double* A, const double* c, ins_rk_t** out);
+int ins_rk_destroy(ins_rk_t* rk);
+/* timestep!(method, stepper, Δt; cache)    step_explicit_runge_kutta.jl:4-59 for closure_model = temp =
+ * bodyforce = nothing.  `u` is updated in place (ghosts filled on return); `visc` = 1/Re.
+ * `planes` as in ins_apply_bc_u_f64 (time-independent Dirichlet data only; otherwise drive the stage loop
+ * from the host with the operator-level calls). */
+int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, double dt, const double* const* planes, void* stream);
+/* Device pointers into the cache (valid until ins_rk_destroy): the stage pressure `p` and `ku[i]`. */
+/* Measurement hook (bench.py `roofline`): while enabled, ins_rk_step_f64 brackets every momentum-RHS
+ * kernel launch with hipEvents recorded on the step's stream.  ins_rk_profile_read is blocking: it waits
+ * for the recorded events, returns the accumulated kernel milliseconds and launch count, and resets. */
+int ins_rk_profile_enable(ins_rk_t* rk, int enable);
+int ins_rk_profile_read(ins_rk_t* rk, double* momentum_ms, int64_t* momentum_launches);
+int ins_rk_pressure(const ins_rk_t* rk, double** p);
+int ins_rk_stage_force(const ins_rk_t* rk, int i, double** ku);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INS_HIP_H */

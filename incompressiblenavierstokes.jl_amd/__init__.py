@@ -1,0 +1,63 @@
+"""MI355X-native hot path of IncompressibleNavierStokes.jl behind the reference's own API names.
+
+Julia's `op!` is spelled `op_` here; indices are 0-based; `backend = ...` becomes `device = ...`.
+Everything numerical runs in hand-written HIP kernels + rocFFT inside libinship.so (C ABI:
+include/ins_hip.h).  There is no CPU fallback: importing this package without the built library, or
+creating a `Setup` without a HIP device, raises.
+"""
+from . import _lib
+from ._lib import INSHipError
+from .boundary_conditions import DirichletBC, PeriodicBC, PressureBC, SymmetricBC
+from .grid import Grid, cosine_grid, max_size, stretched_grid, tanh_grid
+from .initializers import random_field, velocityfield
+from .operators import (
+    apply_bc_p,
+    apply_bc_p_,
+    apply_bc_u,
+    apply_bc_u_,
+    applypressure,
+    applypressure_,
+    convection,
+    convection_,
+    convectiondiffusion_,
+    diffusion,
+    diffusion_,
+    divergence,
+    divergence_,
+    kinetic_energy,
+    kinetic_energy_,
+    laplacian,
+    laplacian_,
+    max_abs_divergence,
+    momentum,
+    momentum_,
+    pressuregradient,
+    pressuregradient_,
+    scalewithvolume,
+    scalewithvolume_,
+    total_kinetic_energy,
+)
+from .pressure import (
+    default_psolver,
+    poisson,
+    poisson_,
+    pressure,
+    project,
+    project_,
+    psolver_cg,
+    psolver_direct,
+    psolver_spectral,
+)
+from .setup import Setup, copyfield, from_numpy, scalarfield, to_numpy, vectorfield
+from .solver import get_cfl_timestep_, get_state, solve_unsteady
+from .time_steppers import (
+    ExplicitRungeKuttaMethod,
+    RKMethods,
+    create_stepper,
+    ode_method_cache,
+    runge_kutta_method,
+    timestep,
+    timestep_,
+)
+
+_lib.load()  # fail loudly at import time if libinship.so is absent

@@ -1,0 +1,107 @@
+"""ctypes binding of libinship.so (the C ABI declared in include/ins_hip.h).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing the operators raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libinship.so")
+
+INS_BC_PERIODIC, INS_BC_DIRICHLET, INS_BC_SYMMETRIC, INS_BC_PRESSURE, INS_BC_HALO = range(5)
+
+c_double_p = C.POINTER(C.c_double)
+vp = C.c_void_p
+
+
+class GridDesc(C.Structure):
+    """`ins_grid_desc_t` (include/ins_hip.h)."""
+
+    _fields_ = [
+        ("D", C.c_int32),
+        ("N", C.c_int32 * 3),
+        ("dx", c_double_p * 3),
+        ("dxu", c_double_p * 3),
+        ("A1", (c_double_p * 3) * 3),
+        ("A2", (c_double_p * 3) * 3),
+        ("iu_lo", (C.c_int32 * 3) * 3),
+        ("iu_hi", (C.c_int32 * 3) * 3),
+        ("ip_lo", C.c_int32 * 3),
+        ("ip_hi", C.c_int32 * 3),
+        ("bc", (C.c_int32 * 2) * 3),
+        ("bc_u", ((C.c_double * 3) * 2) * 3),
+    ]
+
+
+# name -> (restype, argtypes); must list EVERY symbol include/ins_hip.h declares (tests/test_abi.py checks)
+SIGNATURES = {
+    "ins_version": (C.c_int, []),
+    "ins_last_error": (C.c_char_p, []),
+    "ins_set_device": (C.c_int, [C.c_int]),
+    "ins_sync": (C.c_int, [vp]),
+    "ins_grid_create": (C.c_int, [C.POINTER(GridDesc), C.POINTER(vp)]),
+    "ins_grid_destroy": (C.c_int, [vp]),
+    "ins_apply_bc_u_f64": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp), vp]),
+    "ins_apply_bc_p_f64": (C.c_int, [vp, vp, vp]),
+    "ins_scalewithvolume_f64": (C.c_int, [vp, vp, vp]),
+    "ins_divergence_f64": (C.c_int, [vp, vp, vp, vp]),
+    "ins_pressuregradient_f64": (C.c_int, [vp, vp, vp, vp]),
+    "ins_applypressure_f64": (C.c_int, [vp, vp, vp, vp]),
+    "ins_laplacian_f64": (C.c_int, [vp, vp, vp, vp]),
+    "ins_convection_f64": (C.c_int, [vp, vp, vp, vp]),
+    "ins_diffusion_f64": (C.c_int, [vp, C.c_double, vp, vp, vp]),
+    "ins_convectiondiffusion_f64": (C.c_int, [vp, C.c_double, vp, vp, vp]),
+    "ins_momentum_f64": (C.c_int, [vp, C.c_double, vp, vp, vp]),
+    "ins_kinetic_energy_f64": (C.c_int, [vp, vp, vp, C.c_int, vp]),
+    "ins_total_kinetic_energy_f64": (C.c_int, [vp, vp, C.c_int, c_double_p, vp]),
+    "ins_cfl_timestep_f64": (C.c_int, [vp, C.c_double, vp, c_double_p, vp]),
+    "ins_max_abs_divergence_f64": (C.c_int, [vp, vp, c_double_p, vp]),
+    "ins_poisson_spectral_create": (C.c_int, [vp, C.POINTER(vp)]),
+    "ins_poisson_cg_create": (C.c_int, [vp, C.c_double, C.c_double, C.c_int64, C.POINTER(vp)]),
+    "ins_poisson_destroy": (C.c_int, [vp]),
+    "ins_poisson_solve_f64": (C.c_int, [vp, vp, vp]),
+    "ins_poisson_last_info": (C.c_int, [vp, C.POINTER(C.c_int64), c_double_p]),
+    "ins_project_f64": (C.c_int, [vp, vp, vp, vp, vp]),
+    "ins_rk_create": (C.c_int, [vp, vp, C.c_int, c_double_p, c_double_p, C.POINTER(vp)]),
+    "ins_rk_destroy": (C.c_int, [vp]),
+    "ins_rk_step_f64": (C.c_int, [vp, C.c_double, vp, C.c_double, C.c_double, C.POINTER(vp), vp]),
+    "ins_rk_profile_enable": (C.c_int, [vp, C.c_int]),
+    "ins_rk_profile_read": (C.c_int, [vp, c_double_p, C.POINTER(C.c_int64)]),
+    "ins_rk_pressure": (C.c_int, [vp, C.POINTER(vp)]),
+    "ins_rk_stage_force": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+}
+
+_lib = None
+
+
+class INSHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libinship.so (once).  Raises loudly if it is absent — the product has no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise INSHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C incompressiblenavierstokes.jl_amd/csrc`).  There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().ins_last_error()
+        raise INSHipError(f"libinship error {rc}: {msg.decode() if msg else ''}")
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))

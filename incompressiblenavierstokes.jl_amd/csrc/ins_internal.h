@@ -1,0 +1,145 @@
+// Internal definitions shared by the HIP translation units of libinship.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ins_hip.h"
+
+#define INS_EPS 2.220446049250313e-16
+
+// ------------------------------------------------------------------------------------------------
+// Error plumbing: every extern "C" entry returns an INS_ERR_* code and records a message.
+// ------------------------------------------------------------------------------------------------
+void ins_set_error(const char* fmt, ...);
+
+#define INS_HIP_TRY(expr)                                                                   \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      ins_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));   \
+      return INS_ERR_HIP;                                                                   \
+    }                                                                                       \
+  } while (0)
+
+#define INS_FFT_TRY(expr)                                                         \
+  do {                                                                            \
+    hipfftResult _r = (expr);                                                     \
+    if (_r != HIPFFT_SUCCESS) {                                                   \
+      ins_set_error("%s:%d: %s -> hipfftResult %d", __FILE__, __LINE__, #expr, (int)_r); \
+      return INS_ERR_FFT;                                                         \
+    }                                                                             \
+  } while (0)
+
+#define INS_REQUIRE(cond, msg)                                        \
+  do {                                                                \
+    if (!(cond)) {                                                    \
+      ins_set_error("%s:%d: %s (%s)", __FILE__, __LINE__, msg, #cond); \
+      return INS_ERR_INVALID;                                         \
+    }                                                                 \
+  } while (0)
+
+#define INS_LAUNCH_CHECK() INS_HIP_TRY(hipGetLastError())
+
+// ------------------------------------------------------------------------------------------------
+// Device view of the grid, passed to kernels by value (lives in the kernarg segment -> SGPR loads).
+// Metric tables are tiny 1-D device vectors (<= 4 KB each), L1/L2/K$-resident.
+//   rdx  = 1/Δ      rdxu = 1/Δu        (reciprocal tables: the reference's 27 fp64 divisions per cell
+//   mdx  = Δ  > 2eps ? 1/Δ  : 0         become multiplies; <= 1 ulp per term, inside the 1e-12 tolerance)
+//   mdxu = Δu > 2eps ? 1/Δu : 0        (the `(Δ > 2eps) * ∂` strong-zero masks of operators.jl:683-684)
+// ------------------------------------------------------------------------------------------------
+struct GridDev {
+  int D;
+  int N[3];
+  long long sx[3];  // element strides of directions 0..2
+  long long sc;     // component stride = prod(N)
+  const double* dx[3];
+  const double* dxu[3];
+  const double* rdx[3];
+  const double* rdxu[3];
+  const double* mdx[3];
+  const double* mdxu[3];
+  const double* A1[3][3];
+  const double* A2[3][3];
+  int iu_lo[3][3], iu_hi[3][3];
+  int ip_lo[3], ip_hi[3];
+  int bc[3][2];
+  double bc_u[3][2][3];
+};
+
+struct ins_grid {
+  ins_grid_desc_t desc;  // host copy (metric pointers below are re-pointed to `host`)
+  std::vector<double> host;
+  double* dev = nullptr;  // one device slab holding every table
+  size_t dev_count = 0;
+  GridDev g;
+  bool all_periodic = false;
+  bool uniform = false;
+  double h[3] = {0, 0, 0};  // Δx[α] of the first volume (uniform grids)
+  long long ncell = 0;      // prod(N)
+  // scratch for blocking reductions
+  double* red_dev = nullptr;
+  double* red_host = nullptr;  // pinned
+};
+
+enum PoissonKind { POISSON_SPECTRAL = 0, POISSON_CG = 1 };
+
+struct ins_poisson {
+  PoissonKind kind;
+  const ins_grid* grid;
+  // spectral
+  hipfftHandle plan_fwd = 0, plan_inv = 0;
+  bool plans = false;
+  double* pI = nullptr;            // real n^D
+  hipfftDoubleComplex* phat = nullptr;  // (n/2+1) n [n]
+  double* ahat[3] = {nullptr, nullptr, nullptr};
+  int np[3] = {1, 1, 1};
+  int kmax[3] = {1, 1, 1};
+  void* work = nullptr;
+  size_t work_bytes = 0;
+  hipStream_t plan_stream = nullptr;
+  // cg
+  double abstol = 0, reltol = 0;
+  long long maxiter = 0;
+  double *r = nullptr, *L = nullptr, *q = nullptr, *dinv = nullptr;
+  long long last_iter = 0;
+  double last_res = 0;
+};
+
+struct ins_rk {
+  const ins_grid* grid;
+  ins_poisson* ps;
+  int nstage;
+  std::vector<double> A, c;
+  double* ustart = nullptr;
+  std::vector<double*> ku;
+  double* p = nullptr;
+  double* ub[2] = {nullptr, nullptr};  // ping-pong stage velocities of the fused path
+  bool profiling = false;
+  std::vector<hipEvent_t> prof_events;  // (start, stop) pairs around momentum launches
+};
+
+// ------------------------------------------------------------------------------------------------
+// Internal launchers (stream-ordered, non-blocking) used across translation units.
+// ------------------------------------------------------------------------------------------------
+int ins_k_apply_bc_u(const ins_grid* grid, double* u, int dudt, const double* const* planes, hipStream_t s);
+int ins_k_apply_bc_p(const ins_grid* grid, double* p, hipStream_t s);
+int ins_k_momentum(const ins_grid* grid, double visc, const double* u, double* F, hipStream_t s);
+int ins_k_divergence(const ins_grid* grid, const double* u, double* div, hipStream_t s);
+int ins_k_scalewithvolume(const ins_grid* grid, double* p, hipStream_t s);
+int ins_k_applypressure(const ins_grid* grid, double* u, const double* p, hipStream_t s);
+int ins_k_laplacian(const ins_grid* grid, const double* p, double* L, hipStream_t s);
+int ins_k_project(const ins_grid* grid, ins_poisson* ps, double* u, double* p, hipStream_t s);
+int ins_k_poisson_solve(ins_poisson* ps, double* p, hipStream_t s);
+// blocking reductions over an index box of a scalar field; op: 0 sum(a*b), 1 max|a|, 2 min(a)
+int ins_k_reduce(const ins_grid* grid, int op, const double* a, const double* b, const int lo[3], const int hi[3], double* out,
+                 hipStream_t s);
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }

@@ -1,0 +1,516 @@
+// Pressure-Poisson solvers and the projection (pressure.jl).
+//   spectral: rocFFT (through the hipFFT API) D2Z / Z2D on the UNPADDED pressure block + one fused
+//             k-space kernel (symbol division, mean-mode zero, 1/prod(Np) normalisation).
+//   cg      : Jacobi-preconditioned CG with fused vector-update + reduction kernels.
+//   project : for the spectral solver the ghost strip / re-pad copies, scalewithvolume! and the periodic
+//             apply_bc_p! are folded into the divergence and gradient kernels.
+#include <cmath>
+
+#include "ins_internal.h"
+
+namespace {
+
+// K2: pI[i,j,k] = Ω_I * div(u)[Ip.lo + (i,j,k)]     (divergence! + scalewithvolume! + copyto!(pI, view(p, Ip)),
+//                                                    operators.jl:117-125, 81-95, pressure.jl:320)
+template <int D>
+__global__ __launch_bounds__(256) void k_div_to_pI(GridDev g, const double* __restrict__ u, double* __restrict__ pI, int n0, int n1) {
+  const int ii = blockIdx.x * 64 + threadIdx.x;
+  const int jj = blockIdx.y * 4 + threadIdx.y;
+  const int kk = D == 3 ? (int)blockIdx.z : 0;
+  if (ii >= n0 || jj >= n1) return;
+  const int I[3] = {g.ip_lo[0] + ii, g.ip_lo[1] + jj, D == 3 ? g.ip_lo[2] + kk : 0};
+  const long long c = I[0] + I[1] * g.sx[1] + I[2] * g.sx[2];
+  double d = 0.0;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    const double* ua = u + a * g.sc;
+    d += (ua[c] - ua[c - g.sx[a]]) * g.rdx[a][I[a]];
+  }
+  double om = g.dx[0][I[0]] * g.dx[1][I[1]];
+  if (D == 3) om = om * g.dx[2][I[2]];
+  pI[ii + (long long)n0 * (jj + (long long)n1 * kk)] = d * om;
+}
+
+// copyto!(pI, view(p, Ip))  /  copyto!(view(p, Ip), pI)                        pressure.jl:320, 347
+template <int D, bool PACK>
+__global__ __launch_bounds__(256) void k_pack(GridDev g, double* __restrict__ p, double* __restrict__ pI, int n0, int n1) {
+  const int ii = blockIdx.x * 64 + threadIdx.x;
+  const int jj = blockIdx.y * 4 + threadIdx.y;
+  const int kk = D == 3 ? (int)blockIdx.z : 0;
+  if (ii >= n0 || jj >= n1) return;
+  const long long c = (g.ip_lo[0] + ii) + (g.ip_lo[1] + jj) * g.sx[1] + (D == 3 ? (g.ip_lo[2] + kk) * g.sx[2] : 0);
+  const long long q = ii + (long long)n0 * (jj + (long long)n1 * kk);
+  if (PACK)
+    pI[q] = p[c];
+  else
+    p[c] = pI[q];
+}
+
+// K3: phat = -phat / (ax + ay + az) * (1/prod(Np));  phat[0] = 0                 pressure.jl:326-341
+// (the normalisation of `ldiv!(pI, plan, phat)` is folded in: hipFFT's Z2D is unnormalised)
+template <int D>
+__global__ __launch_bounds__(256) void k_symbol(hipfftDoubleComplex* __restrict__ phat, const double* __restrict__ ax,
+                                                const double* __restrict__ ay, const double* __restrict__ az, int k0, int k1,
+                                                double inv_n) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int k = D == 3 ? (int)blockIdx.z : 0;
+  if (i >= k0 || j >= k1) return;
+  const long long q = i + (long long)k0 * (j + (long long)k1 * k);
+  double den = ax[i] + ay[j];
+  if (D == 3) den = den + az[k];
+  hipfftDoubleComplex v = phat[q];
+  const double s = (q == 0) ? 0.0 : -inv_n / den;
+  v.x *= s;
+  v.y *= s;
+  phat[q] = v;
+}
+
+// K4 (periodic, spectral): u[I,α] -= (pI[wrap(I+eα)] - pI[I]) / Δu[α][Iα] on the interior, and the padded,
+// ghost-filled `p` is written in the same pass (copyto!(view(p,Ip),pI) + apply_bc_p! + applypressure!,
+// pressure.jl:347, boundary_conditions.jl:306-318, operators.jl:225-233).
+template <int D>
+__global__ __launch_bounds__(256) void k_grad_from_pI(GridDev g, double* __restrict__ u, double* __restrict__ p,
+                                                      const double* __restrict__ pI, int n0, int n1, int n2) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int k = D == 3 ? (int)blockIdx.z : 0;
+  if (i >= g.N[0] || j >= g.N[1]) return;
+  const int n[3] = {n0, n1, n2};
+  const int I[3] = {i, j, k};
+  int w[3];
+  bool interior = true;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    int q = I[a] - 1;  // Ip.lo == 1 for periodic
+    interior = interior && q >= 0 && q < n[a];
+    q = q < 0 ? q + n[a] : (q >= n[a] ? q - n[a] : q);
+    w[a] = q;
+  }
+  if (D == 2) w[2] = 0;
+  const long long q = w[0] + (long long)n0 * (w[1] + (long long)n1 * w[2]);
+  const long long c = i + j * g.sx[1] + k * g.sx[2];
+  const double pc = pI[q];
+  p[c] = pc;
+  if (!interior) return;
+  const long long qs[3] = {1, n0, (long long)n0 * n1};
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    const long long qn = (w[a] + 1 < n[a]) ? q + qs[a] : q - (long long)(n[a] - 1) * qs[a];
+    u[a * g.sc + c] -= (pI[qn] - pc) * g.rdxu[a][I[a]];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CG kernels (pressure.jl:222-285).  Whole-array updates exactly as the reference's broadcasts; the
+// reductions run over Ip.  Each fused kernel leaves per-block partial sums in `partial`.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double* lds) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int w = (threadIdx.y * 64 + threadIdx.x) >> 6;
+  if (threadIdx.x == 0) lds[w] = v;
+  __syncthreads();
+  return lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+template <int D>
+__device__ __forceinline__ bool cell(const GridDev& g, int (&I)[3], long long& c, bool& inp) {
+  I[0] = blockIdx.x * 64 + threadIdx.x;
+  I[1] = blockIdx.y * 4 + threadIdx.y;
+  I[2] = D == 3 ? (int)blockIdx.z : 0;
+  const bool ok = I[0] < g.N[0] && I[1] < g.N[1];
+  c = I[0] + I[1] * g.sx[1] + I[2] * g.sx[2];
+  inp = ok;
+#pragma unroll
+  for (int a = 0; a < D; ++a) inp = inp && I[a] >= g.ip_lo[a] && I[a] < g.ip_hi[a];
+  return ok;
+}
+
+__device__ __forceinline__ void store_partial(double v, double* partial) {
+  if (threadIdx.x == 0 && threadIdx.y == 0) partial[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] = v;
+}
+
+// dinv = 1/d with d of pressure.jl:196-199
+template <int D>
+__global__ __launch_bounds__(256) void k_cg_diag(GridDev g, double* __restrict__ dinv) {
+  int I[3];
+  long long c;
+  bool inp;
+  if (!cell<D>(g, I, c, inp)) return;
+  double v = 0.0;
+  if (inp) {
+    double om = g.dx[0][I[0]] * g.dx[1][I[1]];
+    if (D == 3) om = om * g.dx[2][I[2]];
+    double d = 0.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) d -= om / g.dx[a][I[a]] * (1 / g.dxu[a][I[a]] + 1 / g.dxu[a][I[a] - 1]);
+    v = 1.0 / d;
+  }
+  dinv[c] = v;
+}
+
+// r = p; p = 0; partial Σ r²       (q .= 0; L = lap(q) = 0; r .= p .- L; residual; p .= 0 — pressure.jl:239-249)
+template <int D>
+__global__ __launch_bounds__(256) void k_cg_init(GridDev g, double* __restrict__ p, double* __restrict__ r, double* __restrict__ q,
+                                                 double* __restrict__ L, double* __restrict__ partial) {
+  __shared__ double lds[4];
+  int I[3];
+  long long c;
+  bool inp;
+  const bool ok = cell<D>(g, I, c, inp);
+  double s = 0.0;
+  if (ok) {
+    const double v = p[c];
+    r[c] = v;
+    p[c] = 0.0;
+    q[c] = 0.0;
+    L[c] = 0.0;
+    if (inp) s = v * v;
+  }
+  s = block_sum(s, lds);
+  store_partial(s, partial);
+}
+
+// L[Ip] = -r/d (preconditioner);  partial Σ L·r                                   pressure.jl:252-255
+template <int D>
+__global__ __launch_bounds__(256) void k_cg_precond(GridDev g, const double* __restrict__ r, const double* __restrict__ dinv,
+                                                    double* __restrict__ L, double* __restrict__ partial) {
+  __shared__ double lds[4];
+  int I[3];
+  long long c;
+  bool inp;
+  const bool ok = cell<D>(g, I, c, inp);
+  double s = 0.0;
+  if (ok && inp) {
+    const double rv = r[c];
+    const double z = -rv * dinv[c];
+    L[c] = z;
+    s = z * rv;
+  }
+  s = block_sum(s, lds);
+  store_partial(s, partial);
+}
+
+// q = L + β q  (whole array)                                                       pressure.jl:260
+__global__ __launch_bounds__(256) void k_cg_dir(long long n, double beta, const double* __restrict__ L, double* __restrict__ q) {
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) q[t] = L[t] + beta * q[t];
+}
+
+// partial Σ q·L over Ip                                                            pressure.jl:266
+template <int D>
+__global__ __launch_bounds__(256) void k_cg_dot(GridDev g, const double* __restrict__ a, const double* __restrict__ b,
+                                                double* __restrict__ partial) {
+  __shared__ double lds[4];
+  int I[3];
+  long long c;
+  bool inp;
+  const bool ok = cell<D>(g, I, c, inp);
+  double s = (ok && inp) ? a[c] * b[c] : 0.0;
+  s = block_sum(s, lds);
+  store_partial(s, partial);
+}
+
+// p += α q; r -= α L (whole arrays); partial Σ r² over Ip                      pressure.jl:270-275
+template <int D>
+__global__ __launch_bounds__(256) void k_cg_update(GridDev g, double alpha, double* __restrict__ p, double* __restrict__ r,
+                                                   const double* __restrict__ q, const double* __restrict__ L,
+                                                   double* __restrict__ partial) {
+  __shared__ double lds[4];
+  int I[3];
+  long long c;
+  bool inp;
+  const bool ok = cell<D>(g, I, c, inp);
+  double s = 0.0;
+  if (ok) {
+    p[c] += alpha * q[c];
+    const double rv = r[c] - alpha * L[c];
+    r[c] = rv;
+    if (inp) s = rv * rv;
+  }
+  s = block_sum(s, lds);
+  store_partial(s, partial);
+}
+
+struct BoxLaunch {
+  dim3 grid, block;
+  int nblk;
+};
+
+inline BoxLaunch full_box(const GridDev& g) {
+  BoxLaunch l;
+  l.block = dim3(64, 4, 1);
+  l.grid = dim3(cdiv(g.N[0], 64), cdiv(g.N[1], 4), (unsigned)g.N[2]);
+  l.nblk = (int)(l.grid.x * l.grid.y * l.grid.z);
+  return l;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// spectral
+// ------------------------------------------------------------------------------------------------
+extern "C" int ins_poisson_spectral_create(const ins_grid_t* G, ins_poisson_t** out) {
+  INS_REQUIRE(G && out, "null argument");
+  // assert_uniform_periodic (utils.jl:1-13)
+  INS_REQUIRE(G->all_periodic, "Spectral psolver requires periodic boundary conditions.");
+  INS_REQUIRE(G->uniform, "Spectral psolver requires uniform grid spacing.");
+  const GridDev& g = G->g;
+  for (int a = 0; a < g.D; ++a) INS_REQUIRE(g.N[a] % 2 == 0, "Spectral psolver requires even number of volumes.");
+  ins_poisson* ps = new ins_poisson();
+  ps->kind = POISSON_SPECTRAL;
+  ps->grid = G;
+  const int D = g.D;
+  long long nreal = 1, ncplx = 1;
+  double om = 1.0;
+  for (int a = 0; a < D; ++a) {
+    ps->np[a] = g.ip_hi[a] - g.ip_lo[a];
+    ps->kmax[a] = a == 0 ? ps->np[a] / 2 + 1 : ps->np[a];
+    nreal *= ps->np[a];
+    ncplx *= ps->kmax[a];
+    om *= G->h[a];
+  }
+  int rc = INS_OK;
+  auto fail = [&](int code) {
+    ins_poisson_destroy(ps);
+    return code;
+  };
+  if (hipMalloc(&ps->pI, nreal * sizeof(double)) != hipSuccess || hipMalloc(&ps->phat, ncplx * sizeof(hipfftDoubleComplex)) != hipSuccess) {
+    ins_set_error("hipMalloc(pI/phat) failed for %lld cells", nreal);
+    return fail(INS_ERR_HIP);
+  }
+  // ahat[α][k] = 4 Ω sinpi(k/Np[α])² / Δx[α]²                                      pressure.jl:305-311
+  for (int a = 0; a < D; ++a) {
+    std::vector<double> ah(ps->kmax[a]);
+    for (int k = 0; k < ps->kmax[a]; ++k) {
+      const double sn = std::sin(M_PI * ((double)k / ps->np[a]));
+      ah[k] = 4 * om * sn * sn / (G->h[a] * G->h[a]);
+    }
+    if (hipMalloc(&ps->ahat[a], ah.size() * sizeof(double)) != hipSuccess ||
+        hipMemcpy(ps->ahat[a], ah.data(), ah.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+      ins_set_error("ahat upload failed");
+      return fail(INS_ERR_HIP);
+    }
+  }
+  // plan_rfft(pI): all D dims, real -> half-complex along x (pressure.jl:316).  hipFFT takes lengths slowest first.
+  hipfftResult r1, r2;
+  if (D == 2) {
+    r1 = hipfftPlan2d(&ps->plan_fwd, ps->np[1], ps->np[0], HIPFFT_D2Z);
+    r2 = hipfftPlan2d(&ps->plan_inv, ps->np[1], ps->np[0], HIPFFT_Z2D);
+  } else {
+    r1 = hipfftPlan3d(&ps->plan_fwd, ps->np[2], ps->np[1], ps->np[0], HIPFFT_D2Z);
+    r2 = hipfftPlan3d(&ps->plan_inv, ps->np[2], ps->np[1], ps->np[0], HIPFFT_Z2D);
+  }
+  if (r1 != HIPFFT_SUCCESS || r2 != HIPFFT_SUCCESS) {
+    ins_set_error("hipfftPlan%dd failed (%d, %d)", D, (int)r1, (int)r2);
+    return fail(INS_ERR_FFT);
+  }
+  ps->plans = true;
+  (void)rc;
+  *out = ps;
+  return INS_OK;
+}
+
+static int spectral_transform(ins_poisson* ps, hipStream_t s) {
+  const GridDev& g = ps->grid->g;
+  INS_FFT_TRY(hipfftSetStream(ps->plan_fwd, s));
+  INS_FFT_TRY(hipfftSetStream(ps->plan_inv, s));
+  INS_FFT_TRY(hipfftExecD2Z(ps->plan_fwd, ps->pI, ps->phat));
+  double inv_n = 1.0;
+  for (int a = 0; a < g.D; ++a) inv_n /= ps->np[a];
+  dim3 block(64, 4, 1), grid(cdiv(ps->kmax[0], 64), cdiv(ps->kmax[1], 4), g.D == 3 ? ps->kmax[2] : 1);
+  if (g.D == 2)
+    hipLaunchKernelGGL(k_symbol<2>, grid, block, 0, s, ps->phat, ps->ahat[0], ps->ahat[1], (const double*)nullptr, ps->kmax[0],
+                       ps->kmax[1], inv_n);
+  else
+    hipLaunchKernelGGL(k_symbol<3>, grid, block, 0, s, ps->phat, ps->ahat[0], ps->ahat[1], ps->ahat[2], ps->kmax[0], ps->kmax[1],
+                       inv_n);
+  INS_LAUNCH_CHECK();
+  INS_FFT_TRY(hipfftExecZ2D(ps->plan_inv, ps->phat, ps->pI));
+  return INS_OK;
+}
+
+static int spectral_solve(ins_poisson* ps, double* p, hipStream_t s) {
+  const GridDev& g = ps->grid->g;
+  dim3 block(64, 4, 1), grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), g.D == 3 ? ps->np[2] : 1);
+  if (g.D == 2)
+    hipLaunchKernelGGL((k_pack<2, true>), grid, block, 0, s, g, p, ps->pI, ps->np[0], ps->np[1]);
+  else
+    hipLaunchKernelGGL((k_pack<3, true>), grid, block, 0, s, g, p, ps->pI, ps->np[0], ps->np[1]);
+  INS_LAUNCH_CHECK();
+  int rc = spectral_transform(ps, s);
+  if (rc) return rc;
+  if (g.D == 2)
+    hipLaunchKernelGGL((k_pack<2, false>), grid, block, 0, s, g, p, ps->pI, ps->np[0], ps->np[1]);
+  else
+    hipLaunchKernelGGL((k_pack<3, false>), grid, block, 0, s, g, p, ps->pI, ps->np[0], ps->np[1]);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CG
+// ------------------------------------------------------------------------------------------------
+extern "C" int ins_poisson_cg_create(const ins_grid_t* G, double abstol, double reltol, int64_t maxiter, ins_poisson_t** out) {
+  INS_REQUIRE(G && out, "null argument");
+  const GridDev& g = G->g;
+  for (int a = 0; a < g.D; ++a)
+    INS_REQUIRE(g.bc[a][0] != INS_BC_HALO && g.bc[a][1] != INS_BC_HALO, "psolver_cg on a slab grid is not implemented");
+  ins_poisson* ps = new ins_poisson();
+  ps->kind = POISSON_CG;
+  ps->grid = G;
+  ps->abstol = abstol;
+  ps->reltol = reltol;
+  long long ndof = 1;
+  for (int a = 0; a < g.D; ++a) ndof *= g.ip_hi[a] - g.ip_lo[a];
+  ps->maxiter = maxiter > 0 ? maxiter : ndof;
+  const size_t bytes = G->ncell * sizeof(double);
+  if (hipMalloc(&ps->r, bytes) != hipSuccess || hipMalloc(&ps->L, bytes) != hipSuccess || hipMalloc(&ps->q, bytes) != hipSuccess ||
+      hipMalloc(&ps->dinv, bytes) != hipSuccess) {
+    ins_set_error("hipMalloc(cg scratch) failed");
+    ins_poisson_destroy(ps);
+    return INS_ERR_HIP;
+  }
+  BoxLaunch l = full_box(g);
+  if (g.D == 2)
+    hipLaunchKernelGGL(k_cg_diag<2>, l.grid, l.block, 0, 0, g, ps->dinv);
+  else
+    hipLaunchKernelGGL(k_cg_diag<3>, l.grid, l.block, 0, 0, g, ps->dinv);
+  if (hipDeviceSynchronize() != hipSuccess) {
+    ins_set_error("cg diag kernel failed");
+    ins_poisson_destroy(ps);
+    return INS_ERR_HIP;
+  }
+  *out = ps;
+  return INS_OK;
+}
+
+// Finish a per-block partial sum on the host.  Blocking.
+static int finish_sum(const ins_grid* G, double* partial_dev, int nblk, hipStream_t s, double* out) {
+  std::vector<double> h(nblk);
+  INS_HIP_TRY(hipMemcpyAsync(h.data(), partial_dev, nblk * sizeof(double), hipMemcpyDeviceToHost, s));
+  INS_HIP_TRY(hipStreamSynchronize(s));
+  double v = 0.0;
+  for (int i = 0; i < nblk; ++i) v += h[i];
+  *out = v;
+  return INS_OK;
+}
+
+static int cg_solve(ins_poisson* ps, double* p, hipStream_t s) {
+  const ins_grid* G = ps->grid;
+  const GridDev& g = G->g;
+  BoxLaunch l = full_box(g);
+  double* partial = nullptr;
+  INS_HIP_TRY(hipMalloc(&partial, l.nblk * sizeof(double)));
+  struct Guard {
+    double* p;
+    ~Guard() { (void)hipFree(p); }
+  } guard{partial};
+  int rc;
+  double ss;
+#define LAUNCH_D(K, ...)                                                        \
+  do {                                                                          \
+    if (g.D == 2)                                                               \
+      hipLaunchKernelGGL(K<2>, l.grid, l.block, 0, s, __VA_ARGS__);             \
+    else                                                                        \
+      hipLaunchKernelGGL(K<3>, l.grid, l.block, 0, s, __VA_ARGS__);             \
+    INS_LAUNCH_CHECK();                                                         \
+  } while (0)
+
+  LAUNCH_D(k_cg_init, g, p, ps->r, ps->q, ps->L, partial);
+  if ((rc = finish_sum(G, partial, l.nblk, s, &ss))) return rc;
+  double residual = std::sqrt(ss);
+  const double tolerance = std::fmax(ps->reltol * residual, ps->abstol);
+  double rho_prev = 1.0;
+  long long it = 0;
+  while (it < ps->maxiter && residual > tolerance) {
+    double rho, qL;
+    LAUNCH_D(k_cg_precond, g, ps->r, ps->dinv, ps->L, partial);
+    if ((rc = finish_sum(G, partial, l.nblk, s, &rho))) return rc;
+    const double beta = rho / rho_prev;
+    hipLaunchKernelGGL(k_cg_dir, dim3(std::min<long long>((G->ncell + 255) / 256, 4096)), dim3(256), 0, s, G->ncell, beta, ps->L, ps->q);
+    INS_LAUNCH_CHECK();
+    if ((rc = ins_k_apply_bc_p(G, ps->q, s))) return rc;
+    if ((rc = ins_k_laplacian(G, ps->q, ps->L, s))) return rc;
+    LAUNCH_D(k_cg_dot, g, ps->q, ps->L, partial);
+    if ((rc = finish_sum(G, partial, l.nblk, s, &qL))) return rc;
+    const double alpha = rho / qL;
+    LAUNCH_D(k_cg_update, g, alpha, p, ps->r, ps->q, ps->L, partial);
+    if ((rc = finish_sum(G, partial, l.nblk, s, &ss))) return rc;
+    rho_prev = rho;
+    residual = std::sqrt(ss);
+    ++it;
+  }
+#undef LAUNCH_D
+  ps->last_iter = it;
+  ps->last_res = residual;
+  return INS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int ins_poisson_destroy(ins_poisson_t* ps) {
+  if (!ps) return INS_OK;
+  if (ps->plans) {
+    (void)hipfftDestroy(ps->plan_fwd);
+    (void)hipfftDestroy(ps->plan_inv);
+  }
+  if (ps->pI) (void)hipFree(ps->pI);
+  if (ps->phat) (void)hipFree(ps->phat);
+  for (int a = 0; a < 3; ++a)
+    if (ps->ahat[a]) (void)hipFree(ps->ahat[a]);
+  if (ps->r) (void)hipFree(ps->r);
+  if (ps->L) (void)hipFree(ps->L);
+  if (ps->q) (void)hipFree(ps->q);
+  if (ps->dinv) (void)hipFree(ps->dinv);
+  delete ps;
+  return INS_OK;
+}
+
+int ins_k_poisson_solve(ins_poisson* ps, double* p, hipStream_t s) {
+  return ps->kind == POISSON_SPECTRAL ? spectral_solve(ps, p, s) : cg_solve(ps, p, s);
+}
+
+extern "C" int ins_poisson_solve_f64(ins_poisson_t* ps, double* p, void* stream) {
+  INS_REQUIRE(ps && p, "null argument");
+  return ins_k_poisson_solve(ps, p, as_stream(stream));
+}
+
+extern "C" int ins_poisson_last_info(const ins_poisson_t* ps, int64_t* iterations, double* residual) {
+  INS_REQUIRE(ps, "null argument");
+  if (iterations) *iterations = ps->last_iter;
+  if (residual) *residual = ps->last_res;
+  return INS_OK;
+}
+
+// project!(u, setup; psolver, p)                                                   pressure.jl:69-82
+int ins_k_project(const ins_grid* G, ins_poisson* ps, double* u, double* p, hipStream_t s) {
+  const GridDev& g = G->g;
+  int rc;
+  if (ps->kind == POISSON_SPECTRAL) {
+    dim3 block(64, 4, 1), grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), g.D == 3 ? ps->np[2] : 1);
+    if (g.D == 2)
+      hipLaunchKernelGGL(k_div_to_pI<2>, grid, block, 0, s, g, u, ps->pI, ps->np[0], ps->np[1]);
+    else
+      hipLaunchKernelGGL(k_div_to_pI<3>, grid, block, 0, s, g, u, ps->pI, ps->np[0], ps->np[1]);
+    INS_LAUNCH_CHECK();
+    if ((rc = spectral_transform(ps, s))) return rc;
+    dim3 gridp(cdiv(g.N[0], 64), cdiv(g.N[1], 4), (unsigned)g.N[2]);
+    if (g.D == 2)
+      hipLaunchKernelGGL(k_grad_from_pI<2>, gridp, block, 0, s, g, u, p, ps->pI, ps->np[0], ps->np[1], 1);
+    else
+      hipLaunchKernelGGL(k_grad_from_pI<3>, gridp, block, 0, s, g, u, p, ps->pI, ps->np[0], ps->np[1], ps->np[2]);
+    INS_LAUNCH_CHECK();
+    return INS_OK;
+  }
+  if ((rc = ins_k_divergence(G, u, p, s))) return rc;
+  if ((rc = ins_k_scalewithvolume(G, p, s))) return rc;
+  if ((rc = ins_k_poisson_solve(ps, p, s))) return rc;
+  if ((rc = ins_k_apply_bc_p(G, p, s))) return rc;
+  return ins_k_applypressure(G, u, p, s);
+}
+
+extern "C" int ins_project_f64(const ins_grid_t* G, ins_poisson_t* ps, double* u, double* p, void* stream) {
+  INS_REQUIRE(G && ps && u && p, "null argument");
+  INS_REQUIRE(ps->grid == G, "psolver was created for a different grid");
+  return ins_k_project(G, ps, u, p, as_stream(stream));
+}

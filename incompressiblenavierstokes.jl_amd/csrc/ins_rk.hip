@@ -1,0 +1,177 @@
+// Explicit Runge-Kutta stage loop (step_explicit_runge_kutta.jl:4-59) and its cache
+// (time_stepper_caches.jl:34-49).
+#include "ins_internal.h"
+
+#define INS_MAX_STAGES 16
+
+int ins_k_momentum_generic(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s);
+int ins_k_momentum_fast3d(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s);
+bool ins_fast3d_supported(const ins_grid* G);
+
+int ins_k_momentum(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s) {
+  if (ins_fast3d_supported(G)) return ins_k_momentum_fast3d(G, visc, u, F, s);
+  return ins_k_momentum_generic(G, visc, u, F, s);
+}
+
+namespace {
+
+struct Combine {
+  int n;
+  double coef[INS_MAX_STAGES];
+  const double* k[INS_MAX_STAGES];
+};
+
+// K6: u = ustart + Σ_j (Δt A[i,j]) ku[j]  in ONE pass (the reference does 1 copy + i axpy passes and does
+// not skip tableau zeros, step_explicit_runge_kutta.jl:35-38).  Summation order as in the reference.
+__global__ __launch_bounds__(256) void k_combine(long long n, const double* __restrict__ ustart, double* __restrict__ u, Combine cb) {
+  const long long stride = (long long)gridDim.x * 256 * 2;
+  for (long long t = ((long long)blockIdx.x * 256 + threadIdx.x) * 2; t < n; t += stride) {
+    if (t + 1 < n) {
+      double2 v = *reinterpret_cast<const double2*>(ustart + t);
+      for (int j = 0; j < cb.n; ++j) {
+        const double2 kv = *reinterpret_cast<const double2*>(cb.k[j] + t);
+        v.x += cb.coef[j] * kv.x;
+        v.y += cb.coef[j] * kv.y;
+      }
+      *reinterpret_cast<double2*>(u + t) = v;
+    } else {
+      double v = ustart[t];
+      for (int j = 0; j < cb.n; ++j) v += cb.coef[j] * cb.k[j][t];
+      u[t] = v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ins_rk_create(const ins_grid_t* G, ins_poisson_t* ps, int nstage, const double* A, const double* c, ins_rk_t** out) {
+  INS_REQUIRE(G && ps && A && c && out, "null argument");
+  INS_REQUIRE(ps->grid == G, "psolver was created for a different grid");
+  INS_REQUIRE(nstage >= 1 && nstage <= INS_MAX_STAGES, "unsupported number of stages");
+  for (int i = 0; i < nstage; ++i)
+    for (int j = i + 1; j < nstage; ++j) INS_REQUIRE(A[i * nstage + j] == 0.0, "shifted tableau must be lower triangular (explicit method)");
+  ins_rk* rk = new ins_rk();
+  rk->grid = G;
+  rk->ps = ps;
+  rk->nstage = nstage;
+  rk->A.assign(A, A + nstage * nstage);
+  rk->c.assign(c, c + nstage);
+  const size_t vbytes = (size_t)G->ncell * G->g.D * sizeof(double);
+  bool ok = hipMalloc(&rk->ustart, vbytes) == hipSuccess && hipMalloc(&rk->p, G->ncell * sizeof(double)) == hipSuccess;
+  rk->ku.assign(nstage, nullptr);
+  for (int i = 0; ok && i < nstage; ++i) ok = hipMalloc(&rk->ku[i], vbytes) == hipSuccess;
+  if (ok) ok = hipMemset(rk->p, 0, G->ncell * sizeof(double)) == hipSuccess && hipMemset(rk->ustart, 0, vbytes) == hipSuccess;
+  for (int i = 0; ok && i < nstage; ++i) ok = hipMemset(rk->ku[i], 0, vbytes) == hipSuccess;
+  if (!ok) {
+    ins_set_error("ins_rk_create: device allocation of %d vector fields failed", nstage + 1);
+    ins_rk_destroy(rk);
+    return INS_ERR_HIP;
+  }
+  *out = rk;
+  return INS_OK;
+}
+
+extern "C" int ins_rk_destroy(ins_rk_t* rk) {
+  if (!rk) return INS_OK;
+  if (rk->ustart) (void)hipFree(rk->ustart);
+  if (rk->p) (void)hipFree(rk->p);
+  for (double* k : rk->ku)
+    if (k) (void)hipFree(k);
+  for (double* b : rk->ub)
+    if (b) (void)hipFree(b);
+  for (hipEvent_t e : rk->prof_events) (void)hipEventDestroy(e);
+  delete rk;
+  return INS_OK;
+}
+
+extern "C" int ins_rk_profile_enable(ins_rk_t* rk, int enable) {
+  INS_REQUIRE(rk, "null argument");
+  rk->profiling = enable != 0;
+  return INS_OK;
+}
+
+extern "C" int ins_rk_profile_read(ins_rk_t* rk, double* momentum_ms, int64_t* momentum_launches) {
+  INS_REQUIRE(rk && momentum_ms && momentum_launches, "null argument");
+  double total = 0.0;
+  const size_t n = rk->prof_events.size() / 2;
+  for (size_t i = 0; i < n; ++i) {
+    float ms = 0.f;
+    INS_HIP_TRY(hipEventSynchronize(rk->prof_events[2 * i + 1]));
+    INS_HIP_TRY(hipEventElapsedTime(&ms, rk->prof_events[2 * i], rk->prof_events[2 * i + 1]));
+    total += ms;
+  }
+  for (hipEvent_t e : rk->prof_events) (void)hipEventDestroy(e);
+  rk->prof_events.clear();
+  *momentum_ms = total;
+  *momentum_launches = (int64_t)n;
+  return INS_OK;
+}
+
+extern "C" int ins_rk_pressure(const ins_rk_t* rk, double** p) {
+  INS_REQUIRE(rk && p, "null argument");
+  *p = rk->p;
+  return INS_OK;
+}
+
+extern "C" int ins_rk_stage_force(const ins_rk_t* rk, int i, double** ku) {
+  INS_REQUIRE(rk && ku, "null argument");
+  INS_REQUIRE(i >= 0 && i < rk->nstage, "stage index out of range");
+  *ku = rk->ku[i];
+  return INS_OK;
+}
+
+extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, double dt, const double* const* planes, void* stream) {
+  INS_REQUIRE(rk && u, "null argument");
+  (void)t;  // boundary data is time-independent on this entry point (see header)
+  const ins_grid* G = rk->grid;
+  hipStream_t s = as_stream(stream);
+  const long long nvec = G->ncell * G->g.D;
+  const double** dplanes = nullptr;
+  struct Guard {
+    const double** p;
+    ~Guard() {
+      if (p) (void)hipFree(p);
+    }
+  } guard{nullptr};
+  if (planes) {
+    INS_HIP_TRY(hipMalloc(&dplanes, 18 * sizeof(double*)));
+    guard.p = dplanes;
+    INS_HIP_TRY(hipMemcpy(dplanes, planes, 18 * sizeof(double*), hipMemcpyHostToDevice));
+  }
+  int rc;
+  // copyto!(ustart, u)                                                   step_explicit_runge_kutta.jl:14
+  INS_HIP_TRY(hipMemcpyAsync(rk->ustart, u, nvec * sizeof(double), hipMemcpyDeviceToDevice, s));
+  const int ns = rk->nstage;
+  for (int i = 0; i < ns; ++i) {
+    if ((rc = ins_k_apply_bc_u(G, u, 0, dplanes, s))) return rc;             // :19
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (rk->profiling) {
+      INS_HIP_TRY(hipEventCreate(&e0));
+      INS_HIP_TRY(hipEventCreate(&e1));
+      INS_HIP_TRY(hipEventRecord(e0, s));
+    }
+    if ((rc = ins_k_momentum(G, visc, u, rk->ku[i], s))) return rc;           // :21
+    if (rk->profiling) {
+      INS_HIP_TRY(hipEventRecord(e1, s));
+      rk->prof_events.push_back(e0);
+      rk->prof_events.push_back(e1);
+    }
+    Combine cb;                                                               // :35-38
+    cb.n = 0;
+    for (int j = 0; j <= i; ++j) {
+      const double coef = dt * rk->A[i * ns + j];
+      if (coef == 0.0) continue;
+      cb.coef[cb.n] = coef;
+      cb.k[cb.n] = rk->ku[j];
+      ++cb.n;
+    }
+    const unsigned nblk = (unsigned)std::min<long long>((nvec / 2 + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_combine, dim3(nblk), dim3(256), 0, s, nvec, rk->ustart, u, cb);
+    INS_LAUNCH_CHECK();
+    if ((rc = ins_k_apply_bc_u(G, u, 0, dplanes, s))) return rc;             // :48
+    if ((rc = ins_k_project(G, rk->ps, u, rk->p, s))) return rc;              // :49
+  }
+  if ((rc = ins_k_apply_bc_u(G, u, 0, dplanes, s))) return rc;               // :55
+  if (planes) INS_HIP_TRY(hipStreamSynchronize(s));                           // dplanes is freed on return
+  return INS_OK;
+}

@@ -1,0 +1,64 @@
+"""`solve_unsteady` and the CFL time step (solver.jl)."""
+import ctypes as C
+
+from . import _lib
+from .pressure import default_psolver
+from .setup import copyfield
+from .time_steppers import RKMethods, create_stepper, ode_method_cache, timestep_
+
+
+def get_state(stepper):
+    """solver.jl:95-98"""
+    return dict(u=stepper.u, temp=stepper.temp, t=stepper.t, n=stepper.n)
+
+
+def get_cfl_timestep_(buf, u, setup):
+    """Get proposed maximum time step for convection and diffusion terms (solver.jl:101-125).
+    `buf` is accepted for signature parity; the reduction scratch is internal.  Blocking."""
+    out = C.c_double()
+    _lib.call("ins_cfl_timestep_f64", setup.handle, setup.Re, setup.ptr(u, True), C.byref(out), setup.stream)
+    return out.value
+
+
+def solve_unsteady(*, setup, tlims, ustart, tempstart=None, method=None, psolver=None, Δt=None, Δt_min=None,
+                   cfl=0.9, n_adapt_Δt=1, docopy=True, processors=None, θ=None, cache=None):
+    """Solve unsteady problem using `method` (solver.jl:18-92).
+
+    `processors` is a dict name -> object with `initialize(state_getter)` / `finalize(init, state_getter)`
+    and an optional `on_step(state)`; returns `((u, temp, t), outputs)` like the reference."""
+    if tempstart is not None:
+        raise NotImplementedError("temperature is outside the HIP hot path")
+    method = method or RKMethods.RK44()
+    psolver = psolver or default_psolver(setup)
+    cache = cache or ode_method_cache(method, setup, psolver)
+    processors = processors or {}
+    if docopy:
+        ustart = copyfield(ustart)
+    tstart, tend = tlims
+    isadaptive = Δt is None
+    stepper = create_stepper(method, setup=setup, psolver=psolver, u=ustart, temp=None, t=tstart)
+    state = {"value": get_state(stepper)}
+    initialized = {k: v.initialize(lambda: state["value"]) for k, v in processors.items()}
+
+    def fire():
+        state["value"] = get_state(stepper)
+        for v in processors.values():
+            if hasattr(v, "on_step"):
+                v.on_step(state["value"])
+
+    if isadaptive:
+        while stepper.t < tend:
+            if stepper.n % n_adapt_Δt == 0:
+                Δt = cfl * get_cfl_timestep_(None, stepper.u, setup)
+                Δt = Δt if Δt_min is None else max(Δt, Δt_min)
+            Δt = min(Δt, tend - stepper.t)
+            stepper = timestep_(method, stepper, Δt, θ=θ, cache=cache)
+            fire()
+    else:
+        nstep = int(round((tend - tstart) / Δt))
+        Δt = (tend - tstart) / nstep
+        for _ in range(nstep):
+            stepper = timestep_(method, stepper, Δt, θ=θ, cache=cache)
+            fire()
+    outputs = {k: processors[k].finalize(initialized[k], lambda: state["value"]) for k in processors}
+    return (stepper.u, None, stepper.t), outputs

@@ -1,0 +1,173 @@
+"""Explicit Runge-Kutta time stepping (time_steppers/methods.jl, RKMethods.jl,
+step_explicit_runge_kutta.jl, time_stepper_caches.jl), host side."""
+import ctypes as C
+from dataclasses import dataclass
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _lib
+from .operators import apply_bc_u_, momentum_
+from .pressure import project_
+from .setup import copyfield, scalarfield, vectorfield
+
+
+@dataclass
+class ExplicitRungeKuttaMethod:
+    """methods.jl:184-190 (A and c already shifted, methods.jl:231-236)."""
+
+    A: np.ndarray
+    b: np.ndarray
+    c: np.ndarray
+    r: float = 0.0
+    p_add_solve: bool = True
+
+
+def runge_kutta_method(A, b, c, r=0.0, **kw):
+    """methods.jl:219-240 (explicit tableaux only: the implicit branch is dead code in the reference)."""
+    A = np.array(A, dtype=np.float64)
+    b = np.array(b, dtype=np.float64)
+    c = np.array(c, dtype=np.float64)
+    s = A.shape[0]
+    if not (A.shape == (s, s) and b.shape == (s,) and c.shape == (s,)):
+        raise ValueError("A, b, and c must have the same sizes")
+    if not np.allclose(np.triu(A), 0):
+        raise NotImplementedError("implicit Runge-Kutta methods are legacy code in the reference (SURVEY.md §2)")
+    A = np.vstack([A[1:, :], b[None, :]])
+    c = np.concatenate([c[1:], [1.0]])
+    return ExplicitRungeKuttaMethod(A, b, c, float(r), **kw)
+
+
+class RKMethods:
+    """Explicit tableaux of RKMethods.jl (same names)."""
+
+    @staticmethod
+    def FE11(**kw):  # RKMethods.jl:45-50
+        return runge_kutta_method([[0.0]], [1.0], [0.0], **kw)
+
+    @staticmethod
+    def SSP22(**kw):  # :54-59
+        A = np.array([[0, 0], [1, 0]], dtype=float)
+        return runge_kutta_method(A, [0.5, 0.5], A.sum(1), **kw)
+
+    @staticmethod
+    def SSP42(**kw):  # :63-69
+        t = 1 / 3
+        A = np.array([[0, 0, 0, 0], [t, 0, 0, 0], [t, t, 0, 0], [t, t, t, 0]])
+        return runge_kutta_method(A, [0.25] * 4, A.sum(1), **kw)
+
+    @staticmethod
+    def SSP33(**kw):  # :73-78
+        A = np.array([[0, 0, 0], [1, 0, 0], [0.25, 0.25, 0]])
+        return runge_kutta_method(A, [1 / 6, 1 / 6, 2 / 3], A.sum(1), **kw)
+
+    @staticmethod
+    def SSP43(**kw):  # :82-87
+        s = 1 / 6
+        A = np.array([[0, 0, 0, 0], [0.5, 0, 0, 0], [0.5, 0.5, 0, 0], [s, s, s, 0]])
+        return runge_kutta_method(A, [s, s, s, 0.5], A.sum(1), **kw)
+
+    @staticmethod
+    def Wray3(**kw):  # :137-147
+        a31 = 8 / 15 - 17 / 60
+        A = np.array([[0, 0, 0], [8 / 15, 0, 0], [a31, 5 / 12, 0]])
+        return runge_kutta_method(A, [a31, 0, 0.75], [0, 8 / 15, a31 + 5 / 12], **kw)
+
+    @staticmethod
+    def RK44(**kw):  # :515-521
+        A = np.array([[0, 0, 0, 0], [0.5, 0, 0, 0], [0, 0.5, 0, 0], [0, 0, 1, 0]])
+        return runge_kutta_method(A, [1 / 6, 1 / 3, 1 / 3, 1 / 6], A.sum(1), **kw)
+
+    @staticmethod
+    def RK44C2(**kw):  # :524-530
+        A = np.array([[0, 0, 0, 0], [0.25, 0, 0, 0], [0, 0.5, 0, 0], [1, -2, 2, 0]])
+        return runge_kutta_method(A, [1 / 6, 0, 2 / 3, 1 / 6], A.sum(1), **kw)
+
+    @staticmethod
+    def RK33P2(**kw):  # :506-512
+        A = np.array([[0, 0, 0], [1 / 3, 0, 0], [-1, 2, 0]])
+        return runge_kutta_method(A, [0, 0.75, 0.25], [0, 1 / 3, 1], **kw)
+
+
+class ERKCache:
+    """`ode_method_cache(method, setup)` (time_stepper_caches.jl:34-49).  The arrays live inside an
+    `ins_rk_t` handle; `ustart`, `ku[i]`, `p` are exposed as zero-copy torch views where the host needs them."""
+
+    def __init__(self, method, setup, psolver):
+        self.method, self.setup, self.psolver = method, setup, psolver
+        ns = len(method.b)
+        A = np.ascontiguousarray(method.A, dtype=np.float64)
+        c = np.ascontiguousarray(method.c, dtype=np.float64)
+        self._handle = C.c_void_p()
+        _lib.call("ins_rk_create", setup.handle, psolver.handle, ns, A.ctypes.data_as(_lib.c_double_p),
+                  c.ctypes.data_as(_lib.c_double_p), C.byref(self._handle))
+
+    @property
+    def handle(self):
+        return self._handle
+
+    def __del__(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            try:
+                _lib.load().ins_rk_destroy(h)
+            except Exception:
+                pass
+
+
+def ode_method_cache(method, setup, psolver=None):
+    """time_stepper_caches.jl:34-49.  (`psolver` is needed up front because the native cache owns the
+    projection scratch; `solve_unsteady` passes it.)"""
+    if psolver is None:
+        from .pressure import default_psolver
+
+        psolver = default_psolver(setup)
+    return ERKCache(method, setup, psolver)
+
+
+def create_stepper(method, *, setup, psolver, u, temp=None, t=0.0, n=0):
+    """step_explicit_runge_kutta.jl:1-2"""
+    return SimpleNamespace(setup=setup, psolver=psolver, u=u, temp=temp, t=t, n=n)
+
+
+def timestep_(method, stepper, Δt, *, θ=None, cache):
+    """Perform one time step, in place (step_explicit_runge_kutta.jl:4-59).
+
+    Fully native (`ins_rk_step_f64`) when boundary data is time-independent; with callable Dirichlet data
+    the stage loop runs here and calls the operator-level kernels so `bc.u(α, x..., t)` can be evaluated
+    between stages (SURVEY.md §8b closure-hook caveat)."""
+    setup, psolver, u, t, n = stepper.setup, stepper.psolver, stepper.u, stepper.t, stepper.n
+    if stepper.temp is not None or setup.closure_model is not None:
+        raise NotImplementedError("temperature / closure models are outside the HIP hot path")
+    if cache.psolver is not psolver:
+        raise ValueError("cache was created for a different psolver")
+    if not setup.needs_bc_planes:
+        _lib.call("ins_rk_step_f64", cache.handle, 1.0 / setup.Re, setup.ptr(u, True), float(t), float(Δt), None, setup.stream)
+        return create_stepper(method, setup=setup, psolver=psolver, u=u, temp=None, t=stepper.t + method.c[-1] * Δt, n=n + 1)
+    # host-driven stage loop (time-dependent boundary data)
+    A, c = method.A, method.c
+    ns = len(method.b)
+    if not hasattr(cache, "_host"):
+        cache._host = dict(ustart=vectorfield(setup), ku=[vectorfield(setup) for _ in range(ns)], p=scalarfield(setup))
+    ustart, ku, p = cache._host["ustart"], cache._host["ku"], cache._host["p"]
+    tstart = t
+    ustart.copy_(u)
+    for i in range(ns):
+        apply_bc_u_(u, t, setup)
+        momentum_(ku[i], u, None, t, setup)
+        t = tstart + c[i] * Δt
+        u.copy_(ustart)
+        for j in range(i + 1):
+            if A[i, j] != 0.0:
+                u.add_(ku[j], alpha=Δt * A[i, j])
+        apply_bc_u_(u, t, setup)
+        project_(u, setup, psolver, p)
+    apply_bc_u_(u, t, setup)
+    return create_stepper(method, setup=setup, psolver=psolver, u=u, temp=None, t=t, n=n + 1)
+
+
+def timestep(method, stepper, Δt, *, θ=None):
+    """Out-of-place twin (step_explicit_runge_kutta.jl:61-120): same result on a copy of `u`."""
+    cache = ode_method_cache(method, stepper.setup, stepper.psolver)
+    s2 = create_stepper(method, setup=stepper.setup, psolver=stepper.psolver, u=copyfield(stepper.u), t=stepper.t, n=stepper.n)
+    return timestep_(method, s2, Δt, θ=θ, cache=cache)

@@ -1,0 +1,348 @@
+"""GPU parity: every HIP entry point (called through the C ABI via the host mirror) against the CPU
+oracle on the same seeded inputs, on the reference's own test geometries plus periodic boxes.
+
+Tolerances: single operator <= 1e-12 relative max-norm (reciprocal-multiply instead of
+divide, FMA contraction); Poisson solve <= 1e-11 relative L2; multi-step RK4 <= 1e-10 relative L2.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from tests import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+OP_TOL = 1e-12
+POISSON_TOL = 1e-11
+STEP_TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def ins():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ins_amd
+
+    return ins_amd
+
+
+def mirror(ins, so, o):
+    """Build the product Setup that corresponds to an oracle setup."""
+    cls = {"PeriodicBC": ins.PeriodicBC, "SymmetricBC": ins.SymmetricBC, "PressureBC": ins.PressureBC}
+
+    def conv(b):
+        if isinstance(b, o.DirichletBC):
+            return ins.DirichletBC(b.u)
+        return cls[type(b).__name__]()
+
+    bcs = tuple(tuple(conv(b) for b in side) for side in so.boundary_conditions)
+    xin = []
+    for a in range(so.grid.D):
+        lo = 2 if isinstance(so.boundary_conditions[a][0], o.PressureBC) else 1
+        xin.append(so.grid.x[a][lo:-1])
+    return ins.Setup(x=xin, boundary_conditions=bcs, Re=so.Re)
+
+
+def relmax(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def rell2(a, b):
+    return float(np.sqrt(np.sum((a - b) ** 2)) / max(np.sqrt(np.sum(b**2)), 1e-300))
+
+
+def periodic_u0(n):
+    return lambda o: fx.setup_periodic(o, n, D=len(n))
+
+
+GEOMS = {
+    "dirichlet2d": fx.setup2d,
+    "dirichlet3d": fx.setup3d,
+    "mixed3d": fx.setup_mixed,
+    "periodic2d": periodic_u0((24, 18)),
+    "periodic3d": periodic_u0((20, 12, 70)),  # ragged: x < one wavefront, z > one tile
+    "periodic3d_wide": periodic_u0((130, 6, 8)),  # x spans three wavefronts
+}
+
+
+@pytest.mark.parametrize("geom", list(GEOMS))
+def test_operators_match_oracle(ins, oracle, geom):
+    o = oracle
+    so = GEOMS[geom](o)
+    sp = mirror(ins, so, o)
+    g = so.grid
+    D = g.D
+    u_h = o.apply_bc_u(fx.randn_field(g.N + (D,), 1), 0.0, so)
+    p_h = o.apply_bc_p(fx.randn_field(g.N, 2), 0.0, so)
+    F0_h = fx.randn_field(g.N + (D,), 3)
+    u, p = ins.from_numpy(sp, u_h), ins.from_numpy(sp, p_h)
+
+    # ghost fills on raw random data (every BC type of the geometry)
+    raw_u, raw_p = fx.randn_field(g.N + (D,), 4), fx.randn_field(g.N, 5)
+    assert np.array_equal(ins.to_numpy(ins.apply_bc_u_(ins.from_numpy(sp, raw_u), 0.0, sp)), o.apply_bc_u(raw_u, 0.0, so))
+    assert np.array_equal(ins.to_numpy(ins.apply_bc_p_(ins.from_numpy(sp, raw_p), 0.0, sp)), o.apply_bc_p(raw_p, 0.0, so))
+
+    assert relmax(ins.to_numpy(ins.divergence(u, sp)), o.divergence(u_h, so)) < OP_TOL
+    assert relmax(ins.to_numpy(ins.scalewithvolume(p, sp)), o.scalewithvolume(p_h, so)) < OP_TOL
+    assert relmax(ins.to_numpy(ins.pressuregradient(p, sp)), o.pressuregradient(p_h, so)) < OP_TOL
+    assert relmax(ins.to_numpy(ins.applypressure(u, p, sp)), o.applypressure_(u_h.copy(order="F"), p_h, so)) < OP_TOL
+    assert relmax(ins.to_numpy(ins.laplacian(p, sp)), o.laplacian(p_h, so)) < OP_TOL
+    # accumulate-into-F semantics of convection!/diffusion!/convectiondiffusion!
+    for name, kw in (("convection_", {}), ("diffusion_", {}), ("diffusion_", {"use_viscosity": False}), ("convectiondiffusion_", {})):
+        want = getattr(o, name)(F0_h.copy(order="F"), u_h, so, **kw)
+        got = ins.to_numpy(getattr(ins, name)(ins.from_numpy(sp, F0_h), u, sp, **kw))
+        assert relmax(got, want) < OP_TOL, name
+    # momentum! overwrites F (fill!(F,0) fused): start from garbage
+    got = ins.to_numpy(ins.momentum_(ins.from_numpy(sp, F0_h), u, None, 0.0, sp))
+    assert relmax(got, o.momentum(u_h, None, 0.0, so)) < OP_TOL
+    for first in (False, True):
+        ke = ins.to_numpy(ins.kinetic_energy(u, sp, interpolate_first=first))
+        assert relmax(ke, o.kinetic_energy_(o.scalarfield(so), u_h, so, interpolate_first=first)) < OP_TOL
+        assert ins.total_kinetic_energy(u, sp, interpolate_first=first) == pytest.approx(
+            o.total_kinetic_energy(u_h, so, interpolate_first=first), rel=1e-12
+        )
+    ip = tuple(slice(lo, hi) for lo, hi in g.Ip)
+    assert ins.max_abs_divergence(u, sp) == pytest.approx(float(np.max(np.abs(o.divergence(u_h, so)[ip]))), rel=1e-12)
+    assert ins.get_cfl_timestep_(None, u, sp) == pytest.approx(o.get_cfl_timestep(u_h, so), rel=1e-12)
+
+
+def test_dirichlet_constant_and_callable_bc(ins, oracle):
+    """apply_bc_u! with tuple constants and with a closure bc.u(α, x..., t) incl. the dudt variant
+    (boundary_conditions.jl:344-375); lid-driven-cavity style (examples/LidDrivenCavity3D.jl)."""
+    o = oracle
+    lid = (1.0, 0.2, 0.0)
+
+    def wall(al, x, y, z, t):
+        return (al == 0) * np.cos(t) * np.sin(np.pi * z) + 0 * (x + y + z)
+
+    for top, bot in ((o.DirichletBC(lid), ins.DirichletBC(lid)), (o.DirichletBC(wall), ins.DirichletBC(wall))):
+        x = (o.cosine_grid(0.0, 1.0, 9), o.cosine_grid(0.0, 1.0, 7), np.linspace(-0.2, 0.2, 6))
+        so = o.make_setup(x, ((o.DirichletBC(), o.DirichletBC()), (o.DirichletBC(), top), (o.PeriodicBC(), o.PeriodicBC())), Re=100.0)
+        sp = ins.Setup(x=x, boundary_conditions=((ins.DirichletBC(), ins.DirichletBC()), (ins.DirichletBC(), bot),
+                                                 (ins.PeriodicBC(), ins.PeriodicBC())), Re=100.0)
+        raw = fx.randn_field(so.grid.N + (3,), 9)
+        for dudt in (False, True):
+            want = o.apply_bc_u(raw, 0.3, so, dudt=dudt)
+            got = ins.to_numpy(ins.apply_bc_u_(ins.from_numpy(sp, raw), 0.3, sp, dudt=dudt))
+            assert np.allclose(got, want, rtol=1e-14, atol=1e-14)
+
+
+# ------------------------------------------------------------------ test/psolvers.jl:1-32 on the GPU
+def test_pressure_solvers_known_answer(ins, oracle):
+    o = oracle
+    so = fx.setup_psolver(o, 32)
+    sp = mirror(ins, so, o)
+    g = so.grid
+    p_exact = np.asfortranarray(0.25 * (np.cos(2 * g.xp[0].reshape(-1, 1)) + np.cos(2 * g.xp[1].reshape(1, -1))))
+    o.apply_bc_p_(p_exact, 0.0, so)
+    pe = ins.from_numpy(sp, p_exact)
+    lap = ins.laplacian(pe, sp)
+    ip = tuple(slice(lo, hi) for lo, hi in g.Ip)
+    for mk in (ins.psolver_cg, ins.psolver_spectral):
+        got = ins.to_numpy(ins.apply_bc_p(ins.poisson(mk(sp), lap), 0.0, sp))
+        assert np.allclose(got[ip], p_exact[ip], rtol=math.sqrt(o.EPS), atol=1e-9)
+    with pytest.raises(NotImplementedError):
+        ins.psolver_direct(sp)
+
+
+@pytest.mark.parametrize("n", [(16, 16), (12, 20, 8), (64, 32, 16)])
+def test_spectral_poisson_matches_oracle(ins, oracle, n):
+    o = oracle
+    so = fx.setup_periodic(o, n, D=len(n))
+    sp = mirror(ins, so, o)
+    f = fx.randn_field(so.grid.N, 6)
+    ip = tuple(slice(lo, hi) for lo, hi in so.grid.Ip)
+    f[ip] -= f[ip].mean()
+    want = o.poisson(o.psolver_spectral(so), f)
+    got = ins.to_numpy(ins.poisson(ins.psolver_spectral(sp), ins.from_numpy(sp, f)))
+    assert rell2(got[ip], want[ip]) < POISSON_TOL
+    # ghost entries are left untouched by the solver (pressure.jl:347 writes view(p, Ip) only)
+    mask = np.ones(so.grid.N, bool)
+    mask[ip] = False
+    assert np.array_equal(got[mask], f[mask])
+
+
+def test_spectral_rejects_nonperiodic_and_odd(ins, oracle):
+    o = oracle
+    sp = mirror(ins, fx.setup2d(o), o)
+    with pytest.raises(ins.INSHipError, match="periodic"):
+        ins.psolver_spectral(sp)
+    sp = ins.Setup(x=(np.linspace(0, 1, 8), np.linspace(0, 1, 9)))
+    with pytest.raises(ins.INSHipError, match="even"):
+        ins.psolver_spectral(sp)
+    sp = ins.Setup(x=(o.cosine_grid(0.0, 1.0, 8), np.linspace(0, 1, 9)))
+    with pytest.raises(ins.INSHipError, match="uniform"):
+        ins.psolver_spectral(sp)
+
+
+@pytest.mark.parametrize("geom", ["dirichlet2d", "dirichlet3d", "mixed3d", "periodic3d"])
+def test_cg_matches_oracle_cg(ins, oracle, geom):
+    o = oracle
+    so = GEOMS[geom](o)
+    sp = mirror(ins, so, o)
+    g = so.grid
+    u_h = o.apply_bc_u(fx.randn_field(g.N + (g.D,), 8), 0.0, so)
+    f = o.scalewithvolume(o.divergence(u_h, so), so)
+    info = {}
+    want = o.poisson(o.psolver_cg(so, info=info), f)
+    solver = ins.psolver_cg(sp)
+    got = ins.to_numpy(ins.poisson(solver, ins.from_numpy(sp, f)))
+    ip = tuple(slice(lo, hi) for lo, hi in g.Ip)
+    it, res = solver.last_info()
+    assert abs(it - info["iterations"]) <= 2
+    assert rell2(got[ip], want[ip]) < 1e-6  # both stop at reltol sqrt(eps); they agree to that level
+
+
+@pytest.mark.parametrize("geom", ["periodic2d", "periodic3d", "dirichlet3d", "mixed3d"])
+def test_project_matches_oracle(ins, oracle, geom):
+    o = oracle
+    so = GEOMS[geom](o)
+    sp = mirror(ins, so, o)
+    g = so.grid
+    u_h = o.apply_bc_u(fx.randn_field(g.N + (g.D,), 12), 0.0, so)
+    periodic = geom.startswith("periodic")
+    pso = o.psolver_spectral(so) if periodic else o.psolver_direct(so)
+    psp = ins.psolver_spectral(sp) if periodic else ins.psolver_cg(sp, reltol=1e-13)
+    want_u = o.project_(u_h.copy(order="F"), so, pso, o.scalarfield(so))
+    u, p = ins.from_numpy(sp, u_h), ins.scalarfield(sp)
+    ins.project_(u, sp, psp, p)
+    tol = POISSON_TOL if periodic else 1e-8
+    assert rell2(ins.to_numpy(u), want_u) < tol
+    ins.apply_bc_u_(u, 0.0, sp)
+    if periodic:
+        assert ins.max_abs_divergence(u, sp) < 1e-9
+    # out-of-place twin == in-place (pressure.jl:52-66 vs 69-82)
+    v = ins.project(ins.from_numpy(sp, u_h), sp, psp)
+    assert rell2(ins.to_numpy(v), want_u) < tol
+    if periodic:  # p is left ghost-filled, like apply_bc_p!(p) in project!
+        want_p = o.scalarfield(so)
+        o.project_(u_h.copy(order="F"), so, pso, want_p)
+        assert rell2(ins.to_numpy(p), want_p) < POISSON_TOL
+
+
+# ------------------------------------------------------------------ RK stepping
+@pytest.mark.parametrize("method", ["RK44", "Wray3", "SSP33", "FE11"])
+def test_rk_step_matches_oracle_periodic3d(ins, oracle, method):
+    o = oracle
+    so = fx.setup_periodic(o, (16, 12, 20), D=3, Re=500.0)
+    sp = mirror(ins, so, o)
+    pso, psp = o.psolver_spectral(so), ins.psolver_spectral(sp)
+    u0 = o.random_field(so, kp=3, seed=2, psolver=pso)
+    mo, mp = getattr(o, method)(), getattr(ins.RKMethods, method)()
+    st = o.solve_unsteady(so, (0.0, 0.03), u0, method=mo, psolver=pso, dt=0.01)
+    (u, _, t), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 0.03), ustart=ins.from_numpy(sp, u0), method=mp, psolver=psp, Δt=0.01)
+    assert t == pytest.approx(0.03)
+    assert rell2(ins.to_numpy(u), st["u"]) < STEP_TOL
+    assert ins.max_abs_divergence(u, sp) < 1e-11
+
+
+def test_rk44_tgv3d_64_ten_steps(ins, oracle):
+    """10 RK4 steps of TGV3D 64³ <= 1e-10 relative L2; max|div u|·Δx <= 1e-12."""
+    o = oracle
+    so = fx.setup_periodic(o, 64, D=3, Re=1000.0)
+    sp = mirror(ins, so, o)
+    pso, psp = o.psolver_spectral(so), ins.psolver_spectral(sp)
+    u0 = o.velocityfield(so, o.tgv3d_ufunc, 0.0, psolver=pso)
+    up = ins.velocityfield(sp, o.tgv3d_ufunc, 0.0, psolver=psp)
+    assert rell2(ins.to_numpy(up), u0) < POISSON_TOL
+    st = o.solve_unsteady(so, (0.0, 0.01), u0, psolver=pso, dt=1e-3)
+    (u, _, t), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 0.01), ustart=up, psolver=psp, Δt=1e-3)
+    assert rell2(ins.to_numpy(u), st["u"]) < STEP_TOL
+    assert ins.max_abs_divergence(u, sp) / 64 < 1e-12
+    assert ins.total_kinetic_energy(u, sp) == pytest.approx(o.total_kinetic_energy(st["u"], so), rel=1e-11)
+
+
+def test_rk44_dirichlet_cavity_matches_oracle(ins, oracle):
+    """Config-5-shaped problem at test size: stretched grid, lid-driven Dirichlet walls, periodic z, CG."""
+    o = oracle
+    lid = (1.0, 0.2, 0.0)
+    x = (o.cosine_grid(0.0, 1.0, 12), o.cosine_grid(0.0, 1.0, 10), np.linspace(-0.2, 0.2, 9))
+    so = o.make_setup(x, ((o.DirichletBC(), o.DirichletBC()), (o.DirichletBC(), o.DirichletBC(lid)), (o.PeriodicBC(), o.PeriodicBC())), Re=100.0)
+    sp = ins.Setup(x=x, boundary_conditions=((ins.DirichletBC(), ins.DirichletBC()), (ins.DirichletBC(), ins.DirichletBC(lid)),
+                                             (ins.PeriodicBC(), ins.PeriodicBC())), Re=100.0)
+    pso, psp = o.psolver_direct(so), ins.psolver_cg(sp, reltol=1e-13)
+    u0 = o.apply_bc_u_(o.vectorfield(so), 0.0, so)
+    st = o.solve_unsteady(so, (0.0, 0.02), u0, psolver=pso, dt=0.005)
+    (u, _, t), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 0.02), ustart=ins.from_numpy(sp, u0), psolver=psp, Δt=0.005)
+    assert rell2(ins.to_numpy(u), st["u"]) < 1e-8
+
+
+def test_timestep_inplace_equals_outofplace(ins, oracle):
+    """test/timesteppers.jl:16-42"""
+    o = oracle
+    so = fx.setup_periodic(o, 16, D=2)
+    sp = mirror(ins, so, o)
+    psp = ins.psolver_spectral(sp)
+    u = ins.random_field(sp, kp=4, psolver=psp, seed=3)
+    m = ins.RKMethods.RK44()
+    s_out = ins.timestep(m, ins.create_stepper(m, setup=sp, psolver=psp, u=ins.copyfield(u), t=0.0), 0.1)
+    cache = ins.ode_method_cache(m, sp, psp)
+    s_in = ins.timestep_(m, ins.create_stepper(m, setup=sp, psolver=psp, u=ins.copyfield(u), t=0.0), 0.1, cache=cache)
+    assert np.allclose(ins.to_numpy(s_in.u), ins.to_numpy(s_out.u), rtol=1e-13, atol=1e-14)
+    assert s_in.n == 1 and s_in.t == pytest.approx(0.1)
+
+
+def test_random_field_is_solenoidal_with_right_spectrum_peak(ins):
+    sp = ins.Setup(x=(np.linspace(0, 1, 33),) * 3, Re=4000.0)
+    u = ins.random_field(sp, kp=4, seed=0)
+    assert ins.max_abs_divergence(u, sp) < 1e-10
+    e = ins.total_kinetic_energy(u, sp)
+    assert 0 < e < 10
+    u2 = ins.random_field(sp, kp=4, seed=0)
+    assert np.array_equal(ins.to_numpy(u), ins.to_numpy(u2))  # seeded => reproducible
+
+
+# ------------------------------------------------------------------ examples/TaylorGreenVortex2D.jl on the GPU
+def test_tgv2d_convergence_on_gpu(ins, oracle):
+    o = oracle
+    Re, tend = 2000.0, 0.5
+    errs = []
+    for n in (8, 16, 32):
+        x = (np.linspace(0, 2 * np.pi, n + 1),) * 2
+        sp = ins.Setup(x=x, Re=Re)
+        ps = ins.psolver_spectral(sp)
+        sol = o.tgv2d_ufunc(Re)
+        u0 = ins.velocityfield(sp, sol(0.0), 0.0, psolver=ps)
+        ut = ins.to_numpy(ins.velocityfield(sp, sol(tend), tend, psolver=ps, doproject=False))
+        (u, _, _), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, tend), ustart=u0, psolver=ps, Δt=0.01)
+        ip = tuple(slice(lo, hi) for lo, hi in sp.grid.Ip)
+        un = ins.to_numpy(u)
+        errs.append(math.sqrt(np.sum((un[ip] - ut[ip]) ** 2)) / math.sqrt(np.sum(ut[ip] ** 2)))
+    assert errs[0] == pytest.approx(2.518e-5, rel=2e-3) and errs[1] == pytest.approx(6.393e-6, rel=2e-3)
+    assert errs[2] == pytest.approx(1.604e-6, rel=2e-3)
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE sizes)
+def test_full_size_256_properties(ins):
+    """TGV3D 256³ (BASELINE config 2): size-independent properties — projection idempotence,
+    divergence-free stage velocities, energy decay, momentum linearity in viscosity."""
+    n = 256
+    sp = ins.Setup(x=(np.linspace(0, 1, n + 1),) * 3, Re=1000.0)
+    ps = ins.psolver_spectral(sp)
+
+    def U(al, x, y, z):
+        if al == 0:
+            return np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y) * np.sin(2 * np.pi * z) / 2
+        if al == 1:
+            return -np.cos(2 * np.pi * x) * np.sin(2 * np.pi * y) * np.sin(2 * np.pi * z) / 2
+        return 0 * (x + y + z)
+
+    u = ins.velocityfield(sp, U, 0.0, psolver=ps)
+    assert ins.max_abs_divergence(u, sp) / n < 1e-12
+    e0 = ins.total_kinetic_energy(u, sp)
+    assert e0 == pytest.approx(1 / 32, rel=2e-3)  # ∫ (u²+v²)/2 over the unit box for this field
+    v = ins.copyfield(u)
+    ins.project_(v, sp, ps, ins.scalarfield(sp))
+    assert float((v - u).abs().max()) < 1e-13  # P² = P
+    (w, _, _), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 2e-3), ustart=u, psolver=ps, Δt=1e-3)
+    assert ins.max_abs_divergence(w, sp) / n < 1e-12
+    assert ins.total_kinetic_energy(w, sp) < e0
+    # momentum is affine in 1/Re: F(Re1) - F(Re2) = (1/Re1 - 1/Re2) * diffusion(u; use_viscosity=false)
+    sp2 = ins.Setup(x=(np.linspace(0, 1, n + 1),) * 3, Re=10.0)
+    F1, F2 = ins.momentum(u, None, 0.0, sp), ins.momentum(u, None, 0.0, sp2)
+    Dm = ins.diffusion(u, sp, use_viscosity=False)
+    lhs, rhs = (F2 - F1), (1 / 10.0 - 1 / 1000.0) * Dm
+    assert float((lhs - rhs).abs().max()) < 1e-9 * float(rhs.abs().max())
