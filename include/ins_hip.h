@@ -122,6 +122,11 @@ int ins_poisson_spectral_create(const ins_grid_t* grid, ins_poisson_t** out);
 /* psolver_cg(setup; abstol, reltol, maxiter)   pressure.jl:209-286 with the Jacobi preconditioner of
  * pressure.jl:188-206.  maxiter <= 0 selects prod(Np) as the reference does. */
 int ins_poisson_cg_create(const ins_grid_t* grid, double abstol, double reltol, int64_t maxiter, ins_poisson_t** out);
+/* CG only.  enable != 0: solve the bordered system [L e; e' 0][p; λ] = [f; 0] that psolver_direct factorises
+ * when L is singular (pressure.jl:133-140), i.e. subtract mean(f[Ip]) before iterating and mean(p[Ip]) after.
+ * This is what makes a non-solvable right-hand side (e.g. the lid of examples/LidDrivenCavity3D.jl:29, whose
+ * normal component is non-zero) behave as it does under the reference's default (direct) solver. */
+int ins_poisson_cg_bordered(ins_poisson_t* ps, int enable);
 int ins_poisson_destroy(ins_poisson_t* ps);
 /* poisson!(psolver, p) = psolver(p)        pressure.jl:22: solves L p = f in place on the padded array.
  * Spectral: asynchronous.  CG: blocking (the reference reads residuals on the host, pressure.jl:244,275). */

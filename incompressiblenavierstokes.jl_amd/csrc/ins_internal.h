@@ -108,6 +108,9 @@ struct ins_poisson {
   double abstol = 0, reltol = 0;
   long long maxiter = 0;
   double *r = nullptr, *L = nullptr, *q = nullptr, *dinv = nullptr;
+  bool bordered = false;
+  bool singular = true;  // no PressureBC side
+  long long ndof = 0;
   long long last_iter = 0;
   double last_res = 0;
 };

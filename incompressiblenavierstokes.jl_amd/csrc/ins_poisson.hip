@@ -131,6 +131,15 @@ __device__ __forceinline__ void store_partial(double v, double* partial) {
   if (threadIdx.x == 0 && threadIdx.y == 0) partial[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] = v;
 }
 
+// p[Ip] -= shift
+template <int D>
+__global__ __launch_bounds__(256) void k_shift(GridDev g, double* __restrict__ p, double shift) {
+  int I[3];
+  long long c;
+  bool inp;
+  if (cell<D>(g, I, c, inp) && inp) p[c] -= shift;
+}
+
 // dinv = 1/d with d of pressure.jl:196-199
 template <int D>
 __global__ __launch_bounds__(256) void k_cg_diag(GridDev g, double* __restrict__ dinv) {
@@ -364,6 +373,9 @@ extern "C" int ins_poisson_cg_create(const ins_grid_t* G, double abstol, double 
   long long ndof = 1;
   for (int a = 0; a < g.D; ++a) ndof *= g.ip_hi[a] - g.ip_lo[a];
   ps->maxiter = maxiter > 0 ? maxiter : ndof;
+  ps->ndof = ndof;
+  for (int a = 0; a < g.D; ++a)
+    if (g.bc[a][0] == INS_BC_PRESSURE || g.bc[a][1] == INS_BC_PRESSURE) ps->singular = false;
   const size_t bytes = G->ncell * sizeof(double);
   if (hipMalloc(&ps->r, bytes) != hipSuccess || hipMalloc(&ps->L, bytes) != hipSuccess || hipMalloc(&ps->q, bytes) != hipSuccess ||
       hipMalloc(&ps->dinv, bytes) != hipSuccess) {
@@ -417,6 +429,12 @@ static int cg_solve(ins_poisson* ps, double* p, hipStream_t s) {
     INS_LAUNCH_CHECK();                                                         \
   } while (0)
 
+  const bool bordered = ps->bordered && ps->singular;
+  if (bordered) {
+    double sum;
+    if ((rc = ins_k_reduce(G, 3, p, nullptr, g.ip_lo, g.ip_hi, &sum, s))) return rc;
+    LAUNCH_D(k_shift, g, p, sum / (double)ps->ndof);
+  }
   LAUNCH_D(k_cg_init, g, p, ps->r, ps->q, ps->L, partial);
   if ((rc = finish_sum(G, partial, l.nblk, s, &ss))) return rc;
   double residual = std::sqrt(ss);
@@ -441,6 +459,11 @@ static int cg_solve(ins_poisson* ps, double* p, hipStream_t s) {
     residual = std::sqrt(ss);
     ++it;
   }
+  if (bordered) {
+    double sum;
+    if ((rc = ins_k_reduce(G, 3, p, nullptr, g.ip_lo, g.ip_hi, &sum, s))) return rc;
+    LAUNCH_D(k_shift, g, p, sum / (double)ps->ndof);
+  }
 #undef LAUNCH_D
   ps->last_iter = it;
   ps->last_res = residual;
@@ -448,6 +471,13 @@ static int cg_solve(ins_poisson* ps, double* p, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+extern "C" int ins_poisson_cg_bordered(ins_poisson_t* ps, int enable) {
+  INS_REQUIRE(ps, "null argument");
+  INS_REQUIRE(ps->kind == POISSON_CG, "bordered mode applies to the CG solver only");
+  ps->bordered = enable != 0;
+  return INS_OK;
+}
+
 extern "C" int ins_poisson_destroy(ins_poisson_t* ps) {
   if (!ps) return INS_OK;
   if (ps->plans) {

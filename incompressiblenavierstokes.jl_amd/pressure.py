@@ -63,9 +63,11 @@ class psolver_cg(_PSolver):
 
     kind = "cg"
 
-    def __init__(self, setup, abstol=0.0, reltol=math.sqrt(np.finfo(np.float64).eps), maxiter=None):
+    def __init__(self, setup, abstol=0.0, reltol=math.sqrt(np.finfo(np.float64).eps), maxiter=None, bordered=False):
         super().__init__(setup)
         _lib.call("ins_poisson_cg_create", setup.handle, float(abstol), float(reltol), int(maxiter or 0), C.byref(self._handle))
+        if bordered:  # psolver_direct's treatment of the singular system (pressure.jl:133-140)
+            _lib.call("ins_poisson_cg_bordered", self._handle, 1)
 
 
 def psolver_direct(setup):
@@ -79,13 +81,13 @@ def psolver_direct(setup):
 
 def default_psolver(setup):
     """Get default Poisson solver from setup (pressure.jl:85-98); the non-spectral branch returns
-    `psolver_cg` with reltol 1e-12 in place of the (unavailable) direct solver."""
+    `psolver_cg(reltol=1e-12, bordered=True)`: the same linear system the direct solver factorises."""
     g = setup.grid
     isperiodic = all(isinstance(a, PeriodicBC) and isinstance(b, PeriodicBC) for a, b in setup.boundary_conditions)
     isuniform = all(np.allclose(d, d[0], rtol=math.sqrt(np.finfo(np.float64).eps), atol=0) for d in g.Δ)
     if isperiodic and isuniform:
         return psolver_spectral(setup)
-    return psolver_cg(setup, reltol=1e-12)
+    return psolver_cg(setup, reltol=1e-12, bordered=True)
 
 
 def poisson_(psolver, f):

@@ -263,7 +263,8 @@ def test_rk44_dirichlet_cavity_matches_oracle(ins, oracle):
     so = o.make_setup(x, ((o.DirichletBC(), o.DirichletBC()), (o.DirichletBC(), o.DirichletBC(lid)), (o.PeriodicBC(), o.PeriodicBC())), Re=100.0)
     sp = ins.Setup(x=x, boundary_conditions=((ins.DirichletBC(), ins.DirichletBC()), (ins.DirichletBC(), ins.DirichletBC(lid)),
                                              (ins.PeriodicBC(), ins.PeriodicBC())), Re=100.0)
-    pso, psp = o.psolver_direct(so), ins.psolver_cg(sp, reltol=1e-13)
+    pso, psp = o.psolver_direct(so), ins.default_psolver(sp)
+    assert psp.kind == "cg"
     u0 = o.apply_bc_u_(o.vectorfield(so), 0.0, so)
     st = o.solve_unsteady(so, (0.0, 0.02), u0, psolver=pso, dt=0.005)
     (u, _, t), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 0.02), ustart=ins.from_numpy(sp, u0), psolver=psp, Δt=0.005)
