@@ -1,0 +1,381 @@
+// K1 (flux form) — fused 3-D momentum-RHS stencil for gfx950: convection_diffusion_kernel! +
+// fill!(F, 0) (operators.jl:647-690, 971) for any boundary conditions and stretched grids.
+//
+// The reference evaluates, per cell and per (α, β), the difference of two face fluxes
+//     φ_αβ(I) = ν (u^α[I+e_β] - u^α[I]) / Δb  -  ½(u^α[I] + u^α[I+e_β]) · (A₂ u^β[I] + A₁ u^β[I+e_α]),
+// f^α[I] += (φ_αβ(I) - φ_αβ(I - e_β)) / Δu_αβ, and so computes every face flux twice.  The lower-face
+// expression of cell I is term-for-term the upper-face expression of cell I - e_β (same widths, same
+// weights: operators.jl:668-675), so this kernel evaluates each face flux ONCE:
+//   * lanes of a wavefront run along x; the x-neighbour's values and the x-flux of the left neighbour
+//     move between lanes with DPP wave shifts (v_mov_b32_dpp wave_shl/wave_shr) — no LDS, no barriers;
+//     lanes 0 and 63 are halo columns, lanes 1..62 produce output;
+//   * each thread keeps R+2 consecutive y-rows of the three components in registers, so y-fluxes are
+//     shared between its rows;
+//   * the workgroup marches along z; the upper z-flux of plane k is carried in registers and becomes
+//     the lower z-flux of plane k+1; plane k+2 is prefetched while plane k is computed.
+// Metrics come from per-direction records (reciprocal widths, ν-scaled masked reciprocals, half
+// interpolation weights): per-lane for x, scalar (SGPR) loads for y and z; on exactly-uniform grids
+// the records are constants.  Algorithmic traffic: 48 B / cell (read u, write F).
+#include <algorithm>
+#include <cstdlib>
+
+#include "ins_internal.h"
+
+// One record per (direction d, index idx); 16 doubles = 128 B so a record is one aligned scalar burst.
+//   vs = ν·mdx[d][idx+1]   diffusion coefficient of the upper d-face for the d-component   (Δb, α == β)
+//   vo = ν·mdxu[d][idx]    ... for the other components                                     (Δb, α != β)
+//   a[β], b[β] = ½A₂[β][d][idx], ½A₁[β][d][idx+1]   half weights of component β read along d
+//   rs = 1/Δu[d][idx], ro = 1/Δ[d][idx]              control-volume width reciprocals (α == β / α != β)
+struct Rec {
+  double vs, vo, a0, b0, a1, b1, a2, b2, rs, ro, pad[6];
+};
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_build_recs(GridDev g, double visc, Rec* __restrict__ r0, Rec* __restrict__ r1,
+                                                    Rec* __restrict__ r2) {
+  const int d = blockIdx.y;
+  Rec* out = d == 0 ? r0 : (d == 1 ? r1 : r2);
+  const int n = g.N[d];
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+    const int ip = min(idx + 1, n - 1);
+    Rec r;
+    r.vs = visc * g.mdx[d][ip];
+    r.vo = visc * g.mdxu[d][idx];
+    r.a0 = 0.5 * g.A2[0][d][idx];
+    r.b0 = 0.5 * g.A1[0][d][ip];
+    r.a1 = 0.5 * g.A2[1][d][idx];
+    r.b1 = 0.5 * g.A1[1][d][ip];
+    r.a2 = 0.5 * g.A2[2][d][idx];
+    r.b2 = 0.5 * g.A1[2][d][ip];
+    r.rs = g.rdxu[d][idx];
+    r.ro = g.rdx[d][idx];
+    for (int q = 0; q < 6; ++q) r.pad[q] = 0.0;
+    out[idx] = r;
+  }
+}
+
+__device__ __forceinline__ double from_next(double v) {  // lane l receives lane l+1
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);  // wave_shl:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_prev(double v) {  // lane l receives lane l-1
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Face flux: ν(up - uc)/Δb - ½(uc + up)(A₂ ub0 + A₁ ub1)
+__device__ __forceinline__ double flux(double uc, double up, double ub0, double ub1, double ha, double hb, double vd) {
+  const double uba = ha * ub0 + hb * ub1;
+  return (up - uc) * vd - (uc + up) * uba;
+}
+
+constexpr int XOUT = 62;  // output columns per wavefront (lanes 1..62)
+
+template <int R>
+struct Plane {
+  double v[3][R + 2];
+};
+
+// XW: wavefronts of a workgroup side by side in x (1, 2 or 4); the other 4/XW stack in y.
+// KMAJOR: k-major sweep — XCD e (= blockIdx & 7) owns the e-th y-range; inside an XCD tiles run x fastest,
+// then y, then z-chunk, so the whole chip works inside a few-plane window (DRAM-friendly streaming) and each
+// XCD's L2 re-serves its slab of the chunk-boundary planes and halo rows.
+template <int R, bool UNIFORM, bool MASKED, int XW, bool NT, bool KMAJOR>
+__global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __restrict__ rx, const Rec* __restrict__ ry,
+                                                       const Rec* __restrict__ rz, const double* __restrict__ u,
+                                                       double* __restrict__ F, int zc, int ntx, int nty, int ntz) {
+  // XCD-aware order: consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous run of
+  // tiles (y fastest) so halo rows/columns shared by neighbouring tiles are hits in that XCD's L2.
+  const int nb = gridDim.x;
+  const int per = nb >> 3;
+  int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  int txi, tyi;
+  if (KMAJOR) {
+    const int nty_local = (nty + 7) >> 3;
+    int seq = (int)(blockIdx.x >> 3);
+    if (seq >= ntx * nty_local * ntz) return;
+    txi = seq % ntx;
+    seq /= ntx;
+    tyi = (int)(blockIdx.x & 7) * nty_local + seq % nty_local;
+    t = seq / nty_local;
+    if (tyi >= nty) return;
+  } else if (t >= ntx * nty * ntz) {
+    return;
+  } else if (XW == 1) {  // y-fastest tile order
+    tyi = t % nty;
+    t /= nty;
+    txi = t % ntx;
+    t /= ntx;
+  } else {  // x-fastest: neighbouring workgroups continue the same rows
+    txi = t % ntx;
+    t /= ntx;
+    tyi = t % nty;
+    t /= nty;
+  }
+  const int tzi = t;
+
+  const int lane = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int wx = wave % XW, wy = wave / XW;
+  const int N0 = g.N[0], N1 = g.N[1], N2 = g.N[2];
+  const int i = (txi * XW + wx) * XOUT + lane;  // lane 0 = left halo column
+  if (i - lane > N0 - 2) return;                // whole wavefront right of the domain (no barriers: safe)
+  const int ic = min(i, N0 - 1);
+  const int jb = 1 + (tyi * (4 / XW) + wy) * R; // first output row of this wavefront
+  if (jb > N1 - 2) return;
+  const int k0 = 1 + tzi * zc;
+  const int k1 = min(k0 + zc, N2 - 1);          // planes [k0, k1)
+  const long long sz = g.sx[2];
+  const bool xout = lane >= 1 && lane <= XOUT && i <= N0 - 2;
+
+  long long rowoff[R + 2];
+#pragma unroll
+  for (int rr = 0; rr < R + 2; ++rr) rowoff[rr] = (long long)min(jb - 1 + rr, N1 - 1) * N0 + ic;
+
+  auto load_plane = [&](Plane<R>& P, int kk) {
+    const double* base = u + (long long)kk * sz;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int rr = 0; rr < R + 2; ++rr) P.v[c][rr] = base[c * g.sc + rowoff[rr]];
+  };
+
+  const Rec X = rx[UNIFORM ? 1 : min(i, N0 - 2)];
+  bool dofx[3];
+  if (MASKED) {
+#pragma unroll
+    for (int al = 0; al < 3; ++al) dofx[al] = i >= g.iu_lo[al][0] && i < g.iu_hi[al][0];
+  }
+
+  double zprev[3][R];
+
+  // z-fluxes through the upper face of plane k (C = plane k, Nx = plane k+1)
+  auto zflux = [&](const Plane<R>& C, const Plane<R>& Nx, int k, double (&out)[3][R]) {
+    const Rec Z = rz[UNIFORM ? 1 : k];
+#pragma unroll
+    for (int rr = 1; rr <= R; ++rr) {
+      const Rec Y = ry[UNIFORM ? 1 : min(jb - 1 + rr, N1 - 2)];
+      const double Wc = C.v[2][rr];
+      out[0][rr - 1] = flux(C.v[0][rr], Nx.v[0][rr], Wc, from_next(Wc), X.a2, X.b2, Z.vo);
+      out[1][rr - 1] = flux(C.v[1][rr], Nx.v[1][rr], Wc, C.v[2][rr + 1], Y.a2, Y.b2, Z.vo);
+      out[2][rr - 1] = flux(Wc, Nx.v[2][rr], Wc, Nx.v[2][rr], Z.a2, Z.b2, Z.vs);
+    }
+  };
+
+  auto body = [&](const Plane<R>& C, const Plane<R>& Nx, int k) {
+    const Rec Z = rz[UNIFORM ? 1 : k];
+    const bool kin_u = !MASKED || (k >= g.iu_lo[0][2] && k < g.iu_hi[0][2]);
+    const bool kin_v = !MASKED || (k >= g.iu_lo[1][2] && k < g.iu_hi[1][2]);
+    const bool kin_w = !MASKED || (k >= g.iu_lo[2][2] && k < g.iu_hi[2][2]);
+    // y-fluxes through the face between rows rr and rr+1, rr = 0..R
+    double fyu[R + 1], fyv[R + 1], fyw[R + 1];
+#pragma unroll
+    for (int rr = 0; rr <= R; ++rr) {
+      const Rec Y = ry[UNIFORM ? 1 : min(jb - 1 + rr, N1 - 2)];
+      const double Vc = C.v[1][rr];
+      fyu[rr] = flux(C.v[0][rr], C.v[0][rr + 1], Vc, from_next(Vc), X.a1, X.b1, Y.vo);
+      fyv[rr] = flux(Vc, C.v[1][rr + 1], Vc, C.v[1][rr + 1], Y.a1, Y.b1, Y.vs);
+      fyw[rr] = flux(C.v[2][rr], C.v[2][rr + 1], Vc, Nx.v[1][rr], Z.a1, Z.b1, Y.vo);
+    }
+    double znew[3][R];
+    zflux(C, Nx, k, znew);
+#pragma unroll
+    for (int rr = 1; rr <= R; ++rr) {
+      const int j = jb - 1 + rr;
+      const Rec Y = ry[UNIFORM ? 1 : min(j, N1 - 2)];
+      const double Uc = C.v[0][rr], Vc = C.v[1][rr], Wc = C.v[2][rr];
+      const double Un = from_next(Uc), Vn = from_next(Vc), Wn = from_next(Wc);
+      const double fxu = flux(Uc, Un, Uc, Un, X.a0, X.b0, X.vs);
+      const double fxv = flux(Vc, Vn, Uc, C.v[0][rr + 1], Y.a0, Y.b0, X.vo);
+      const double fxw = flux(Wc, Wn, Uc, Nx.v[0][rr], Z.a0, Z.b0, X.vo);
+      double fu = (fxu - from_prev(fxu)) * X.rs;
+      double fv = (fxv - from_prev(fxv)) * X.ro;
+      double fw = (fxw - from_prev(fxw)) * X.ro;
+      fu += (fyu[rr] - fyu[rr - 1]) * Y.ro;
+      fv += (fyv[rr] - fyv[rr - 1]) * Y.rs;
+      fw += (fyw[rr] - fyw[rr - 1]) * Y.ro;
+      fu += (znew[0][rr - 1] - zprev[0][rr - 1]) * Z.ro;
+      fv += (znew[1][rr - 1] - zprev[1][rr - 1]) * Z.ro;
+      fw += (znew[2][rr - 1] - zprev[2][rr - 1]) * Z.rs;
+      zprev[0][rr - 1] = znew[0][rr - 1];
+      zprev[1][rr - 1] = znew[1][rr - 1];
+      zprev[2][rr - 1] = znew[2][rr - 1];
+      if (MASKED) {
+        const bool ju = j >= g.iu_lo[0][1] && j < g.iu_hi[0][1];
+        const bool jv = j >= g.iu_lo[1][1] && j < g.iu_hi[1][1];
+        const bool jw = j >= g.iu_lo[2][1] && j < g.iu_hi[2][1];
+        fu = (dofx[0] && ju && kin_u) ? fu : 0.0;
+        fv = (dofx[1] && jv && kin_v) ? fv : 0.0;
+        fw = (dofx[2] && jw && kin_w) ? fw : 0.0;
+      }
+      if (xout && j <= N1 - 2) {
+        const long long c = i + (long long)j * N0 + (long long)k * sz;
+        if (NT) {  // F is not re-read by this kernel: keep it out of L2's way
+          __builtin_nontemporal_store(fu, &F[c]);
+          __builtin_nontemporal_store(fv, &F[c + g.sc]);
+          __builtin_nontemporal_store(fw, &F[c + 2 * g.sc]);
+        } else {
+          F[c] = fu;
+          F[c + g.sc] = fv;
+          F[c + 2 * g.sc] = fw;
+        }
+      }
+    }
+  };
+
+  Plane<R> A, B, Cc;
+  load_plane(A, k0 - 1);
+  load_plane(B, k0);
+  load_plane(Cc, min(k0 + 1, N2 - 1));
+  zflux(A, B, k0 - 1, zprev);
+  int k = k0;
+  // 3-buffer rotation, unrolled so every register index is static: compute plane k from (cur, next)
+  // while the load of plane k+2 into the third buffer is in flight.
+  while (true) {
+    load_plane(A, min(k + 2, N2 - 1));
+    body(B, Cc, k);
+    if (++k >= k1) break;
+    load_plane(B, min(k + 2, N2 - 1));
+    body(Cc, A, k);
+    if (++k >= k1) break;
+    load_plane(Cc, min(k + 2, N2 - 1));
+    body(A, B, k);
+    if (++k >= k1) break;
+  }
+}
+
+// Zero the ghost shell of a vector field (the part of `fill!(F, 0)` the interior sweep does not cover).
+__global__ __launch_bounds__(256) void k_zero_shell(GridDev g, double* __restrict__ F) {
+  const int N0 = g.N[0], N1 = g.N[1], N2 = g.N[2];
+  const long long nface_z = (long long)N0 * N1, nface_y = (long long)N0 * N2, nface_x = (long long)N1 * N2;
+  const long long total = 2 * (nface_z + nface_y + nface_x);
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    long long r = t;
+    long long c;
+    if (r < 2 * nface_z) {
+      const int side = r >= nface_z;
+      r -= side * nface_z;
+      c = r + (side ? (long long)(N2 - 1) * g.sx[2] : 0);
+    } else if ((r -= 2 * nface_z) < 2 * nface_y) {
+      const int side = r >= nface_y;
+      r -= side * nface_y;
+      const int ii = (int)(r % N0), kk = (int)(r / N0);
+      c = ii + (side ? (long long)(N1 - 1) * g.sx[1] : 0) + kk * g.sx[2];
+    } else {
+      r -= 2 * nface_y;
+      const int side = r >= nface_x;
+      r -= side * nface_x;
+      const int jj = (int)(r % N1), kk = (int)(r / N1);
+      c = (side ? N0 - 1 : 0) + jj * g.sx[1] + kk * g.sx[2];
+    }
+    F[c] = 0.0;
+    F[c + g.sc] = 0.0;
+    F[c + 2 * g.sc] = 0.0;
+  }
+}
+
+}  // namespace
+
+// Defaults (0 = pick per grid, see pick_* below); measured on MI355X, profiles/r01_k1_scan.txt.
+static int g_rows = 0;
+static int g_zchunk = 0;
+static int g_xw = 0;
+static int g_nt = 0;
+static int g_kmajor = 1;
+
+// Tuning knobs for experiments (not part of the public ABI).
+extern "C" void ins_tune_flux3d(int rows, int zchunk, int xw, int nt, int kmajor) {
+  g_kmajor = kmajor != 0;
+  g_rows = (rows >= 1 && rows <= 4) ? rows : 0;
+  g_zchunk = zchunk >= 1 ? zchunk : 0;
+  g_xw = (xw == 1 || xw == 2 || xw == 4) ? xw : 0;
+  g_nt = nt != 0;
+}
+
+int ins_flux3d_prepare(const ins_grid* G, double visc, hipStream_t s) {
+  ins_grid* M = const_cast<ins_grid*>(G);  // metric-record cache keyed by ν
+  const GridDev& g = G->g;
+  if (!M->rec_dev) {
+    const size_t n = (size_t)g.N[0] + g.N[1] + g.N[2];
+    INS_HIP_TRY(hipMalloc(&M->rec_dev, n * sizeof(Rec)));
+    M->rec_visc = -1.0;
+  }
+  if (M->rec_visc != visc) {
+    Rec* r0 = reinterpret_cast<Rec*>(M->rec_dev);
+    Rec* r1 = r0 + g.N[0];
+    Rec* r2 = r1 + g.N[1];
+    const int nmax = std::max(g.N[0], std::max(g.N[1], g.N[2]));
+    hipLaunchKernelGGL(k_build_recs, dim3(cdiv(nmax, 256), 3), dim3(256), 0, s, g, visc, r0, r1, r2);
+    INS_LAUNCH_CHECK();
+    M->rec_visc = visc;
+  }
+  return INS_OK;
+}
+
+template <int R, int XW, bool NT>
+static int launch_flux(const ins_grid* G, const double* u, double* F, hipStream_t s) {
+  const GridDev& g = G->g;
+  const Rec* r0 = reinterpret_cast<const Rec*>(G->rec_dev);
+  const Rec* r1 = r0 + g.N[0];
+  const Rec* r2 = r1 + g.N[1];
+  const int zc = g_zchunk ? g_zchunk : (g.N[2] >= 384 ? 8 : 4);
+  const int ntx = cdiv(g.N[0] - 2, XOUT * XW), nty = cdiv(g.N[1] - 2, (4 / XW) * R), ntz = cdiv(g.N[2] - 2, zc);
+  const long long ntiles = (long long)ntx * nty * ntz;
+  dim3 block(64, 4, 1);
+  const bool masked = !G->all_dof;
+  if (g_kmajor) {
+    const unsigned nb = (unsigned)(8LL * ntx * ((nty + 7) / 8) * ntz);
+    if (G->uniform_exact && !masked)
+      hipLaunchKernelGGL((k_momentum_flux<R, true, false, XW, NT, true>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz);
+    else if (!masked)
+      hipLaunchKernelGGL((k_momentum_flux<R, false, false, XW, NT, true>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz);
+    else
+      hipLaunchKernelGGL((k_momentum_flux<R, false, true, XW, NT, true>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz);
+  } else {
+    const unsigned nb = (unsigned)((ntiles + 7) / 8 * 8);
+    if (G->uniform_exact && !masked)
+      hipLaunchKernelGGL((k_momentum_flux<R, true, false, XW, NT, false>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz);
+    else if (!masked)
+      hipLaunchKernelGGL((k_momentum_flux<R, false, false, XW, NT, false>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz);
+    else
+      hipLaunchKernelGGL((k_momentum_flux<R, false, true, XW, NT, false>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz);
+  }
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+template <int R>
+static int launch_flux_r(const ins_grid* G, const double* u, double* F, hipStream_t s) {
+  // wavefronts side by side in x: 4 when the row needs >= 8 of them, else 2 (fewer mostly-empty workgroups)
+  const int waves_x = cdiv(G->g.N[0] - 2, XOUT);
+  const int xw = g_xw ? g_xw : (waves_x >= 8 ? 4 : (waves_x >= 2 ? 2 : 1));
+  if (xw == 4) return g_nt ? launch_flux<R, 4, true>(G, u, F, s) : launch_flux<R, 4, false>(G, u, F, s);
+  if (xw == 2) return g_nt ? launch_flux<R, 2, true>(G, u, F, s) : launch_flux<R, 2, false>(G, u, F, s);
+  return g_nt ? launch_flux<R, 1, true>(G, u, F, s) : launch_flux<R, 1, false>(G, u, F, s);
+}
+
+int ins_k_momentum_flux3d(const ins_grid* G, double visc, const double* u, double* F, bool zero_shell, hipStream_t s) {
+  int rc = ins_flux3d_prepare(G, visc, s);
+  if (rc) return rc;
+  // rows per thread: 4 (3 for the masked variant, which would spill at 4)
+  const int rows = g_rows ? g_rows : (G->all_dof ? 4 : 3);
+  switch (rows) {
+    case 1: rc = launch_flux_r<1>(G, u, F, s); break;
+    case 3: rc = launch_flux_r<3>(G, u, F, s); break;
+    case 4: rc = launch_flux_r<4>(G, u, F, s); break;
+    default: rc = launch_flux_r<2>(G, u, F, s); break;
+  }
+  if (rc) return rc;
+  if (zero_shell) {
+    const GridDev& g = G->g;
+    const long long total = 2LL * ((long long)g.N[0] * g.N[1] + (long long)g.N[0] * g.N[2] + (long long)g.N[1] * g.N[2]);
+    hipLaunchKernelGGL(k_zero_shell, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048)), dim3(256), 0, s, g, F);
+    INS_LAUNCH_CHECK();
+  }
+  return INS_OK;
+}

@@ -145,6 +145,22 @@ extern "C" int ins_grid_create(const ins_grid_desc_t* d, ins_grid_t** out) {
       if (std::fabs(x - y) > 1.4901161193847656e-08 * std::fmax(std::fabs(x), std::fabs(y))) G->uniform = false;
     }
   }
+  // Flux-kernel dispatch flags.  all_dof: Iu[α] == interior box for every α.  uniform_exact: the metric
+  // records the flux kernel reads (index range 0..N-2, see ins_fast3d_flux.hip) are bitwise constant, so
+  // the constant-record kernel returns exactly what the table-driven one does.
+  G->all_dof = true;
+  G->uniform_exact = true;
+  for (int a = 0; a < D; ++a)
+    for (int b = 0; b < D; ++b)
+      if (d->iu_lo[a][b] != 1 || d->iu_hi[a][b] != d->N[b] - 1) G->all_dof = false;
+  for (int a = 0; a < D && G->uniform_exact; ++a) {
+    const int n = d->N[a];
+    for (int i = 0; i <= n - 2 && G->uniform_exact; ++i) {
+      bool same = d->dx[a][i + 1] == d->dx[a][2] && d->dxu[a][i] == d->dxu[a][1] && d->dx[a][i] == d->dx[a][1];
+      for (int b = 0; b < D; ++b) same = same && d->A2[b][a][i] == 0.5 && d->A1[b][a][i + 1] == 0.5;
+      if (!same) G->uniform_exact = false;
+    }
+  }
   e = hipMalloc(&G->red_dev, 4096 * sizeof(double));
   if (e == hipSuccess) e = hipHostMalloc(&G->red_host, 4096 * sizeof(double));
   if (e != hipSuccess) {
@@ -160,6 +176,7 @@ extern "C" int ins_grid_destroy(ins_grid_t* G) {
   if (!G) return INS_OK;
   if (G->dev) (void)hipFree(G->dev);
   if (G->red_dev) (void)hipFree(G->red_dev);
+  if (G->rec_dev) (void)hipFree(G->rec_dev);
   if (G->red_host) (void)hipHostFree(G->red_host);
   delete G;
   return INS_OK;

@@ -83,6 +83,10 @@ struct ins_grid {
   bool uniform = false;
   double h[3] = {0, 0, 0};  // Δx[α] of the first volume (uniform grids)
   long long ncell = 0;      // prod(N)
+  bool all_dof = false;        // every interior volume is a DOF of every component (all-periodic)
+  bool uniform_exact = false;  // all metric records bitwise identical over the used index range
+  void* rec_dev = nullptr;     // flux-kernel metric records (ins_fast3d_flux.hip), built lazily
+  double rec_visc = -1.0;
   // scratch for blocking reductions
   double* red_dev = nullptr;
   double* red_host = nullptr;  // pinned

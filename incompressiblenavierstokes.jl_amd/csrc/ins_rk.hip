@@ -6,6 +6,7 @@
 
 int ins_k_momentum_generic(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s);
 int ins_k_momentum_fast3d(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s);
+int ins_k_momentum_fast3d_opts(const ins_grid* G, double visc, const double* u, double* F, bool zero_shell, hipStream_t s);
 bool ins_fast3d_supported(const ins_grid* G);
 
 int ins_k_momentum(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s) {
@@ -150,7 +151,10 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
       INS_HIP_TRY(hipEventCreate(&e1));
       INS_HIP_TRY(hipEventRecord(e0, s));
     }
-    if ((rc = ins_k_momentum(G, visc, u, rk->ku[i], s))) return rc;           // :21
+    // ku[i]'s ghost shell is zero from ins_rk_create and never written, so the fast path skips re-zeroing it
+    rc = ins_fast3d_supported(G) ? ins_k_momentum_fast3d_opts(G, visc, u, rk->ku[i], false, s)
+                                 : ins_k_momentum_generic(G, visc, u, rk->ku[i], s);   // :21
+    if (rc) return rc;
     if (rk->profiling) {
       INS_HIP_TRY(hipEventRecord(e1, s));
       rk->prof_events.push_back(e0);
