@@ -76,6 +76,7 @@ __device__ __forceinline__ double flux(double uc, double up, double ub0, double 
 
 constexpr int XOUT = 62;  // output columns per wavefront (lanes 1..62)
 
+
 template <int R>
 struct Plane {
   double v[3][R + 2];
@@ -85,17 +86,14 @@ struct Plane {
 // KMAJOR: k-major sweep — XCD e (= blockIdx & 7) owns the e-th y-range; inside an XCD tiles run x fastest,
 // then y, then z-chunk, so the whole chip works inside a few-plane window (DRAM-friendly streaming) and each
 // XCD's L2 re-serves its slab of the chunk-boundary planes and halo rows.
-template <int R, bool UNIFORM, bool MASKED, int XW, bool NT, bool KMAJOR>
+template <int R, bool UNIFORM, bool MASKED, int XW, bool FUSE>
 __global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __restrict__ rx, const Rec* __restrict__ ry,
                                                        const Rec* __restrict__ rz, const double* __restrict__ u,
-                                                       double* __restrict__ F, int zc, int ntx, int nty, int ntz) {
+                                                       double* __restrict__ F, int zc, int ntx, int nty, int ntz, RkEpi epi) {
   // XCD-aware order: consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous run of
   // tiles (y fastest) so halo rows/columns shared by neighbouring tiles are hits in that XCD's L2.
-  const int nb = gridDim.x;
-  const int per = nb >> 3;
-  int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  int txi, tyi;
-  if (KMAJOR) {
+  int txi, tyi, t;
+  {
     const int nty_local = (nty + 7) >> 3;
     int seq = (int)(blockIdx.x >> 3);
     if (seq >= ntx * nty_local * ntz) return;
@@ -104,18 +102,6 @@ __global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __r
     tyi = (int)(blockIdx.x & 7) * nty_local + seq % nty_local;
     t = seq / nty_local;
     if (tyi >= nty) return;
-  } else if (t >= ntx * nty * ntz) {
-    return;
-  } else if (XW == 1) {  // y-fastest tile order
-    tyi = t % nty;
-    t /= nty;
-    txi = t % ntx;
-    t /= ntx;
-  } else {  // x-fastest: neighbouring workgroups continue the same rows
-    txi = t % ntx;
-    t /= ntx;
-    tyi = t % nty;
-    t /= nty;
   }
   const int tzi = t;
 
@@ -215,11 +201,31 @@ __global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __r
       }
       if (xout && j <= N1 - 2) {
         const long long c = i + (long long)j * N0 + (long long)k * sz;
-        if (NT) {  // F is not re-read by this kernel: keep it out of L2's way
-          __builtin_nontemporal_store(fu, &F[c]);
-          __builtin_nontemporal_store(fv, &F[c + g.sc]);
-          __builtin_nontemporal_store(fw, &F[c + 2 * g.sc]);
-        } else {
+        if (FUSE) {
+          double su, sv, sw;
+          if (epi.ustart) {
+            su = epi.ustart[c];
+            sv = epi.ustart[c + g.sc];
+            sw = epi.ustart[c + 2 * g.sc];
+          } else {
+            su = Uc;
+            sv = Vc;
+            sw = Wc;
+          }
+          for (int q = 0; q < epi.n; ++q) {
+            const double* kq = epi.k[q];
+            su += epi.coef[q] * kq[c];
+            sv += epi.coef[q] * kq[c + g.sc];
+            sw += epi.coef[q] * kq[c + 2 * g.sc];
+          }
+          su += epi.coef_self * fu;
+          sv += epi.coef_self * fv;
+          sw += epi.coef_self * fw;
+          epi.ustar[c] = su;
+          epi.ustar[c + g.sc] = sv;
+          epi.ustar[c + 2 * g.sc] = sw;
+        }
+        if (!FUSE || epi.write_k) {
           F[c] = fu;
           F[c + g.sc] = fv;
           F[c + 2 * g.sc] = fw;
@@ -281,20 +287,16 @@ __global__ __launch_bounds__(256) void k_zero_shell(GridDev g, double* __restric
 
 }  // namespace
 
-// Defaults (0 = pick per grid, see pick_* below); measured on MI355X, profiles/r01_k1_scan.txt.
+// Defaults (0 = pick per grid, see below); measured on MI355X, profiles/r01_k1_scan.txt.
 static int g_rows = 0;
 static int g_zchunk = 0;
 static int g_xw = 0;
-static int g_nt = 0;
-static int g_kmajor = 1;
 
 // Tuning knobs for experiments (not part of the public ABI).
-extern "C" void ins_tune_flux3d(int rows, int zchunk, int xw, int nt, int kmajor) {
-  g_kmajor = kmajor != 0;
-  g_rows = (rows >= 1 && rows <= 4) ? rows : 0;
+extern "C" void ins_tune_flux3d(int rows, int zchunk, int xw) {
+  g_rows = (rows >= 2 && rows <= 4) ? rows : 0;
   g_zchunk = zchunk >= 1 ? zchunk : 0;
   g_xw = (xw == 1 || xw == 2 || xw == 4) ? xw : 0;
-  g_nt = nt != 0;
 }
 
 int ins_flux3d_prepare(const ins_grid* G, double visc, hipStream_t s) {
@@ -317,60 +319,57 @@ int ins_flux3d_prepare(const ins_grid* G, double visc, hipStream_t s) {
   return INS_OK;
 }
 
-template <int R, int XW, bool NT>
-static int launch_flux(const ins_grid* G, const double* u, double* F, hipStream_t s) {
+template <int R, int XW, bool FUSE>
+static int launch_flux(const ins_grid* G, const double* u, double* F, const RkEpi& epi, hipStream_t s) {
   const GridDev& g = G->g;
   const Rec* r0 = reinterpret_cast<const Rec*>(G->rec_dev);
   const Rec* r1 = r0 + g.N[0];
   const Rec* r2 = r1 + g.N[1];
   const int zc = g_zchunk ? g_zchunk : (g.N[2] >= 384 ? 8 : 4);
   const int ntx = cdiv(g.N[0] - 2, XOUT * XW), nty = cdiv(g.N[1] - 2, (4 / XW) * R), ntz = cdiv(g.N[2] - 2, zc);
-  const long long ntiles = (long long)ntx * nty * ntz;
   dim3 block(64, 4, 1);
   const bool masked = !G->all_dof;
-  if (g_kmajor) {
-    const unsigned nb = (unsigned)(8LL * ntx * ((nty + 7) / 8) * ntz);
-    if (G->uniform_exact && !masked)
-      hipLaunchKernelGGL((k_momentum_flux<R, true, false, XW, NT, true>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz);
-    else if (!masked)
-      hipLaunchKernelGGL((k_momentum_flux<R, false, false, XW, NT, true>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz);
-    else
-      hipLaunchKernelGGL((k_momentum_flux<R, false, true, XW, NT, true>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz);
-  } else {
-    const unsigned nb = (unsigned)((ntiles + 7) / 8 * 8);
-    if (G->uniform_exact && !masked)
-      hipLaunchKernelGGL((k_momentum_flux<R, true, false, XW, NT, false>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz);
-    else if (!masked)
-      hipLaunchKernelGGL((k_momentum_flux<R, false, false, XW, NT, false>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz);
-    else
-      hipLaunchKernelGGL((k_momentum_flux<R, false, true, XW, NT, false>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz);
+  const unsigned nb = (unsigned)(8LL * ntx * ((nty + 7) / 8) * ntz);
+  if (G->uniform_exact && !masked)
+    hipLaunchKernelGGL((k_momentum_flux<R, true, false, XW, FUSE>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi);
+  else if (!masked)
+    hipLaunchKernelGGL((k_momentum_flux<R, false, false, XW, FUSE>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi);
+  else if (!FUSE)
+    hipLaunchKernelGGL((k_momentum_flux<(R > 3 ? 3 : R), false, true, XW, false>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx,
+                       cdiv(g.N[1] - 2, (4 / XW) * (R > 3 ? 3 : R)), ntz, epi);
+  else {
+    ins_set_error("fused RK epilogue needs an all-periodic grid");
+    return INS_ERR_UNSUPPORTED;
   }
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
 
-template <int R>
-static int launch_flux_r(const ins_grid* G, const double* u, double* F, hipStream_t s) {
+template <bool FUSE>
+static int launch_flux_any(const ins_grid* G, const double* u, double* F, const RkEpi& epi, hipStream_t s) {
   // wavefronts side by side in x: 4 when the row needs >= 8 of them, else 2 (fewer mostly-empty workgroups)
   const int waves_x = cdiv(G->g.N[0] - 2, XOUT);
   const int xw = g_xw ? g_xw : (waves_x >= 8 ? 4 : (waves_x >= 2 ? 2 : 1));
-  if (xw == 4) return g_nt ? launch_flux<R, 4, true>(G, u, F, s) : launch_flux<R, 4, false>(G, u, F, s);
-  if (xw == 2) return g_nt ? launch_flux<R, 2, true>(G, u, F, s) : launch_flux<R, 2, false>(G, u, F, s);
-  return g_nt ? launch_flux<R, 1, true>(G, u, F, s) : launch_flux<R, 1, false>(G, u, F, s);
+  const int rows = g_rows ? g_rows : 4;  // rows per thread (the masked variant caps itself at 3: no spills)
+#define INS_FLUX_CASE(RR)                                                          \
+  if (rows == RR) {                                                                \
+    if (xw == 4) return launch_flux<RR, 4, FUSE>(G, u, F, epi, s);                 \
+    if (xw == 2) return launch_flux<RR, 2, FUSE>(G, u, F, epi, s);                 \
+    return launch_flux<RR, 1, FUSE>(G, u, F, epi, s);                              \
+  }
+  INS_FLUX_CASE(2)
+  INS_FLUX_CASE(3)
+  INS_FLUX_CASE(4)
+#undef INS_FLUX_CASE
+  return INS_ERR_INVALID;
 }
 
 int ins_k_momentum_flux3d(const ins_grid* G, double visc, const double* u, double* F, bool zero_shell, hipStream_t s) {
   int rc = ins_flux3d_prepare(G, visc, s);
   if (rc) return rc;
-  // rows per thread: 4 (3 for the masked variant, which would spill at 4)
-  const int rows = g_rows ? g_rows : (G->all_dof ? 4 : 3);
-  switch (rows) {
-    case 1: rc = launch_flux_r<1>(G, u, F, s); break;
-    case 3: rc = launch_flux_r<3>(G, u, F, s); break;
-    case 4: rc = launch_flux_r<4>(G, u, F, s); break;
-    default: rc = launch_flux_r<2>(G, u, F, s); break;
-  }
-  if (rc) return rc;
+  RkEpi epi;
+  memset(&epi, 0, sizeof(epi));
+  if ((rc = launch_flux_any<false>(G, u, F, epi, s))) return rc;
   if (zero_shell) {
     const GridDev& g = G->g;
     const long long total = 2LL * ((long long)g.N[0] * g.N[1] + (long long)g.N[0] * g.N[2] + (long long)g.N[1] * g.N[2]);
@@ -378,4 +377,11 @@ int ins_k_momentum_flux3d(const ins_grid* G, double visc, const double* u, doubl
     INS_LAUNCH_CHECK();
   }
   return INS_OK;
+}
+
+// K1 + K6: k_i = momentum(u_in) (stored when epi.write_k) and the stage velocity u* (interior) in one pass.
+int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s) {
+  int rc = ins_flux3d_prepare(G, visc, s);
+  if (rc) return rc;
+  return launch_flux_any<true>(G, u_in, k_out, epi, s);
 }

@@ -13,6 +13,7 @@
 #include "ins_hip.h"
 
 #define INS_EPS 2.220446049250313e-16
+#define INS_MAX_STAGES 16
 
 // ------------------------------------------------------------------------------------------------
 // Error plumbing: every extern "C" entry returns an INS_ERR_* code and records a message.
@@ -131,6 +132,20 @@ struct ins_rk {
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;  // (start, stop) pairs around momentum launches
 };
+
+// Runge-Kutta stage epilogue fused behind the stencil (K1 + K6): with f = momentum(u) still in registers,
+//   u* = ustart + Σ_j (Δt A[i,j]) k_j + (Δt A[i,i]) f          (step_explicit_runge_kutta.jl:35-38, same order)
+// is written in the same pass, and k_i = f is stored only when a later stage needs it.
+struct RkEpi {
+  int n;                    // previous-stage terms with non-zero coefficient
+  int write_k;              // store k_i
+  double coef[INS_MAX_STAGES];
+  const double* k[INS_MAX_STAGES];
+  double coef_self;         // Δt A[i,i]
+  const double* ustart;     // nullptr: ustart is the stencil input itself (first stage)
+  double* ustar;            // stage velocity out (interior volumes only)
+};
+
 
 // ------------------------------------------------------------------------------------------------
 // Internal launchers (stream-ordered, non-blocking) used across translation units.

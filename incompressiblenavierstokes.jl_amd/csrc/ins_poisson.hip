@@ -12,7 +12,9 @@ namespace {
 
 // K2: pI[i,j,k] = Ω_I * div(u)[Ip.lo + (i,j,k)]     (divergence! + scalewithvolume! + copyto!(pI, view(p, Ip)),
 //                                                    operators.jl:117-125, 81-95, pressure.jl:320)
-template <int D>
+// WRAP: read u[I - e_a] through the periodic image instead of the ghost volume, so the stage velocity needs no
+// ghost fill before the projection (apply_bc_u! at step_explicit_runge_kutta.jl:48 folded away).
+template <int D, bool WRAP = false>
 __global__ __launch_bounds__(256) void k_div_to_pI(GridDev g, const double* __restrict__ u, double* __restrict__ pI, int n0, int n1) {
   const int ii = blockIdx.x * 64 + threadIdx.x;
   const int jj = blockIdx.y * 4 + threadIdx.y;
@@ -24,7 +26,8 @@ __global__ __launch_bounds__(256) void k_div_to_pI(GridDev g, const double* __re
 #pragma unroll
   for (int a = 0; a < D; ++a) {
     const double* ua = u + a * g.sc;
-    d += (ua[c] - ua[c - g.sx[a]]) * g.rdx[a][I[a]];
+    const long long cm = (WRAP && I[a] == 1) ? c + (long long)(g.N[a] - 3) * g.sx[a] : c - g.sx[a];
+    d += (ua[c] - ua[cm]) * g.rdx[a][I[a]];
   }
   double om = g.dx[0][I[0]] * g.dx[1][I[1]];
   if (D == 3) om = om * g.dx[2][I[2]];
@@ -98,6 +101,51 @@ __global__ __launch_bounds__(256) void k_grad_from_pI(GridDev g, double* __restr
   for (int a = 0; a < D; ++a) {
     const long long qn = (w[a] + 1 < n[a]) ? q + qs[a] : q - (long long)(n[a] - 1) * qs[a];
     u[a * g.sc + c] -= (pI[qn] - pc) * g.rdxu[a][I[a]];
+  }
+}
+
+// K4 for the fused periodic RK path (3-D): one work-item per interior volume subtracts the pressure gradient
+// (operators.jl:225-233, p read from the unpadded pI with periodic wrap) and ALSO writes the periodic ghost
+// images of the updated velocity (boundary_conditions.jl:276-288) — up to 7 images for a corner volume — so no
+// separate apply_bc_u! pass is needed before the next stage.  KEEP_P: also store the padded, ghost-filled p.
+template <bool KEEP_P>
+__global__ __launch_bounds__(256) void k_grad_ghost3(GridDev g, double* __restrict__ u, double* __restrict__ p,
+                                                     const double* __restrict__ pI, int n0, int n1, int n2) {
+  const int ii = blockIdx.x * 64 + threadIdx.x;
+  const int jj = blockIdx.y * 4 + threadIdx.y;
+  const int kk = blockIdx.z;
+  if (ii >= n0 || jj >= n1) return;
+  const int n[3] = {n0, n1, n2};
+  const int w[3] = {ii, jj, kk};
+  const int I[3] = {ii + 1, jj + 1, kk + 1};
+  const long long q = ii + (long long)n0 * (jj + (long long)n1 * kk);
+  const long long qs[3] = {1, n0, (long long)n0 * n1};
+  const long long c = I[0] + I[1] * g.sx[1] + I[2] * g.sx[2];
+  const double pc = pI[q];
+  double un[3];
+  int img[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const long long qn = (w[a] + 1 < n[a]) ? q + qs[a] : q - (long long)(n[a] - 1) * qs[a];
+    un[a] = u[a * g.sc + c] - (pI[qn] - pc) * g.rdxu[a][I[a]];
+    img[a] = I[a] == 1 ? g.N[a] - 1 : (I[a] == g.N[a] - 2 ? 0 : -1);
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    bool ok = true;
+    long long cc = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const bool use = (m >> a) & 1;
+      ok = ok && (!use || img[a] >= 0);
+      cc += (long long)(use ? img[a] : I[a]) * g.sx[a];
+    }
+    if (ok) {
+      u[cc] = un[0];
+      u[cc + g.sc] = un[1];
+      u[cc + 2 * g.sc] = un[2];
+      if (KEEP_P) p[cc] = pc;
+    }
   }
 }
 
@@ -537,6 +585,23 @@ int ins_k_project(const ins_grid* G, ins_poisson* ps, double* u, double* p, hipS
   if ((rc = ins_k_poisson_solve(ps, p, s))) return rc;
   if ((rc = ins_k_apply_bc_p(G, p, s))) return rc;
   return ins_k_applypressure(G, u, p, s);
+}
+
+// project! for the fused periodic RK stage: u holds valid INTERIOR values only; on return its interior is
+// divergence-free and its ghost volumes are filled.  3-D, all-periodic, spectral solver.
+int ins_k_project_periodic_fused(const ins_grid* G, ins_poisson* ps, double* u, double* p, bool keep_p, hipStream_t s) {
+  const GridDev& g = G->g;
+  dim3 block(64, 4, 1), grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), ps->np[2]);
+  hipLaunchKernelGGL((k_div_to_pI<3, true>), grid, block, 0, s, g, u, ps->pI, ps->np[0], ps->np[1]);
+  INS_LAUNCH_CHECK();
+  int rc = spectral_transform(ps, s);
+  if (rc) return rc;
+  if (keep_p)
+    hipLaunchKernelGGL(k_grad_ghost3<true>, grid, block, 0, s, g, u, p, ps->pI, ps->np[0], ps->np[1], ps->np[2]);
+  else
+    hipLaunchKernelGGL(k_grad_ghost3<false>, grid, block, 0, s, g, u, p, ps->pI, ps->np[0], ps->np[1], ps->np[2]);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
 }
 
 extern "C" int ins_project_f64(const ins_grid_t* G, ins_poisson_t* ps, double* u, double* p, void* stream) {

@@ -1,13 +1,17 @@
 // Explicit Runge-Kutta stage loop (step_explicit_runge_kutta.jl:4-59) and its cache
 // (time_stepper_caches.jl:34-49).
+#include <cstdlib>
+
 #include "ins_internal.h"
 
-#define INS_MAX_STAGES 16
 
 int ins_k_momentum_generic(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s);
 int ins_k_momentum_fast3d(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s);
 int ins_k_momentum_fast3d_opts(const ins_grid* G, double visc, const double* u, double* F, bool zero_shell, hipStream_t s);
 bool ins_fast3d_supported(const ins_grid* G);
+
+int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s);
+int ins_k_project_periodic_fused(const ins_grid* G, ins_poisson* ps, double* u, double* p, bool keep_p, hipStream_t s);
 
 int ins_k_momentum(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s) {
   if (ins_fast3d_supported(G)) return ins_k_momentum_fast3d(G, visc, u, F, s);
@@ -121,11 +125,72 @@ extern "C" int ins_rk_stage_force(const ins_rk_t* rk, int i, double** ku) {
   return INS_OK;
 }
 
+// Fused periodic path (3-D, all-periodic, spectral solver): per stage
+//   K1+K6  k_i = momentum(u_in), u* = ustart + Σ Δt a_ij k_j      (one pass; u* goes to a ping-pong buffer)
+//   K2     pI = Ω div(u*) with periodic wrap                      (no ghost fill of u* needed)
+//   rocFFT forward, K3 symbol, rocFFT inverse
+//   K4     u* -= ∇p on the interior + its periodic ghost images    (no apply_bc_u! launch)
+// Same arithmetic, in the same order, as the reference stage loop (step_explicit_runge_kutta.jl:17-50);
+// `ustart` is the caller's `u`, which stays untouched until the last stage writes the result into it.
+static int rk_step_fused_periodic(ins_rk* rk, double visc, double* u, double dt, hipStream_t s) {
+  const ins_grid* G = rk->grid;
+  const int ns = rk->nstage;
+  const size_t vbytes = (size_t)G->ncell * 3 * sizeof(double);
+  for (int b = 0; b < 2; ++b)
+    if (!rk->ub[b]) {
+      INS_HIP_TRY(hipMalloc(&rk->ub[b], vbytes));
+      INS_HIP_TRY(hipMemsetAsync(rk->ub[b], 0, vbytes, s));
+    }
+  int rc;
+  if ((rc = ins_k_apply_bc_u(G, u, 0, nullptr, s))) return rc;  // :19 (first stage; later ghosts come from K4)
+  const double* in = u;
+  for (int i = 0; i < ns; ++i) {
+    double* out = (i == ns - 1 && ns > 1) ? u : rk->ub[i & 1];
+    RkEpi epi;
+    memset(&epi, 0, sizeof(epi));
+    for (int j = 0; j < i; ++j) {
+      const double coef = dt * rk->A[i * ns + j];
+      if (coef == 0.0) continue;
+      epi.coef[epi.n] = coef;
+      epi.k[epi.n] = rk->ku[j];
+      ++epi.n;
+    }
+    epi.coef_self = dt * rk->A[i * ns + i];
+    epi.ustart = (i == 0) ? nullptr : u;
+    epi.ustar = out;
+    for (int i2 = i + 1; i2 < ns; ++i2)
+      if (rk->A[i2 * ns + i] != 0.0) epi.write_k = 1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (rk->profiling) {
+      INS_HIP_TRY(hipEventCreate(&e0));
+      INS_HIP_TRY(hipEventCreate(&e1));
+      INS_HIP_TRY(hipEventRecord(e0, s));
+    }
+    if ((rc = ins_k_momentum_rk_fused(G, visc, in, rk->ku[i], epi, s))) return rc;
+    if (rk->profiling) {
+      INS_HIP_TRY(hipEventRecord(e1, s));
+      rk->prof_events.push_back(e0);
+      rk->prof_events.push_back(e1);
+    }
+    if ((rc = ins_k_project_periodic_fused(G, rk->ps, out, rk->p, i == ns - 1, s))) return rc;
+    in = out;
+  }
+  if (ns == 1) INS_HIP_TRY(hipMemcpyAsync(u, rk->ub[0], vbytes, hipMemcpyDeviceToDevice, s));
+  return INS_OK;
+}
+
 extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, double dt, const double* const* planes, void* stream) {
   INS_REQUIRE(rk && u, "null argument");
   (void)t;  // boundary data is time-independent on this entry point (see header)
   const ins_grid* G = rk->grid;
   hipStream_t s = as_stream(stream);
+  {
+    static const bool no_fuse = getenv("INS_DISABLE_FUSED_RK") != nullptr;
+    const GridDev& g = G->g;
+    bool ok = !no_fuse && !planes && g.D == 3 && G->all_periodic && G->all_dof && rk->ps->kind == POISSON_SPECTRAL && ins_fast3d_supported(G);
+    for (int a = 0; ok && a < 3; ++a) ok = rk->ps->np[a] >= 2;
+    if (ok) return rk_step_fused_periodic(rk, visc, u, dt, s);
+  }
   const long long nvec = G->ncell * G->g.D;
   const double** dplanes = nullptr;
   struct Guard {
