@@ -82,13 +82,12 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
     if world > 1:
         from bench_dist import run_distributed  # z-slab path
 
         return run_distributed(args, ins)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
 
     n = args.n
     x = (np.linspace(0.0, 1.0, n + 1),) * 3

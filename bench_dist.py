@@ -1,0 +1,94 @@
+"""Multi-GPU leg of bench.py: z-slab decomposition, one rank per GPU over RCCL (torch.distributed "nccl").
+
+Weak scaling: every rank holds 256^3 cells.  The global box is the TGV on [0,1]^3 with
+(nx, ny, nz) = (256, 256, 512) at N=2, (256, 512, 512) at N=4 and 512^3 at N=8 (= BASELINE configs[3])."""
+import json
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+GLOBAL_GRIDS = {1: (256, 256, 256), 2: (256, 256, 512), 4: (256, 512, 512), 8: (512, 512, 512)}
+
+
+def tgv_local(lay, L=(1.0, 1.0, 1.0)):
+    """TGV initial condition (examples/TaylorGreenVortex3D.jl:30-37) evaluated directly on this rank's padded slab
+    (face positions xu[α]); periodic in all directions, so ghosts are just the same formula."""
+    nx, ny, nz = lay.n
+    h = [L[a] / lay.n[a] for a in range(3)]
+    xi = (np.arange(-1, nx + 1) + 0.5) * h[0]
+    yj = (np.arange(-1, ny + 1) + 0.5) * h[1]
+    zk = (np.arange(-1, lay.nzl + 1) + lay.z0 + 0.5) * h[2]
+    xf, yf = xi + 0.5 * h[0], yj + 0.5 * h[1]
+    X, Y, Z = xf[:, None, None], yj[None, :, None], zk[None, None, :]
+    u = np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y) * np.sin(2 * np.pi * Z) / 2
+    X, Y = xi[:, None, None], yf[None, :, None]
+    v = -np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Y) * np.sin(2 * np.pi * Z) / 2
+    out = np.zeros((nx + 2, ny + 2, lay.nzl + 2, 3), order="F")
+    out[..., 0] = u
+    out[..., 1] = v
+    return out
+
+
+def run_distributed(args, ins):
+    world = int(os.environ["WORLD_SIZE"])
+    rank = int(os.environ["RANK"])
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("INS_BENCH_BACKEND", "nccl")  # "gloo": rehearsal with several ranks on one GPU
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank if backend == "nccl" else local_rank % ndev)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+    n = GLOBAL_GRIDS.get(world)
+    if n is None:
+        n = (args.n, args.n, args.n * world)
+    lay = ins.SlabLayout(n, world, rank)
+    K = ins.HipSlabKernels(lay, Re=1000.0, device=dev)
+    comm = ins.SlabComm()
+    st = ins.SlabStepper(ins.RKMethods.RK44(), lay, K, comm)
+    u = K.vector()
+    u.copy_(torch.from_numpy(np.ascontiguousarray(tgv_local(lay))).to(dev))
+    st.project_(u)  # velocityfield(...; doproject = true)  (initializers.jl:38-42)
+    st.halo_u(u)
+    dt = 1e-3
+    for _ in range(args.warmup):
+        st.step_(u, dt)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st.step_(u, dt)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t1 = time.perf_counter()
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    div = st.max_abs_divergence(u)
+    finite = bool(torch.isfinite(u).all())
+    if rank == 0:
+        ms = float(el) * 1e3 / args.steps
+        cells = float(n[0]) * n[1] * n[2]
+        out = {
+            "metric": "M lattice-cell updates/sec (RK4 step incl. Poisson), 3D TGV fp64",
+            "value": cells / (ms * 1e-3) / 1e6,
+            "unit": "M cell-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"TaylorGreenVortex3D {n[0]}x{n[1]}x{n[2]} periodic fp64, RK44 + distributed spectral Poisson, dt=1e-3, Re=1e3",
+                       "grid": list(n), "decomposition": f"z-slabs x{world} (256^3 cells per GPU), RCCL halo + all-to-all transposes"},
+            "check": {"max_abs_div_times_dx": div * (1.0 / n[0]), "finite": finite, "backend": backend},
+        }
+        print(json.dumps(out))
+    dist.destroy_process_group()

@@ -156,6 +156,38 @@ int ins_rk_profile_read(ins_rk_t* rk, double* momentum_ms, int64_t* momentum_lau
 int ins_rk_pressure(const ins_rk_t* rk, double** p);
 int ins_rk_stage_force(const ins_rk_t* rk, int i, double** ku);
 
+/* ---------------------------------------------------------------------------------- multi-GPU z-slabs
+ * One process per GPU.  Rank r owns nz/P interior z-planes (+1 ghost plane per side); its
+ * `ins_grid_t` is created with bc[2] = {INS_BC_HALO, INS_BC_HALO} and the local slice of the z metrics.
+ * These entry points do only the rank-LOCAL work; the host performs the exchanges between them (RCCL via
+ * torch.distributed in this repo, `ncclSend/Recv` + all-to-all from Julia): u halo planes before the stencil,
+ * the last w-plane before the divergence, two transposes inside the Poisson solve, the first p-plane before
+ * the gradient.  The reference has no multi-device code; these replace the same reference lines as the
+ * single-GPU entry points they mirror. */
+typedef struct ins_slab_fft ins_slab_fft_t;
+/* Stage kernel (K1 + K6): k_out = momentum!(u_in) (operators.jl:967-976) when k_out != NULL, and
+ * ustar[interior] = ustart + Σ_q coefs[q]·ks[q] + coef_self·momentum(u_in)  (step_explicit_runge_kutta.jl:35-38);
+ * ustart == NULL means ustart = u_in.  Needs valid ghosts in u_in; 3-D all-DOF grids (periodic box or slab). */
+int ins_stage_momentum_f64(const ins_grid_t* grid, double visc, const double* u_in, double* k_out, const double* ustart,
+                           double* ustar, int nterms, const double* coefs, const double* const* ks, double coef_self, void* stream);
+/* pI[nx,ny,nzl] = Ω·divergence(u) on the slab interior (operators.jl:117-125, 81-95; pressure.jl:320): x, y via
+ * periodic wrap, z via the ghost plane. */
+int ins_slab_divergence_f64(const ins_grid_t* grid, const double* u, double* pI, void* stream);
+/* u -= ∇p on the slab interior from the unpadded pI and `p_top` = the next rank's first pI plane
+ * (operators.jl:225-233); writes the periodic x / y ghost images of u (boundary_conditions.jl:276-288). */
+int ins_slab_applypressure_f64(const ins_grid_t* grid, double* u, const double* pI, const double* p_top, void* stream);
+/* Distributed psolver_spectral (pressure.jl:289-351).  np = GLOBAL interior sizes, h = uniform spacings. */
+int ins_slab_fft_create(const int32_t np[3], const double h[3], int rank, int nranks, ins_slab_fft_t** out);
+int ins_slab_fft_destroy(ins_slab_fft_t* fft);
+/* Element counts of the caller-provided buffers: pI (doubles) and each complex work/send/recv buffer (complex). */
+int ins_slab_fft_sizes(const ins_slab_fft_t* fft, int64_t* real_elems, int64_t* complex_elems);
+/* 2-D R2C per local plane, packed for the transpose: sendbuf = [dest q][kz_local][ky_local][kx] */
+int ins_slab_fft_forward_xy(ins_slab_fft_t* fft, double* pI, double* work, double* sendbuf, void* stream);
+/* after the all-to-all (buf = [kz][ky_local][kx]): z-FFT, symbol division (pressure.jl:326-341), inverse z-FFT */
+int ins_slab_fft_solve_z(ins_slab_fft_t* fft, double* buf, void* stream);
+/* after the all-to-all back (recvbuf = [src q][kz_local][ky_local][kx]): unpack, 2-D C2R -> pI */
+int ins_slab_fft_inverse_xy(ins_slab_fft_t* fft, double* recvbuf, double* work, double* pI, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

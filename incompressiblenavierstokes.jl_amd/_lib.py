@@ -70,6 +70,15 @@ SIGNATURES = {
     "ins_rk_profile_read": (C.c_int, [vp, c_double_p, C.POINTER(C.c_int64)]),
     "ins_rk_pressure": (C.c_int, [vp, C.POINTER(vp)]),
     "ins_rk_stage_force": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+    "ins_stage_momentum_f64": (C.c_int, [vp, C.c_double, vp, vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), C.c_double, vp]),
+    "ins_slab_divergence_f64": (C.c_int, [vp, vp, vp, vp]),
+    "ins_slab_applypressure_f64": (C.c_int, [vp, vp, vp, vp, vp]),
+    "ins_slab_fft_create": (C.c_int, [C.POINTER(C.c_int32), c_double_p, C.c_int, C.c_int, C.POINTER(vp)]),
+    "ins_slab_fft_destroy": (C.c_int, [vp]),
+    "ins_slab_fft_sizes": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ins_slab_fft_forward_xy": (C.c_int, [vp, vp, vp, vp, vp]),
+    "ins_slab_fft_solve_z": (C.c_int, [vp, vp, vp]),
+    "ins_slab_fft_inverse_xy": (C.c_int, [vp, vp, vp, vp, vp]),
 }
 
 _lib = None

@@ -40,13 +40,21 @@ class PressureBC(AbstractBC):
     code = _lib.INS_BC_PRESSURE
 
 
+class HaloBC(AbstractBC):
+    """Not a physical boundary: the z-face of a slab whose ghost plane is filled by the neighbouring rank
+    (multi-GPU decomposition).  Ghost layout as PeriodicBC (one ghost volume, the width of the
+    adjacent interior volume — exact on the uniform grids the spectral solver requires)."""
+
+    code = _lib.INS_BC_HALO
+
+
 def padghost_(bc, x, isright):
     """boundary_conditions.jl:42-61 on a python list."""
     if isinstance(bc, PeriodicBC):
         x.append(x[-1] + (x[1] - x[0])) if isright else x.insert(0, x[0] - (x[-1] - x[-2]))
     elif isinstance(bc, DirichletBC):
         x.append(x[-1]) if isright else x.insert(0, x[0])
-    elif isinstance(bc, SymmetricBC):
+    elif isinstance(bc, (SymmetricBC, HaloBC)):
         x.append(x[-1] + (x[-1] - x[-2])) if isright else x.insert(0, x[0] - (x[1] - x[0]))
     elif isinstance(bc, PressureBC):
         if isright:
@@ -60,7 +68,7 @@ def padghost_(bc, x, isright):
 
 def offset_u(bc, isright, isnormal):
     """boundary_conditions.jl:79-88"""
-    if isinstance(bc, PeriodicBC):
+    if isinstance(bc, (PeriodicBC, HaloBC)):
         return 1
     if isinstance(bc, (DirichletBC, SymmetricBC)):
         return 1 + int(isright and isnormal)

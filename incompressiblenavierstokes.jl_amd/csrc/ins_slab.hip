@@ -1,0 +1,285 @@
+// z-slab pieces of the multi-GPU path.  One process per GPU; rank r owns nzl = nz/P interior
+// z-planes plus one ghost plane on each side, x and y stay whole.  This translation unit holds only the
+// LOCAL work; the exchanges between ranks (u / p halo planes, the two FFT transposes) are done by the host
+// with RCCL through torch.distributed (incompressiblenavierstokes.jl_amd/distributed.py).
+//
+// Distributed spectral solve (pressure.jl:289-351 restated for slabs):
+//   forward_xy : 2-D R2C over (x, y) for each local plane, then pack to [dest q][kz_local][ky_local][kx]
+//   (all-to-all)   -> every rank holds all nz planes of its ny/P rows:  [kz][ky_local][kx]
+//   solve_z    : 1-D FFT along z, divide by the Laplacian symbol (mean mode zeroed, 1/prod(Np) folded in), inverse
+//   (all-to-all back)
+//   inverse_xy : unpack, 2-D C2R per plane -> pI
+#include <cmath>
+
+#include "ins_internal.h"
+
+struct ins_slab_fft {
+  int np[3];         // global interior sizes
+  int rank, nranks;
+  int nzl, nyl, kxn; // local planes, local rows (transposed layout), nx/2+1
+  hipfftHandle xy_fwd = 0, xy_inv = 0, z_fwd = 0;
+  bool plans = false;
+  double *ax = nullptr, *ay = nullptr, *az = nullptr;  // symbol vectors (ay: this rank's ky range)
+};
+
+namespace {
+
+// work[kzl][ky][kx]  <->  buf[q][kzl][kyl][kx],  ky = q*nyl + kyl        (complex = double2)
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_transpose_pack(double2* __restrict__ work, double2* __restrict__ buf, int kxn, int ny, int nyl,
+                                                        int nzl) {
+  const int kx = blockIdx.x * 64 + threadIdx.x;
+  const int ky = blockIdx.y * 4 + threadIdx.y;
+  const int kz = blockIdx.z;
+  if (kx >= kxn || ky >= ny) return;
+  const int q = ky / nyl, kyl = ky - q * nyl;
+  const long long w = kx + (long long)kxn * (ky + (long long)ny * kz);
+  const long long b = kx + (long long)kxn * (kyl + (long long)nyl * (kz + (long long)nzl * q));
+  if (PACK)
+    buf[b] = work[w];
+  else
+    work[w] = buf[b];
+}
+
+// K3 on the transposed layout [kz][kyl][kx]
+__global__ __launch_bounds__(256) void k_symbol_slab(double2* __restrict__ phat, const double* __restrict__ ax, const double* __restrict__ ay,
+                                                     const double* __restrict__ az, int kxn, int nyl, int nz, double inv_n, int zero_mean) {
+  const int kx = blockIdx.x * 64 + threadIdx.x;
+  const int ky = blockIdx.y * 4 + threadIdx.y;
+  const int kz = blockIdx.z;
+  if (kx >= kxn || ky >= nyl) return;
+  const long long q = kx + (long long)kxn * (ky + (long long)nyl * kz);
+  const double den = ax[kx] + ay[ky] + az[kz];
+  const bool mean = zero_mean && kx == 0 && ky == 0 && kz == 0;
+  const double s = mean ? 0.0 : -inv_n / den;
+  double2 v = phat[q];
+  v.x *= s;
+  v.y *= s;
+  phat[q] = v;
+}
+
+// K2 on a slab: x, y neighbours through periodic wrap, z through the ghost plane (filled by the halo exchange)
+__global__ __launch_bounds__(256) void k_div_slab(GridDev g, const double* __restrict__ u, double* __restrict__ pI, int n0, int n1) {
+  const int ii = blockIdx.x * 64 + threadIdx.x;
+  const int jj = blockIdx.y * 4 + threadIdx.y;
+  const int kk = blockIdx.z;
+  if (ii >= n0 || jj >= n1) return;
+  const int I[3] = {1 + ii, 1 + jj, 1 + kk};
+  const long long c = I[0] + I[1] * g.sx[1] + I[2] * g.sx[2];
+  double d = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double* ua = u + a * g.sc;
+    const long long cm = (a < 2 && I[a] == 1) ? c + (long long)(g.N[a] - 3) * g.sx[a] : c - g.sx[a];
+    d += (ua[c] - ua[cm]) * g.rdx[a][I[a]];
+  }
+  const double om = g.dx[0][I[0]] * g.dx[1][I[1]] * g.dx[2][I[2]];
+  pI[ii + (long long)n0 * (jj + (long long)n1 * kk)] = d * om;
+}
+
+// K4 on a slab: like k_grad_ghost3 but the z-neighbour of the top local plane comes from `p_top` (the next
+// rank's first pI plane) and only x / y ghost images are written (z ghosts belong to the halo exchange).
+__global__ __launch_bounds__(256) void k_grad_slab(GridDev g, double* __restrict__ u, const double* __restrict__ pI,
+                                                   const double* __restrict__ p_top, int n0, int n1, int n2) {
+  const int ii = blockIdx.x * 64 + threadIdx.x;
+  const int jj = blockIdx.y * 4 + threadIdx.y;
+  const int kk = blockIdx.z;
+  if (ii >= n0 || jj >= n1) return;
+  const int I[3] = {ii + 1, jj + 1, kk + 1};
+  const long long q = ii + (long long)n0 * (jj + (long long)n1 * kk);
+  const long long c = I[0] + I[1] * g.sx[1] + I[2] * g.sx[2];
+  const double pc = pI[q];
+  const double px = pI[(ii + 1 < n0) ? q + 1 : q - (n0 - 1)];
+  const double py = pI[(jj + 1 < n1) ? q + n0 : q - (long long)(n1 - 1) * n0];
+  const double pz = (kk + 1 < n2) ? pI[q + (long long)n0 * n1] : p_top[ii + (long long)n0 * jj];
+  double un[3];
+  un[0] = u[c] - (px - pc) * g.rdxu[0][I[0]];
+  un[1] = u[g.sc + c] - (py - pc) * g.rdxu[1][I[1]];
+  un[2] = u[2 * g.sc + c] - (pz - pc) * g.rdxu[2][I[2]];
+  int img[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) img[a] = I[a] == 1 ? g.N[a] - 1 : (I[a] == g.N[a] - 2 ? 0 : -1);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    bool ok = true;
+    long long cc = I[2] * g.sx[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const bool use = (m >> a) & 1;
+      ok = ok && (!use || img[a] >= 0);
+      cc += (long long)(use ? img[a] : I[a]) * g.sx[a];
+    }
+    if (ok) {
+      u[cc] = un[0];
+      u[cc + g.sc] = un[1];
+      u[cc + 2 * g.sc] = un[2];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ins_slab_fft_create(const int32_t np[3], const double h[3], int rank, int nranks, ins_slab_fft_t** out) {
+  INS_REQUIRE(np && h && out, "null argument");
+  INS_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank");
+  INS_REQUIRE(np[2] % nranks == 0 && np[1] % nranks == 0, "nz and ny must be divisible by the number of ranks");
+  for (int a = 0; a < 3; ++a) INS_REQUIRE(np[a] >= 2 && np[a] % 2 == 0, "Spectral psolver requires even number of volumes.");
+  ins_slab_fft* S = new ins_slab_fft();
+  for (int a = 0; a < 3; ++a) S->np[a] = np[a];
+  S->rank = rank;
+  S->nranks = nranks;
+  S->nzl = np[2] / nranks;
+  S->nyl = np[1] / nranks;
+  S->kxn = np[0] / 2 + 1;
+  const double om = h[0] * h[1] * h[2];
+  auto symbol = [&](int a, int k) {  // pressure.jl:305-311
+    const double sn = std::sin(M_PI * ((double)k / np[a]));
+    return 4 * om * sn * sn / (h[a] * h[a]);
+  };
+  std::vector<double> ax(S->kxn), ay(S->nyl), az(np[2]);
+  for (int k = 0; k < S->kxn; ++k) ax[k] = symbol(0, k);
+  for (int k = 0; k < S->nyl; ++k) ay[k] = symbol(1, rank * S->nyl + k);
+  for (int k = 0; k < np[2]; ++k) az[k] = symbol(2, k);
+  bool ok = hipMalloc(&S->ax, ax.size() * 8) == hipSuccess && hipMalloc(&S->ay, ay.size() * 8) == hipSuccess &&
+            hipMalloc(&S->az, az.size() * 8) == hipSuccess;
+  ok = ok && hipMemcpy(S->ax, ax.data(), ax.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(S->ay, ay.data(), ay.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(S->az, az.data(), az.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    ins_set_error("ins_slab_fft_create: symbol upload failed");
+    ins_slab_fft_destroy(S);
+    return INS_ERR_HIP;
+  }
+  // batched 2-D transforms over (y, x) for nzl planes; 1-D transforms along z (stride nyl*kxn) for nyl*kxn lines
+  int n2[2] = {np[1], np[0]};
+  int nz1[1] = {np[2]};
+  const int lines = S->nyl * S->kxn;
+  hipfftResult r1 = hipfftPlanMany(&S->xy_fwd, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, S->nzl);
+  hipfftResult r2 = hipfftPlanMany(&S->xy_inv, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, S->nzl);
+  hipfftResult r3 = hipfftPlanMany(&S->z_fwd, 1, nz1, nz1, lines, 1, nz1, lines, 1, HIPFFT_Z2Z, lines);
+  if (r1 != HIPFFT_SUCCESS || r2 != HIPFFT_SUCCESS || r3 != HIPFFT_SUCCESS) {
+    ins_set_error("ins_slab_fft_create: hipfftPlanMany failed (%d, %d, %d)", (int)r1, (int)r2, (int)r3);
+    ins_slab_fft_destroy(S);
+    return INS_ERR_FFT;
+  }
+  S->plans = true;
+  *out = S;
+  return INS_OK;
+}
+
+extern "C" int ins_slab_fft_destroy(ins_slab_fft_t* S) {
+  if (!S) return INS_OK;
+  if (S->plans) {
+    (void)hipfftDestroy(S->xy_fwd);
+    (void)hipfftDestroy(S->xy_inv);
+    (void)hipfftDestroy(S->z_fwd);
+  }
+  if (S->ax) (void)hipFree(S->ax);
+  if (S->ay) (void)hipFree(S->ay);
+  if (S->az) (void)hipFree(S->az);
+  delete S;
+  return INS_OK;
+}
+
+extern "C" int ins_slab_fft_sizes(const ins_slab_fft_t* S, int64_t* real_elems, int64_t* complex_elems) {
+  INS_REQUIRE(S && real_elems && complex_elems, "null argument");
+  *real_elems = (int64_t)S->np[0] * S->np[1] * S->nzl;
+  *complex_elems = (int64_t)S->kxn * S->np[1] * S->nzl;  // == kxn * nyl * nz
+  return INS_OK;
+}
+
+extern "C" int ins_slab_fft_forward_xy(ins_slab_fft_t* S, double* pI, double* work, double* sendbuf, void* stream) {
+  INS_REQUIRE(S && pI && work && sendbuf, "null argument");
+  hipStream_t s = as_stream(stream);
+  INS_FFT_TRY(hipfftSetStream(S->xy_fwd, s));
+  INS_FFT_TRY(hipfftExecD2Z(S->xy_fwd, pI, reinterpret_cast<hipfftDoubleComplex*>(work)));
+  dim3 block(64, 4, 1), grid(cdiv(S->kxn, 64), cdiv(S->np[1], 4), S->nzl);
+  hipLaunchKernelGGL(k_transpose_pack<true>, grid, block, 0, s, reinterpret_cast<double2*>(work), reinterpret_cast<double2*>(sendbuf), S->kxn,
+                     S->np[1], S->nyl, S->nzl);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+extern "C" int ins_slab_fft_solve_z(ins_slab_fft_t* S, double* buf, void* stream) {
+  INS_REQUIRE(S && buf, "null argument");
+  hipStream_t s = as_stream(stream);
+  hipfftDoubleComplex* c = reinterpret_cast<hipfftDoubleComplex*>(buf);
+  INS_FFT_TRY(hipfftSetStream(S->z_fwd, s));
+  INS_FFT_TRY(hipfftExecZ2Z(S->z_fwd, c, c, HIPFFT_FORWARD));
+  const double inv_n = 1.0 / ((double)S->np[0] * S->np[1] * S->np[2]);
+  dim3 block(64, 4, 1), grid(cdiv(S->kxn, 64), cdiv(S->nyl, 4), S->np[2]);
+  hipLaunchKernelGGL(k_symbol_slab, grid, block, 0, s, reinterpret_cast<double2*>(buf), S->ax, S->ay, S->az, S->kxn, S->nyl, S->np[2], inv_n,
+                     S->rank == 0);
+  INS_LAUNCH_CHECK();
+  INS_FFT_TRY(hipfftExecZ2Z(S->z_fwd, c, c, HIPFFT_BACKWARD));
+  return INS_OK;
+}
+
+extern "C" int ins_slab_fft_inverse_xy(ins_slab_fft_t* S, double* recvbuf, double* work, double* pI, void* stream) {
+  INS_REQUIRE(S && recvbuf && work && pI, "null argument");
+  hipStream_t s = as_stream(stream);
+  dim3 block(64, 4, 1), grid(cdiv(S->kxn, 64), cdiv(S->np[1], 4), S->nzl);
+  hipLaunchKernelGGL(k_transpose_pack<false>, grid, block, 0, s, reinterpret_cast<double2*>(work), reinterpret_cast<double2*>(recvbuf), S->kxn,
+                     S->np[1], S->nyl, S->nzl);
+  INS_LAUNCH_CHECK();
+  INS_FFT_TRY(hipfftSetStream(S->xy_inv, s));
+  INS_FFT_TRY(hipfftExecZ2D(S->xy_inv, reinterpret_cast<hipfftDoubleComplex*>(work), pI));
+  return INS_OK;
+}
+
+static int check_slab_grid(const ins_grid* G) {
+  INS_REQUIRE(G, "null argument");
+  const GridDev& g = G->g;
+  INS_REQUIRE(g.D == 3, "slab kernels are 3-D");
+  INS_REQUIRE(g.bc[0][0] == INS_BC_PERIODIC && g.bc[1][0] == INS_BC_PERIODIC, "slab kernels need periodic x and y");
+  INS_REQUIRE(g.bc[2][0] == INS_BC_HALO && g.bc[2][1] == INS_BC_HALO, "slab grid must mark z as INS_BC_HALO");
+  INS_REQUIRE(G->all_dof, "slab grid must be all-DOF");
+  return INS_OK;
+}
+
+extern "C" int ins_slab_divergence_f64(const ins_grid_t* G, const double* u, double* pI, void* stream) {
+  int rc = check_slab_grid(G);
+  if (rc) return rc;
+  INS_REQUIRE(u && pI, "null argument");
+  const GridDev& g = G->g;
+  const int n0 = g.N[0] - 2, n1 = g.N[1] - 2, n2 = g.N[2] - 2;
+  hipLaunchKernelGGL(k_div_slab, dim3(cdiv(n0, 64), cdiv(n1, 4), n2), dim3(64, 4, 1), 0, as_stream(stream), g, u, pI, n0, n1);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+extern "C" int ins_slab_applypressure_f64(const ins_grid_t* G, double* u, const double* pI, const double* p_top, void* stream) {
+  int rc = check_slab_grid(G);
+  if (rc) return rc;
+  INS_REQUIRE(u && pI && p_top, "null argument");
+  const GridDev& g = G->g;
+  const int n0 = g.N[0] - 2, n1 = g.N[1] - 2, n2 = g.N[2] - 2;
+  hipLaunchKernelGGL(k_grad_slab, dim3(cdiv(n0, 64), cdiv(n1, 4), n2), dim3(64, 4, 1), 0, as_stream(stream), g, u, pI, p_top, n0, n1, n2);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+// K1 + K6 on any all-DOF 3-D grid (a slab, or a whole periodic box): k_out = momentum(u_in) when k_out != NULL,
+// ustar(interior) = ustart + Σ_q coefs[q] ks[q] + coef_self * momentum(u_in); ustart == NULL means ustart = u_in.
+extern "C" int ins_stage_momentum_f64(const ins_grid_t* G, double visc, const double* u_in, double* k_out, const double* ustart,
+                                      double* ustar, int nterms, const double* coefs, const double* const* ks, double coef_self,
+                                      void* stream) {
+  INS_REQUIRE(G && u_in && ustar, "null argument");
+  INS_REQUIRE(G->g.D == 3 && G->all_dof, "stage kernel needs a 3-D all-DOF grid (periodic box or slab)");
+  INS_REQUIRE(nterms >= 0 && nterms <= INS_MAX_STAGES, "too many stage terms");
+  INS_REQUIRE(nterms == 0 || (coefs && ks), "null stage terms");
+  INS_REQUIRE(ustar != u_in, "the stage velocity cannot overwrite the stencil input");
+  RkEpi epi;
+  memset(&epi, 0, sizeof(epi));
+  epi.n = nterms;
+  for (int q = 0; q < nterms; ++q) {
+    epi.coef[q] = coefs[q];
+    epi.k[q] = ks[q];
+  }
+  epi.coef_self = coef_self;
+  epi.ustart = ustart;
+  epi.ustar = ustar;
+  epi.write_k = k_out != nullptr;
+  static double* dummy = nullptr;
+  return ins_k_momentum_rk_fused(G, visc, u_in, k_out ? k_out : dummy, epi, as_stream(stream));
+}

@@ -1,0 +1,279 @@
+"""Multi-GPU z-slab path: one process per GPU, exchanges over torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" for CPU rehearsals).
+
+The reference has no multi-device code; this module distributes exactly the reference's stage loop
+(step_explicit_runge_kutta.jl:17-50) over ranks:
+
+    rank r owns interior z-planes [r*nz/P, (r+1)*nz/P) (+ one ghost plane per side); x, y stay whole.
+    per stage:  halo(u)  ->  K1+K6 (k_i, u*)  ->  halo(w-plane of u*)  ->  K2 (Ω div u* -> pI)
+                -> 2-D FFT(x,y) + pack -> all-to-all -> z-FFT / symbol / inverse z-FFT -> all-to-all
+                -> unpack + inverse 2-D FFT -> halo(first p plane) -> K4 (u* -= ∇p, x/y ghost images)
+
+`SlabStepper` holds only index bookkeeping and communication; the rank-local numerics come from a
+`kernels` object: `HipSlabKernels` below (libinship, the product) — tests inject a CPU implementation to
+rehearse the communication pattern under gloo without a GPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .boundary_conditions import HaloBC, PeriodicBC
+from .setup import Setup, vectorfield
+
+
+class SlabLayout:
+    """Index bookkeeping of the z-slab decomposition of an (nx, ny, nz) periodic box over `world` ranks."""
+
+    def __init__(self, n, world, rank):
+        self.n = tuple(int(v) for v in n)
+        self.world, self.rank = int(world), int(rank)
+        nx, ny, nz = self.n
+        if nz % world or ny % world:
+            raise ValueError(f"nz={nz} and ny={ny} must be divisible by the number of ranks ({world})")
+        self.nzl = nz // world
+        self.nyl = ny // world
+        self.z0 = rank * self.nzl
+        self.kxn = nx // 2 + 1
+        self.prev = (rank - 1) % world
+        self.next = (rank + 1) % world
+
+    @property
+    def local_shape(self):  # padded local field shape
+        return (self.n[0] + 2, self.n[1] + 2, self.nzl + 2)
+
+
+class SlabComm:
+    """Point-to-point plane exchange and the transpose all-to-all over a torch.distributed group.
+    With the gloo backend and device tensors the payload is staged through the host (rehearsal mode)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+
+    def _stage(self, t):
+        return self.backend == "gloo" and t.is_cuda
+
+    def exchange(self, sends, recvs):
+        """sends: [(tensor, dst)], recvs: [(tensor, src)] — all contiguous, matched pairwise across ranks."""
+        if self.world == 1:
+            for (s, _), (r, _) in zip(sends, recvs):
+                r.copy_(s)
+            return
+        stage = any(self._stage(t) for t, _ in sends)
+        if stage:
+            hs = [(t.cpu(), d) for t, d in sends]
+            hr = [(torch.empty(t.shape, dtype=t.dtype), s) for t, s in recvs]
+        else:
+            hs, hr = sends, recvs
+        ops = [dist.P2POp(dist.isend, t, d, self.group) for t, d in hs] + [dist.P2POp(dist.irecv, t, s, self.group) for t, s in hr]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if stage:
+            for (t, _), (h, _) in zip(recvs, hr):
+                t.copy_(h)
+
+    def all_to_all(self, recv, send):
+        if self.world == 1:
+            recv.copy_(send)
+            return
+        if self._stage(send):
+            hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(hr, hs, group=self.group)
+            recv.copy_(hr)
+        else:
+            dist.all_to_all_single(recv, send, group=self.group)
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier(self.group)
+
+
+class HipSlabKernels:
+    """Rank-local numerics of the slab path: HIP kernels + rocFFT through the C ABI (include/ins_hip.h)."""
+
+    def __init__(self, layout, L=(1.0, 1.0, 1.0), Re=1000.0, device=None):
+        self.layout = lay = layout
+        nx, ny, nz = lay.n
+        h = [L[a] / lay.n[a] for a in range(3)]
+        x = np.linspace(0.0, L[0], nx + 1)
+        y = np.linspace(0.0, L[1], ny + 1)
+        z = np.linspace(0.0, L[2], nz + 1)[lay.z0 : lay.z0 + lay.nzl + 1]
+        per = (PeriodicBC(), PeriodicBC())
+        self.setup = Setup(x=(x, y, z), boundary_conditions=(per, per, (HaloBC(), HaloBC())), Re=Re, device=device)
+        self.device = self.setup.device
+        np3 = (C.c_int32 * 3)(nx, ny, nz)
+        h3 = (C.c_double * 3)(*h)
+        self._fft = C.c_void_p()
+        _lib.call("ins_slab_fft_create", np3, h3, lay.rank, lay.world, C.byref(self._fft))
+        nr, nc = C.c_int64(), C.c_int64()
+        _lib.call("ins_slab_fft_sizes", self._fft, C.byref(nr), C.byref(nc))
+        self.real_elems, self.complex_elems = nr.value, nc.value
+        self.cell_volume = float(h[0] * h[1] * h[2])
+
+    def __del__(self):
+        h, self._fft = getattr(self, "_fft", None), None
+        if h:
+            try:
+                _lib.load().ins_slab_fft_destroy(h)
+            except Exception:
+                pass
+
+    # ---- allocation -------------------------------------------------------------------------
+    def vector(self):
+        return vectorfield(self.setup)
+
+    def real(self):
+        return torch.zeros(self.real_elems, dtype=torch.float64, device=self.device)
+
+    def cplx(self):
+        return torch.zeros(2 * self.complex_elems, dtype=torch.float64, device=self.device)
+
+    def from_global(self, uglob):
+        """Cut this rank's slab (with z ghost planes, periodic) out of a global padded host field."""
+        lay = self.layout
+        nz = lay.n[2]
+        ks = [(lay.z0 + k - 1) % nz + 1 for k in range(lay.nzl + 2)]  # global padded plane indices
+        local = np.asfortranarray(np.asarray(uglob)[:, :, ks, :])
+        f = self.vector()
+        f.copy_(torch.from_numpy(np.ascontiguousarray(local)).to(self.device))
+        return f
+
+    # ---- views used by the exchanges --------------------------------------------------------
+    @staticmethod
+    def plane(u, c, k):
+        """Contiguous (N1*N0) view of component c, padded z-plane k of a local vector field."""
+        return u.permute(3, 2, 1, 0)[c, k]
+
+    def p_plane(self, pI, k):
+        n0, n1 = self.layout.n[0], self.layout.n[1]
+        return pI[k * n0 * n1 : (k + 1) * n0 * n1]
+
+    # ---- kernels ----------------------------------------------------------------------------
+    def _p(self, t):
+        return C.c_void_p(t.data_ptr())
+
+    def fill_xy_ghosts(self, u):
+        s = self.setup
+        _lib.call("ins_apply_bc_u_f64", s.handle, s.ptr(u, True), 0, None, s.stream)
+
+    def stage_momentum(self, u_in, k_out, ustart, ustar, coefs, ks, coef_self):
+        s = self.setup
+        n = len(coefs)
+        carr = (C.c_double * max(n, 1))(*coefs)
+        karr = (C.c_void_p * max(n, 1))(*[k.data_ptr() for k in ks])
+        _lib.call("ins_stage_momentum_f64", s.handle, 1.0 / s.Re, s.ptr(u_in, True), s.ptr(k_out, True) if k_out is not None else None,
+                  s.ptr(ustart, True) if ustart is not None else None, s.ptr(ustar, True), n, carr, karr, float(coef_self), s.stream)
+
+    def divergence(self, u, pI):
+        s = self.setup
+        _lib.call("ins_slab_divergence_f64", s.handle, s.ptr(u, True), self._p(pI), s.stream)
+
+    def fft_forward_xy(self, pI, work, sendbuf):
+        _lib.call("ins_slab_fft_forward_xy", self._fft, self._p(pI), self._p(work), self._p(sendbuf), self.setup.stream)
+
+    def fft_solve_z(self, buf):
+        _lib.call("ins_slab_fft_solve_z", self._fft, self._p(buf), self.setup.stream)
+
+    def fft_inverse_xy(self, recvbuf, work, pI):
+        _lib.call("ins_slab_fft_inverse_xy", self._fft, self._p(recvbuf), self._p(work), self._p(pI), self.setup.stream)
+
+    def applypressure(self, u, pI, p_top):
+        s = self.setup
+        _lib.call("ins_slab_applypressure_f64", s.handle, s.ptr(u, True), self._p(pI), self._p(p_top), s.stream)
+
+    def sync(self):
+        torch.cuda.synchronize(self.device)
+
+
+class SlabStepper:
+    """Explicit Runge-Kutta stepping of a periodic box decomposed into z-slabs
+    (step_explicit_runge_kutta.jl:4-59 distributed; same arithmetic in the same order on every cell)."""
+
+    def __init__(self, method, layout, kernels, comm):
+        self.method, self.lay, self.k, self.comm = method, layout, kernels, comm
+        ns = len(method.b)
+        self.ku = [kernels.vector() for _ in range(ns)]
+        self.ub = [kernels.vector(), kernels.vector()]
+        self.pI = kernels.real()
+        self.work = kernels.cplx()
+        self.bufa = kernels.cplx()
+        self.bufb = kernels.cplx()
+        self.p_top = kernels.real()[: layout.n[0] * layout.n[1]].clone()
+        self.n = 0
+
+    # -- exchanges ---------------------------------------------------------------------------
+    def halo_u(self, u, comps=(0, 1, 2), down_only=False):
+        """Fill the z ghost planes of `u`: plane nzl -> next rank's plane 0 (and plane 1 -> prev rank's
+        plane nzl+1 unless `down_only`).  Planes span the full padded x/y extent, so edges stay consistent
+        (boundary_conditions.jl:97-103)."""
+        lay, K = self.lay, self.k
+        sends, recvs = [], []
+        for c in comps:
+            sends.append((K.plane(u, c, lay.nzl), lay.next))
+            recvs.append((K.plane(u, c, 0), lay.prev))
+        if not down_only:
+            for c in comps:
+                sends.append((K.plane(u, c, 1), lay.prev))
+                recvs.append((K.plane(u, c, lay.nzl + 1), lay.next))
+        self.comm.exchange(sends, recvs)
+
+    def halo_p(self):
+        """First local pI plane -> previous rank's `p_top`."""
+        lay, K = self.lay, self.k
+        self.comm.exchange([(K.p_plane(self.pI, 0), lay.prev)], [(self.p_top, lay.next)])
+
+    # -- projection (pressure.jl:69-82 on slabs) ---------------------------------------------------
+    def project_(self, u):
+        K = self.k
+        self.halo_u(u, comps=(2,), down_only=True)  # divergence needs w[I - e_z] only (operators.jl:122)
+        K.divergence(u, self.pI)
+        K.fft_forward_xy(self.pI, self.work, self.bufa)
+        self.comm.all_to_all(self.bufb, self.bufa)
+        K.fft_solve_z(self.bufb)
+        self.comm.all_to_all(self.bufa, self.bufb)
+        K.fft_inverse_xy(self.bufa, self.work, self.pI)
+        self.halo_p()
+        K.applypressure(u, self.pI, self.p_top)
+        return u
+
+    # -- one RK step -------------------------------------------------------------------------
+    def step_(self, u, Δt):
+        m, K = self.method, self.k
+        A = m.A
+        ns = len(m.b)
+        K.fill_xy_ghosts(u)
+        self.halo_u(u)
+        u_in = u
+        for i in range(ns):
+            out = u if (i == ns - 1 and ns > 1) else self.ub[i & 1]
+            coefs, ks = [], []
+            for j in range(i):
+                cf = Δt * A[i, j]
+                if cf != 0.0:
+                    coefs.append(cf)
+                    ks.append(self.ku[j])
+            write_k = any(A[i2, i] != 0.0 for i2 in range(i + 1, ns))
+            K.stage_momentum(u_in, self.ku[i] if write_k else None, None if i == 0 else u, out, coefs, ks, Δt * A[i, i])
+            self.project_(out)
+            self.halo_u(out)  # z ghosts for the next stencil (x/y ghosts were written by K4)
+            u_in = out
+        if ns == 1:
+            u.copy_(self.ub[0])
+        self.n += 1
+        return u
+
+    def max_abs_divergence(self, u):
+        """Global maximum(abs, Ω⁻¹ pI) diagnostic (uses the projection scratch)."""
+        self.halo_u(u, comps=(2,), down_only=True)
+        self.k.divergence(u, self.pI)
+        v = (self.pI.abs().max() / self.k.cell_volume).reshape(1).to(torch.float64)
+        if self.comm.world > 1:
+            vv = v.cpu() if self.comm.backend == "gloo" else v
+            dist.all_reduce(vv, op=dist.ReduceOp.MAX, group=self.comm.group)
+            v = vv
+        return float(v)

@@ -1,0 +1,126 @@
+"""CPU stand-in for the rank-local slab kernels, built on the oracle — TEST INFRASTRUCTURE ONLY.
+Injected into `SlabStepper` by tests/test_dist_gloo.py so the decomposition bookkeeping and the
+torch.distributed exchanges can be rehearsed under gloo without a GPU."""
+import numpy as np
+import torch
+
+from oracle import ins_oracle as o
+
+
+class OracleSlabKernels:
+    def __init__(self, layout, L=(1.0, 1.0, 1.0), Re=1000.0):
+        self.layout = lay = layout
+        nx, ny, nz = lay.n
+        self.h = [L[a] / lay.n[a] for a in range(3)]
+        x = np.linspace(0.0, L[0], nx + 1)
+        y = np.linspace(0.0, L[1], ny + 1)
+        z = np.linspace(0.0, L[2], nz + 1)[lay.z0 : lay.z0 + lay.nzl + 1]
+        self.setup = o.make_setup((x, y, z), Re=Re)  # periodic metrics == uniform halo metrics
+        self.N = self.setup.grid.N
+        om = float(np.prod(self.h))
+        sym = lambda a, k: 4 * om * np.sin(np.pi * (k / lay.n[a])) ** 2 / self.h[a] ** 2
+        self.ax = sym(0, np.arange(lay.kxn))
+        self.ay = sym(1, lay.rank * lay.nyl + np.arange(lay.nyl))
+        self.az = sym(2, np.arange(nz))
+        self.real_elems = nx * ny * lay.nzl
+        self.complex_elems = lay.kxn * ny * lay.nzl
+        self.cell_volume = om
+
+    # allocation
+    def vector(self):
+        shape = self.N + (3,)
+        return torch.zeros(tuple(reversed(shape)), dtype=torch.float64).permute(3, 2, 1, 0)
+
+    def real(self):
+        return torch.zeros(self.real_elems, dtype=torch.float64)
+
+    def cplx(self):
+        return torch.zeros(2 * self.complex_elems, dtype=torch.float64)
+
+    def from_global(self, uglob):
+        lay = self.layout
+        nz = lay.n[2]
+        ks = [(lay.z0 + k - 1) % nz + 1 for k in range(lay.nzl + 2)]
+        f = self.vector()
+        f.numpy()[...] = np.asarray(uglob)[:, :, ks, :]
+        return f
+
+    @staticmethod
+    def plane(u, c, k):
+        return u.permute(3, 2, 1, 0)[c, k]
+
+    def p_plane(self, pI, k):
+        n0, n1 = self.layout.n[0], self.layout.n[1]
+        return pI[k * n0 * n1 : (k + 1) * n0 * n1]
+
+    # kernels
+    @staticmethod
+    def _fill_xy(a, planes=slice(None)):
+        N0, N1 = a.shape[0], a.shape[1]
+        a[0, :, planes] = a[N0 - 2, :, planes]
+        a[N0 - 1, :, planes] = a[1, :, planes]
+        a[:, 0, planes] = a[:, N1 - 2, planes]
+        a[:, N1 - 1, planes] = a[:, 1, planes]
+
+    def fill_xy_ghosts(self, u):
+        self._fill_xy(u.numpy())
+
+    def stage_momentum(self, u_in, k_out, ustart, ustar, coefs, ks, coef_self):
+        F = o.momentum(np.asfortranarray(u_in.numpy()), None, 0.0, self.setup)
+        inner = (slice(1, -1),) * 3
+        base = (u_in if ustart is None else ustart).numpy()[inner].copy()
+        for cf, k in zip(coefs, ks):
+            base = base + cf * k.numpy()[inner]
+        base = base + coef_self * F[inner]
+        if k_out is not None:
+            k_out.numpy()[...] = F
+        ustar.numpy()[inner] = base
+
+    def divergence(self, u, pI):
+        a = np.asfortranarray(u.numpy().copy())
+        self._fill_xy(a)
+        d = o.scalewithvolume(o.divergence(a, self.setup), self.setup)
+        pI.numpy()[...] = d[1:-1, 1:-1, 1:-1].reshape(-1, order="F")
+
+    def _c(self, buf):
+        return buf.numpy().view(np.complex128)
+
+    def fft_forward_xy(self, pI, work, sendbuf):
+        lay = self.layout
+        nx, ny = lay.n[0], lay.n[1]
+        a = pI.numpy().reshape(lay.nzl, ny, nx)  # C-order view of the column-major (nx, ny, nzl) block
+        w = np.fft.rfftn(a, axes=(1, 2))  # [kzl][ky][kx]
+        packed = w.reshape(lay.nzl, lay.world, lay.nyl, lay.kxn).transpose(1, 0, 2, 3)  # [q][kzl][kyl][kx]
+        self._c(sendbuf)[...] = np.ascontiguousarray(packed).reshape(-1)
+
+    def fft_solve_z(self, buf):
+        lay = self.layout
+        c = self._c(buf).reshape(lay.n[2], lay.nyl, lay.kxn)
+        f = np.fft.fft(c, axis=0)
+        den = self.az[:, None, None] + self.ay[None, :, None] + self.ax[None, None, :]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            f = -f / den
+        if lay.rank == 0:
+            f[0, 0, 0] = 0.0
+        c[...] = np.fft.ifft(f, axis=0)
+
+    def fft_inverse_xy(self, recvbuf, work, pI):
+        lay = self.layout
+        nx, ny = lay.n[0], lay.n[1]
+        blocks = self._c(recvbuf).reshape(lay.world, lay.nzl, lay.nyl, lay.kxn)  # [src q][kzl][kyl][kx]
+        w = blocks.transpose(1, 0, 2, 3).reshape(lay.nzl, ny, lay.kxn)
+        pI.numpy()[...] = np.fft.irfftn(w, s=(ny, nx), axes=(1, 2)).reshape(-1)
+
+    def applypressure(self, u, pI, p_top):
+        lay = self.layout
+        nx, ny = lay.n[0], lay.n[1]
+        p = np.zeros(self.N, order="F")
+        p[1:-1, 1:-1, 1:-1] = pI.numpy().reshape((nx, ny, lay.nzl), order="F")
+        p[1:-1, 1:-1, -1] = p_top.numpy().reshape((nx, ny), order="F")
+        self._fill_xy(p)
+        a = u.numpy()
+        o.applypressure_(a, p, self.setup)
+        self._fill_xy(a, planes=slice(1, lay.nzl + 1))
+
+    def sync(self):
+        pass
