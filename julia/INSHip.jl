@@ -1,0 +1,134 @@
+# INSHip.jl — glue that makes libinship.so a backend of IncompressibleNavierStokes.jl.
+#
+# UNTESTED: Julia is not installed in the build container (SURVEY.md §8b/§8c), so this file has never been
+# executed.  It shows the binding a maintainer would add (a weak-dependency package extension in the style of
+# ext/IncompressibleNavierStokesCUDSSExt.jl): AMDGPU.jl is used for device memory ONLY (ROCArray allocation and
+# raw pointers); every kernel lives behind the C ABI of include/ins_hip.h.  No KernelAbstractions kernels run.
+module INSHip
+
+using IncompressibleNavierStokes
+using AMDGPU: ROCArray, ROCBackend, HIP
+import IncompressibleNavierStokes:
+    apply_bc_u!, apply_bc_p!, divergence!, scalewithvolume!, pressuregradient!, applypressure!, laplacian!,
+    convection!, diffusion!, convectiondiffusion!, momentum!, project!, poisson!, psolver_spectral, psolver_cg,
+    timestep!, ode_method_cache, ExplicitRungeKuttaMethod, PeriodicBC, DirichletBC, SymmetricBC, PressureBC
+
+const lib = get(ENV, "INSHIP_LIB", "libinship.so")
+
+# ins_grid_desc_t (include/ins_hip.h) — field order and types must match the C struct exactly.
+struct GridDesc
+    D::Int32
+    N::NTuple{3,Int32}
+    dx::NTuple{3,Ptr{Float64}}
+    dxu::NTuple{3,Ptr{Float64}}
+    A1::NTuple{9,Ptr{Float64}}     # [α][β] row-major
+    A2::NTuple{9,Ptr{Float64}}
+    iu_lo::NTuple{9,Int32}
+    iu_hi::NTuple{9,Int32}
+    ip_lo::NTuple{3,Int32}
+    ip_hi::NTuple{3,Int32}
+    bc::NTuple{6,Int32}            # [β][side]
+    bc_u::NTuple{18,Float64}       # [β][side][α]
+end
+
+check(rc) = rc == 0 || error("libinship: ", unsafe_string(ccall((:ins_last_error, lib), Cstring, ())))
+stream() = Ptr{Cvoid}(HIP.stream().stream)   # the task-local HIP stream AMDGPU.jl is using
+bccode(::PeriodicBC) = Int32(0); bccode(::DirichletBC) = Int32(1); bccode(::SymmetricBC) = Int32(2); bccode(::PressureBC) = Int32(3)
+
+"Device handle for `setup.grid`, built once per setup from the HOST copies of the 1-D metric vectors (grid.jl:177-248)."
+function grid_handle(setup)
+    g = setup.grid
+    D = g.dimension()
+    host(v) = Array(v)                                   # metrics are tiny; the library keeps its own device copy
+    Δ, Δu = host.(g.Δ), host.(g.Δu)
+    A = [(host(g.A[α][β][1]), host(g.A[α][β][2])) for α = 1:D, β = 1:D]
+    pad3(f, T) = ntuple(i -> i <= D ? f(i) : zero(T), 3)
+    ptr3(v) = ntuple(i -> i <= D ? pointer(v[i]) : Ptr{Float64}(0), 3)
+    idx9(f, T) = ntuple(k -> (α = (k - 1) ÷ 3 + 1; β = (k - 1) % 3 + 1; α <= D && β <= D ? f(α, β) : zero(T)), 9)
+    desc = GridDesc(
+        D, pad3(i -> Int32(g.N[i]), Int32), ptr3(Δ), ptr3(Δu),
+        idx9((α, β) -> pointer(A[α, β][1]), Ptr{Float64}), idx9((α, β) -> pointer(A[α, β][2]), Ptr{Float64}),
+        idx9((α, β) -> Int32(first(g.Iu[α].indices[β]) - 1), Int32),    # Julia a:b -> [a-1, b)
+        idx9((α, β) -> Int32(last(g.Iu[α].indices[β])), Int32),
+        pad3(i -> Int32(first(g.Ip.indices[i]) - 1), Int32), pad3(i -> Int32(last(g.Ip.indices[i])), Int32),
+        ntuple(k -> (β = (k - 1) ÷ 2 + 1; s = (k - 1) % 2 + 1; β <= D ? bccode(setup.boundary_conditions[β][s]) : Int32(0)), 6),
+        ntuple(_ -> 0.0, 18),   # constant Dirichlet data: fill from bc.u::Tuple as [β][side][α]
+    )
+    h = Ref{Ptr{Cvoid}}()
+    GC.@preserve Δ Δu A check(ccall((:ins_grid_create, lib), Cint, (Ref{GridDesc}, Ref{Ptr{Cvoid}}), desc, h))
+    h[]
+end
+
+# One cached handle per setup (setup is an immutable NamedTuple: key on objectid of its grid).
+const HANDLES = Dict{UInt,Ptr{Cvoid}}()
+handle(setup) = get!(() -> grid_handle(setup), HANDLES, objectid(setup.grid))
+iship(setup) = setup.backend isa ROCBackend && setup.grid.x[1] isa ROCArray{Float64}
+
+# ---- operators (operators.jl) -------------------------------------------------------------------------------
+function divergence!(div::ROCArray{Float64}, u::ROCArray{Float64}, setup)
+    check(ccall((:ins_divergence_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                handle(setup), pointer(u), pointer(div), stream()))
+    div
+end
+function momentum!(F::ROCArray{Float64}, u::ROCArray{Float64}, temp::Nothing, t, setup)
+    isnothing(setup.bodyforce) || error("bodyforce is outside the HIP hot path")
+    check(ccall((:ins_momentum_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                handle(setup), 1 / setup.Re, pointer(u), pointer(F), stream()))
+    F
+end
+function applypressure!(u::ROCArray{Float64}, p::ROCArray{Float64}, setup)
+    check(ccall((:ins_applypressure_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                handle(setup), pointer(u), pointer(p), stream()))
+    u
+end
+function apply_bc_u!(u::ROCArray{Float64}, t, setup; dudt = false, kwargs...)
+    # closures bc.u(α, x..., t) are evaluated into plane buffers on the host side (see INTEGRATION.md); constants go through the descriptor
+    check(ccall((:ins_apply_bc_u_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint, Ptr{Ptr{Float64}}, Ptr{Cvoid}),
+                handle(setup), pointer(u), dudt, C_NULL, stream()))
+    u
+end
+# scalewithvolume!, pressuregradient!, laplacian!, convection!, diffusion!, convectiondiffusion!, apply_bc_p!
+# follow the same three-line pattern with ins_<name>_f64.
+
+# ---- pressure solvers (pressure.jl) --------------------------------------------------------------------------
+struct HipPSolver
+    h::Ptr{Cvoid}
+    setup::Any
+end
+function psolver_spectral(setup, ::Val{:hip})
+    h = Ref{Ptr{Cvoid}}()
+    check(ccall((:ins_poisson_spectral_create, lib), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), handle(setup), h))
+    HipPSolver(h[], setup)
+end
+(s::HipPSolver)(p::ROCArray{Float64}) =
+    (check(ccall((:ins_poisson_solve_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Cvoid}), s.h, pointer(p), stream())); p)
+function project!(u::ROCArray{Float64}, setup; psolver::HipPSolver, p::ROCArray{Float64})
+    check(ccall((:ins_project_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                handle(setup), psolver.h, pointer(u), pointer(p), stream()))
+    u
+end
+
+# ---- explicit RK (step_explicit_runge_kutta.jl) -----------------------------------------------------------------
+struct HipRKCache
+    h::Ptr{Cvoid}
+end
+function ode_method_cache(method::ExplicitRungeKuttaMethod, setup, psolver::HipPSolver)
+    ns = length(method.b)
+    A = collect(transpose(method.A))        # row-major for C; method.A is already the SHIFTED tableau (methods.jl:231-236)
+    h = Ref{Ptr{Cvoid}}()
+    check(ccall((:ins_rk_create, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Ref{Ptr{Cvoid}}),
+                handle(setup), psolver.h, ns, A, method.c, h))
+    HipRKCache(h[])
+end
+function timestep!(method::ExplicitRungeKuttaMethod, stepper, Δt; θ = nothing, cache::HipRKCache)
+    (; setup, psolver, u, temp, t, n) = stepper
+    # The fused native step is valid only without closure model / temperature / unsteady body force (SURVEY.md §8b caveat);
+    # otherwise fall back to the operator-level methods above so user callbacks can run between kernels.
+    (isnothing(setup.closure_model) && isnothing(temp) && isnothing(setup.bodyforce)) ||
+        return invoke(timestep!, Tuple{ExplicitRungeKuttaMethod,Any,Any}, method, stepper, Δt; θ, cache)
+    check(ccall((:ins_rk_step_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Cdouble, Cdouble, Ptr{Ptr{Float64}}, Ptr{Cvoid}),
+                cache.h, 1 / setup.Re, pointer(u), t, Δt, C_NULL, stream()))
+    IncompressibleNavierStokes.create_stepper(method; setup, psolver, u, temp, t = t + method.c[end] * Δt, n = n + 1)
+end
+
+end # module
