@@ -288,9 +288,13 @@ __global__ __launch_bounds__(256) void k_zero_shell(GridDev g, double* __restric
 }  // namespace
 
 // Defaults (0 = pick per grid, see below); measured on MI355X, profiles/r01_k1_scan.txt.
-static int g_rows = 0;
-static int g_zchunk = 0;
-static int g_xw = 0;
+static int env_int(const char* name) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+}
+static int g_rows = env_int("INS_FLUX_ROWS");
+static int g_zchunk = env_int("INS_FLUX_ZC");
+static int g_xw = env_int("INS_FLUX_XW");
 
 // Tuning knobs for experiments (not part of the public ABI).
 extern "C" void ins_tune_flux3d(int rows, int zchunk, int xw) {

@@ -1,0 +1,163 @@
+// Plan self-check.  rocFFT in ROCm 7.2 (gfx950) can return WRONG real transforms depending on which plans
+// were created earlier in the process (reproducer: tools/dbg_hipfft.cpp — with a 32x32 batched D2Z/Z2D pair alive,
+// a new 16x64 D2Z plan is off by O(1)); a round trip does not reveal it because real pre/post-processing with a
+// wrong twiddle table is still self-inverse.  Every spectral solver therefore validates its freshly created real
+// plans once: a few output bins of two batches are compared with a direct DFT evaluated on the host, and the
+// inverse plan is validated through a round trip of the (now trusted) forward plan.
+#include <cmath>
+#include <complex>
+
+#include <rocfft/rocfft.h>
+
+#include <atomic>
+
+#include "ins_internal.h"
+
+// fwd: D2Z plan over `rank` dims n[0..rank-1] (slowest first), batch `batch`, contiguous default layout.
+int ins_validate_real_plans(hipfftHandle fwd, hipfftHandle inv, int rank, const int* n, int batch) {
+  long long nreal = 1, ncplx = 1;
+  for (int d = 0; d < rank; ++d) {
+    nreal *= n[d];
+    ncplx *= (d == rank - 1) ? n[d] / 2 + 1 : n[d];
+  }
+  const int kxn = n[rank - 1] / 2 + 1;
+  std::vector<double> in((size_t)nreal * batch);
+  unsigned s = 2463534242u;
+  for (auto& v : in) {
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    v = (double)(s >> 8) / (1 << 24) - 0.5;
+  }
+  double *din = nullptr, *dback = nullptr;
+  hipfftDoubleComplex* dout = nullptr;
+  struct Guard {
+    double*& a;
+    double*& b;
+    hipfftDoubleComplex*& c;
+    ~Guard() {
+      if (a) (void)hipFree(a);
+      if (b) (void)hipFree(b);
+      if (c) (void)hipFree(c);
+    }
+  } guard{din, dback, dout};
+  INS_HIP_TRY(hipMalloc(&din, in.size() * sizeof(double)));
+  INS_HIP_TRY(hipMalloc(&dback, in.size() * sizeof(double)));
+  INS_HIP_TRY(hipMalloc(&dout, (size_t)ncplx * batch * sizeof(hipfftDoubleComplex)));
+  INS_HIP_TRY(hipMemcpy(din, in.data(), in.size() * sizeof(double), hipMemcpyHostToDevice));
+  INS_FFT_TRY(hipfftSetStream(fwd, nullptr));
+  INS_FFT_TRY(hipfftSetStream(inv, nullptr));
+  INS_FFT_TRY(hipfftExecD2Z(fwd, din, dout));
+  INS_HIP_TRY(hipDeviceSynchronize());
+  std::vector<std::complex<double>> out((size_t)ncplx * batch);
+  INS_HIP_TRY(hipMemcpy(out.data(), dout, out.size() * sizeof(hipfftDoubleComplex), hipMemcpyDeviceToHost));
+  // direct DFT of a handful of bins in the first and the last batch
+  double worst = 0.0, scale = 0.0;
+  const int nb = batch > 1 ? 2 : 1;
+  for (int bi = 0; bi < nb; ++bi) {
+    const int b = bi == 0 ? 0 : batch - 1;
+    const double* x = in.data() + (size_t)b * nreal;
+    for (int probe = 0; probe < 6; ++probe) {
+      int k[3] = {0, 0, 0}, nn[3] = {1, 1, 1};
+      for (int d = 0; d < rank; ++d) nn[3 - rank + d] = n[d];
+      // probes spread over the spectrum, including the last kx bin
+      k[2] = (probe * 7 + 1) % kxn;
+      if (probe == 5) k[2] = kxn - 1;
+      k[1] = (probe * 5 + 2) % nn[1];
+      k[0] = (probe * 3 + 1) % nn[0];
+      std::complex<double> acc = 0.0;
+      for (int a = 0; a < nn[0]; ++a)
+        for (int c = 0; c < nn[1]; ++c) {
+          const double ph0 = (double)k[0] * a / nn[0] + (double)k[1] * c / nn[1];
+          std::complex<double> row = 0.0;
+          const double* xr = x + ((size_t)a * nn[1] + c) * nn[2];
+          for (int e = 0; e < nn[2]; ++e) {
+            const double ph = -2.0 * M_PI * ((double)k[2] * e / nn[2]);
+            row += xr[e] * std::complex<double>(std::cos(ph), std::sin(ph));
+          }
+          const double p0 = -2.0 * M_PI * ph0;
+          acc += row * std::complex<double>(std::cos(p0), std::sin(p0));
+        }
+      const size_t idx = (size_t)b * ncplx + ((size_t)k[0] * nn[1] + k[1]) * kxn + k[2];
+      worst = std::fmax(worst, std::abs(acc - out[idx]));
+      scale = std::fmax(scale, std::abs(acc));
+    }
+  }
+  if (!(worst <= 1e-9 * std::fmax(scale, 1.0))) {
+    ins_set_error("rocFFT returned a wrong D2Z transform for lengths [%d x %d x %d] batch %d (error %.3e of %.3e): known ROCm 7.2 "
+                  "plan-cache bug when real plans of other sizes are alive in the process (tools/dbg_hipfft.cpp); destroy the other "
+                  "solvers first",
+                  rank > 2 ? n[rank - 3] : 1, rank > 1 ? n[rank - 2] : 1, n[rank - 1], batch, worst, scale);
+    return INS_ERR_FFT;
+  }
+  // inverse through the round trip
+  INS_FFT_TRY(hipfftExecZ2D(inv, dout, dback));
+  INS_HIP_TRY(hipDeviceSynchronize());
+  std::vector<double> back(in.size());
+  INS_HIP_TRY(hipMemcpy(back.data(), dback, back.size() * sizeof(double), hipMemcpyDeviceToHost));
+  double err = 0.0;
+  for (size_t i = 0; i < in.size(); i += 97) err = std::fmax(err, std::fabs(back[i] / (double)nreal - in[i]));
+  if (!(err <= 1e-10)) {
+    ins_set_error("rocFFT Z2D plan failed its round-trip check (error %.3e)", err);
+    return INS_ERR_FFT;
+  }
+  return INS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Plan factory used by every spectral solver: create the D2Z / Z2D pair, validate it, and if validation fails
+// while no other solver of this library holds rocFFT plans, reset rocFFT's process-wide caches
+// (rocfft_cleanup + rocfft_setup) and try once more.  With other solvers alive the reset would invalidate their
+// plans, so the error is returned instead (message says what to do).
+// ------------------------------------------------------------------------------------------------------------
+static std::atomic<int> g_live_fft_solvers{0};
+
+void ins_fft_solver_released() { g_live_fft_solvers.fetch_sub(1); }
+
+static hipfftResult make_pair(hipfftHandle* fwd, hipfftHandle* inv, int rank, int* n, int batch) {
+  hipfftResult r1, r2;
+  if (batch > 1 || rank == 1) {
+    r1 = hipfftPlanMany(fwd, rank, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, batch);
+    if (r1 != HIPFFT_SUCCESS) return r1;
+    r2 = hipfftPlanMany(inv, rank, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, batch);
+  } else if (rank == 2) {
+    r1 = hipfftPlan2d(fwd, n[0], n[1], HIPFFT_D2Z);
+    if (r1 != HIPFFT_SUCCESS) return r1;
+    r2 = hipfftPlan2d(inv, n[0], n[1], HIPFFT_Z2D);
+  } else {
+    r1 = hipfftPlan3d(fwd, n[0], n[1], n[2], HIPFFT_D2Z);
+    if (r1 != HIPFFT_SUCCESS) return r1;
+    r2 = hipfftPlan3d(inv, n[0], n[1], n[2], HIPFFT_Z2D);
+  }
+  if (r2 != HIPFFT_SUCCESS) (void)hipfftDestroy(*fwd);
+  return r2;
+}
+
+int ins_fft_make_real_plans(hipfftHandle* fwd, hipfftHandle* inv, int rank, int* n, int batch) {
+  hipfftResult r = make_pair(fwd, inv, rank, n, batch);
+  if (r != HIPFFT_SUCCESS) {
+    ins_set_error("hipfftPlan (rank %d, batch %d) failed: %d", rank, batch, (int)r);
+    return INS_ERR_FFT;
+  }
+  int rc = ins_validate_real_plans(*fwd, *inv, rank, n, batch);
+  if (rc == INS_ERR_FFT && g_live_fft_solvers.load() == 0) {
+    (void)hipfftDestroy(*fwd);
+    (void)hipfftDestroy(*inv);
+    (void)hipDeviceSynchronize();
+    rocfft_cleanup();
+    rocfft_setup();
+    r = make_pair(fwd, inv, rank, n, batch);
+    if (r != HIPFFT_SUCCESS) {
+      ins_set_error("hipfftPlan (rank %d, batch %d) failed after rocFFT reset: %d", rank, batch, (int)r);
+      return INS_ERR_FFT;
+    }
+    rc = ins_validate_real_plans(*fwd, *inv, rank, n, batch);
+  }
+  if (rc) {
+    (void)hipfftDestroy(*fwd);
+    (void)hipfftDestroy(*inv);
+    return rc;
+  }
+  g_live_fft_solvers.fetch_add(1);
+  return INS_OK;
+}

@@ -109,6 +109,8 @@ struct ins_poisson {
   void* work = nullptr;
   size_t work_bytes = 0;
   hipStream_t plan_stream = nullptr;
+  bool zfused = false;      // 3-D: batched 2-D (x,y) plans + the fused z kernel (ins_zsolve.hip)
+  double* tw = nullptr;     // z twiddles
   // cg
   double abstol = 0, reltol = 0;
   long long maxiter = 0;
@@ -163,6 +165,14 @@ int ins_k_poisson_solve(ins_poisson* ps, double* p, hipStream_t s);
 // blocking reductions over an index box of a scalar field; op: 0 sum(a*b), 1 max|a|, 2 min(a)
 int ins_k_reduce(const ins_grid* grid, int op, const double* a, const double* b, const int lo[3], const int hi[3], double* out,
                  hipStream_t s);
+
+int ins_validate_real_plans(hipfftHandle fwd, hipfftHandle inv, int rank, const int* n, int batch);
+int ins_fft_make_real_plans(hipfftHandle* fwd, hipfftHandle* inv, int rank, int* n, int batch);
+void ins_fft_solver_released();
+bool ins_zsolve_supported(int nz);
+int ins_zsolve_twiddles(int nz, double** out);
+int ins_k_zsolve(double* data, int nz, long long nl, const double* ax, int kxn, const double* ay, const double* az, const double* tw,
+                 double inv_n, bool zero_mean, hipStream_t s);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }

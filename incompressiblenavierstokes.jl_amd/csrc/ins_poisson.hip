@@ -350,20 +350,17 @@ extern "C" int ins_poisson_spectral_create(const ins_grid_t* G, ins_poisson_t** 
     }
   }
   // plan_rfft(pI): all D dims, real -> half-complex along x (pressure.jl:316).  hipFFT takes lengths slowest first.
-  hipfftResult r1, r2;
-  if (D == 2) {
-    r1 = hipfftPlan2d(&ps->plan_fwd, ps->np[1], ps->np[0], HIPFFT_D2Z);
-    r2 = hipfftPlan2d(&ps->plan_inv, ps->np[1], ps->np[0], HIPFFT_Z2D);
-  } else {
-    r1 = hipfftPlan3d(&ps->plan_fwd, ps->np[2], ps->np[1], ps->np[0], HIPFFT_D2Z);
-    r2 = hipfftPlan3d(&ps->plan_inv, ps->np[2], ps->np[1], ps->np[0], HIPFFT_Z2D);
+  // plan_rfft(pI): all D dims, real -> half-complex along x (pressure.jl:316); hipFFT takes lengths slowest first.
+  // 3-D with a power-of-two nz: batched 2-D (x,y) plans + ONE fused z kernel (FFT · symbol · inverse FFT) = 5 passes.
+  {
+    int nfull[3] = {ps->np[2], ps->np[1], ps->np[0]};
+    ps->zfused = D == 3 && ins_zsolve_supported(ps->np[2]);
+    rc = ps->zfused ? ins_fft_make_real_plans(&ps->plan_fwd, &ps->plan_inv, 2, nfull + 1, ps->np[2])
+                    : ins_fft_make_real_plans(&ps->plan_fwd, &ps->plan_inv, D, nfull + (3 - D), 1);
+    if (rc) return fail(rc);
+    ps->plans = true;
+    if (ps->zfused && (rc = ins_zsolve_twiddles(ps->np[2], &ps->tw))) return fail(rc);
   }
-  if (r1 != HIPFFT_SUCCESS || r2 != HIPFFT_SUCCESS) {
-    ins_set_error("hipfftPlan%dd failed (%d, %d)", D, (int)r1, (int)r2);
-    return fail(INS_ERR_FFT);
-  }
-  ps->plans = true;
-  (void)rc;
   *out = ps;
   return INS_OK;
 }
@@ -375,6 +372,13 @@ static int spectral_transform(ins_poisson* ps, hipStream_t s) {
   INS_FFT_TRY(hipfftExecD2Z(ps->plan_fwd, ps->pI, ps->phat));
   double inv_n = 1.0;
   for (int a = 0; a < g.D; ++a) inv_n /= ps->np[a];
+  if (ps->zfused) {
+    int rc = ins_k_zsolve(reinterpret_cast<double*>(ps->phat), ps->np[2], (long long)ps->kmax[0] * ps->kmax[1], ps->ahat[0], ps->kmax[0],
+                          ps->ahat[1], ps->ahat[2], ps->tw, inv_n, true, s);
+    if (rc) return rc;
+    INS_FFT_TRY(hipfftExecZ2D(ps->plan_inv, ps->phat, ps->pI));
+    return INS_OK;
+  }
   dim3 block(64, 4, 1), grid(cdiv(ps->kmax[0], 64), cdiv(ps->kmax[1], 4), g.D == 3 ? ps->kmax[2] : 1);
   if (g.D == 2)
     hipLaunchKernelGGL(k_symbol<2>, grid, block, 0, s, ps->phat, ps->ahat[0], ps->ahat[1], (const double*)nullptr, ps->kmax[0],
@@ -531,7 +535,9 @@ extern "C" int ins_poisson_destroy(ins_poisson_t* ps) {
   if (ps->plans) {
     (void)hipfftDestroy(ps->plan_fwd);
     (void)hipfftDestroy(ps->plan_inv);
+    ins_fft_solver_released();
   }
+  if (ps->tw) (void)hipFree(ps->tw);
   if (ps->pI) (void)hipFree(ps->pI);
   if (ps->phat) (void)hipFree(ps->phat);
   for (int a = 0; a < 3; ++a)

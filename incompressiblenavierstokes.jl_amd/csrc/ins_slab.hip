@@ -18,8 +18,9 @@ struct ins_slab_fft {
   int rank, nranks;
   int nzl, nyl, kxn; // local planes, local rows (transposed layout), nx/2+1
   hipfftHandle xy_fwd = 0, xy_inv = 0, z_fwd = 0;
-  bool plans = false;
+  bool plans = false, has_z_plan = false;
   double *ax = nullptr, *ay = nullptr, *az = nullptr;  // symbol vectors (ay: this rank's ky range)
+  double* tw = nullptr;                                 // twiddles of the fused z kernel (power-of-two nz)
 };
 
 namespace {
@@ -154,15 +155,31 @@ extern "C" int ins_slab_fft_create(const int32_t np[3], const double h[3], int r
   int n2[2] = {np[1], np[0]};
   int nz1[1] = {np[2]};
   const int lines = S->nyl * S->kxn;
-  hipfftResult r1 = hipfftPlanMany(&S->xy_fwd, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, S->nzl);
-  hipfftResult r2 = hipfftPlanMany(&S->xy_inv, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, S->nzl);
-  hipfftResult r3 = hipfftPlanMany(&S->z_fwd, 1, nz1, nz1, lines, 1, nz1, lines, 1, HIPFFT_Z2Z, lines);
-  if (r1 != HIPFFT_SUCCESS || r2 != HIPFFT_SUCCESS || r3 != HIPFFT_SUCCESS) {
-    ins_set_error("ins_slab_fft_create: hipfftPlanMany failed (%d, %d, %d)", (int)r1, (int)r2, (int)r3);
-    ins_slab_fft_destroy(S);
-    return INS_ERR_FFT;
+  const bool zfused = ins_zsolve_supported(np[2]);  // then no rocFFT z plan is needed at all
+  {
+    int rcv = ins_fft_make_real_plans(&S->xy_fwd, &S->xy_inv, 2, n2, S->nzl);  // validated (ins_fftcheck.hip)
+    if (rcv) {
+      ins_slab_fft_destroy(S);
+      return rcv;
+    }
+    S->plans = true;
   }
-  S->plans = true;
+  if (!zfused) {
+    hipfftResult r3 = hipfftPlanMany(&S->z_fwd, 1, nz1, nz1, lines, 1, nz1, lines, 1, HIPFFT_Z2Z, lines);
+    if (r3 != HIPFFT_SUCCESS) {
+      ins_set_error("ins_slab_fft_create: hipfftPlanMany(z) failed (%d)", (int)r3);
+      ins_slab_fft_destroy(S);
+      return INS_ERR_FFT;
+    }
+    S->has_z_plan = true;
+  }
+  if (zfused) {
+    int rc = ins_zsolve_twiddles(np[2], &S->tw);
+    if (rc) {
+      ins_slab_fft_destroy(S);
+      return rc;
+    }
+  }
   *out = S;
   return INS_OK;
 }
@@ -172,8 +189,10 @@ extern "C" int ins_slab_fft_destroy(ins_slab_fft_t* S) {
   if (S->plans) {
     (void)hipfftDestroy(S->xy_fwd);
     (void)hipfftDestroy(S->xy_inv);
-    (void)hipfftDestroy(S->z_fwd);
+    if (S->has_z_plan) (void)hipfftDestroy(S->z_fwd);
+    ins_fft_solver_released();
   }
+  if (S->tw) (void)hipFree(S->tw);
   if (S->ax) (void)hipFree(S->ax);
   if (S->ay) (void)hipFree(S->ay);
   if (S->az) (void)hipFree(S->az);
@@ -203,6 +222,9 @@ extern "C" int ins_slab_fft_forward_xy(ins_slab_fft_t* S, double* pI, double* wo
 extern "C" int ins_slab_fft_solve_z(ins_slab_fft_t* S, double* buf, void* stream) {
   INS_REQUIRE(S && buf, "null argument");
   hipStream_t s = as_stream(stream);
+  if (S->tw)  // one fused pass instead of z-FFT + symbol + inverse z-FFT
+    return ins_k_zsolve(buf, S->np[2], (long long)S->nyl * S->kxn, S->ax, S->kxn, S->ay, S->az, S->tw,
+                        1.0 / ((double)S->np[0] * S->np[1] * S->np[2]), S->rank == 0, s);
   hipfftDoubleComplex* c = reinterpret_cast<hipfftDoubleComplex*>(buf);
   INS_FFT_TRY(hipfftSetStream(S->z_fwd, s));
   INS_FFT_TRY(hipfftExecZ2Z(S->z_fwd, c, c, HIPFFT_FORWARD));

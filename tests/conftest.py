@@ -26,3 +26,14 @@ def oracle():
     from oracle import ins_oracle
 
     return ins_oracle
+
+
+@pytest.fixture(autouse=True)
+def _collect_between_tests():
+    """Destroy solver handles promptly: rocFFT (ROCm 7.2) corrupts a real plan created while another live plan
+    has the same nx*ny but a different shape (tools/dbg_hipfft2.cpp); libinship detects that at plan creation
+    (csrc/ins_fftcheck.hip) and raises, so tests must not leave solvers of earlier tests alive."""
+    yield
+    import gc
+
+    gc.collect()

@@ -33,13 +33,18 @@ def test_one_rank_slab_equals_single_gpu_path(oracle, n):
     sp = ins.Setup(x=x, Re=800.0)
     ps = ins.psolver_spectral(sp)
     (uref, _, _), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 0.02), ustart=ins.from_numpy(sp, u0), psolver=ps, Δt=0.01)
+    uref = ins.to_numpy(uref)
+    del ps, sp  # keep one solver's rocFFT plans alive at a time (ROCm 7.2 plan-cache bug, csrc/ins_fftcheck.hip)
+    import gc
+
+    gc.collect()
     lay = ins.SlabLayout(n, 1, 0)
     K = ins.HipSlabKernels(lay, Re=800.0)
     st = ins.SlabStepper(ins.RKMethods.RK44(), lay, K, ins.SlabComm())
     u = K.from_global(u0)
     for _ in range(2):
         st.step_(u, 0.01)
-    assert rell2(ins.to_numpy(u), ins.to_numpy(uref)) < 1e-12
+    assert rell2(ins.to_numpy(u), uref) < 1e-12
     assert st.max_abs_divergence(u) < 1e-10
 
 
