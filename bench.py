@@ -5,9 +5,12 @@
   python bench.py --gpus 1 --steps K --warmup W          (N = 1: TGV3D 256^3 = BASELINE configs[1])
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (z-slab decomposition)
 
-Prints ONE JSON line on rank 0.  `roofline` is the fused momentum-RHS stencil (48 algorithmic B/cell,
-SURVEY.md §8d) timed live with HIP events on the step's stream; `cpu_baseline` is the CPU oracle (a numpy
-restatement, NOT Julia) timed on a bounded sample on this host.
+Prints ONE JSON line on rank 0.  `roofline` is the dominant kernel of the step — the momentum-RHS stencil with the
+RK stage combination fused behind it (K1+K6) — timed live with HIP events recorded on the step's own
+stream inside the timed region; its algorithmic bytes per launch are the compulsory reads/writes of each RK stage
+(RK44: 72/96/96/144 B per cell).  `roofline_k1` is the plain momentum-RHS stencil (48 B/cell) timed
+after the run on the final state.  `cpu_baseline` is the CPU oracle (a numpy restatement, NOT Julia) timed on a
+bounded sample on this host.
 """
 import argparse
 import json
@@ -34,32 +37,36 @@ def tgv3d(al, x, y, z):
     return 0 * (x + y + z)
 
 
-def cpu_baseline(budget_s=20.0):
-    """Time the CPU oracle (numpy port of the reference's pass structure) on TGV3D at a size that fits
-    the time budget; returns the dict for the JSON line."""
+def cpu_baseline(budget_s=15.0):
+    """Time the CPU restatement (oracle/c: C + OpenMP stencil passes in the reference's unfused pass structure, scipy
+    pocketfft for the FFTs; NOT Julia) on a bounded TGV3D sample on this host's cores."""
     from oracle import ins_oracle as o
+    from oracle.c_port import CPort
 
-    n = 64
+    n = 128
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     x = (np.linspace(0.0, 1.0, n + 1),) * 3
     so = o.make_setup(x, Re=1000.0)
     ps = o.psolver_spectral(so)
-    u = o.velocityfield(so, o.tgv3d_ufunc, 0.0, psolver=ps)
+    u = np.asfortranarray(o.velocityfield(so, o.tgv3d_ufunc, 0.0, psolver=ps))
     m = o.RK44()
     cache = o.ode_method_cache(m, so)
-    st = dict(setup=so, psolver=ps, u=u, t=0.0, n=0)
-    st = o.timestep_(m, st, 1e-3, cache)  # warm-up
+    port = CPort(so, workers=cores)
+    port.timestep_(m, u, 1e-3, cache)  # warm-up
     t0 = time.perf_counter()
     steps = 0
-    while time.perf_counter() - t0 < budget_s and steps < 50:
-        st = o.timestep_(m, st, 1e-3, cache)
+    while time.perf_counter() - t0 < budget_s and steps < 200:
+        port.timestep_(m, u, 1e-3, cache)
         steps += 1
     dt = time.perf_counter() - t0
     return {
         "value": n**3 * steps / dt / 1e6,
         "unit": "M cell-updates/s",
-        "cores": 1,
+        "cores": cores,
         "kind": "port",
-        "sample": f"numpy CPU restatement (not Julia), TGV3D {n}^3 fp64, {steps} RK4 steps in {dt:.1f} s on 1 core",
+        "sample": f"C+OpenMP CPU restatement (not Julia; reference's unfused pass structure, pocketfft), TGV3D {n}^3 fp64, "
+                  f"{steps} RK4 steps in {dt:.1f} s on {cores} threads",
     }
 
 
@@ -117,7 +124,36 @@ def main():
     cells = float(n) ** 3
     value = cells / (ms_per_step * 1e-3) / 1e6
     k1_avg_ms = k1_ms.value / max(k1_n.value, 1)
-    k1_gbs = K1_BYTES_PER_CELL * cells / (k1_avg_ms * 1e-3) / 1e9
+    # compulsory bytes per cell of the fused stage kernel: R u_in + (R ustart, not for stage 1) + R k_j (non-zero a_ij)
+    # + W u* + (W k_i when a later stage needs it)                       step_explicit_runge_kutta.jl:35-38
+    A = method.A
+    ns = len(method.b)
+    stage_bytes = []
+    for i in range(ns):
+        nk = sum(1 for j in range(i) if A[i, j] != 0.0)
+        wk = any(A[i2, i] != 0.0 for i2 in range(i + 1, ns))
+        stage_bytes.append(24 * (1 + (1 if i > 0 else 0) + nk + 1 + (1 if wk else 0)))
+    fused_bytes_per_cell = float(np.mean(stage_bytes))
+    k1_gbs = fused_bytes_per_cell * cells / (k1_avg_ms * 1e-3) / 1e9
+    # plain K1 (momentum! only), 48 B/cell, on the final state
+    F = ins.vectorfield(setup)
+    for _ in range(3):
+        ins.momentum_(F, stepper.u, None, 0.0, setup)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(20):
+        ins.momentum_(F, stepper.u, None, 0.0, setup)
+    ev1.record()
+    torch.cuda.synchronize()
+    k1_plain_ms = ev0.elapsed_time(ev1) / 20
+    k1_plain_gbs = K1_BYTES_PER_CELL * cells / (k1_plain_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
+    if n == 256 and os.path.exists(tfile):  # PMC counters cannot be read in-process: committed rocprofv3 --pmc result
+        try:
+            traffic = json.load(open(tfile))["per_kernel"]["k_momentum_flux(K1+K6)"]["hbm_total_GB"] * 1e9
+        except Exception:
+            traffic = None
     div = ins.max_abs_divergence(stepper.u, setup)
     energy = ins.total_kinetic_energy(stepper.u, setup)
     assert np.isfinite(energy) and div / n < 1e-10, f"bench state is not a valid flow: div={div}, E={energy}"
@@ -138,16 +174,28 @@ def main():
         "config": {"workload": f"TaylorGreenVortex3D {n}^3 periodic fp64, RK44 + spectral Poisson, dt=1e-3, Re=1e3",
                    "grid": [n, n, n], "decomposition": "single GPU"},
         "roofline": {
-            "kernel": "momentum-RHS stencil (convection+diffusion, fill fused)",
+            "kernel": "k_momentum_flux FUSE (K1+K6: momentum-RHS stencil + RK stage combination)",
             "bound": "hbm",
             "achieved": k1_gbs,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": k1_gbs / HBM_PEAK_GBS,
-            "traffic": None,
-            "bytes_per_cell": K1_BYTES_PER_CELL,
+            "traffic": traffic,
+            "traffic_note": "B per launch, HBM FETCH(x2 gfx950)+WRITE from rocprofv3 --pmc, profiles/r01b_pmc_traffic.json",
+            "bytes_per_cell": fused_bytes_per_cell,
+            "bytes_per_cell_by_stage": stage_bytes,
             "avg_launch_ms": k1_avg_ms,
             "launches": k1_n.value,
+        },
+        "roofline_k1": {
+            "kernel": "k_momentum_flux (K1: momentum-RHS stencil alone, ins_momentum_f64)",
+            "bound": "hbm",
+            "achieved": k1_plain_gbs,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": k1_plain_gbs / HBM_PEAK_GBS,
+            "bytes_per_cell": K1_BYTES_PER_CELL,
+            "avg_launch_ms": k1_plain_ms,
         },
         "step_bandwidth": {"design_bytes_per_cell": 1104, "achieved_GBs": 1104 * cells / (ms_per_step * 1e-3) / 1e9},
         "check": {"max_abs_div_times_dx": div / n, "kinetic_energy": energy},

@@ -253,3 +253,25 @@ def test_cfl_timestep(oracle):
     u[..., 0] = 2.0
     dt = o.get_cfl_timestep(u, s)
     assert dt == pytest.approx(min(s.Re * (1 / 16) ** 2 / 2, (1 / 16) / 2.0))
+
+
+def test_c_port_matches_numpy_oracle(oracle):
+    """The C/OpenMP restatement (oracle/c, bench.py's CPU baseline) against the numpy oracle: 2 RK44 steps."""
+    import subprocess, os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle", "c")], stdout=subprocess.DEVNULL)
+    from oracle.c_port import CPort
+
+    o = oracle
+    s = fx.setup_periodic(o, (12, 10, 14), D=3, Re=300.0)
+    ps = o.psolver_spectral(s)
+    u0 = o.random_field(s, kp=2, seed=4, psolver=ps)
+    st = o.solve_unsteady(s, (0.0, 0.02), u0, psolver=ps, dt=0.01)
+    port = CPort(s, workers=2)
+    m = o.RK44()
+    cache = o.ode_method_cache(m, s)
+    u = np.asfortranarray(u0.copy())
+    for _ in range(2):
+        port.timestep_(m, u, 0.01, cache)
+    assert np.allclose(u, st["u"], rtol=1e-12, atol=1e-14)
