@@ -37,6 +37,19 @@ def tgv3d(al, x, y, z):
     return 0 * (x + y + z)
 
 
+def host_cores():
+    """Threads this process may really use: cgroup CPU quota if set (a 1-GPU box gets a 16-CPU share of a big host),
+    else the affinity mask, capped at 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(budget_s=15.0):
     """Time the CPU restatement (oracle/c: C + OpenMP stencil passes in the reference's unfused pass structure, scipy
     pocketfft for the FFTs; NOT Julia) on a bounded TGV3D sample on this host's cores."""
@@ -44,8 +57,8 @@ def cpu_baseline(budget_s=15.0):
     from oracle.c_port import CPort
 
     n = 128
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = host_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     x = (np.linspace(0.0, 1.0, n + 1),) * 3
     so = o.make_setup(x, Re=1000.0)
     ps = o.psolver_spectral(so)
