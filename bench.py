@@ -8,7 +8,7 @@
 Prints ONE JSON line on rank 0.  `roofline` is the dominant kernel of the step — the momentum-RHS stencil with the
 RK stage combination fused behind it (K1+K6) — timed live with HIP events recorded on the step's own
 stream inside the timed region; its algorithmic bytes per launch are the compulsory reads/writes of each RK stage
-(RK44: 72/96/96/144 B per cell).  `roofline_k1` is the plain momentum-RHS stencil (48 B/cell) timed
+(RK44: 72/104/104/152 B per cell — stages >= 2 read p as well and apply the previous projection in registers).  `roofline_k1` is the plain momentum-RHS stencil (48 B/cell) timed
 after the run on the final state.  `cpu_baseline` is the CPU oracle (a numpy restatement, NOT Julia) timed on a
 bounded sample on this host.
 """
@@ -145,7 +145,8 @@ def main():
     for i in range(ns):
         nk = sum(1 for j in range(i) if A[i, j] != 0.0)
         wk = any(A[i2, i] != 0.0 for i2 in range(i + 1, ns))
-        stage_bytes.append(24 * (1 + (1 if i > 0 else 0) + nk + 1 + (1 if wk else 0)))
+        inkernel_p = 8 if (i > 0 and ns > 1 and not os.environ.get("INS_DISABLE_INKERNEL_CORR")) else 0  # stages >= 2 also read p
+        stage_bytes.append(24 * (1 + (1 if i > 0 else 0) + nk + 1 + (1 if wk else 0)) + inkernel_p)
     fused_bytes_per_cell = float(np.mean(stage_bytes))
     k1_gbs = fused_bytes_per_cell * cells / (k1_avg_ms * 1e-3) / 1e9
     # plain K1 (momentum! only), 48 B/cell, on the final state
@@ -187,7 +188,8 @@ def main():
         "config": {"workload": f"TaylorGreenVortex3D {n}^3 periodic fp64, RK44 + spectral Poisson, dt=1e-3, Re=1e3",
                    "grid": [n, n, n], "decomposition": "single GPU"},
         "roofline": {
-            "kernel": "k_momentum_flux FUSE (K1+K6: momentum-RHS stencil + RK stage combination)",
+            "kernel": "k_momentum_flux FUSE[/CORR] (K1+K6: momentum-RHS stencil + RK stage combination; stages >= 2 also apply "
+                      "the previous projection's gradient-subtract in registers)",
             "bound": "hbm",
             "achieved": k1_gbs,
             "peak": HBM_PEAK_GBS,

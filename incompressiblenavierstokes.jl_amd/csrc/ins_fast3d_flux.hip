@@ -86,10 +86,18 @@ struct Plane {
 // KMAJOR: k-major sweep — XCD e (= blockIdx & 7) owns the e-th y-range; inside an XCD tiles run x fastest,
 // then y, then z-chunk, so the whole chip works inside a few-plane window (DRAM-friendly streaming) and each
 // XCD's L2 re-serves its slab of the chunk-boundary planes and halo rows.
-template <int R, bool UNIFORM, bool MASKED, int XW, bool FUSE>
+// CORR (fused periodic RK path, stages >= 2): `u` is the PREVIOUS stage's uncorrected velocity u* (interior
+// volumes only, no valid ghosts) and `pI` the unpadded pressure of its projection; every plane is corrected in
+// registers as it arrives, u = u* - (p[I+e_α] - p[I]) / Δu (applypressure!, operators.jl:225-233), with all
+// neighbours addressed through the periodic image (apply_bc_u!, boundary_conditions.jl:276-288).  That removes
+// the gradient-subtract pass (K4) of every stage but the last.  Lanes 62 and 63 are halo columns then
+// (lane 63 only supplies p to lane 62), so 61 columns are produced per wavefront.
+template <int R, bool UNIFORM, bool MASKED, int XW, bool FUSE, bool CORR>
 __global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __restrict__ rx, const Rec* __restrict__ ry,
                                                        const Rec* __restrict__ rz, const double* __restrict__ u,
-                                                       double* __restrict__ F, int zc, int ntx, int nty, int ntz, RkEpi epi) {
+                                                       double* __restrict__ F, int zc, int ntx, int nty, int ntz, RkEpi epi,
+                                                       const double* __restrict__ pI) {
+  constexpr int XO = CORR ? XOUT - 1 : XOUT;
   // XCD-aware order: consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous run of
   // tiles (y fastest) so halo rows/columns shared by neighbouring tiles are hits in that XCD's L2.
   int txi, tyi, t;
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __r
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const int wx = wave % XW, wy = wave / XW;
   const int N0 = g.N[0], N1 = g.N[1], N2 = g.N[2];
-  const int i = (txi * XW + wx) * XOUT + lane;  // lane 0 = left halo column
+  const int i = (txi * XW + wx) * XO + lane;  // lane 0 = left halo column
   if (i - lane > N0 - 2) return;                // whole wavefront right of the domain (no barriers: safe)
   const int ic = min(i, N0 - 1);
   const int jb = 1 + (tyi * (4 / XW) + wy) * R; // first output row of this wavefront
@@ -117,21 +125,58 @@ __global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __r
   const int k0 = 1 + tzi * zc;
   const int k1 = min(k0 + zc, N2 - 1);          // planes [k0, k1)
   const long long sz = g.sx[2];
-  const bool xout = lane >= 1 && lane <= XOUT && i <= N0 - 2;
+  const bool xout = lane >= 1 && lane <= XO && i <= N0 - 2;
+  const int n0 = N0 - 2, n1 = N1 - 2, n2 = N2 - 2;
+  auto wrap = [](int idx, int n) {  // padded index -> interior index in [0, n) through the periodic image
+    int q = idx - 1;
+    q = q < 0 ? q + n : (q >= n ? q - n : q);
+    return q;
+  };
 
-  long long rowoff[R + 2];
+  long long rowoff[R + 2];  // element offset of (row, column) inside a padded plane
+  long long prow[R + 3];    // ... inside an unpadded pI plane (CORR only)
 #pragma unroll
-  for (int rr = 0; rr < R + 2; ++rr) rowoff[rr] = (long long)min(jb - 1 + rr, N1 - 1) * N0 + ic;
+  for (int rr = 0; rr < R + 2; ++rr) {
+    if (CORR)
+      rowoff[rr] = (long long)(wrap(min(jb - 1 + rr, N1), n1) + 1) * N0 + (wrap(min(i, N0), n0) + 1);
+    else
+      rowoff[rr] = (long long)min(jb - 1 + rr, N1 - 1) * N0 + ic;
+  }
+  if (CORR) {
+#pragma unroll
+    // one index beyond the padded range is still a valid periodic image: the right ghost column / row / plane is
+    // corrected with p of ITS right neighbour (image index 2)
+    for (int rr = 0; rr < R + 3; ++rr) prow[rr] = (long long)wrap(min(jb - 1 + rr, N1 + 1), n1) * n0 + wrap(min(i, N0), n0);
+  }
 
+  // kk = padded plane index (CORR: wrapped into the interior)
   auto load_plane = [&](Plane<R>& P, int kk) {
-    const double* base = u + (long long)kk * sz;
+    const double* base = u + (long long)(CORR ? wrap(kk, n2) + 1 : kk) * sz;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int rr = 0; rr < R + 2; ++rr) P.v[c][rr] = base[c * g.sc + rowoff[rr]];
   };
+  auto load_p = [&](double (&P)[R + 3], int kk) {
+    const double* base = pI + (long long)wrap(kk, n2) * n0 * n1;
+#pragma unroll
+    for (int rr = 0; rr < R + 3; ++rr) P[rr] = base[prow[rr]];
+  };
 
   const Rec X = rx[UNIFORM ? 1 : min(i, N0 - 2)];
+  // u = u* - ∇p for one register plane (padded plane index kk; Pc = p rows of plane kk, Pn = of plane kk+1)
+  auto correct = [&](Plane<R>& P, const double (&Pc)[R + 3], const double (&Pn)[R + 3], int kk) {
+    const Rec Z = rz[UNIFORM ? 1 : min(max(kk, 1), N2 - 2)];
+#pragma unroll
+    for (int rr = 0; rr < R + 2; ++rr) {
+      const Rec Y = ry[UNIFORM ? 1 : min(max(jb - 1 + rr, 1), N1 - 2)];
+      const double pc = Pc[rr];
+      P.v[0][rr] -= (from_next(pc) - pc) * X.rs;
+      P.v[1][rr] -= (Pc[rr + 1] - pc) * Y.rs;
+      P.v[2][rr] -= (Pn[rr] - pc) * Z.rs;
+    }
+  };
+
   bool dofx[3];
   if (MASKED) {
 #pragma unroll
@@ -235,23 +280,73 @@ __global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __r
   };
 
   Plane<R> A, B, Cc;
-  load_plane(A, k0 - 1);
-  load_plane(B, k0);
-  load_plane(Cc, min(k0 + 1, N2 - 1));
-  zflux(A, B, k0 - 1, zprev);
-  int k = k0;
-  // 3-buffer rotation, unrolled so every register index is static: compute plane k from (cur, next)
-  // while the load of plane k+2 into the third buffer is in flight.
-  while (true) {
-    load_plane(A, min(k + 2, N2 - 1));
-    body(B, Cc, k);
-    if (++k >= k1) break;
-    load_plane(B, min(k + 2, N2 - 1));
-    body(Cc, A, k);
-    if (++k >= k1) break;
-    load_plane(Cc, min(k + 2, N2 - 1));
-    body(A, B, k);
-    if (++k >= k1) break;
+  if (!CORR) {
+    load_plane(A, k0 - 1);
+    load_plane(B, k0);
+    load_plane(Cc, min(k0 + 1, N2 - 1));
+    zflux(A, B, k0 - 1, zprev);
+    int k = k0;
+    // 3-buffer rotation, unrolled so every register index is static: compute plane k from (cur, next)
+    // while the load of plane k+2 into the third buffer is in flight.
+    while (true) {
+      load_plane(A, min(k + 2, N2 - 1));
+      body(B, Cc, k);
+      if (++k >= k1) break;
+      load_plane(B, min(k + 2, N2 - 1));
+      body(Cc, A, k);
+      if (++k >= k1) break;
+      load_plane(Cc, min(k + 2, N2 - 1));
+      body(A, B, k);
+      if (++k >= k1) break;
+    }
+  } else {
+    // Same rotation with the pressure correction applied to each plane when it becomes `next`:
+    // invariant at the top of iteration k: cur = corrected plane k, nxt = RAW plane k+1, Pa = p(k+1), Pb = p(k+2).
+    double Pa[R + 3], Pb[R + 3];
+    load_p(Pa, k0 - 1);
+    load_p(Pb, k0);
+    load_plane(A, k0 - 1);
+    load_plane(B, k0);
+    correct(A, Pa, Pb, k0 - 1);
+    load_p(Pa, k0 + 1);
+    correct(B, Pb, Pa, k0);
+    load_plane(Cc, k0 + 1);
+    load_p(Pb, k0 + 2);
+    zflux(A, B, k0 - 1, zprev);
+    int k = k0;
+    while (true) {
+      correct(Cc, Pa, Pb, k + 1);      // plane k+1 with p(k+1), p(k+2)
+      load_plane(A, k + 2);
+      load_p(Pa, k + 3);
+      body(B, Cc, k);
+      if (++k >= k1) break;
+      correct(A, Pb, Pa, k + 1);
+      load_plane(B, k + 2);
+      load_p(Pb, k + 3);
+      body(Cc, A, k);
+      if (++k >= k1) break;
+      correct(B, Pa, Pb, k + 1);
+      load_plane(Cc, k + 2);
+      load_p(Pa, k + 3);
+      body(A, B, k);
+      if (++k >= k1) break;
+      // second half of the period-6 rotation (the two p buffers have swapped roles)
+      correct(Cc, Pb, Pa, k + 1);
+      load_plane(A, k + 2);
+      load_p(Pb, k + 3);
+      body(B, Cc, k);
+      if (++k >= k1) break;
+      correct(A, Pa, Pb, k + 1);
+      load_plane(B, k + 2);
+      load_p(Pa, k + 3);
+      body(Cc, A, k);
+      if (++k >= k1) break;
+      correct(B, Pb, Pa, k + 1);
+      load_plane(Cc, k + 2);
+      load_p(Pb, k + 3);
+      body(A, B, k);
+      if (++k >= k1) break;
+    }
   }
 }
 
@@ -324,23 +419,34 @@ int ins_flux3d_prepare(const ins_grid* G, double visc, hipStream_t s) {
 }
 
 template <int R, int XW, bool FUSE>
-static int launch_flux(const ins_grid* G, const double* u, double* F, const RkEpi& epi, hipStream_t s) {
+static int launch_flux(const ins_grid* G, const double* u, double* F, const RkEpi& epi, const double* pI, hipStream_t s) {
   const GridDev& g = G->g;
   const Rec* r0 = reinterpret_cast<const Rec*>(G->rec_dev);
   const Rec* r1 = r0 + g.N[0];
   const Rec* r2 = r1 + g.N[1];
   const int zc = g_zchunk ? g_zchunk : (g.N[2] >= 384 ? 8 : 4);
-  const int ntx = cdiv(g.N[0] - 2, XOUT * XW), nty = cdiv(g.N[1] - 2, (4 / XW) * R), ntz = cdiv(g.N[2] - 2, zc);
-  dim3 block(64, 4, 1);
+  const bool corr = pI != nullptr;
   const bool masked = !G->all_dof;
+  constexpr int RC = R > 3 ? 3 : R;              // register-heavy variants cap the rows per thread: masked 3,
+  constexpr int RK = R > 2 ? 2 : R;              // correcting 2 (236 VGPRs; 3 rows need all 256 and run slower)
+  const int reff = corr ? RK : (masked ? RC : R);
+  const int xo = corr ? XOUT - 1 : XOUT;
+  const int ntx = cdiv(g.N[0] - 2, xo * XW), nty = cdiv(g.N[1] - 2, (4 / XW) * reff), ntz = cdiv(g.N[2] - 2, zc);
+  dim3 block(64, 4, 1);
   const unsigned nb = (unsigned)(8LL * ntx * ((nty + 7) / 8) * ntz);
-  if (G->uniform_exact && !masked)
-    hipLaunchKernelGGL((k_momentum_flux<R, true, false, XW, FUSE>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi);
+  if (corr) {
+    if (!(FUSE && G->uniform_exact && !masked)) {
+      ins_set_error("in-kernel pressure correction needs the fused path on an exactly uniform periodic grid");
+      return INS_ERR_UNSUPPORTED;
+    }
+    if constexpr (FUSE)
+      hipLaunchKernelGGL((k_momentum_flux<RK, true, false, XW, true, true>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
+  } else if (G->uniform_exact && !masked)
+    hipLaunchKernelGGL((k_momentum_flux<R, true, false, XW, FUSE, false>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
   else if (!masked)
-    hipLaunchKernelGGL((k_momentum_flux<R, false, false, XW, FUSE>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi);
+    hipLaunchKernelGGL((k_momentum_flux<R, false, false, XW, FUSE, false>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
   else if (!FUSE)
-    hipLaunchKernelGGL((k_momentum_flux<(R > 3 ? 3 : R), false, true, XW, false>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx,
-                       cdiv(g.N[1] - 2, (4 / XW) * (R > 3 ? 3 : R)), ntz, epi);
+    hipLaunchKernelGGL((k_momentum_flux<RC, false, true, XW, false, false>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
   else {
     ins_set_error("fused RK epilogue needs an all-periodic grid");
     return INS_ERR_UNSUPPORTED;
@@ -350,16 +456,16 @@ static int launch_flux(const ins_grid* G, const double* u, double* F, const RkEp
 }
 
 template <bool FUSE>
-static int launch_flux_any(const ins_grid* G, const double* u, double* F, const RkEpi& epi, hipStream_t s) {
+static int launch_flux_any(const ins_grid* G, const double* u, double* F, const RkEpi& epi, const double* pI, hipStream_t s) {
   // wavefronts side by side in x: 4 when the row needs >= 8 of them, else 2 (fewer mostly-empty workgroups)
   const int waves_x = cdiv(G->g.N[0] - 2, XOUT);
   const int xw = g_xw ? g_xw : (waves_x >= 8 ? 4 : (waves_x >= 2 ? 2 : 1));
-  const int rows = g_rows ? g_rows : 4;  // rows per thread (the masked variant caps itself at 3: no spills)
+  const int rows = g_rows ? g_rows : 4;  // rows per thread (masked / correcting variants cap themselves at 3: registers)
 #define INS_FLUX_CASE(RR)                                                          \
   if (rows == RR) {                                                                \
-    if (xw == 4) return launch_flux<RR, 4, FUSE>(G, u, F, epi, s);                 \
-    if (xw == 2) return launch_flux<RR, 2, FUSE>(G, u, F, epi, s);                 \
-    return launch_flux<RR, 1, FUSE>(G, u, F, epi, s);                              \
+    if (xw == 4) return launch_flux<RR, 4, FUSE>(G, u, F, epi, pI, s);             \
+    if (xw == 2) return launch_flux<RR, 2, FUSE>(G, u, F, epi, pI, s);             \
+    return launch_flux<RR, 1, FUSE>(G, u, F, epi, pI, s);                          \
   }
   INS_FLUX_CASE(2)
   INS_FLUX_CASE(3)
@@ -373,7 +479,7 @@ int ins_k_momentum_flux3d(const ins_grid* G, double visc, const double* u, doubl
   if (rc) return rc;
   RkEpi epi;
   memset(&epi, 0, sizeof(epi));
-  if ((rc = launch_flux_any<false>(G, u, F, epi, s))) return rc;
+  if ((rc = launch_flux_any<false>(G, u, F, epi, nullptr, s))) return rc;
   if (zero_shell) {
     const GridDev& g = G->g;
     const long long total = 2LL * ((long long)g.N[0] * g.N[1] + (long long)g.N[0] * g.N[2] + (long long)g.N[1] * g.N[2]);
@@ -387,5 +493,14 @@ int ins_k_momentum_flux3d(const ins_grid* G, double visc, const double* u, doubl
 int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s) {
   int rc = ins_flux3d_prepare(G, visc, s);
   if (rc) return rc;
-  return launch_flux_any<true>(G, u_in, k_out, epi, s);
+  return launch_flux_any<true>(G, u_in, k_out, epi, nullptr, s);
+}
+
+// Same, but u_in is the previous stage's UNCORRECTED u* (interior only) and pI its unpadded pressure: the
+// projection's gradient-subtract is applied in registers (periodic, exactly-uniform grids).
+int ins_k_momentum_rk_fused_corr(const ins_grid* G, double visc, const double* ustar_prev, const double* pI, double* k_out, const RkEpi& epi,
+                                 hipStream_t s) {
+  int rc = ins_flux3d_prepare(G, visc, s);
+  if (rc) return rc;
+  return launch_flux_any<true>(G, ustar_prev, k_out, epi, pI, s);
 }

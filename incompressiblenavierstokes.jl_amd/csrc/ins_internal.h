@@ -161,6 +161,9 @@ int ins_k_applypressure(const ins_grid* grid, double* u, const double* p, hipStr
 int ins_k_laplacian(const ins_grid* grid, const double* p, double* L, hipStream_t s);
 int ins_k_project(const ins_grid* grid, ins_poisson* ps, double* u, double* p, hipStream_t s);
 int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s);
+int ins_k_momentum_rk_fused_corr(const ins_grid* G, double visc, const double* ustar_prev, const double* pI, double* k_out, const RkEpi& epi,
+                                 hipStream_t s);
+int ins_k_project_periodic_solve_only(const ins_grid* G, ins_poisson* ps, const double* u, hipStream_t s);
 int ins_k_poisson_solve(ins_poisson* ps, double* p, hipStream_t s);
 // blocking reductions over an index box of a scalar field; op: 0 sum(a*b), 1 max|a|, 2 min(a)
 int ins_k_reduce(const ins_grid* grid, int op, const double* a, const double* b, const int lo[3], const int hi[3], double* out,

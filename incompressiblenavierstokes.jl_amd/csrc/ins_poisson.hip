@@ -610,6 +610,16 @@ int ins_k_project_periodic_fused(const ins_grid* G, ins_poisson* ps, double* u, 
   return INS_OK;
 }
 
+// First half of the fused periodic projection only: pI <- solution of L p = Ω div(u) (u: interior volumes valid).
+// The gradient-subtract is left to the next stage's stencil kernel (k_momentum_flux<..., CORR>).
+int ins_k_project_periodic_solve_only(const ins_grid* G, ins_poisson* ps, const double* u, hipStream_t s) {
+  const GridDev& g = G->g;
+  dim3 block(64, 4, 1), grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), ps->np[2]);
+  hipLaunchKernelGGL((k_div_to_pI<3, true>), grid, block, 0, s, g, u, ps->pI, ps->np[0], ps->np[1]);
+  INS_LAUNCH_CHECK();
+  return spectral_transform(ps, s);
+}
+
 extern "C" int ins_project_f64(const ins_grid_t* G, ins_poisson_t* ps, double* u, double* p, void* stream) {
   INS_REQUIRE(G && ps && u && p, "null argument");
   INS_REQUIRE(ps->grid == G, "psolver was created for a different grid");

@@ -143,6 +143,10 @@ static int rk_step_fused_periodic(ins_rk* rk, double visc, double* u, double dt,
     }
   int rc;
   if ((rc = ins_k_apply_bc_u(G, u, 0, nullptr, s))) return rc;  // :19 (first stage; later ghosts come from K4)
+  // On exactly-uniform grids stages >= 2 read the previous stage's UNCORRECTED u* plus its pressure and apply
+  // the projection's gradient-subtract in registers (k_momentum_flux<..., CORR>), so K4 runs for the last stage only.
+  static const bool no_corr = getenv("INS_DISABLE_INKERNEL_CORR") != nullptr;
+  const bool inkernel = !no_corr && G->uniform_exact && ns > 1 && G->g.N[0] >= 8 && G->g.N[1] >= 8 && G->g.N[2] >= 8;
   const double* in = u;
   for (int i = 0; i < ns; ++i) {
     double* out = (i == ns - 1 && ns > 1) ? u : rk->ub[i & 1];
@@ -166,13 +170,17 @@ static int rk_step_fused_periodic(ins_rk* rk, double visc, double* u, double dt,
       INS_HIP_TRY(hipEventCreate(&e1));
       INS_HIP_TRY(hipEventRecord(e0, s));
     }
-    if ((rc = ins_k_momentum_rk_fused(G, visc, in, rk->ku[i], epi, s))) return rc;
+    rc = (inkernel && i > 0) ? ins_k_momentum_rk_fused_corr(G, visc, in, rk->ps->pI, rk->ku[i], epi, s)
+                             : ins_k_momentum_rk_fused(G, visc, in, rk->ku[i], epi, s);
+    if (rc) return rc;
     if (rk->profiling) {
       INS_HIP_TRY(hipEventRecord(e1, s));
       rk->prof_events.push_back(e0);
       rk->prof_events.push_back(e1);
     }
-    if ((rc = ins_k_project_periodic_fused(G, rk->ps, out, rk->p, i == ns - 1, s))) return rc;
+    rc = (inkernel && i < ns - 1) ? ins_k_project_periodic_solve_only(G, rk->ps, out, s)
+                                  : ins_k_project_periodic_fused(G, rk->ps, out, rk->p, i == ns - 1, s);
+    if (rc) return rc;
     in = out;
   }
   if (ns == 1) INS_HIP_TRY(hipMemcpyAsync(u, rk->ub[0], vbytes, hipMemcpyDeviceToDevice, s));

@@ -55,8 +55,9 @@ __global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long
                                                 const double2* __restrict__ tw_g, double inv_n, int zero_mean) {
   constexpr int N = 1 << LOGN;
   constexpr bool ODD = LOGN & 1;
-  __shared__ double2 buf[N * TK];
-  __shared__ double2 tw[N];
+  extern __shared__ double2 lds_dyn[];  // dynamic: tiles above 64 KB need the opt-in limit
+  double2* buf = lds_dyn;               // [N][TK]
+  double2* tw = lds_dyn + N * TK;       // [N]
   const int t = threadIdx.x;
   const long long l0 = (long long)blockIdx.x * TK;
   const int col = t % TK;
@@ -159,7 +160,13 @@ template <int LOGN, int TK>
 int launch_zsolve(double2* data, long long nl, const double* ax, int kxn, const double* ay, const double* az, const double2* tw,
                   double inv_n, bool zero_mean, hipStream_t s) {
   const unsigned nb = (unsigned)((nl + TK - 1) / TK);
-  hipLaunchKernelGGL((k_zsolve<LOGN, TK>), dim3(nb), dim3(256), 0, s, data, nl, ax, kxn, ay, az, tw, inv_n, zero_mean ? 1 : 0);
+  constexpr size_t lds = ((size_t)(1 << LOGN) * TK + (1 << LOGN)) * sizeof(double2);
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    INS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_zsolve<LOGN, TK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_zsolve<LOGN, TK>), dim3(nb), dim3(256), lds, s, data, nl, ax, kxn, ay, az, tw, inv_n, zero_mean ? 1 : 0);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -211,8 +218,8 @@ int ins_k_zsolve(double* data, int nz, long long nl, const double* ax, int kxn, 
     case 64: return launch_zsolve<6, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s);
     case 128: return launch_zsolve<7, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s);
     case 256: return launch_zsolve<8, 8>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s);
-    case 512: return launch_zsolve<9, 4>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s);
-    case 1024: return launch_zsolve<10, 2>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s);
+    case 512: return launch_zsolve<9, 8>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s);    // 72 KB tile
+    case 1024: return launch_zsolve<10, 4>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s);  // 80 KB tile
   }
   ins_set_error("ins_k_zsolve: unsupported nz = %d", nz);
   return INS_ERR_UNSUPPORTED;
