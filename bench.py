@@ -162,10 +162,10 @@ def main():
     k1_plain_ms = ev0.elapsed_time(ev1) / 20
     k1_plain_gbs = K1_BYTES_PER_CELL * cells / (k1_plain_ms * 1e-3) / 1e9
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
+    tfile = os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")
     if n == 256 and os.path.exists(tfile):  # PMC counters cannot be read in-process: committed rocprofv3 --pmc result
         try:
-            traffic = json.load(open(tfile))["per_kernel"]["k_momentum_flux(K1+K6)"]["hbm_total_GB"] * 1e9
+            traffic = json.load(open(tfile))["per_kernel"]["stage kernel, RK44 step average"]["hbm_total_GB"] * 1e9
         except Exception:
             traffic = None
     div = ins.max_abs_divergence(stepper.u, setup)
@@ -196,7 +196,7 @@ def main():
             "unit": "GB/s",
             "frac": k1_gbs / HBM_PEAK_GBS,
             "traffic": traffic,
-            "traffic_note": "B per launch, HBM FETCH(x2 gfx950)+WRITE from rocprofv3 --pmc, profiles/r01b_pmc_traffic.json",
+            "traffic_note": "B per launch, HBM FETCH(x2 gfx950)+WRITE from rocprofv3 --pmc, profiles/r01d_pmc_traffic.json",
             "bytes_per_cell": fused_bytes_per_cell,
             "bytes_per_cell_by_stage": stage_bytes,
             "avg_launch_ms": k1_avg_ms,

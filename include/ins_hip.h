@@ -148,6 +148,11 @@ int ins_rk_destroy(ins_rk_t* rk);
  * from the host with the operator-level calls). */
 int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, double dt, const double* const* planes, void* stream);
 /* Device pointers into the cache (valid until ins_rk_destroy): the stage pressure `p` and `ku[i]`. */
+/* K6 alone: out = base + Σ_q coefs[q]·ks[q] over whole vector fields, summed in index order — the stage-combination
+ * broadcasts `u .= ustart; u .+= Δt A[i,j] ku[j]` (step_explicit_runge_kutta.jl:35-38) and LMWray3's state_copyto! /
+ * state_axpy! (step_lmwray3.jl:44-54) in one pass.  out may alias base.  Used by host-driven stage loops. */
+int ins_combine_f64(const ins_grid_t* grid, const double* base, double* out, int nterms, const double* coefs,
+                    const double* const* ks, void* stream);
 /* Measurement hook (bench.py `roofline`): while enabled, ins_rk_step_f64 brackets every momentum-RHS
  * kernel launch with hipEvents recorded on the step's stream.  ins_rk_profile_read is blocking: it waits
  * for the recorded events, returns the accumulated kernel milliseconds and launch count, and resets. */

@@ -50,9 +50,11 @@ from .pressure import (
     psolver_spectral,
 )
 from .setup import Setup, copyfield, from_numpy, scalarfield, to_numpy, vectorfield
+from .sciml import create_right_hand_side, right_hand_side_
 from .solver import get_cfl_timestep_, get_state, solve_unsteady
 from .time_steppers import (
     ExplicitRungeKuttaMethod,
+    LMWray3,
     RKMethods,
     create_stepper,
     ode_method_cache,

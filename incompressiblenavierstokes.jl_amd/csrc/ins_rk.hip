@@ -28,7 +28,7 @@ struct Combine {
 
 // K6: u = ustart + Σ_j (Δt A[i,j]) ku[j]  in ONE pass (the reference does 1 copy + i axpy passes and does
 // not skip tableau zeros, step_explicit_runge_kutta.jl:35-38).  Summation order as in the reference.
-__global__ __launch_bounds__(256) void k_combine(long long n, const double* __restrict__ ustart, double* __restrict__ u, Combine cb) {
+__global__ __launch_bounds__(256) void k_combine(long long n, const double* ustart, double* u, Combine cb) {
   const long long stride = (long long)gridDim.x * 256 * 2;
   for (long long t = ((long long)blockIdx.x * 256 + threadIdx.x) * 2; t < n; t += stride) {
     if (t + 1 < n) {
@@ -48,6 +48,26 @@ __global__ __launch_bounds__(256) void k_combine(long long n, const double* __re
 }
 
 }  // namespace
+
+extern "C" int ins_combine_f64(const ins_grid_t* G, const double* base, double* out, int nterms, const double* coefs,
+                               const double* const* ks, void* stream) {
+  INS_REQUIRE(G && base && out, "null argument");
+  INS_REQUIRE(nterms >= 0 && nterms <= INS_MAX_STAGES && (nterms == 0 || (coefs && ks)), "bad stage terms");
+  Combine cb;
+  cb.n = 0;
+  for (int q = 0; q < nterms; ++q) {
+    if (coefs[q] == 0.0) continue;
+    INS_REQUIRE(ks[q], "null stage field");
+    cb.coef[cb.n] = coefs[q];
+    cb.k[cb.n] = ks[q];
+    ++cb.n;
+  }
+  const long long nvec = G->ncell * G->g.D;
+  const unsigned nblk = (unsigned)std::min<long long>((nvec / 2 + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_combine, dim3(nblk), dim3(256), 0, as_stream(stream), nvec, base, out, cb);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
 
 extern "C" int ins_rk_create(const ins_grid_t* G, ins_poisson_t* ps, int nstage, const double* A, const double* c, ins_rk_t** out) {
   INS_REQUIRE(G && ps && A && c && out, "null argument");

@@ -89,6 +89,53 @@ class RKMethods:
         return runge_kutta_method(A, [0, 0.75, 0.25], [0, 1 / 3, 1], **kw)
 
 
+class LMWray3:
+    """Low memory Wray 3rd order scheme. Uses 3 vector fields and one scalar field (methods.jl:243-248)."""
+
+    a = (8 / 15, 5 / 12, 3 / 4)
+    b = (1 / 4, 0.0)
+    c = (0.0, 8 / 15, 2 / 3)
+
+
+def combine_(out, base, coefs, ks, setup):
+    """out = base + Σ coefs[q]·ks[q] (K6; `out` may be `base`)."""
+    n = len(coefs)
+    carr = (C.c_double * max(n, 1))(*coefs)
+    karr = (C.c_void_p * max(n, 1))(*[setup.ptr(k, True).value for k in ks])
+    _lib.call("ins_combine_f64", setup.handle, setup.ptr(base, True), setup.ptr(out, True), n, carr, karr, setup.stream)
+    return out
+
+
+class LMWray3Cache:
+    """`ode_method_cache(::LMWray3, setup)` (time_stepper_caches.jl:51-66): ustart, ONE ku, p."""
+
+    def __init__(self, setup, psolver):
+        self.setup, self.psolver = setup, psolver
+        self.ustart, self.ku, self.p = vectorfield(setup), vectorfield(setup), scalarfield(setup)
+
+
+def _timestep_lmwray3_(method, stepper, Δt, cache):
+    """step_lmwray3.jl:4-107 (closure_model = temp = nothing): operator-level kernels driven from the host."""
+    setup, psolver, u, n = stepper.setup, stepper.psolver, stepper.u, stepper.n
+    ustart, ku, p = cache.ustart, cache.ku, cache.p
+    tstart = stepper.t
+    combine_(ustart, u, [], [], setup)                       # state_copyto!(xstart, x)
+    nstage = len(method.a)
+    t = tstart
+    for i in range(nstage):
+        t = tstart + method.c[i] * Δt
+        apply_bc_u_(u, t, setup)                             # f!
+        momentum_(ku, u, None, t, setup)
+        combine_(u, ustart, [method.a[i] * Δt], [ku], setup) # x = xstart + Δt a[i] dx
+        apply_bc_u_(u, t, setup)                             # correct!
+        project_(u, setup, psolver, p)
+        if i != nstage - 1:
+            combine_(ustart, ustart, [method.b[i] * Δt], [ku], setup)
+    t = tstart + Δt
+    apply_bc_u_(u, t, setup)
+    return create_stepper(method, setup=setup, psolver=psolver, u=u, temp=None, t=t, n=n + 1)
+
+
 class ERKCache:
     """`ode_method_cache(method, setup)` (time_stepper_caches.jl:34-49).  The arrays live inside an
     `ins_rk_t` handle; `ustart`, `ku[i]`, `p` are exposed as zero-copy torch views where the host needs them."""
@@ -122,6 +169,8 @@ def ode_method_cache(method, setup, psolver=None):
         from .pressure import default_psolver
 
         psolver = default_psolver(setup)
+    if isinstance(method, LMWray3):
+        return LMWray3Cache(setup, psolver)
     return ERKCache(method, setup, psolver)
 
 
@@ -139,6 +188,8 @@ def timestep_(method, stepper, Δt, *, θ=None, cache):
     setup, psolver, u, t, n = stepper.setup, stepper.psolver, stepper.u, stepper.t, stepper.n
     if stepper.temp is not None or setup.closure_model is not None:
         raise NotImplementedError("temperature / closure models are outside the HIP hot path")
+    if isinstance(method, LMWray3):
+        return _timestep_lmwray3_(method, stepper, Δt, cache)
     if cache.psolver is not psolver:
         raise ValueError("cache was created for a different psolver")
     if not setup.needs_bc_planes:
@@ -151,15 +202,12 @@ def timestep_(method, stepper, Δt, *, θ=None, cache):
         cache._host = dict(ustart=vectorfield(setup), ku=[vectorfield(setup) for _ in range(ns)], p=scalarfield(setup))
     ustart, ku, p = cache._host["ustart"], cache._host["ku"], cache._host["p"]
     tstart = t
-    ustart.copy_(u)
+    combine_(ustart, u, [], [], setup)
     for i in range(ns):
         apply_bc_u_(u, t, setup)
         momentum_(ku[i], u, None, t, setup)
         t = tstart + c[i] * Δt
-        u.copy_(ustart)
-        for j in range(i + 1):
-            if A[i, j] != 0.0:
-                u.add_(ku[j], alpha=Δt * A[i, j])
+        combine_(u, ustart, [Δt * A[i, j] for j in range(i + 1)], [ku[j] for j in range(i + 1)], setup)
         apply_bc_u_(u, t, setup)
         project_(u, setup, psolver, p)
     apply_bc_u_(u, t, setup)

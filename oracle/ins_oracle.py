@@ -904,6 +904,38 @@ def timestep_(method, stepper, dt, cache):
     return dict(setup=setup, psolver=psolver, u=u, t=t, n=n + 1)
 
 
+def timestep_lmwray3_(stepper, dt, cache):
+    """step_lmwray3.jl:4-107 (low-storage Wray RK3; closure_model = temp = nothing)."""
+    setup, psolver, u, n = (stepper[k] for k in ("setup", "psolver", "u", "n"))
+    a, b, c = (8 / 15, 5 / 12, 3 / 4), (1 / 4, 0.0), (0.0, 8 / 15, 2 / 3)
+    ustart, ku, p = cache["ustart"], cache["ku"][0], cache["p"]
+    tstart = stepper["t"]
+    ustart[...] = u
+    t = tstart
+    for i in range(3):
+        t = tstart + c[i] * dt
+        apply_bc_u_(u, t, setup)
+        momentum_(ku, u, None, t, setup)
+        u[...] = ustart
+        u += a[i] * dt * ku
+        apply_bc_u_(u, t, setup)
+        project_(u, setup, psolver, p)
+        if i != 2:
+            ustart += b[i] * dt * ku
+    t = tstart + dt
+    apply_bc_u_(u, t, setup)
+    return dict(setup=setup, psolver=psolver, u=u, t=t, n=n + 1)
+
+
+def right_hand_side(u, setup, psolver, t):
+    """sciml.jl:13-19 / 35-47: project(bc_dudt(momentum(bc(u))))."""
+    tmp = apply_bc_u(u, t, setup)
+    F = momentum(tmp, None, t, setup)
+    apply_bc_u_(F, t, setup, dudt=True)
+    project_(F, setup, psolver, scalarfield(setup))
+    return F
+
+
 def get_cfl_timestep(u, setup):  # solver.jl:101-125
     g = setup.grid
     D = g.D

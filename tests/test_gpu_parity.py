@@ -364,3 +364,35 @@ def test_fused_z_pass_matches_oracle(ins, oracle, nz):
     want = o.poisson(o.psolver_spectral(so), f)
     got = ins.to_numpy(ins.poisson(ins.psolver_spectral(sp), ins.from_numpy(sp, f)))
     assert rell2(got[ip], want[ip]) < POISSON_TOL
+
+
+@pytest.mark.parametrize("geom", ["periodic3d", "dirichlet3d", "periodic2d"])
+def test_lmwray3_and_right_hand_side_match_oracle(ins, oracle, geom):
+    """§8f: LMWray3 (step_lmwray3.jl:4-107) and right_hand_side! (sciml.jl:35-47) — same kernels, re-orchestrated."""
+    o = oracle
+    so = GEOMS[geom](o)
+    sp = mirror(ins, so, o)
+    g = so.grid
+    periodic = geom.startswith("periodic")
+    pso = o.psolver_spectral(so) if periodic else o.psolver_direct(so)
+    psp = ins.psolver_spectral(sp) if periodic else ins.default_psolver(sp)
+    u0 = o.project(o.apply_bc_u(0.1 * fx.randn_field(g.N + (g.D,), 31), 0.0, so), so, pso)
+    o.apply_bc_u_(u0, 0.0, so)
+    tol = STEP_TOL if periodic else 1e-7
+    # right_hand_side!
+    want = o.right_hand_side(u0, so, pso, 0.0)
+    dudt = ins.vectorfield(sp)
+    u_dev = ins.from_numpy(sp, u0)
+    ins.right_hand_side_(dudt, u_dev, (sp, psp), 0.0)
+    assert rell2(ins.to_numpy(dudt), want) < tol
+    assert np.array_equal(ins.to_numpy(u_dev), u0)  # "be careful to not touch u in this function" (sciml.jl:41)
+    assert rell2(ins.to_numpy(ins.create_right_hand_side(sp, psp)(u_dev, None, 0.0)), want) < tol
+    # LMWray3
+    st = dict(setup=so, psolver=pso, u=u0.copy(order="F"), t=0.0, n=0)
+    cache = o.ode_method_cache(o.Wray3(), so)
+    for _ in range(2):
+        st = o.timestep_lmwray3_(st, 0.005, cache)
+    m = ins.LMWray3()
+    (u, _, t), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 0.01), ustart=u_dev, method=m, psolver=psp, Δt=0.005)
+    assert t == pytest.approx(0.01)
+    assert rell2(ins.to_numpy(u), st["u"]) < tol

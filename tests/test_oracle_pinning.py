@@ -275,3 +275,19 @@ def test_c_port_matches_numpy_oracle(oracle):
     for _ in range(2):
         port.timestep_(m, u, 0.01, cache)
     assert np.allclose(u, st["u"], rtol=1e-12, atol=1e-14)
+
+
+def test_lmwray3_equals_wray3_tableau(oracle):
+    """LMWray3 (step_lmwray3.jl) is the low-storage form of RKMethods.Wray3: on a periodic box the two steppers
+    agree to round-off — pins the oracle's low-storage restatement against its (already pinned) ERK loop."""
+    o = oracle
+    s = fx.setup_periodic(o, (10, 8, 12), D=3, Re=200.0)
+    ps = o.psolver_spectral(s)
+    u0 = o.random_field(s, kp=2, seed=9, psolver=ps)
+    ref = o.solve_unsteady(s, (0.0, 0.02), u0, method=o.Wray3(), psolver=ps, dt=0.01)["u"]
+    st = dict(setup=s, psolver=ps, u=u0.copy(order="F"), t=0.0, n=0)
+    cache = o.ode_method_cache(o.Wray3(), s)
+    for _ in range(2):
+        st = o.timestep_lmwray3_(st, 0.01, cache)
+    assert np.allclose(st["u"], ref, rtol=1e-11, atol=1e-13)
+    assert st["t"] == pytest.approx(0.02) and st["n"] == 2
