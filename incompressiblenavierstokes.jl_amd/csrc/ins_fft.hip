@@ -1,0 +1,369 @@
+// Own FFT passes of the spectral Poisson solve for power-of-two boxes (pressure.jl:316-347 without rocFFT).
+//
+// Five passes over HBM, every transform done in LDS with the same in-place radix-4/2 engine as ins_zsolve.hip:
+//   1. k_xfwd : real -> half-complex along x (contiguous).  Two neighbouring y-rows are packed as one complex row
+//               (re = row j, im = row j+1), transformed with ONE complex FFT and separated by Hermitian symmetry.
+//               SRC = 1 computes the right-hand side Ω·div(u*) on the fly (divergence! + scalewithvolume! +
+//               copyto!(pI, ...): operators.jl:117-125, 81-95, pressure.jl:320) — K2 is folded into this pass.
+//   2. k_yfft<FWD>: along y for every (z-plane, kx) line; output stays in digit-reversed ky order (the symbol
+//               vector ây is permuted to match, nothing is ever reordered).
+//   3. k_zsolve (ins_zsolve.hip): z-FFT · symbol · inverse z-FFT.
+//   4. k_yfft<INV>: decimation-in-time from the digit-reversed order back to natural ky.
+//   5. k_xinv : half-complex -> real along x for row pairs, writes the unpadded pI.
+// Normalisation 1/(nx ny nz) is folded into the symbol (pass 3).  rocFFT is not involved at all, which also keeps
+// this path clear of the ROCm 7.2 real-plan cache bug (ins_fftcheck.hip).
+#include <cmath>
+
+#include "ins_internal.h"
+
+namespace {
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 cmulc(double2 a, double2 b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }
+__device__ __forceinline__ double2 mul_pi(double2 a) { return make_double2(-a.y, a.x); }
+
+// Storage position of frequency k after the DIF stages (radix-2 first when log2 N is odd, then radix 4):
+// inverse of freq_of_pos() in ins_zsolve.hip.
+template <int LOGN>
+__host__ __device__ __forceinline__ int pos_of_freq(int k) {
+  constexpr bool ODD = LOGN & 1;
+  int p = 0, L = 1 << LOGN;
+  if (ODD) {
+    p += (k & 1) * (L / 2);
+    k >>= 1;
+    L /= 2;
+  }
+#pragma unroll
+  for (int s = 0; s < LOGN / 2; ++s) {
+    p += (k & 3) * (L / 4);
+    k >>= 2;
+    L /= 4;
+  }
+  return p;
+}
+
+// In-place transforms of NC independent lines held in LDS; element (r, c) lives at buf[r*SR + c*SC].
+// RFAST: consecutive work-items take consecutive butterflies of one line (x layout, SR == 1) instead of the
+// same butterfly of consecutive lines (y/z layout, SC == 1) — keeps LDS accesses unit-stride in both layouts.
+template <int LOGN, int NC, int SR, int SC, bool RFAST>
+__device__ __forceinline__ void fft_dif(double2* __restrict__ buf, const double2* __restrict__ tw, int t) {
+  constexpr int N = 1 << LOGN;
+  constexpr bool ODD = LOGN & 1;
+  int L = N;
+  if (ODD) {
+    for (int w = t; w < (N / 2) * NC; w += 256) {
+      const int c = RFAST ? w / (N / 2) : w % NC, j = RFAST ? w % (N / 2) : w / NC;
+      double2* x = buf + c * SC;
+      const double2 a0 = x[j * SR], a1 = x[(j + N / 2) * SR];
+      x[j * SR] = cadd(a0, a1);
+      x[(j + N / 2) * SR] = cmul(csub(a0, a1), tw[j]);
+    }
+    L = N / 2;
+    __syncthreads();
+  }
+#pragma unroll 1
+  for (; L >= 4; L >>= 2) {
+    const int Q = L / 4, step = N / L;
+    for (int w = t; w < (N / 4) * NC; w += 256) {
+      const int c = RFAST ? w / (N / 4) : w % NC, b = RFAST ? w % (N / 4) : w / NC;
+      const int g = b / Q, j = b - g * Q;
+      double2* x = buf + c * SC + (g * L + j) * SR;
+      const double2 a0 = x[0], a1 = x[Q * SR], a2 = x[2 * Q * SR], a3 = x[3 * Q * SR];
+      const double2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
+      double2 y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
+      if (L > 4) {
+        y1 = cmul(y1, tw[j * step]);
+        y2 = cmul(y2, tw[2 * j * step]);
+        y3 = cmul(y3, tw[3 * j * step]);
+      }
+      x[0] = cadd(t0, t2);
+      x[Q * SR] = y1;
+      x[2 * Q * SR] = y2;
+      x[3 * Q * SR] = y3;
+    }
+    __syncthreads();
+  }
+}
+
+template <int LOGN, int NC, int SR, int SC, bool RFAST>
+__device__ __forceinline__ void fft_dit(double2* __restrict__ buf, const double2* __restrict__ tw, int t) {
+  constexpr int N = 1 << LOGN;
+  constexpr bool ODD = LOGN & 1;
+#pragma unroll 1
+  for (int L = 4; L <= (ODD ? N / 2 : N); L <<= 2) {
+    const int Q = L / 4, step = N / L;
+    for (int w = t; w < (N / 4) * NC; w += 256) {
+      const int c = RFAST ? w / (N / 4) : w % NC, b = RFAST ? w % (N / 4) : w / NC;
+      const int g = b / Q, j = b - g * Q;
+      double2* x = buf + c * SC + (g * L + j) * SR;
+      double2 x0 = x[0], x1 = x[Q * SR], x2 = x[2 * Q * SR], x3 = x[3 * Q * SR];
+      if (L > 4) {
+        x1 = cmulc(x1, tw[j * step]);
+        x2 = cmulc(x2, tw[2 * j * step]);
+        x3 = cmulc(x3, tw[3 * j * step]);
+      }
+      const double2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = mul_pi(csub(x1, x3));
+      x[0] = cadd(t0, t2);
+      x[Q * SR] = cadd(t1, t3);
+      x[2 * Q * SR] = csub(t0, t2);
+      x[3 * Q * SR] = csub(t1, t3);
+    }
+    __syncthreads();
+  }
+  if (ODD) {
+    for (int w = t; w < (N / 2) * NC; w += 256) {
+      const int c = RFAST ? w / (N / 2) : w % NC, j = RFAST ? w % (N / 2) : w / NC;
+      double2* x = buf + c * SC;
+      const double2 x0 = x[j * SR], x1 = cmulc(x[(j + N / 2) * SR], tw[j]);
+      x[j * SR] = cadd(x0, x1);
+      x[(j + N / 2) * SR] = csub(x0, x1);
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Pass 2 / 4: FFT along y.  data[plane][ky][kx]; a workgroup owns TK consecutive kx of one plane.
+// ------------------------------------------------------------------------------------------------------------
+template <int LOGN, int TK, bool INVERSE>
+__global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kxn, const double2* __restrict__ tw_g) {
+  constexpr int N = 1 << LOGN;
+  extern __shared__ double2 lds_dyn[];
+  double2* buf = lds_dyn;          // [N][TK]
+  double2* tw = lds_dyn + N * TK;  // [N]
+  const int t = threadIdx.x;
+  const int col = t % TK;
+  const int kx = blockIdx.x * TK + col;
+  const bool live = kx < kxn;
+  double2* base = data + (long long)blockIdx.y * N * kxn + kx;
+  for (int m = t; m < N; m += 256) tw[m] = tw_g[m];
+  constexpr int RPT = 256 / TK;
+  for (int r = t / TK; r < N; r += RPT) buf[r * TK + col] = live ? base[(long long)r * kxn] : make_double2(0.0, 0.0);
+  __syncthreads();
+  if (INVERSE)
+    fft_dit<LOGN, TK, TK, 1, false>(buf, tw, t);
+  else
+    fft_dif<LOGN, TK, TK, 1, false>(buf, tw, t);
+  if (live)
+    for (int r = t / TK; r < N; r += RPT) base[(long long)r * kxn] = buf[r * TK + col];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Pass 1: x forward, NP row pairs per workgroup.  SRC 0: rows come from pI; SRC 1: rows = Ω·div(u) (K2 fused).
+// ------------------------------------------------------------------------------------------------------------
+template <int LOGN, int NP, int SRC>
+__global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restrict__ src, double2* __restrict__ out, int n1,
+                                              const double2* __restrict__ tw_g) {
+  constexpr int N = 1 << LOGN;
+  constexpr int KXN = N / 2 + 1;
+  extern __shared__ double2 lds_dyn[];
+  double2* buf = lds_dyn;          // [NP][N]
+  double2* tw = lds_dyn + NP * N;  // [N]
+  const int t = threadIdx.x;
+  const int kz = blockIdx.y;       // interior plane index
+  const int j0 = blockIdx.x * 2 * NP;
+  for (int m = t; m < N; m += 256) tw[m] = tw_g[m];
+  double* bufd = reinterpret_cast<double*>(buf);
+  for (int idx = t; idx < 2 * NP * N; idx += 256) {
+    const int row = idx / N, i = idx - row * N;
+    const int j = j0 + row;
+    double v = 0.0;
+    if (j < n1) {
+      if (SRC == 0) {
+        v = src[i + (long long)N * (j + (long long)n1 * kz)];
+      } else {
+        // Ω · div(u*) at interior cell (i, j, kz): periodic wrap instead of ghost reads (k_div_to_pI<3, true>)
+        const int I0 = i + 1, I1 = j + 1, I2 = kz + 1;
+        const long long c = I0 + I1 * g.sx[1] + I2 * g.sx[2];
+        const long long cx = I0 == 1 ? c + (long long)(g.N[0] - 3) : c - 1;
+        const long long cy = I1 == 1 ? c + (long long)(g.N[1] - 3) * g.sx[1] : c - g.sx[1];
+        const long long cz = I2 == 1 ? c + (long long)(g.N[2] - 3) * g.sx[2] : c - g.sx[2];
+        double d = 0.0;
+        d += (src[c] - src[cx]) * g.rdx[0][I0];
+        d += (src[g.sc + c] - src[g.sc + cy]) * g.rdx[1][I1];
+        d += (src[2 * g.sc + c] - src[2 * g.sc + cz]) * g.rdx[2][I2];
+        const double om = g.dx[0][I0] * g.dx[1][I1] * g.dx[2][I2];
+        v = d * om;
+      }
+    }
+    bufd[2 * ((row >> 1) * N + i) + (row & 1)] = v;
+  }
+  __syncthreads();
+  fft_dif<LOGN, NP, 1, N, true>(buf, tw, t);
+  // separate the two real rows:  A[k] = (Z[k] + conj Z[N-k]) / 2,   B[k] = (Z[k] - conj Z[N-k]) / (2i)
+  for (int idx = t; idx < NP * KXN; idx += 256) {
+    const int p = idx / KXN, s = idx - p * KXN;
+    const int j = j0 + 2 * p;
+    if (j >= n1) continue;
+    const double2 zk = buf[p * N + pos_of_freq<LOGN>(s)];
+    const double2 zm = buf[p * N + pos_of_freq<LOGN>((N - s) & (N - 1))];
+    const double2 a = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+    const double2 b = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+    const long long o = s + (long long)KXN * (j + (long long)n1 * kz);
+    out[o] = a;
+    out[o + KXN] = b;  // row j + 1 (n1 is even)
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Pass 5: x inverse for NP row pairs: Z[k] = A[k] + i B[k], Z[N-k] = conj A[k] + i conj B[k]  ->  DIT  ->  pI rows.
+// ------------------------------------------------------------------------------------------------------------
+template <int LOGN, int NP>
+__global__ __launch_bounds__(256) void k_xinv(const double2* __restrict__ in, double* __restrict__ pI, int n1,
+                                              const double2* __restrict__ tw_g) {
+  constexpr int N = 1 << LOGN;
+  constexpr int KXN = N / 2 + 1;
+  extern __shared__ double2 lds_dyn[];
+  double2* buf = lds_dyn;
+  double2* tw = lds_dyn + NP * N;
+  const int t = threadIdx.x;
+  const int kz = blockIdx.y;
+  const int j0 = blockIdx.x * 2 * NP;
+  for (int m = t; m < N; m += 256) tw[m] = tw_g[m];
+  for (int idx = t; idx < NP * KXN; idx += 256) {
+    const int p = idx / KXN, s = idx - p * KXN;
+    const int j = j0 + 2 * p;
+    double2 a = make_double2(0.0, 0.0), b = a;
+    if (j < n1) {
+      const long long o = s + (long long)KXN * (j + (long long)n1 * kz);
+      a = in[o];
+      b = in[o + KXN];
+    }
+    if (s == 0 || s == N / 2) {  // C2R semantics: DC and Nyquist bins are real
+      a.y = 0.0;
+      b.y = 0.0;
+    }
+    buf[p * N + pos_of_freq<LOGN>(s)] = make_double2(a.x - b.y, a.y + b.x);
+    if (s != 0 && s != N / 2) buf[p * N + pos_of_freq<LOGN>(N - s)] = make_double2(a.x + b.y, b.x - a.y);
+  }
+  __syncthreads();
+  fft_dit<LOGN, NP, 1, N, true>(buf, tw, t);
+  const double* bufd = reinterpret_cast<const double*>(buf);
+  for (int idx = t; idx < 2 * NP * N; idx += 256) {
+    const int row = idx / N, i = idx - row * N;
+    const int j = j0 + row;
+    if (j < n1) pI[i + (long long)N * (j + (long long)n1 * kz)] = bufd[2 * ((row >> 1) * N + i) + (row & 1)];
+  }
+}
+
+template <typename K>
+int set_lds(K kernel, size_t lds) {
+  if (lds > 64 * 1024) INS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return INS_OK;
+}
+
+template <int LOGN>
+int launch_y(double2* data, int kxn, int nplanes, const double2* tw, bool inverse, hipStream_t s) {
+  constexpr int N = 1 << LOGN;
+  constexpr int TK = N <= 256 ? 16 : (N == 512 ? 8 : 4);  // 256-B segments per row where LDS allows (<= 80 KB tiles)
+  constexpr size_t lds = ((size_t)N * TK + N) * sizeof(double2);
+  dim3 grid((kxn + TK - 1) / TK, nplanes);
+  if (inverse) {
+    int rc = set_lds(&k_yfft<LOGN, TK, true>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_yfft<LOGN, TK, true>), grid, dim3(256), lds, s, data, kxn, tw);
+  } else {
+    int rc = set_lds(&k_yfft<LOGN, TK, false>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_yfft<LOGN, TK, false>), grid, dim3(256), lds, s, data, kxn, tw);
+  }
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+template <int LOGN>
+int launch_xfwd(const GridDev& g, const double* src, int from_u, double2* out, int n1, int n2, const double2* tw, hipStream_t s) {
+  constexpr int N = 1 << LOGN;
+  constexpr int NP = N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N);
+  constexpr size_t lds = ((size_t)NP * N + N) * sizeof(double2);
+  dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
+  if (from_u)
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 1>), grid, dim3(256), lds, s, g, src, out, n1, tw);
+  else
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 0>), grid, dim3(256), lds, s, g, src, out, n1, tw);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+template <int LOGN>
+int launch_xinv(const double2* in, double* pI, int n1, int n2, const double2* tw, hipStream_t s) {
+  constexpr int N = 1 << LOGN;
+  constexpr int NP = N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N);
+  constexpr size_t lds = ((size_t)NP * N + N) * sizeof(double2);
+  dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
+  hipLaunchKernelGGL((k_xinv<LOGN, NP>), grid, dim3(256), lds, s, in, pI, n1, tw);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+}  // namespace
+
+#define INS_POW2_SWITCH(n, CALL)            \
+  switch (n) {                              \
+    case 16: return CALL(4);                \
+    case 32: return CALL(5);                \
+    case 64: return CALL(6);                \
+    case 128: return CALL(7);               \
+    case 256: return CALL(8);               \
+    case 512: return CALL(9);               \
+    case 1024: return CALL(10);             \
+  }                                         \
+  ins_set_error("own FFT: unsupported length %d", n); \
+  return INS_ERR_UNSUPPORTED;
+
+bool ins_ownfft_supported(const int np[3]) {
+  if (getenv("INS_DISABLE_OWNFFT")) return false;
+  for (int a = 0; a < 3; ++a)
+    if (np[a] < 16 || np[a] > 1024 || (np[a] & (np[a] - 1))) return false;
+  return ins_zsolve_supported(np[2]);
+}
+
+// ây permuted to the digit-reversed storage order that pass 2 leaves behind: out[pos] = ay[freq(pos)].
+void ins_ownfft_permute_symbol(int n, const double* ay, double* out) {
+  int logn = 0;
+  while ((1 << logn) < n) ++logn;
+  for (int k = 0; k < n; ++k) {
+    int p = 0, kk = k, L = n;
+    if (logn & 1) {
+      p += (kk & 1) * (L / 2);
+      kk >>= 1;
+      L /= 2;
+    }
+    for (int s = 0; s < logn / 2; ++s) {
+      p += (kk & 3) * (L / 4);
+      kk >>= 2;
+      L /= 4;
+    }
+    out[p] = ay[k];
+  }
+}
+
+int ins_k_ownfft_xfwd(const ins_grid* G, const double* src, int from_u, double* phat, int n0, int n1, int n2, const double* tw,
+                      hipStream_t s) {
+  static const GridDev no_grid{};  // SRC = 0 never touches the grid
+  const GridDev& g = G ? G->g : no_grid;
+  double2* out = reinterpret_cast<double2*>(phat);
+  const double2* w = reinterpret_cast<const double2*>(tw);
+#define CALL(LG) launch_xfwd<LG>(g, src, from_u, out, n1, n2, w, s)
+  INS_POW2_SWITCH(n0, CALL)
+#undef CALL
+}
+
+int ins_k_ownfft_xinv(const double* phat, double* pI, int n0, int n1, int n2, const double* tw, hipStream_t s) {
+  const double2* in = reinterpret_cast<const double2*>(phat);
+  const double2* w = reinterpret_cast<const double2*>(tw);
+#define CALL(LG) launch_xinv<LG>(in, pI, n1, n2, w, s)
+  INS_POW2_SWITCH(n0, CALL)
+#undef CALL
+}
+
+int ins_k_ownfft_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s) {
+  double2* d = reinterpret_cast<double2*>(phat);
+  const double2* w = reinterpret_cast<const double2*>(tw);
+#define CALL(LG) launch_y<LG>(d, kxn, n2, w, inverse, s)
+  INS_POW2_SWITCH(n1, CALL)
+#undef CALL
+}

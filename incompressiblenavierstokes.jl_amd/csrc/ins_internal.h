@@ -110,7 +110,10 @@ struct ins_poisson {
   size_t work_bytes = 0;
   hipStream_t plan_stream = nullptr;
   bool zfused = false;      // 3-D: batched 2-D (x,y) plans + the fused z kernel (ins_zsolve.hip)
+  bool ownfft = false;      // 3-D power-of-two box: all five passes are own LDS kernels (ins_fft.hip), no rocFFT
   double* tw = nullptr;     // z twiddles
+  double* tw_x = nullptr;   // x / y twiddles (ownfft)
+  double* tw_y = nullptr;
   // cg
   double abstol = 0, reltol = 0;
   long long maxiter = 0;
@@ -173,6 +176,11 @@ int ins_validate_real_plans(hipfftHandle fwd, hipfftHandle inv, int rank, const 
 int ins_fft_make_real_plans(hipfftHandle* fwd, hipfftHandle* inv, int rank, int* n, int batch);
 void ins_fft_solver_released();
 bool ins_zsolve_supported(int nz);
+bool ins_ownfft_supported(const int np[3]);
+void ins_ownfft_permute_symbol(int n, const double* ay, double* out);
+int ins_k_ownfft_xfwd(const ins_grid* G, const double* src, int from_u, double* phat, int n0, int n1, int n2, const double* tw, hipStream_t s);
+int ins_k_ownfft_xinv(const double* phat, double* pI, int n0, int n1, int n2, const double* tw, hipStream_t s);
+int ins_k_ownfft_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s);
 int ins_zsolve_twiddles(int nz, double** out);
 int ins_k_zsolve(double* data, int nz, long long nl, const double* ax, int kxn, const double* ay, const double* az, const double* tw,
                  double inv_n, bool zero_mean, hipStream_t s);

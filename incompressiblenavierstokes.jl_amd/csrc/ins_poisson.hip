@@ -336,12 +336,18 @@ extern "C" int ins_poisson_spectral_create(const ins_grid_t* G, ins_poisson_t** 
     ins_set_error("hipMalloc(pI/phat) failed for %lld cells", nreal);
     return fail(INS_ERR_HIP);
   }
+  ps->ownfft = D == 3 && ins_ownfft_supported(ps->np);
   // ahat[α][k] = 4 Ω sinpi(k/Np[α])² / Δx[α]²                                      pressure.jl:305-311
   for (int a = 0; a < D; ++a) {
     std::vector<double> ah(ps->kmax[a]);
     for (int k = 0; k < ps->kmax[a]; ++k) {
       const double sn = std::sin(M_PI * ((double)k / ps->np[a]));
       ah[k] = 4 * om * sn * sn / (G->h[a] * G->h[a]);
+    }
+    if (ps->ownfft && a == 1) {  // the own y pass leaves ky in digit-reversed order (ins_fft.hip)
+      std::vector<double> perm(ah.size());
+      ins_ownfft_permute_symbol(ps->np[1], ah.data(), perm.data());
+      ah.swap(perm);
     }
     if (hipMalloc(&ps->ahat[a], ah.size() * sizeof(double)) != hipSuccess ||
         hipMemcpy(ps->ahat[a], ah.data(), ah.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
@@ -352,7 +358,12 @@ extern "C" int ins_poisson_spectral_create(const ins_grid_t* G, ins_poisson_t** 
   // plan_rfft(pI): all D dims, real -> half-complex along x (pressure.jl:316).  hipFFT takes lengths slowest first.
   // plan_rfft(pI): all D dims, real -> half-complex along x (pressure.jl:316); hipFFT takes lengths slowest first.
   // 3-D with a power-of-two nz: batched 2-D (x,y) plans + ONE fused z kernel (FFT · symbol · inverse FFT) = 5 passes.
-  {
+  if (ps->ownfft) {  // no rocFFT plans at all
+    if ((rc = ins_zsolve_twiddles(ps->np[0], &ps->tw_x))) return fail(rc);
+    if ((rc = ins_zsolve_twiddles(ps->np[1], &ps->tw_y))) return fail(rc);
+    if ((rc = ins_zsolve_twiddles(ps->np[2], &ps->tw))) return fail(rc);
+    ps->zfused = true;
+  } else {
     int nfull[3] = {ps->np[2], ps->np[1], ps->np[0]};
     ps->zfused = D == 3 && ins_zsolve_supported(ps->np[2]);
     rc = ps->zfused ? ins_fft_make_real_plans(&ps->plan_fwd, &ps->plan_inv, 2, nfull + 1, ps->np[2])
@@ -365,8 +376,22 @@ extern "C" int ins_poisson_spectral_create(const ins_grid_t* G, ins_poisson_t** 
   return INS_OK;
 }
 
+// pI -> pI through the five own passes; from_u != nullptr: the right-hand side Ω·div(u) is formed inside pass 1
+static int ownfft_transform(ins_poisson* ps, const double* from_u, hipStream_t s) {
+  const int n0 = ps->np[0], n1 = ps->np[1], n2 = ps->np[2], kxn = ps->kmax[0];
+  double* ph = reinterpret_cast<double*>(ps->phat);
+  int rc;
+  if ((rc = ins_k_ownfft_xfwd(ps->grid, from_u ? from_u : ps->pI, from_u != nullptr, ph, n0, n1, n2, ps->tw_x, s))) return rc;
+  if ((rc = ins_k_ownfft_y(ph, kxn, n1, n2, ps->tw_y, false, s))) return rc;
+  const double inv_n = 1.0 / ((double)n0 * n1 * n2);
+  if ((rc = ins_k_zsolve(ph, n2, (long long)kxn * n1, ps->ahat[0], kxn, ps->ahat[1], ps->ahat[2], ps->tw, inv_n, true, s))) return rc;
+  if ((rc = ins_k_ownfft_y(ph, kxn, n1, n2, ps->tw_y, true, s))) return rc;
+  return ins_k_ownfft_xinv(ph, ps->pI, n0, n1, n2, ps->tw_x, s);
+}
+
 static int spectral_transform(ins_poisson* ps, hipStream_t s) {
   const GridDev& g = ps->grid->g;
+  if (ps->ownfft) return ownfft_transform(ps, nullptr, s);
   INS_FFT_TRY(hipfftSetStream(ps->plan_fwd, s));
   INS_FFT_TRY(hipfftSetStream(ps->plan_inv, s));
   INS_FFT_TRY(hipfftExecD2Z(ps->plan_fwd, ps->pI, ps->phat));
@@ -538,6 +563,8 @@ extern "C" int ins_poisson_destroy(ins_poisson_t* ps) {
     ins_fft_solver_released();
   }
   if (ps->tw) (void)hipFree(ps->tw);
+  if (ps->tw_x) (void)hipFree(ps->tw_x);
+  if (ps->tw_y) (void)hipFree(ps->tw_y);
   if (ps->pI) (void)hipFree(ps->pI);
   if (ps->phat) (void)hipFree(ps->phat);
   for (int a = 0; a < 3; ++a)
@@ -598,9 +625,14 @@ int ins_k_project(const ins_grid* G, ins_poisson* ps, double* u, double* p, hipS
 int ins_k_project_periodic_fused(const ins_grid* G, ins_poisson* ps, double* u, double* p, bool keep_p, hipStream_t s) {
   const GridDev& g = G->g;
   dim3 block(64, 4, 1), grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), ps->np[2]);
-  hipLaunchKernelGGL((k_div_to_pI<3, true>), grid, block, 0, s, g, u, ps->pI, ps->np[0], ps->np[1]);
-  INS_LAUNCH_CHECK();
-  int rc = spectral_transform(ps, s);
+  int rc;
+  if (ps->ownfft) {  // K2 lives inside the x-forward pass
+    rc = ownfft_transform(ps, u, s);
+  } else {
+    hipLaunchKernelGGL((k_div_to_pI<3, true>), grid, block, 0, s, g, u, ps->pI, ps->np[0], ps->np[1]);
+    INS_LAUNCH_CHECK();
+    rc = spectral_transform(ps, s);
+  }
   if (rc) return rc;
   if (keep_p)
     hipLaunchKernelGGL(k_grad_ghost3<true>, grid, block, 0, s, g, u, p, ps->pI, ps->np[0], ps->np[1], ps->np[2]);
@@ -614,6 +646,7 @@ int ins_k_project_periodic_fused(const ins_grid* G, ins_poisson* ps, double* u, 
 // The gradient-subtract is left to the next stage's stencil kernel (k_momentum_flux<..., CORR>).
 int ins_k_project_periodic_solve_only(const ins_grid* G, ins_poisson* ps, const double* u, hipStream_t s) {
   const GridDev& g = G->g;
+  if (ps->ownfft) return ownfft_transform(ps, u, s);
   dim3 block(64, 4, 1), grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), ps->np[2]);
   hipLaunchKernelGGL((k_div_to_pI<3, true>), grid, block, 0, s, g, u, ps->pI, ps->np[0], ps->np[1]);
   INS_LAUNCH_CHECK();

@@ -21,6 +21,9 @@ struct ins_slab_fft {
   bool plans = false, has_z_plan = false;
   double *ax = nullptr, *ay = nullptr, *az = nullptr;  // symbol vectors (ay: this rank's ky range)
   double* tw = nullptr;                                 // twiddles of the fused z kernel (power-of-two nz)
+  bool ownfft = false;                                  // power-of-two box: own x / y passes too (ins_fft.hip), no rocFFT
+  double *tw_x = nullptr, *tw_y = nullptr;
+  const ins_grid* dummy_grid = nullptr;
 };
 
 namespace {
@@ -139,7 +142,15 @@ extern "C" int ins_slab_fft_create(const int32_t np[3], const double h[3], int r
   };
   std::vector<double> ax(S->kxn), ay(S->nyl), az(np[2]);
   for (int k = 0; k < S->kxn; ++k) ax[k] = symbol(0, k);
-  for (int k = 0; k < S->nyl; ++k) ay[k] = symbol(1, rank * S->nyl + k);
+  S->ownfft = ins_ownfft_supported(np);
+  if (S->ownfft) {  // the own y pass leaves ky in digit-reversed storage order: slice the permuted symbol vector
+    std::vector<double> full(np[1]), perm(np[1]);
+    for (int k = 0; k < np[1]; ++k) full[k] = symbol(1, k);
+    ins_ownfft_permute_symbol(np[1], full.data(), perm.data());
+    for (int k = 0; k < S->nyl; ++k) ay[k] = perm[rank * S->nyl + k];
+  } else {
+    for (int k = 0; k < S->nyl; ++k) ay[k] = symbol(1, rank * S->nyl + k);
+  }
   for (int k = 0; k < np[2]; ++k) az[k] = symbol(2, k);
   bool ok = hipMalloc(&S->ax, ax.size() * 8) == hipSuccess && hipMalloc(&S->ay, ay.size() * 8) == hipSuccess &&
             hipMalloc(&S->az, az.size() * 8) == hipSuccess;
@@ -156,7 +167,14 @@ extern "C" int ins_slab_fft_create(const int32_t np[3], const double h[3], int r
   int nz1[1] = {np[2]};
   const int lines = S->nyl * S->kxn;
   const bool zfused = ins_zsolve_supported(np[2]);  // then no rocFFT z plan is needed at all
-  {
+  if (S->ownfft) {
+    int rcv = ins_zsolve_twiddles(np[0], &S->tw_x);
+    if (!rcv) rcv = ins_zsolve_twiddles(np[1], &S->tw_y);
+    if (rcv) {
+      ins_slab_fft_destroy(S);
+      return rcv;
+    }
+  } else {
     int rcv = ins_fft_make_real_plans(&S->xy_fwd, &S->xy_inv, 2, n2, S->nzl);  // validated (ins_fftcheck.hip)
     if (rcv) {
       ins_slab_fft_destroy(S);
@@ -193,6 +211,8 @@ extern "C" int ins_slab_fft_destroy(ins_slab_fft_t* S) {
     ins_fft_solver_released();
   }
   if (S->tw) (void)hipFree(S->tw);
+  if (S->tw_x) (void)hipFree(S->tw_x);
+  if (S->tw_y) (void)hipFree(S->tw_y);
   if (S->ax) (void)hipFree(S->ax);
   if (S->ay) (void)hipFree(S->ay);
   if (S->az) (void)hipFree(S->az);
@@ -210,8 +230,14 @@ extern "C" int ins_slab_fft_sizes(const ins_slab_fft_t* S, int64_t* real_elems, 
 extern "C" int ins_slab_fft_forward_xy(ins_slab_fft_t* S, double* pI, double* work, double* sendbuf, void* stream) {
   INS_REQUIRE(S && pI && work && sendbuf, "null argument");
   hipStream_t s = as_stream(stream);
-  INS_FFT_TRY(hipfftSetStream(S->xy_fwd, s));
-  INS_FFT_TRY(hipfftExecD2Z(S->xy_fwd, pI, reinterpret_cast<hipfftDoubleComplex*>(work)));
+  if (S->ownfft) {
+    int rc = ins_k_ownfft_xfwd(nullptr, pI, 0, work, S->np[0], S->np[1], S->nzl, S->tw_x, s);
+    if (!rc) rc = ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s);
+    if (rc) return rc;
+  } else {
+    INS_FFT_TRY(hipfftSetStream(S->xy_fwd, s));
+    INS_FFT_TRY(hipfftExecD2Z(S->xy_fwd, pI, reinterpret_cast<hipfftDoubleComplex*>(work)));
+  }
   dim3 block(64, 4, 1), grid(cdiv(S->kxn, 64), cdiv(S->np[1], 4), S->nzl);
   hipLaunchKernelGGL(k_transpose_pack<true>, grid, block, 0, s, reinterpret_cast<double2*>(work), reinterpret_cast<double2*>(sendbuf), S->kxn,
                      S->np[1], S->nyl, S->nzl);
@@ -244,6 +270,11 @@ extern "C" int ins_slab_fft_inverse_xy(ins_slab_fft_t* S, double* recvbuf, doubl
   hipLaunchKernelGGL(k_transpose_pack<false>, grid, block, 0, s, reinterpret_cast<double2*>(work), reinterpret_cast<double2*>(recvbuf), S->kxn,
                      S->np[1], S->nyl, S->nzl);
   INS_LAUNCH_CHECK();
+  if (S->ownfft) {
+    int rc = ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, true, s);
+    if (!rc) rc = ins_k_ownfft_xinv(work, pI, S->np[0], S->np[1], S->nzl, S->tw_x, s);
+    return rc;
+  }
   INS_FFT_TRY(hipfftSetStream(S->xy_inv, s));
   INS_FFT_TRY(hipfftExecZ2D(S->xy_inv, reinterpret_cast<hipfftDoubleComplex*>(work), pI));
   return INS_OK;

@@ -396,3 +396,26 @@ def test_lmwray3_and_right_hand_side_match_oracle(ins, oracle, geom):
     (u, _, t), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 0.01), ustart=u_dev, method=m, psolver=psp, Δt=0.005)
     assert t == pytest.approx(0.01)
     assert rell2(ins.to_numpy(u), st["u"]) < tol
+
+
+@pytest.mark.parametrize("n", [(16, 16, 16), (32, 16, 64), (128, 32, 16), (64, 128, 32), (256, 16, 16), (16, 256, 32),
+                               (512, 16, 16), (16, 512, 16), (1024, 16, 16), (16, 1024, 16)])
+def test_own_fft_passes_match_oracle(ins, oracle, n):
+    """All-own-kernel spectral solve on power-of-two boxes (csrc/ins_fft.hip: paired-row real x transform, digit-reversed
+    y pass, fused z pass) — every supported length incl. the odd-log2 ones, in each direction; both the generic
+    psolver(p) entry and the fused projection (right-hand side formed inside the x pass)."""
+    o = oracle
+    so = fx.setup_periodic(o, n, D=3)
+    sp = mirror(ins, so, o)
+    pso, psp = o.psolver_spectral(so), ins.psolver_spectral(sp)
+    f = fx.randn_field(so.grid.N, 23)
+    ip = tuple(slice(lo, hi) for lo, hi in so.grid.Ip)
+    f[ip] -= f[ip].mean()
+    want = o.poisson(pso, f)
+    got = ins.to_numpy(ins.poisson(psp, ins.from_numpy(sp, f)))
+    assert rell2(got[ip], want[ip]) < POISSON_TOL
+    u_h = o.apply_bc_u(fx.randn_field(so.grid.N + (3,), 24), 0.0, so)
+    want_u = o.project_(u_h.copy(order="F"), so, pso, o.scalarfield(so))
+    u = ins.from_numpy(sp, u_h)
+    ins.project_(u, sp, psp, ins.scalarfield(sp))
+    assert rell2(ins.to_numpy(u), want_u) < POISSON_TOL

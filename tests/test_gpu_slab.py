@@ -78,11 +78,13 @@ def _worker(rank, world, port, n, nsteps, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_multi_rank_slab_on_one_gpu_matches_oracle(tmp_path, oracle, world):
+@pytest.mark.parametrize("world,n", [(2, (66, 16, 24)), (4, (66, 16, 24)), (2, (64, 16, 32)), (4, (64, 32, 32))])
+def test_multi_rank_slab_on_one_gpu_matches_oracle(tmp_path, oracle, world, n):
+    """(66,16,24): rocFFT x/y + rocFFT z; power-of-two boxes: own x/y passes with the digit-reversed ky order split
+    across ranks + the fused z kernel."""
     _need_gpu()
     o = oracle
-    n, nsteps = (66, 16, 24), 2
+    nsteps = 2
     mp.spawn(_worker, args=(world, _free_port(), n, nsteps, str(tmp_path)), nprocs=world, join=True)
     x = tuple(np.linspace(0.0, 1.0, ni + 1) for ni in n)
     so = o.make_setup(x, Re=500.0)
