@@ -161,6 +161,26 @@ def main():
     torch.cuda.synchronize()
     k1_plain_ms = ev0.elapsed_time(ev1) / 20
     k1_plain_gbs = K1_BYTES_PER_CELL * cells / (k1_plain_ms * 1e-3) / 1e9
+    del F
+    # the north-star size for the stencil alone: K1 at 512^3 on a solenoidal-free random field (2 x 3.3 GB, 10 launches)
+    k1_512 = None
+    if n != 512 and not os.environ.get("INS_BENCH_SKIP_K1_512"):
+        s5 = ins.Setup(x=(np.linspace(0.0, 1.0, 513),) * 3, Re=1000.0, device=dev)
+        u5, F5 = ins.vectorfield(s5), ins.vectorfield(s5)
+        u5.copy_(torch.randn(u5.shape, dtype=torch.float64, device=dev))
+        ins.apply_bc_u_(u5, 0.0, s5)
+        for _ in range(3):
+            ins.momentum_(F5, u5, None, 0.0, s5)
+        ev0.record()
+        for _ in range(10):
+            ins.momentum_(F5, u5, None, 0.0, s5)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms5 = ev0.elapsed_time(ev1) / 10
+        k1_512 = {"kernel": "k_momentum_flux (K1 alone) at 512^3, random data", "bound": "hbm", "achieved": K1_BYTES_PER_CELL * 512.0**3 / (ms5 * 1e-3) / 1e9,
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_cell": K1_BYTES_PER_CELL, "avg_launch_ms": ms5}
+        k1_512["frac"] = k1_512["achieved"] / HBM_PEAK_GBS
+        del u5, F5, s5
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")
     if n == 256 and os.path.exists(tfile):  # PMC counters cannot be read in-process: committed rocprofv3 --pmc result
@@ -212,6 +232,7 @@ def main():
             "bytes_per_cell": K1_BYTES_PER_CELL,
             "avg_launch_ms": k1_plain_ms,
         },
+        "roofline_k1_512": k1_512,
         "step_bandwidth": {"design_bytes_per_cell": 1104, "achieved_GBs": 1104 * cells / (ms_per_step * 1e-3) / 1e9},
         "check": {"max_abs_div_times_dx": div / n, "kinetic_energy": energy},
     }
