@@ -49,8 +49,11 @@ def run_distributed(args, ins):
         n = (args.n, args.n, args.n * world)
     lay = ins.SlabLayout(n, world, rank)
     K = ins.HipSlabKernels(lay, Re=1000.0, device=dev)
-    comm = ins.SlabComm()
-    st = ins.SlabStepper(ins.RKMethods.RK44(), lay, K, comm)
+    # second communicator so that back-transposes of finished kx-chunks run beside forward ones (full-duplex xGMI links)
+    nchunks = int(os.environ.get("INS_SLAB_CHUNKS", "4"))
+    g2 = dist.new_group(ranks=list(range(world))) if nchunks > 1 else None
+    comm = ins.SlabComm(group2=g2)
+    st = ins.SlabStepper(ins.RKMethods.RK44(), lay, K, comm, chunks=nchunks)
     u = K.vector()
     u.copy_(torch.from_numpy(np.ascontiguousarray(tgv_local(lay))).to(dev))
     st.project_(u)  # velocityfield(...; doproject = true)  (initializers.jl:38-42)
@@ -88,7 +91,7 @@ def run_distributed(args, ins):
             "data": "synthetic",
             "config": {"workload": f"TaylorGreenVortex3D {n[0]}x{n[1]}x{n[2]} periodic fp64, RK44 + distributed spectral Poisson, dt=1e-3, Re=1e3",
                        "grid": list(n), "decomposition": f"z-slabs x{world} (256^3 cells per GPU), RCCL halo + all-to-all transposes"},
-            "check": {"max_abs_div_times_dx": div * (1.0 / n[0]), "finite": finite, "backend": backend},
+            "check": {"max_abs_div_times_dx": div * (1.0 / n[0]), "finite": finite, "backend": backend, "kx_chunks": len(st.chunks)},
         }
         print(json.dumps(out))
     dist.destroy_process_group()

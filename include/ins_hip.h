@@ -193,6 +193,16 @@ int ins_slab_fft_solve_z(ins_slab_fft_t* fft, double* buf, void* stream);
 /* after the all-to-all back (recvbuf = [src q][kz_local][ky_local][kx]): unpack, 2-D C2R -> pI */
 int ins_slab_fft_inverse_xy(ins_slab_fft_t* fft, double* recvbuf, double* work, double* pI, void* stream);
 
+/* kx-chunked variants of the three calls above: chunk [kx0, kx0+kxc) of the half spectrum is packed contiguously
+ * ([dest q][kz_local][ky_local][kxc]), so the transposes of different chunks can overlap each other (full-duplex links,
+ * two communicators) and the z solve.  Chunks need a power-of-two nz (ins_slab_fft_can_chunk). */
+int ins_slab_fft_can_chunk(const ins_slab_fft_t* fft);
+int ins_slab_fft_xy_forward_only(ins_slab_fft_t* fft, double* pI, double* work, void* stream);
+int ins_slab_fft_pack_chunk(ins_slab_fft_t* fft, double* work, double* sendbuf, int kx0, int kxc, void* stream);
+int ins_slab_fft_solve_z_chunk(ins_slab_fft_t* fft, double* buf, int kx0, int kxc, void* stream);
+int ins_slab_fft_unpack_chunk(ins_slab_fft_t* fft, double* recvbuf, double* work, int kx0, int kxc, void* stream);
+int ins_slab_fft_xy_inverse_only(ins_slab_fft_t* fft, double* work, double* pI, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,12 @@ SIGNATURES = {
     "ins_slab_fft_forward_xy": (C.c_int, [vp, vp, vp, vp, vp]),
     "ins_slab_fft_solve_z": (C.c_int, [vp, vp, vp]),
     "ins_slab_fft_inverse_xy": (C.c_int, [vp, vp, vp, vp, vp]),
+    "ins_slab_fft_can_chunk": (C.c_int, [vp]),
+    "ins_slab_fft_xy_forward_only": (C.c_int, [vp, vp, vp, vp]),
+    "ins_slab_fft_pack_chunk": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
+    "ins_slab_fft_solve_z_chunk": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+    "ins_slab_fft_unpack_chunk": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
+    "ins_slab_fft_xy_inverse_only": (C.c_int, [vp, vp, vp, vp]),
 }
 
 _lib = None

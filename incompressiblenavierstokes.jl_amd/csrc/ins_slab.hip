@@ -28,17 +28,18 @@ struct ins_slab_fft {
 
 namespace {
 
-// work[kzl][ky][kx]  <->  buf[q][kzl][kyl][kx],  ky = q*nyl + kyl        (complex = double2)
+// work[kzl][ky][kx]  <->  buf[q][kzl][kyl][kxl],  ky = q*nyl + kyl,  kx = kx0 + kxl, kxl < kxc   (complex = double2)
+// A chunk [kx0, kx0+kxc) of the spectrum is packed contiguously so that it can travel (and be solved) on its own.
 template <bool PACK>
 __global__ __launch_bounds__(256) void k_transpose_pack(double2* __restrict__ work, double2* __restrict__ buf, int kxn, int ny, int nyl,
-                                                        int nzl) {
-  const int kx = blockIdx.x * 64 + threadIdx.x;
+                                                        int nzl, int kx0, int kxc) {
+  const int kxl = blockIdx.x * 64 + threadIdx.x;
   const int ky = blockIdx.y * 4 + threadIdx.y;
   const int kz = blockIdx.z;
-  if (kx >= kxn || ky >= ny) return;
+  if (kxl >= kxc || ky >= ny) return;
   const int q = ky / nyl, kyl = ky - q * nyl;
-  const long long w = kx + (long long)kxn * (ky + (long long)ny * kz);
-  const long long b = kx + (long long)kxn * (kyl + (long long)nyl * (kz + (long long)nzl * q));
+  const long long w = (kx0 + kxl) + (long long)kxn * (ky + (long long)ny * kz);
+  const long long b = kxl + (long long)kxc * (kyl + (long long)nyl * (kz + (long long)nzl * q));
   if (PACK)
     buf[b] = work[w];
   else
@@ -227,49 +228,18 @@ extern "C" int ins_slab_fft_sizes(const ins_slab_fft_t* S, int64_t* real_elems, 
   return INS_OK;
 }
 
-extern "C" int ins_slab_fft_forward_xy(ins_slab_fft_t* S, double* pI, double* work, double* sendbuf, void* stream) {
-  INS_REQUIRE(S && pI && work && sendbuf, "null argument");
-  hipStream_t s = as_stream(stream);
+static int slab_xy_forward(ins_slab_fft* S, double* pI, double* work, hipStream_t s) {
   if (S->ownfft) {
     int rc = ins_k_ownfft_xfwd(nullptr, pI, 0, work, S->np[0], S->np[1], S->nzl, S->tw_x, s);
     if (!rc) rc = ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s);
-    if (rc) return rc;
-  } else {
-    INS_FFT_TRY(hipfftSetStream(S->xy_fwd, s));
-    INS_FFT_TRY(hipfftExecD2Z(S->xy_fwd, pI, reinterpret_cast<hipfftDoubleComplex*>(work)));
+    return rc;
   }
-  dim3 block(64, 4, 1), grid(cdiv(S->kxn, 64), cdiv(S->np[1], 4), S->nzl);
-  hipLaunchKernelGGL(k_transpose_pack<true>, grid, block, 0, s, reinterpret_cast<double2*>(work), reinterpret_cast<double2*>(sendbuf), S->kxn,
-                     S->np[1], S->nyl, S->nzl);
-  INS_LAUNCH_CHECK();
+  INS_FFT_TRY(hipfftSetStream(S->xy_fwd, s));
+  INS_FFT_TRY(hipfftExecD2Z(S->xy_fwd, pI, reinterpret_cast<hipfftDoubleComplex*>(work)));
   return INS_OK;
 }
 
-extern "C" int ins_slab_fft_solve_z(ins_slab_fft_t* S, double* buf, void* stream) {
-  INS_REQUIRE(S && buf, "null argument");
-  hipStream_t s = as_stream(stream);
-  if (S->tw)  // one fused pass instead of z-FFT + symbol + inverse z-FFT
-    return ins_k_zsolve(buf, S->np[2], (long long)S->nyl * S->kxn, S->ax, S->kxn, S->ay, S->az, S->tw,
-                        1.0 / ((double)S->np[0] * S->np[1] * S->np[2]), S->rank == 0, s);
-  hipfftDoubleComplex* c = reinterpret_cast<hipfftDoubleComplex*>(buf);
-  INS_FFT_TRY(hipfftSetStream(S->z_fwd, s));
-  INS_FFT_TRY(hipfftExecZ2Z(S->z_fwd, c, c, HIPFFT_FORWARD));
-  const double inv_n = 1.0 / ((double)S->np[0] * S->np[1] * S->np[2]);
-  dim3 block(64, 4, 1), grid(cdiv(S->kxn, 64), cdiv(S->nyl, 4), S->np[2]);
-  hipLaunchKernelGGL(k_symbol_slab, grid, block, 0, s, reinterpret_cast<double2*>(buf), S->ax, S->ay, S->az, S->kxn, S->nyl, S->np[2], inv_n,
-                     S->rank == 0);
-  INS_LAUNCH_CHECK();
-  INS_FFT_TRY(hipfftExecZ2Z(S->z_fwd, c, c, HIPFFT_BACKWARD));
-  return INS_OK;
-}
-
-extern "C" int ins_slab_fft_inverse_xy(ins_slab_fft_t* S, double* recvbuf, double* work, double* pI, void* stream) {
-  INS_REQUIRE(S && recvbuf && work && pI, "null argument");
-  hipStream_t s = as_stream(stream);
-  dim3 block(64, 4, 1), grid(cdiv(S->kxn, 64), cdiv(S->np[1], 4), S->nzl);
-  hipLaunchKernelGGL(k_transpose_pack<false>, grid, block, 0, s, reinterpret_cast<double2*>(work), reinterpret_cast<double2*>(recvbuf), S->kxn,
-                     S->np[1], S->nyl, S->nzl);
-  INS_LAUNCH_CHECK();
+static int slab_xy_inverse(ins_slab_fft* S, double* work, double* pI, hipStream_t s) {
   if (S->ownfft) {
     int rc = ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, true, s);
     if (!rc) rc = ins_k_ownfft_xinv(work, pI, S->np[0], S->np[1], S->nzl, S->tw_x, s);
@@ -279,6 +249,76 @@ extern "C" int ins_slab_fft_inverse_xy(ins_slab_fft_t* S, double* recvbuf, doubl
   INS_FFT_TRY(hipfftExecZ2D(S->xy_inv, reinterpret_cast<hipfftDoubleComplex*>(work), pI));
   return INS_OK;
 }
+
+template <bool PACK>
+static int slab_pack(ins_slab_fft* S, double* work, double* buf, int kx0, int kxc, hipStream_t s) {
+  INS_REQUIRE(kx0 >= 0 && kxc >= 1 && kx0 + kxc <= S->kxn, "bad kx chunk");
+  dim3 block(64, 4, 1), grid(cdiv(kxc, 64), cdiv(S->np[1], 4), S->nzl);
+  hipLaunchKernelGGL(k_transpose_pack<PACK>, grid, block, 0, s, reinterpret_cast<double2*>(work), reinterpret_cast<double2*>(buf), S->kxn,
+                     S->np[1], S->nyl, S->nzl, kx0, kxc);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+static int slab_solve_z(ins_slab_fft* S, double* buf, int kx0, int kxc, hipStream_t s) {
+  INS_REQUIRE(kx0 >= 0 && kxc >= 1 && kx0 + kxc <= S->kxn, "bad kx chunk");
+  const double inv_n = 1.0 / ((double)S->np[0] * S->np[1] * S->np[2]);
+  if (S->tw)  // one fused pass instead of z-FFT + symbol + inverse z-FFT; a chunk is just a narrower [kz][kyl][kxc] array
+    return ins_k_zsolve(buf, S->np[2], (long long)S->nyl * kxc, S->ax + kx0, kxc, S->ay, S->az, S->tw, inv_n, S->rank == 0 && kx0 == 0, s);
+  INS_REQUIRE(kx0 == 0 && kxc == S->kxn, "kx chunks need a power-of-two nz (fused z kernel)");
+  hipfftDoubleComplex* c = reinterpret_cast<hipfftDoubleComplex*>(buf);
+  INS_FFT_TRY(hipfftSetStream(S->z_fwd, s));
+  INS_FFT_TRY(hipfftExecZ2Z(S->z_fwd, c, c, HIPFFT_FORWARD));
+  dim3 block(64, 4, 1), grid(cdiv(S->kxn, 64), cdiv(S->nyl, 4), S->np[2]);
+  hipLaunchKernelGGL(k_symbol_slab, grid, block, 0, s, reinterpret_cast<double2*>(buf), S->ax, S->ay, S->az, S->kxn, S->nyl, S->np[2], inv_n,
+                     S->rank == 0);
+  INS_LAUNCH_CHECK();
+  INS_FFT_TRY(hipfftExecZ2Z(S->z_fwd, c, c, HIPFFT_BACKWARD));
+  return INS_OK;
+}
+
+extern "C" int ins_slab_fft_forward_xy(ins_slab_fft_t* S, double* pI, double* work, double* sendbuf, void* stream) {
+  INS_REQUIRE(S && pI && work && sendbuf, "null argument");
+  int rc = slab_xy_forward(S, pI, work, as_stream(stream));
+  if (rc) return rc;
+  return slab_pack<true>(S, work, sendbuf, 0, S->kxn, as_stream(stream));
+}
+
+extern "C" int ins_slab_fft_solve_z(ins_slab_fft_t* S, double* buf, void* stream) {
+  INS_REQUIRE(S && buf, "null argument");
+  return slab_solve_z(S, buf, 0, S->kxn, as_stream(stream));
+}
+
+extern "C" int ins_slab_fft_inverse_xy(ins_slab_fft_t* S, double* recvbuf, double* work, double* pI, void* stream) {
+  INS_REQUIRE(S && recvbuf && work && pI, "null argument");
+  int rc = slab_pack<false>(S, work, recvbuf, 0, S->kxn, as_stream(stream));
+  if (rc) return rc;
+  return slab_xy_inverse(S, work, pI, as_stream(stream));
+}
+
+// ---- kx-chunked variants: the transposes of different chunks can overlap each other and the z solve -------------
+extern "C" int ins_slab_fft_xy_forward_only(ins_slab_fft_t* S, double* pI, double* work, void* stream) {
+  INS_REQUIRE(S && pI && work, "null argument");
+  return slab_xy_forward(S, pI, work, as_stream(stream));
+}
+extern "C" int ins_slab_fft_pack_chunk(ins_slab_fft_t* S, double* work, double* sendbuf, int kx0, int kxc, void* stream) {
+  INS_REQUIRE(S && work && sendbuf, "null argument");
+  return slab_pack<true>(S, work, sendbuf, kx0, kxc, as_stream(stream));
+}
+extern "C" int ins_slab_fft_solve_z_chunk(ins_slab_fft_t* S, double* buf, int kx0, int kxc, void* stream) {
+  INS_REQUIRE(S && buf, "null argument");
+  return slab_solve_z(S, buf, kx0, kxc, as_stream(stream));
+}
+extern "C" int ins_slab_fft_unpack_chunk(ins_slab_fft_t* S, double* recvbuf, double* work, int kx0, int kxc, void* stream) {
+  INS_REQUIRE(S && recvbuf && work, "null argument");
+  return slab_pack<false>(S, work, recvbuf, kx0, kxc, as_stream(stream));
+}
+extern "C" int ins_slab_fft_xy_inverse_only(ins_slab_fft_t* S, double* work, double* pI, void* stream) {
+  INS_REQUIRE(S && work && pI, "null argument");
+  return slab_xy_inverse(S, work, pI, as_stream(stream));
+}
+/* 1 when kx chunks are supported (power-of-two nz -> fused z kernel). */
+extern "C" int ins_slab_fft_can_chunk(const ins_slab_fft_t* S) { return S && S->tw != nullptr; }
 
 static int check_slab_grid(const ins_grid* G) {
   INS_REQUIRE(G, "null argument");

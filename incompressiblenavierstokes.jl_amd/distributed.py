@@ -49,8 +49,9 @@ class SlabComm:
     """Point-to-point plane exchange and the transpose all-to-all over a torch.distributed group.
     With the gloo backend and device tensors the payload is staged through the host (rehearsal mode)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, group2=None):
         self.group = group
+        self.group2 = group2 if group2 is not None else group  # second communicator: back-transposes run beside forward ones
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
@@ -87,6 +88,17 @@ class SlabComm:
             recv.copy_(hr)
         else:
             dist.all_to_all_single(recv, send, group=self.group)
+
+    class _Done:
+        def wait(self):
+            return None
+
+    def all_to_all_async(self, recv, send, which=0):
+        """Start a transpose; returns a handle whose wait() orders the current stream after it (no host block on RCCL)."""
+        if self.world == 1 or self._stage(send):
+            self.all_to_all(recv, send)
+            return SlabComm._Done()
+        return dist.all_to_all_single(recv, send, group=self.group2 if which else self.group, async_op=True)
 
     def barrier(self):
         if self.world > 1:
@@ -182,6 +194,25 @@ class HipSlabKernels:
     def fft_inverse_xy(self, recvbuf, work, pI):
         _lib.call("ins_slab_fft_inverse_xy", self._fft, self._p(recvbuf), self._p(work), self._p(pI), self.setup.stream)
 
+    # kx-chunked pieces
+    def can_chunk(self):
+        return bool(_lib.load().ins_slab_fft_can_chunk(self._fft))
+
+    def fft_xy_forward(self, pI, work):
+        _lib.call("ins_slab_fft_xy_forward_only", self._fft, self._p(pI), self._p(work), self.setup.stream)
+
+    def pack_chunk(self, work, sendbuf, kx0, kxc):
+        _lib.call("ins_slab_fft_pack_chunk", self._fft, self._p(work), self._p(sendbuf), kx0, kxc, self.setup.stream)
+
+    def solve_z_chunk(self, buf, kx0, kxc):
+        _lib.call("ins_slab_fft_solve_z_chunk", self._fft, self._p(buf), kx0, kxc, self.setup.stream)
+
+    def unpack_chunk(self, recvbuf, work, kx0, kxc):
+        _lib.call("ins_slab_fft_unpack_chunk", self._fft, self._p(recvbuf), self._p(work), kx0, kxc, self.setup.stream)
+
+    def fft_xy_inverse(self, work, pI):
+        _lib.call("ins_slab_fft_xy_inverse_only", self._fft, self._p(work), self._p(pI), self.setup.stream)
+
     def applypressure(self, u, pI, p_top):
         s = self.setup
         _lib.call("ins_slab_applypressure_f64", s.handle, s.ptr(u, True), self._p(pI), self._p(p_top), s.stream)
@@ -194,8 +225,12 @@ class SlabStepper:
     """Explicit Runge-Kutta stepping of a periodic box decomposed into z-slabs
     (step_explicit_runge_kutta.jl:4-59 distributed; same arithmetic in the same order on every cell)."""
 
-    def __init__(self, method, layout, kernels, comm):
+    def __init__(self, method, layout, kernels, comm, chunks=1):
         self.method, self.lay, self.k, self.comm = method, layout, kernels, comm
+        # kx-chunks of the half spectrum for the pipelined transposes (1 = one all-to-all each way)
+        chunks = max(1, min(int(chunks), layout.kxn)) if kernels.can_chunk() else 1
+        edges = [round(c * layout.kxn / chunks) for c in range(chunks + 1)]
+        self.chunks = [(edges[c], edges[c + 1] - edges[c]) for c in range(chunks) if edges[c + 1] > edges[c]]
         ns = len(method.b)
         self.ku = [kernels.vector() for _ in range(ns)]
         self.ub = [kernels.vector(), kernels.vector()]
@@ -232,11 +267,30 @@ class SlabStepper:
         K = self.k
         self.halo_u(u, comps=(2,), down_only=True)  # divergence needs w[I - e_z] only (operators.jl:122)
         K.divergence(u, self.pI)
-        K.fft_forward_xy(self.pI, self.work, self.bufa)
-        self.comm.all_to_all(self.bufb, self.bufa)
-        K.fft_solve_z(self.bufb)
-        self.comm.all_to_all(self.bufa, self.bufb)
-        K.fft_inverse_xy(self.bufa, self.work, self.pI)
+        if len(self.chunks) == 1:
+            K.fft_forward_xy(self.pI, self.work, self.bufa)
+            self.comm.all_to_all(self.bufb, self.bufa)
+            K.fft_solve_z(self.bufb)
+            self.comm.all_to_all(self.bufa, self.bufb)
+            K.fft_inverse_xy(self.bufa, self.work, self.pI)
+        else:
+            # pipelined over kx-chunks: transpose(c+1) || z-solve(c) || back-transpose(c-1) on two communicators
+            lay = self.lay
+            per_kx = 2 * lay.world * lay.nzl * lay.nyl  # doubles per unit of kx in a packed chunk
+            sl = [slice(per_kx * k0, per_kx * (k0 + kc)) for k0, kc in self.chunks]
+            K.fft_xy_forward(self.pI, self.work)
+            fwd, bwd = [], []
+            for (k0, kc), r in zip(self.chunks, sl):
+                K.pack_chunk(self.work, self.bufa[r], k0, kc)
+                fwd.append(self.comm.all_to_all_async(self.bufb[r], self.bufa[r], 0))
+            for (k0, kc), r, h in zip(self.chunks, sl, fwd):
+                h.wait()
+                K.solve_z_chunk(self.bufb[r], k0, kc)
+                bwd.append(self.comm.all_to_all_async(self.bufa[r], self.bufb[r], 1))
+            for (k0, kc), r, h in zip(self.chunks, sl, bwd):
+                h.wait()
+                K.unpack_chunk(self.bufa[r], self.work, k0, kc)
+            K.fft_xy_inverse(self.work, self.pI)
         self.halo_p()
         K.applypressure(u, self.pI, self.p_top)
         return u

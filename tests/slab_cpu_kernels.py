@@ -111,6 +111,42 @@ class OracleSlabKernels:
         w = blocks.transpose(1, 0, 2, 3).reshape(lay.nzl, ny, lay.kxn)
         pI.numpy()[...] = np.fft.irfftn(w, s=(ny, nx), axes=(1, 2)).reshape(-1)
 
+    # kx-chunked pieces (same contracts as HipSlabKernels)
+    def can_chunk(self):
+        return True
+
+    def fft_xy_forward(self, pI, work):
+        lay = self.layout
+        a = pI.numpy().reshape(lay.nzl, lay.n[1], lay.n[0])
+        self._c(work)[...] = np.fft.rfftn(a, axes=(1, 2)).reshape(-1)
+
+    def pack_chunk(self, work, sendbuf, kx0, kxc):
+        lay = self.layout
+        w = self._c(work).reshape(lay.nzl, lay.world, lay.nyl, lay.kxn)[:, :, :, kx0 : kx0 + kxc]
+        self._c(sendbuf)[...] = np.ascontiguousarray(w.transpose(1, 0, 2, 3)).reshape(-1)
+
+    def solve_z_chunk(self, buf, kx0, kxc):
+        lay = self.layout
+        c = self._c(buf).reshape(lay.n[2], lay.nyl, kxc)
+        f = np.fft.fft(c, axis=0)
+        den = self.az[:, None, None] + self.ay[None, :, None] + self.ax[None, None, kx0 : kx0 + kxc]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            f = -f / den
+        if lay.rank == 0 and kx0 == 0:
+            f[0, 0, 0] = 0.0
+        c[...] = np.fft.ifft(f, axis=0)
+
+    def unpack_chunk(self, recvbuf, work, kx0, kxc):
+        lay = self.layout
+        blocks = self._c(recvbuf).reshape(lay.world, lay.nzl, lay.nyl, kxc)
+        w = self._c(work).reshape(lay.nzl, lay.world, lay.nyl, lay.kxn)
+        w[:, :, :, kx0 : kx0 + kxc] = blocks.transpose(1, 0, 2, 3)
+
+    def fft_xy_inverse(self, work, pI):
+        lay = self.layout
+        w = self._c(work).reshape(lay.nzl, lay.n[1], lay.kxn)
+        pI.numpy()[...] = np.fft.irfftn(w, s=(lay.n[1], lay.n[0]), axes=(1, 2)).reshape(-1)
+
     def applypressure(self, u, pI, p_top):
         lay = self.layout
         nx, ny = lay.n[0], lay.n[1]

@@ -54,7 +54,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, nsteps, out_dir):
+def _worker(rank, world, port, n, nsteps, out_dir, chunks=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -67,7 +67,7 @@ def _worker(rank, world, port, n, nsteps, out_dir):
         u0 = o.random_field(so, kp=2, seed=7)
         lay = ins.SlabLayout(n, world, rank)
         K = ins.HipSlabKernels(lay, Re=500.0, device="cuda:0")
-        st = ins.SlabStepper(ins.RKMethods.RK44(), lay, K, ins.SlabComm())
+        st = ins.SlabStepper(ins.RKMethods.RK44(), lay, K, ins.SlabComm(), chunks=chunks)
         u = K.from_global(u0)
         for _ in range(nsteps):
             st.step_(u, 0.01)
@@ -78,14 +78,15 @@ def _worker(rank, world, port, n, nsteps, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, (66, 16, 24)), (4, (66, 16, 24)), (2, (64, 16, 32)), (4, (64, 32, 32))])
-def test_multi_rank_slab_on_one_gpu_matches_oracle(tmp_path, oracle, world, n):
+@pytest.mark.parametrize("world,n,chunks", [(2, (66, 16, 24), 1), (4, (66, 16, 24), 1), (2, (64, 16, 32), 1), (4, (64, 32, 32), 1),
+                                            (2, (64, 16, 32), 4), (2, (66, 16, 32), 3)])
+def test_multi_rank_slab_on_one_gpu_matches_oracle(tmp_path, oracle, world, n, chunks):
     """(66,16,24): rocFFT x/y + rocFFT z; power-of-two boxes: own x/y passes with the digit-reversed ky order split
     across ranks + the fused z kernel."""
     _need_gpu()
     o = oracle
     nsteps = 2
-    mp.spawn(_worker, args=(world, _free_port(), n, nsteps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, nsteps, str(tmp_path), chunks), nprocs=world, join=True)
     x = tuple(np.linspace(0.0, 1.0, ni + 1) for ni in n)
     so = o.make_setup(x, Re=500.0)
     ps = o.psolver_spectral(so)
