@@ -202,6 +202,13 @@ int ins_slab_fft_pack_chunk(ins_slab_fft_t* fft, double* work, double* sendbuf, 
 int ins_slab_fft_solve_z_chunk(ins_slab_fft_t* fft, double* buf, int kx0, int kxc, void* stream);
 int ins_slab_fft_unpack_chunk(ins_slab_fft_t* fft, double* recvbuf, double* work, int kx0, int kxc, void* stream);
 int ins_slab_fft_xy_inverse_only(ins_slab_fft_t* fft, double* work, double* pI, void* stream);
+/* Power-of-two boxes (ins_slab_fft_is_own): the own y pass writes / reads the packed exchange buffer directly, with uniform
+ * chunk width cw (chunk c = kx in [c*cw, min((c+1)*cw, nx/2+1))), so no pack / unpack pass exists; with from_u != 0 the
+ * right-hand side Ω·div(u) is formed inside the x pass from the slab's velocity (`src` = u on `grid`, z via ghost planes). */
+int ins_slab_fft_is_own(const ins_slab_fft_t* fft);
+int ins_slab_fft_forward_packed(ins_slab_fft_t* fft, const ins_grid_t* grid, const double* src, int from_u, double* work, double* sendbuf,
+                                int cw, void* stream);
+int ins_slab_fft_inverse_packed(ins_slab_fft_t* fft, double* recvbuf, double* work, double* pI, int cw, void* stream);
 
 #ifdef __cplusplus
 }

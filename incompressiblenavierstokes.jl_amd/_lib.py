@@ -86,6 +86,9 @@ SIGNATURES = {
     "ins_slab_fft_solve_z_chunk": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "ins_slab_fft_unpack_chunk": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     "ins_slab_fft_xy_inverse_only": (C.c_int, [vp, vp, vp, vp]),
+    "ins_slab_fft_is_own": (C.c_int, [vp]),
+    "ins_slab_fft_forward_packed": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp]),
+    "ins_slab_fft_inverse_packed": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
 }
 
 _lib = None

@@ -128,8 +128,17 @@ __device__ __forceinline__ void fft_dit(double2* __restrict__ buf, const double2
 // ------------------------------------------------------------------------------------------------------------
 // Pass 2 / 4: FFT along y.  data[plane][ky][kx]; a workgroup owns TK consecutive kx of one plane.
 // ------------------------------------------------------------------------------------------------------------
-template <int LOGN, int TK, bool INVERSE>
-__global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kxn, const double2* __restrict__ tw_g) {
+// PACKED (slab path): the other side of the pass is the transposed, kx-chunked exchange buffer
+//   packed[chunk c][dest/src rank q][kz_local][ky_local][kx_local],  ky_pos = q*nyl + ky_local,  kx = c*cw + kx_local,
+// so the forward pass writes what the all-to-all sends and the inverse pass reads what it received — no separate
+// pack / unpack passes (ins_slab.hip k_transpose_pack is only used with rocFFT plans).
+struct PackMap {
+  double2* packed;
+  int nyl, nzl, cw;
+};
+
+template <int LOGN, int TK, bool INVERSE, bool PACKED>
+__global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kxn, const double2* __restrict__ tw_g, PackMap pm) {
   constexpr int N = 1 << LOGN;
   extern __shared__ double2 lds_dyn[];
   double2* buf = lds_dyn;          // [N][TK]
@@ -139,20 +148,44 @@ __global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kx
   const int kx = blockIdx.x * TK + col;
   const bool live = kx < kxn;
   double2* base = data + (long long)blockIdx.y * N * kxn + kx;
+  // packed address of (row r, this kx, this plane)
+  long long pbase = 0, prow = 0, pq = 0;
+  if (PACKED) {
+    const int c = kx / pm.cw, kxl = kx - c * pm.cw;
+    const int kxc = min(pm.cw, kxn - c * pm.cw);
+    const long long nranks = N / pm.nyl;
+    pbase = nranks * pm.nzl * pm.nyl * (long long)(c * pm.cw) + kxl + (long long)kxc * pm.nyl * blockIdx.y;
+    prow = kxc;                                   // stride of ky_local
+    pq = (long long)kxc * pm.nyl * pm.nzl;        // stride of the rank index q
+  }
+  auto paddr = [&](int r) {
+    const int q = r / pm.nyl, kyl = r - q * pm.nyl;
+    return pbase + prow * kyl + pq * q;
+  };
   for (int m = t; m < N; m += 256) tw[m] = tw_g[m];
   constexpr int RPT = 256 / TK;
-  for (int r = t / TK; r < N; r += RPT) buf[r * TK + col] = live ? base[(long long)r * kxn] : make_double2(0.0, 0.0);
+  for (int r = t / TK; r < N; r += RPT) {
+    double2 v = make_double2(0.0, 0.0);
+    if (live) v = (PACKED && INVERSE) ? pm.packed[paddr(r)] : base[(long long)r * kxn];
+    buf[r * TK + col] = v;
+  }
   __syncthreads();
   if (INVERSE)
     fft_dit<LOGN, TK, TK, 1, false>(buf, tw, t);
   else
     fft_dif<LOGN, TK, TK, 1, false>(buf, tw, t);
   if (live)
-    for (int r = t / TK; r < N; r += RPT) base[(long long)r * kxn] = buf[r * TK + col];
+    for (int r = t / TK; r < N; r += RPT) {
+      if (PACKED && !INVERSE)
+        pm.packed[paddr(r)] = buf[r * TK + col];
+      else
+        base[(long long)r * kxn] = buf[r * TK + col];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Pass 1: x forward, NP row pairs per workgroup.  SRC 0: rows come from pI; SRC 1: rows = Ω·div(u) (K2 fused).
+// Pass 1: x forward, NP row pairs per workgroup.  SRC 0: rows come from pI; SRC 1: rows = Ω·div(u) (K2 fused, periodic
+// wrap in all directions); SRC 2: the same on a z-slab (z neighbour from the ghost plane).
 // ------------------------------------------------------------------------------------------------------------
 template <int LOGN, int NP, int SRC>
 __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restrict__ src, double2* __restrict__ out, int n1,
@@ -180,7 +213,7 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
         const long long c = I0 + I1 * g.sx[1] + I2 * g.sx[2];
         const long long cx = I0 == 1 ? c + (long long)(g.N[0] - 3) : c - 1;
         const long long cy = I1 == 1 ? c + (long long)(g.N[1] - 3) * g.sx[1] : c - g.sx[1];
-        const long long cz = I2 == 1 ? c + (long long)(g.N[2] - 3) * g.sx[2] : c - g.sx[2];
+        const long long cz = (SRC == 1 && I2 == 1) ? c + (long long)(g.N[2] - 3) * g.sx[2] : c - g.sx[2];  // SRC 2: slab ghost plane
         double d = 0.0;
         d += (src[c] - src[cx]) * g.rdx[0][I0];
         d += (src[g.sc + c] - src[g.sc + cy]) * g.rdx[1][I1];
@@ -256,20 +289,30 @@ int set_lds(K kernel, size_t lds) {
 }
 
 template <int LOGN>
-int launch_y(double2* data, int kxn, int nplanes, const double2* tw, bool inverse, hipStream_t s) {
+int launch_y(double2* data, int kxn, int nplanes, const double2* tw, bool inverse, const PackMap* pm, hipStream_t s) {
   constexpr int N = 1 << LOGN;
   constexpr int TK = N <= 256 ? 16 : (N == 512 ? 8 : 4);  // 256-B segments per row where LDS allows (<= 80 KB tiles)
   constexpr size_t lds = ((size_t)N * TK + N) * sizeof(double2);
   dim3 grid((kxn + TK - 1) / TK, nplanes);
-  if (inverse) {
-    int rc = set_lds(&k_yfft<LOGN, TK, true>, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL((k_yfft<LOGN, TK, true>), grid, dim3(256), lds, s, data, kxn, tw);
+  PackMap none{nullptr, 1, 1, 1};
+#define INS_Y_LAUNCH(INV, PK)                                                                                   \
+  do {                                                                                                          \
+    int rc = set_lds(&k_yfft<LOGN, TK, INV, PK>, lds);                                                          \
+    if (rc) return rc;                                                                                          \
+    hipLaunchKernelGGL((k_yfft<LOGN, TK, INV, PK>), grid, dim3(256), lds, s, data, kxn, tw, pm ? *pm : none);   \
+  } while (0)
+  if (pm) {
+    if (inverse)
+      INS_Y_LAUNCH(true, true);
+    else
+      INS_Y_LAUNCH(false, true);
   } else {
-    int rc = set_lds(&k_yfft<LOGN, TK, false>, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL((k_yfft<LOGN, TK, false>), grid, dim3(256), lds, s, data, kxn, tw);
+    if (inverse)
+      INS_Y_LAUNCH(true, false);
+    else
+      INS_Y_LAUNCH(false, false);
   }
+#undef INS_Y_LAUNCH
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -280,7 +323,9 @@ int launch_xfwd(const GridDev& g, const double* src, int from_u, double2* out, i
   constexpr int NP = N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N);
   constexpr size_t lds = ((size_t)NP * N + N) * sizeof(double2);
   dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
-  if (from_u)
+  if (from_u == 2)
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 2>), grid, dim3(256), lds, s, g, src, out, n1, tw);
+  else if (from_u)
     hipLaunchKernelGGL((k_xfwd<LOGN, NP, 1>), grid, dim3(256), lds, s, g, src, out, n1, tw);
   else
     hipLaunchKernelGGL((k_xfwd<LOGN, NP, 0>), grid, dim3(256), lds, s, g, src, out, n1, tw);
@@ -363,7 +408,18 @@ int ins_k_ownfft_xinv(const double* phat, double* pI, int n0, int n1, int n2, co
 int ins_k_ownfft_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s) {
   double2* d = reinterpret_cast<double2*>(phat);
   const double2* w = reinterpret_cast<const double2*>(tw);
-#define CALL(LG) launch_y<LG>(d, kxn, n2, w, inverse, s)
+#define CALL(LG) launch_y<LG>(d, kxn, n2, w, inverse, nullptr, s)
+  INS_POW2_SWITCH(n1, CALL)
+#undef CALL
+}
+
+// y pass whose far side is the packed, kx-chunked transpose buffer (see PackMap): forward writes it, inverse reads it.
+int ins_k_ownfft_y_packed(double* phat, double* packed, int kxn, int n1, int nzl, int nyl, int cw, const double* tw, bool inverse,
+                          hipStream_t s) {
+  double2* d = reinterpret_cast<double2*>(phat);
+  const double2* w = reinterpret_cast<const double2*>(tw);
+  PackMap pm{reinterpret_cast<double2*>(packed), nyl, nzl, cw};
+#define CALL(LG) launch_y<LG>(d, kxn, nzl, w, inverse, &pm, s)
   INS_POW2_SWITCH(n1, CALL)
 #undef CALL
 }

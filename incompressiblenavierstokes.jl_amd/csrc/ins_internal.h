@@ -181,6 +181,8 @@ void ins_ownfft_permute_symbol(int n, const double* ay, double* out);
 int ins_k_ownfft_xfwd(const ins_grid* G, const double* src, int from_u, double* phat, int n0, int n1, int n2, const double* tw, hipStream_t s);
 int ins_k_ownfft_xinv(const double* phat, double* pI, int n0, int n1, int n2, const double* tw, hipStream_t s);
 int ins_k_ownfft_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s);
+int ins_k_ownfft_y_packed(double* phat, double* packed, int kxn, int n1, int nzl, int nyl, int cw, const double* tw, bool inverse,
+                          hipStream_t s);
 int ins_zsolve_twiddles(int nz, double** out);
 int ins_k_zsolve(double* data, int nz, long long nl, const double* ax, int kxn, const double* ay, const double* az, const double* tw,
                  double inv_n, bool zero_mean, hipStream_t s);

@@ -317,6 +317,34 @@ extern "C" int ins_slab_fft_xy_inverse_only(ins_slab_fft_t* S, double* work, dou
   INS_REQUIRE(S && work && pI, "null argument");
   return slab_xy_inverse(S, work, pI, as_stream(stream));
 }
+// ---- power-of-two boxes: own passes write / read the packed exchange buffer directly (no pack / unpack passes), and the
+// right-hand side can be formed inside the x pass straight from the slab's u (K2 fused) -------------------------------
+extern "C" int ins_slab_fft_forward_packed(ins_slab_fft_t* S, const ins_grid_t* G, const double* src, int from_u, double* work, double* sendbuf,
+                                           int cw, void* stream) {
+  INS_REQUIRE(S && src && work && sendbuf, "null argument");
+  INS_REQUIRE(S->ownfft, "packed passes need a power-of-two box");
+  INS_REQUIRE(cw >= 1 && cw <= S->kxn, "bad chunk width");
+  if (from_u) {
+    INS_REQUIRE(G && G->g.D == 3 && G->g.N[0] == S->np[0] + 2 && G->g.N[1] == S->np[1] + 2 && G->g.N[2] == S->nzl + 2, "grid does not match the slab");
+  }
+  hipStream_t s = as_stream(stream);
+  int rc = ins_k_ownfft_xfwd(from_u ? G : nullptr, src, from_u ? 2 : 0, work, S->np[0], S->np[1], S->nzl, S->tw_x, s);
+  if (rc) return rc;
+  return ins_k_ownfft_y_packed(work, sendbuf, S->kxn, S->np[1], S->nzl, S->nyl, cw, S->tw_y, false, s);
+}
+
+extern "C" int ins_slab_fft_inverse_packed(ins_slab_fft_t* S, double* recvbuf, double* work, double* pI, int cw, void* stream) {
+  INS_REQUIRE(S && recvbuf && work && pI, "null argument");
+  INS_REQUIRE(S->ownfft, "packed passes need a power-of-two box");
+  INS_REQUIRE(cw >= 1 && cw <= S->kxn, "bad chunk width");
+  hipStream_t s = as_stream(stream);
+  int rc = ins_k_ownfft_y_packed(work, recvbuf, S->kxn, S->np[1], S->nzl, S->nyl, cw, S->tw_y, true, s);
+  if (rc) return rc;
+  return ins_k_ownfft_xinv(work, pI, S->np[0], S->np[1], S->nzl, S->tw_x, s);
+}
+
+extern "C" int ins_slab_fft_is_own(const ins_slab_fft_t* S) { return S && S->ownfft; }
+
 /* 1 when kx chunks are supported (power-of-two nz -> fused z kernel). */
 extern "C" int ins_slab_fft_can_chunk(const ins_slab_fft_t* S) { return S && S->tw != nullptr; }
 

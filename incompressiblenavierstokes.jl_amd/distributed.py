@@ -213,6 +213,18 @@ class HipSlabKernels:
     def fft_xy_inverse(self, work, pI):
         _lib.call("ins_slab_fft_xy_inverse_only", self._fft, self._p(work), self._p(pI), self.setup.stream)
 
+    # power-of-two boxes: passes that write / read the packed exchange buffer directly
+    def is_own(self):
+        return bool(_lib.load().ins_slab_fft_is_own(self._fft))
+
+    def fft_forward_packed(self, u, work, sendbuf, cw):
+        """Ω·div(u) formed inside the x pass (K2 fused), y pass writes the packed, kx-chunked send buffer."""
+        s = self.setup
+        _lib.call("ins_slab_fft_forward_packed", self._fft, s.handle, s.ptr(u, True), 1, self._p(work), self._p(sendbuf), cw, s.stream)
+
+    def fft_inverse_packed(self, recvbuf, work, pI, cw):
+        _lib.call("ins_slab_fft_inverse_packed", self._fft, self._p(recvbuf), self._p(work), self._p(pI), cw, self.setup.stream)
+
     def applypressure(self, u, pI, p_top):
         s = self.setup
         _lib.call("ins_slab_applypressure_f64", s.handle, s.ptr(u, True), self._p(pI), self._p(p_top), s.stream)
@@ -229,8 +241,9 @@ class SlabStepper:
         self.method, self.lay, self.k, self.comm = method, layout, kernels, comm
         # kx-chunks of the half spectrum for the pipelined transposes (1 = one all-to-all each way)
         chunks = max(1, min(int(chunks), layout.kxn)) if kernels.can_chunk() else 1
-        edges = [round(c * layout.kxn / chunks) for c in range(chunks + 1)]
-        self.chunks = [(edges[c], edges[c + 1] - edges[c]) for c in range(chunks) if edges[c + 1] > edges[c]]
+        self.cw = -(-layout.kxn // chunks)  # uniform chunk width (the last chunk may be narrower)
+        self.chunks = [(k0, min(self.cw, layout.kxn - k0)) for k0 in range(0, layout.kxn, self.cw)]
+        self.packed = bool(getattr(kernels, "is_own", lambda: False)())
         ns = len(method.b)
         self.ku = [kernels.vector() for _ in range(ns)]
         self.ub = [kernels.vector(), kernels.vector()]
@@ -266,6 +279,25 @@ class SlabStepper:
     def project_(self, u):
         K = self.k
         self.halo_u(u, comps=(2,), down_only=True)  # divergence needs w[I - e_z] only (operators.jl:122)
+        if self.packed:
+            # power-of-two box: [K2 + x pass] -> y pass straight into the send buffer -> chunked transposes around the
+            # z pass -> y pass straight out of the receive buffer -> x pass: no divergence / pack / unpack passes
+            lay = self.lay
+            per_kx = 2 * lay.world * lay.nzl * lay.nyl
+            sl = [slice(per_kx * k0, per_kx * (k0 + kc)) for k0, kc in self.chunks]
+            K.fft_forward_packed(u, self.work, self.bufa, self.cw)
+            fwd = [self.comm.all_to_all_async(self.bufb[r], self.bufa[r], 0) for r in sl]
+            bwd = []
+            for (k0, kc), r, h in zip(self.chunks, sl, fwd):
+                h.wait()
+                K.solve_z_chunk(self.bufb[r], k0, kc)
+                bwd.append(self.comm.all_to_all_async(self.bufa[r], self.bufb[r], 1))
+            for h in bwd:
+                h.wait()
+            K.fft_inverse_packed(self.bufa, self.work, self.pI, self.cw)
+            self.halo_p()
+            K.applypressure(u, self.pI, self.p_top)
+            return u
         K.divergence(u, self.pI)
         if len(self.chunks) == 1:
             K.fft_forward_xy(self.pI, self.work, self.bufa)

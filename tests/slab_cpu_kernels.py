@@ -8,7 +8,8 @@ from oracle import ins_oracle as o
 
 
 class OracleSlabKernels:
-    def __init__(self, layout, L=(1.0, 1.0, 1.0), Re=1000.0):
+    def __init__(self, layout, L=(1.0, 1.0, 1.0), Re=1000.0, own=False):
+        self.own = own  # mimic the power-of-two path: packed passes, no pack / unpack calls
         self.layout = lay = layout
         nx, ny, nz = lay.n
         self.h = [L[a] / lay.n[a] for a in range(3)]
@@ -146,6 +147,27 @@ class OracleSlabKernels:
         lay = self.layout
         w = self._c(work).reshape(lay.nzl, lay.n[1], lay.kxn)
         pI.numpy()[...] = np.fft.irfftn(w, s=(lay.n[1], lay.n[0]), axes=(1, 2)).reshape(-1)
+
+    def is_own(self):
+        return self.own
+
+    def fft_forward_packed(self, u, work, sendbuf, cw):
+        lay = self.layout
+        pI = self.real()
+        self.divergence(u, pI)
+        self.fft_xy_forward(pI, work)
+        per_kx = 2 * lay.world * lay.nzl * lay.nyl
+        for k0 in range(0, lay.kxn, cw):
+            kc = min(cw, lay.kxn - k0)
+            self.pack_chunk(work, sendbuf[per_kx * k0 : per_kx * (k0 + kc)], k0, kc)
+
+    def fft_inverse_packed(self, recvbuf, work, pI, cw):
+        lay = self.layout
+        per_kx = 2 * lay.world * lay.nzl * lay.nyl
+        for k0 in range(0, lay.kxn, cw):
+            kc = min(cw, lay.kxn - k0)
+            self.unpack_chunk(recvbuf[per_kx * k0 : per_kx * (k0 + kc)], work, k0, kc)
+        self.fft_xy_inverse(work, pI)
 
     def applypressure(self, u, pI, p_top):
         lay = self.layout

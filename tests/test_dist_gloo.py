@@ -17,7 +17,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, nsteps, method_name, out_dir, chunks=1):
+def _worker(rank, world, port, n, nsteps, method_name, out_dir, chunks=1, own=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -29,11 +29,11 @@ def _worker(rank, world, port, n, nsteps, method_name, out_dir, chunks=1):
         so = o.make_setup(x, Re=500.0)
         u0 = o.random_field(so, kp=2, seed=7)
         lay = ins.SlabLayout(n, world, rank)
-        K = OracleSlabKernels(lay, Re=500.0)
+        K = OracleSlabKernels(lay, Re=500.0, own=own)
         comm = ins.SlabComm(group2=dist.new_group(ranks=list(range(world))) if chunks > 1 else None)
         method = getattr(ins.RKMethods, method_name)()
         st = ins.SlabStepper(method, lay, K, comm, chunks=chunks)
-        assert len(st.chunks) == min(chunks, lay.kxn)
+        assert len(st.chunks) == min(chunks, lay.kxn) and st.packed == own
         u = K.from_global(u0)
         for _ in range(nsteps):
             st.step_(u, 0.01)
@@ -44,13 +44,14 @@ def _worker(rank, world, port, n, nsteps, method_name, out_dir, chunks=1):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("method_name,chunks", [("RK44", 1), ("Wray3", 1), ("FE11", 1), ("RK44", 3)])
-def test_slab_stepper_two_ranks_matches_single_domain(tmp_path, oracle, method_name, chunks):
-    """chunks > 1: the transposes pipelined over kx-chunks on two process groups."""
+@pytest.mark.parametrize("method_name,chunks,own", [("RK44", 1, False), ("Wray3", 1, False), ("FE11", 1, False), ("RK44", 3, False),
+                                                    ("RK44", 1, True), ("RK44", 3, True)])
+def test_slab_stepper_two_ranks_matches_single_domain(tmp_path, oracle, method_name, chunks, own):
+    """chunks > 1: the transposes pipelined over kx-chunks on two process groups; own: the packed-pass branch."""
     o = oracle
     n, world, nsteps = (12, 8, 12), 2, 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, nsteps, method_name, str(tmp_path), chunks), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, nsteps, method_name, str(tmp_path), chunks, own), nprocs=world, join=True)
     x = tuple(np.linspace(0.0, 1.0, ni + 1) for ni in n)
     so = o.make_setup(x, Re=500.0)
     ps = o.psolver_spectral(so)
