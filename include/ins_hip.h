@@ -75,6 +75,9 @@ int ins_sync(void* stream);
 /* ---------------------------------------------------------------------------------- Grid  (grid.jl:100) */
 int ins_grid_create(const ins_grid_desc_t* desc, ins_grid_t** out);
 int ins_grid_destroy(ins_grid_t* grid);
+/* 1 when every metric record the fused kernels read is bitwise constant (uniform grid whose spacing and weights are exact);
+ * the constant-record kernels and the in-kernel pressure correction require it. */
+int ins_grid_is_uniform_exact(const ins_grid_t* grid);
 
 /* ---------------------------------------------------------------------------------- ghost fill */
 /* apply_bc_u!(u, t, setup; dudt)   boundary_conditions.jl:159-167 (+276-288, 344-375, 414-428, 472-482).
@@ -175,6 +178,13 @@ typedef struct ins_slab_fft ins_slab_fft_t;
  * ustart == NULL means ustart = u_in.  Needs valid ghosts in u_in; 3-D all-DOF grids (periodic box or slab). */
 int ins_stage_momentum_f64(const ins_grid_t* grid, double visc, const double* u_in, double* k_out, const double* ustart,
                            double* ustar, int nterms, const double* coefs, const double* const* ks, double coef_self, void* stream);
+/* Same stage kernel for stages >= 2 of a slab with the PREVIOUS stage's projection applied in registers
+ * (applypressure! + periodic apply_bc_u!, operators.jl:225-233, boundary_conditions.jl:276-288): `ustar_prev` = that stage's
+ * uncorrected velocity with valid z-ghost planes; `p_ext` = its pressure as [1 plane below | nz/P local planes | 2 planes above],
+ * unpadded in x and y.  Removes ins_slab_applypressure_f64 from every stage but the last.  Exactly-uniform slabs only. */
+int ins_stage_momentum_corr_f64(const ins_grid_t* grid, double visc, const double* ustar_prev, const double* p_ext, double* k_out,
+                                const double* ustart, double* ustar, int nterms, const double* coefs, const double* const* ks,
+                                double coef_self, void* stream);
 /* pI[nx,ny,nzl] = Ω·divergence(u) on the slab interior (operators.jl:117-125, 81-95; pressure.jl:320): x, y via
  * periodic wrap, z via the ghost plane. */
 int ins_slab_divergence_f64(const ins_grid_t* grid, const double* u, double* pI, void* stream);

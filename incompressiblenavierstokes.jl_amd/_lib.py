@@ -41,6 +41,7 @@ SIGNATURES = {
     "ins_sync": (C.c_int, [vp]),
     "ins_grid_create": (C.c_int, [C.POINTER(GridDesc), C.POINTER(vp)]),
     "ins_grid_destroy": (C.c_int, [vp]),
+    "ins_grid_is_uniform_exact": (C.c_int, [vp]),
     "ins_apply_bc_u_f64": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp), vp]),
     "ins_apply_bc_p_f64": (C.c_int, [vp, vp, vp]),
     "ins_scalewithvolume_f64": (C.c_int, [vp, vp, vp]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     "ins_rk_pressure": (C.c_int, [vp, C.POINTER(vp)]),
     "ins_rk_stage_force": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
     "ins_stage_momentum_f64": (C.c_int, [vp, C.c_double, vp, vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), C.c_double, vp]),
+    "ins_stage_momentum_corr_f64": (C.c_int, [vp, C.c_double, vp, vp, vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), C.c_double, vp]),
     "ins_slab_divergence_f64": (C.c_int, [vp, vp, vp, vp]),
     "ins_slab_applypressure_f64": (C.c_int, [vp, vp, vp, vp, vp]),
     "ins_slab_fft_create": (C.c_int, [C.POINTER(C.c_int32), c_double_p, C.c_int, C.c_int, C.POINTER(vp)]),

@@ -92,7 +92,9 @@ struct Plane {
 // neighbours addressed through the periodic image (apply_bc_u!, boundary_conditions.jl:276-288).  That removes
 // the gradient-subtract pass (K4) of every stage but the last.  Lanes 62 and 63 are halo columns then
 // (lane 63 only supplies p to lane 62), so 61 columns are produced per wavefront.
-template <int R, bool UNIFORM, bool MASKED, int XW, bool FUSE, bool CORR>
+// CORR = 2: the same on a z-slab — x, y through the periodic image, z through exchanged ghost planes: `u` has valid z-ghost
+// planes of u*, and `pI` is the EXTENDED pressure buffer [1 ghost plane below | nzl local planes | 2 ghost planes above].
+template <int R, bool UNIFORM, bool MASKED, int XW, bool FUSE, int CORR>
 __global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __restrict__ rx, const Rec* __restrict__ ry,
                                                        const Rec* __restrict__ rz, const double* __restrict__ u,
                                                        double* __restrict__ F, int zc, int ntx, int nty, int ntz, RkEpi epi,
@@ -149,16 +151,16 @@ __global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __r
     for (int rr = 0; rr < R + 3; ++rr) prow[rr] = (long long)wrap(min(jb - 1 + rr, N1 + 1), n1) * n0 + wrap(min(i, N0), n0);
   }
 
-  // kk = padded plane index (CORR: wrapped into the interior)
+  // kk = padded plane index (CORR 1: wrapped into the interior; CORR 2: ghost planes are valid, clamp the unused overshoot)
   auto load_plane = [&](Plane<R>& P, int kk) {
-    const double* base = u + (long long)(CORR ? wrap(kk, n2) + 1 : kk) * sz;
+    const double* base = u + (long long)(CORR == 1 ? wrap(kk, n2) + 1 : (CORR == 2 ? min(kk, N2 - 1) : kk)) * sz;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int rr = 0; rr < R + 2; ++rr) P.v[c][rr] = base[c * g.sc + rowoff[rr]];
   };
   auto load_p = [&](double (&P)[R + 3], int kk) {
-    const double* base = pI + (long long)wrap(kk, n2) * n0 * n1;
+    const double* base = pI + (long long)(CORR == 2 ? min(kk, N2) : wrap(kk, n2)) * n0 * n1;
 #pragma unroll
     for (int rr = 0; rr < R + 3; ++rr) P[rr] = base[prow[rr]];
   };
@@ -419,7 +421,7 @@ int ins_flux3d_prepare(const ins_grid* G, double visc, hipStream_t s) {
 }
 
 template <int R, int XW, bool FUSE>
-static int launch_flux(const ins_grid* G, const double* u, double* F, const RkEpi& epi, const double* pI, hipStream_t s) {
+static int launch_flux(const ins_grid* G, const double* u, double* F, const RkEpi& epi, const double* pI, int corr_mode, hipStream_t s) {
   const GridDev& g = G->g;
   const Rec* r0 = reinterpret_cast<const Rec*>(G->rec_dev);
   const Rec* r1 = r0 + g.N[0];
@@ -440,13 +442,18 @@ static int launch_flux(const ins_grid* G, const double* u, double* F, const RkEp
       return INS_ERR_UNSUPPORTED;
     }
     if constexpr (FUSE)
-      hipLaunchKernelGGL((k_momentum_flux<RK, true, false, XW, true, true>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
+      {
+        if (corr_mode == 2)
+          hipLaunchKernelGGL((k_momentum_flux<RK, true, false, XW, true, 2>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
+        else
+          hipLaunchKernelGGL((k_momentum_flux<RK, true, false, XW, true, 1>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
+      }
   } else if (G->uniform_exact && !masked)
-    hipLaunchKernelGGL((k_momentum_flux<R, true, false, XW, FUSE, false>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
+    hipLaunchKernelGGL((k_momentum_flux<R, true, false, XW, FUSE, 0>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
   else if (!masked)
-    hipLaunchKernelGGL((k_momentum_flux<R, false, false, XW, FUSE, false>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
+    hipLaunchKernelGGL((k_momentum_flux<R, false, false, XW, FUSE, 0>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
   else if (!FUSE)
-    hipLaunchKernelGGL((k_momentum_flux<RC, false, true, XW, false, false>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
+    hipLaunchKernelGGL((k_momentum_flux<RC, false, true, XW, false, 0>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
   else {
     ins_set_error("fused RK epilogue needs an all-periodic grid");
     return INS_ERR_UNSUPPORTED;
@@ -456,16 +463,16 @@ static int launch_flux(const ins_grid* G, const double* u, double* F, const RkEp
 }
 
 template <bool FUSE>
-static int launch_flux_any(const ins_grid* G, const double* u, double* F, const RkEpi& epi, const double* pI, hipStream_t s) {
+static int launch_flux_any(const ins_grid* G, const double* u, double* F, const RkEpi& epi, const double* pI, int corr_mode, hipStream_t s) {
   // wavefronts side by side in x: 4 when the row needs >= 8 of them, else 2 (fewer mostly-empty workgroups)
   const int waves_x = cdiv(G->g.N[0] - 2, XOUT);
   const int xw = g_xw ? g_xw : (waves_x >= 8 ? 4 : (waves_x >= 2 ? 2 : 1));
   const int rows = g_rows ? g_rows : 4;  // rows per thread (masked / correcting variants cap themselves at 3: registers)
 #define INS_FLUX_CASE(RR)                                                          \
   if (rows == RR) {                                                                \
-    if (xw == 4) return launch_flux<RR, 4, FUSE>(G, u, F, epi, pI, s);             \
-    if (xw == 2) return launch_flux<RR, 2, FUSE>(G, u, F, epi, pI, s);             \
-    return launch_flux<RR, 1, FUSE>(G, u, F, epi, pI, s);                          \
+    if (xw == 4) return launch_flux<RR, 4, FUSE>(G, u, F, epi, pI, corr_mode, s);  \
+    if (xw == 2) return launch_flux<RR, 2, FUSE>(G, u, F, epi, pI, corr_mode, s);  \
+    return launch_flux<RR, 1, FUSE>(G, u, F, epi, pI, corr_mode, s);               \
   }
   INS_FLUX_CASE(2)
   INS_FLUX_CASE(3)
@@ -479,7 +486,7 @@ int ins_k_momentum_flux3d(const ins_grid* G, double visc, const double* u, doubl
   if (rc) return rc;
   RkEpi epi;
   memset(&epi, 0, sizeof(epi));
-  if ((rc = launch_flux_any<false>(G, u, F, epi, nullptr, s))) return rc;
+  if ((rc = launch_flux_any<false>(G, u, F, epi, nullptr, 0, s))) return rc;
   if (zero_shell) {
     const GridDev& g = G->g;
     const long long total = 2LL * ((long long)g.N[0] * g.N[1] + (long long)g.N[0] * g.N[2] + (long long)g.N[1] * g.N[2]);
@@ -493,7 +500,7 @@ int ins_k_momentum_flux3d(const ins_grid* G, double visc, const double* u, doubl
 int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s) {
   int rc = ins_flux3d_prepare(G, visc, s);
   if (rc) return rc;
-  return launch_flux_any<true>(G, u_in, k_out, epi, nullptr, s);
+  return launch_flux_any<true>(G, u_in, k_out, epi, nullptr, 0, s);
 }
 
 // Same, but u_in is the previous stage's UNCORRECTED u* (interior only) and pI its unpadded pressure: the
@@ -502,5 +509,13 @@ int ins_k_momentum_rk_fused_corr(const ins_grid* G, double visc, const double* u
                                  hipStream_t s) {
   int rc = ins_flux3d_prepare(G, visc, s);
   if (rc) return rc;
-  return launch_flux_any<true>(G, ustar_prev, k_out, epi, pI, s);
+  return launch_flux_any<true>(G, ustar_prev, k_out, epi, pI, 1, s);
+}
+
+// Slab flavour: z neighbours from ghost planes; p_ext = [1 plane below | local planes | 2 planes above] (unpadded in x, y).
+int ins_k_momentum_rk_fused_corr_slab(const ins_grid* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out,
+                                      const RkEpi& epi, hipStream_t s) {
+  int rc = ins_flux3d_prepare(G, visc, s);
+  if (rc) return rc;
+  return launch_flux_any<true>(G, ustar_prev, k_out, epi, p_ext, 2, s);
 }

@@ -172,6 +172,8 @@ extern "C" int ins_grid_create(const ins_grid_desc_t* d, ins_grid_t** out) {
   return INS_OK;
 }
 
+extern "C" int ins_grid_is_uniform_exact(const ins_grid_t* G) { return G && G->uniform_exact && G->all_dof; }
+
 extern "C" int ins_grid_destroy(ins_grid_t* G) {
   if (!G) return INS_OK;
   if (G->dev) (void)hipFree(G->dev);

@@ -382,6 +382,34 @@ extern "C" int ins_slab_applypressure_f64(const ins_grid_t* G, double* u, const 
 
 // K1 + K6 on any all-DOF 3-D grid (a slab, or a whole periodic box): k_out = momentum(u_in) when k_out != NULL,
 // ustar(interior) = ustart + Σ_q coefs[q] ks[q] + coef_self * momentum(u_in); ustart == NULL means ustart = u_in.
+// Stage kernel with the PREVIOUS stage's projection applied in registers (k_momentum_flux<..., CORR = 2>): `ustar_prev` is that
+// stage's uncorrected velocity with valid z-ghost planes, `p_ext` = [1 plane below | nzl local planes | 2 planes above] of its
+// pressure (unpadded in x, y).  Exactly-uniform slabs only.
+extern "C" int ins_stage_momentum_corr_f64(const ins_grid_t* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out,
+                                           const double* ustart, double* ustar, int nterms, const double* coefs, const double* const* ks,
+                                           double coef_self, void* stream) {
+  int rc = check_slab_grid(G);
+  if (rc) return rc;
+  INS_REQUIRE(ustar_prev && p_ext && ustar && ustart, "null argument");
+  INS_REQUIRE(G->uniform_exact, "in-kernel correction needs an exactly uniform grid");
+  INS_REQUIRE(G->g.N[2] >= 4, "slab needs at least two local planes");
+  INS_REQUIRE(nterms >= 0 && nterms <= INS_MAX_STAGES && (nterms == 0 || (coefs && ks)), "bad stage terms");
+  INS_REQUIRE(ustar != ustar_prev, "the stage velocity cannot overwrite the stencil input");
+  RkEpi epi;
+  memset(&epi, 0, sizeof(epi));
+  epi.n = nterms;
+  for (int q = 0; q < nterms; ++q) {
+    epi.coef[q] = coefs[q];
+    epi.k[q] = ks[q];
+  }
+  epi.coef_self = coef_self;
+  epi.ustart = ustart;
+  epi.ustar = ustar;
+  epi.write_k = k_out != nullptr;
+  static double* dummy = nullptr;
+  return ins_k_momentum_rk_fused_corr_slab(G, visc, ustar_prev, p_ext, k_out ? k_out : dummy, epi, as_stream(stream));
+}
+
 extern "C" int ins_stage_momentum_f64(const ins_grid_t* G, double visc, const double* u_in, double* k_out, const double* ustart,
                                       double* ustar, int nterms, const double* coefs, const double* const* ks, double coef_self,
                                       void* stream) {

@@ -181,6 +181,23 @@ class HipSlabKernels:
         _lib.call("ins_stage_momentum_f64", s.handle, 1.0 / s.Re, s.ptr(u_in, True), s.ptr(k_out, True) if k_out is not None else None,
                   s.ptr(ustart, True) if ustart is not None else None, s.ptr(ustar, True), n, carr, karr, float(coef_self), s.stream)
 
+    def supports_inkernel(self):
+        """Stages >= 2 can apply the previous projection in registers (exactly-uniform slab with >= 2 local planes)."""
+        return bool(_lib.load().ins_grid_is_uniform_exact(self.setup.handle)) and self.layout.nzl >= 2 and self.is_own()
+
+    def pext(self):
+        """Extended pressure buffer [1 plane below | nzl local planes | 2 planes above], unpadded in x, y."""
+        n0, n1 = self.layout.n[0], self.layout.n[1]
+        return torch.zeros(self.real_elems + 3 * n0 * n1, dtype=torch.float64, device=self.device)
+
+    def stage_momentum_corr(self, ustar_prev, p_ext, k_out, ustart, ustar, coefs, ks, coef_self):
+        s = self.setup
+        n = len(coefs)
+        carr = (C.c_double * max(n, 1))(*coefs)
+        karr = (C.c_void_p * max(n, 1))(*[k.data_ptr() for k in ks])
+        _lib.call("ins_stage_momentum_corr_f64", s.handle, 1.0 / s.Re, s.ptr(ustar_prev, True), self._p(p_ext),
+                  s.ptr(k_out, True) if k_out is not None else None, s.ptr(ustart, True), s.ptr(ustar, True), n, carr, karr, float(coef_self), s.stream)
+
     def divergence(self, u, pI):
         s = self.setup
         _lib.call("ins_slab_divergence_f64", s.handle, s.ptr(u, True), self._p(pI), s.stream)
@@ -247,7 +264,14 @@ class SlabStepper:
         ns = len(method.b)
         self.ku = [kernels.vector() for _ in range(ns)]
         self.ub = [kernels.vector(), kernels.vector()]
-        self.pI = kernels.real()
+        self.inkernel = bool(getattr(kernels, "supports_inkernel", lambda: False)()) and len(method.b) > 1
+        plane = layout.n[0] * layout.n[1]
+        if self.inkernel:  # pI lives inside the extended buffer so that its ghost planes can be exchanged in place
+            self.pX = kernels.pext()
+            self.pI = self.pX[plane : plane * (layout.nzl + 1)]
+        else:
+            self.pX = None
+            self.pI = kernels.real()
         self.work = kernels.cplx()
         self.bufa = kernels.cplx()
         self.bufb = kernels.cplx()
@@ -275,8 +299,19 @@ class SlabStepper:
         lay, K = self.lay, self.k
         self.comm.exchange([(K.p_plane(self.pI, 0), lay.prev)], [(self.p_top, lay.next)])
 
+    def halo_p_ext(self):
+        """Ghost planes of the extended pressure buffer: my last plane -> next rank's `below`; my first two planes ->
+        previous rank's two `above` planes."""
+        lay, K = self.lay, self.k
+        plane = lay.n[0] * lay.n[1]
+        pX, nzl = self.pX, lay.nzl
+        sends = [(pX[plane * nzl : plane * (nzl + 1)], lay.next), (pX[plane : plane * 3], lay.prev)]
+        recvs = [(pX[0:plane], lay.prev), (pX[plane * (nzl + 1) : plane * (nzl + 3)], lay.next)]
+        self.comm.exchange(sends, recvs)
+
     # -- projection (pressure.jl:69-82 on slabs) ---------------------------------------------------
-    def project_(self, u):
+    def project_(self, u, apply=True):
+        """apply=False: solve only (pI <- p); the gradient-subtract is left to the next stage's stencil kernel."""
         K = self.k
         self.halo_u(u, comps=(2,), down_only=True)  # divergence needs w[I - e_z] only (operators.jl:122)
         if self.packed:
@@ -295,8 +330,9 @@ class SlabStepper:
             for h in bwd:
                 h.wait()
             K.fft_inverse_packed(self.bufa, self.work, self.pI, self.cw)
-            self.halo_p()
-            K.applypressure(u, self.pI, self.p_top)
+            if apply:
+                self.halo_p()
+                K.applypressure(u, self.pI, self.p_top)
             return u
         K.divergence(u, self.pI)
         if len(self.chunks) == 1:
@@ -344,9 +380,18 @@ class SlabStepper:
                     coefs.append(cf)
                     ks.append(self.ku[j])
             write_k = any(A[i2, i] != 0.0 for i2 in range(i + 1, ns))
-            K.stage_momentum(u_in, self.ku[i] if write_k else None, None if i == 0 else u, out, coefs, ks, Δt * A[i, i])
-            self.project_(out)
-            self.halo_u(out)  # z ghosts for the next stencil (x/y ghosts were written by K4)
+            last = i == ns - 1
+            if self.inkernel and i > 0:
+                # previous stage's projection applied in registers from (u*, p) — no K4 pass for that stage
+                K.stage_momentum_corr(u_in, self.pX, self.ku[i] if write_k else None, u, out, coefs, ks, Δt * A[i, i])
+            else:
+                K.stage_momentum(u_in, self.ku[i] if write_k else None, None if i == 0 else u, out, coefs, ks, Δt * A[i, i])
+            if self.inkernel and not last:
+                self.project_(out, apply=False)
+                self.halo_p_ext()
+            else:
+                self.project_(out)
+            self.halo_u(out)  # z ghost planes for the next stencil (x/y ghosts: K4 images, or periodic addressing in-kernel)
             u_in = out
         if ns == 1:
             u.copy_(self.ub[0])

@@ -148,6 +148,29 @@ class OracleSlabKernels:
         w = self._c(work).reshape(lay.nzl, lay.n[1], lay.kxn)
         pI.numpy()[...] = np.fft.irfftn(w, s=(lay.n[1], lay.n[0]), axes=(1, 2)).reshape(-1)
 
+    def supports_inkernel(self):
+        return self.own and self.layout.nzl >= 2
+
+    def pext(self):
+        n0, n1 = self.layout.n[0], self.layout.n[1]
+        return torch.zeros(self.real_elems + 3 * n0 * n1, dtype=torch.float64)
+
+    def stage_momentum_corr(self, ustar_prev, p_ext, k_out, ustart, ustar, coefs, ks, coef_self):
+        """u = u* - grad p on every padded plane (x, y periodic; z from the exchanged ghost planes), then the plain stage."""
+        lay = self.layout
+        n0, n1, nzl = lay.n[0], lay.n[1], lay.nzl
+        us = ustar_prev.numpy()[1:-1, 1:-1, :, :]
+        pp = p_ext.numpy().reshape((n0, n1, nzl + 3), order="F")
+        pc = pp[:, :, : nzl + 2]
+        corr = np.zeros(self.N + (3,), order="F")
+        corr[1:-1, 1:-1, :, 0] = us[..., 0] - (np.roll(pp, -1, axis=0)[:, :, : nzl + 2] - pc) / self.h[0]
+        corr[1:-1, 1:-1, :, 1] = us[..., 1] - (np.roll(pp, -1, axis=1)[:, :, : nzl + 2] - pc) / self.h[1]
+        corr[1:-1, 1:-1, :, 2] = us[..., 2] - (pp[:, :, 1 : nzl + 3] - pc) / self.h[2]
+        self._fill_xy(corr)
+        t = self.vector()
+        t.numpy()[...] = corr
+        self.stage_momentum(t, k_out, ustart, ustar, coefs, ks, coef_self)
+
     def is_own(self):
         return self.own
 

@@ -33,7 +33,7 @@ def _worker(rank, world, port, n, nsteps, method_name, out_dir, chunks=1, own=Fa
         comm = ins.SlabComm(group2=dist.new_group(ranks=list(range(world))) if chunks > 1 else None)
         method = getattr(ins.RKMethods, method_name)()
         st = ins.SlabStepper(method, lay, K, comm, chunks=chunks)
-        assert len(st.chunks) == min(chunks, lay.kxn) and st.packed == own
+        assert len(st.chunks) == min(chunks, lay.kxn) and st.packed == own and st.inkernel == (own and len(method.b) > 1)
         u = K.from_global(u0)
         for _ in range(nsteps):
             st.step_(u, 0.01)
@@ -45,7 +45,7 @@ def _worker(rank, world, port, n, nsteps, method_name, out_dir, chunks=1, own=Fa
 
 
 @pytest.mark.parametrize("method_name,chunks,own", [("RK44", 1, False), ("Wray3", 1, False), ("FE11", 1, False), ("RK44", 3, False),
-                                                    ("RK44", 1, True), ("RK44", 3, True)])
+                                                    ("RK44", 1, True), ("RK44", 3, True), ("Wray3", 2, True), ("FE11", 1, True)])
 def test_slab_stepper_two_ranks_matches_single_domain(tmp_path, oracle, method_name, chunks, own):
     """chunks > 1: the transposes pipelined over kx-chunks on two process groups; own: the packed-pass branch."""
     o = oracle

@@ -74,6 +74,7 @@ def _worker(rank, world, port, n, nsteps, out_dir, chunks=1):
         div = st.max_abs_divergence(u)
         np.save(os.path.join(out_dir, f"u_{rank}.npy"), ins.to_numpy(u))
         np.save(os.path.join(out_dir, f"div_{rank}.npy"), np.array([div]))
+        np.save(os.path.join(out_dir, f"flags_{rank}.npy"), np.array([int(st.packed), int(st.inkernel), len(st.chunks)]))
     finally:
         dist.destroy_process_group()
 
@@ -98,3 +99,6 @@ def test_multi_rank_slab_on_one_gpu_matches_oracle(tmp_path, oracle, world, n, c
         ks = [(r * nzl + k - 1) % n[2] + 1 for k in range(nzl + 2)]
         assert rell2(got, st["u"][:, :, ks, :]) < 1e-10
         assert float(np.load(tmp_path / f"div_{r}.npy")[0]) < 1e-10
+        packed, inkernel, nch = np.load(tmp_path / f"flags_{r}.npy")
+        pow2 = all(v & (v - 1) == 0 for v in n)
+        assert bool(packed) == pow2 and bool(inkernel) == pow2 and nch == chunks  # the fast slab pipeline really ran
