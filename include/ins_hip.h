@@ -130,6 +130,13 @@ int ins_poisson_cg_create(const ins_grid_t* grid, double abstol, double reltol, 
  * This is what makes a non-solvable right-hand side (e.g. the lid of examples/LidDrivenCavity3D.jl:29, whose
  * normal component is non-zero) behave as it does under the reference's default (direct) solver. */
 int ins_poisson_cg_bordered(ins_poisson_t* ps, int enable);
+/* psolver_direct(setup)                    pressure.jl:101-154 (replaces the SuiteSparse / cuDSS factorisation of
+ * `laplacian_mat`, matrices.jl:484-492).  Fast diagonalisation of the separable operator L = Σα Tα ⊗ (⊗β≠α Dβ):
+ * V[α] is the Np[α] x Np[α] column-major matrix of Dα-orthonormal generalised eigenvectors (Tα Vα = Dα Vα Λα),
+ * lam[α] its Np[α] eigenvalues; V[2], lam[2] are ignored in 2-D.  Host pointers, copied.  A solve is six fp64
+ * GEMMs (rocBLAS) plus the 1/(λx+λy+λz) scaling; when no side is a PressureBC the bordered system of
+ * pressure.jl:133-140 is solved (mean(f) removed, null mode dropped, mean(p[Ip]) = 0).  Asynchronous. */
+int ins_poisson_fdm_create(const ins_grid_t* grid, const double* const* V, const double* const* lam, ins_poisson_t** out);
 int ins_poisson_destroy(ins_poisson_t* ps);
 /* poisson!(psolver, p) = psolver(p)        pressure.jl:22: solves L p = f in place on the padded array.
  * Spectral: asynchronous.  CG: blocking (the reference reads residuals on the host, pressure.jl:244,275). */

@@ -60,6 +60,7 @@ SIGNATURES = {
     "ins_poisson_spectral_create": (C.c_int, [vp, C.POINTER(vp)]),
     "ins_poisson_cg_create": (C.c_int, [vp, C.c_double, C.c_double, C.c_int64, C.POINTER(vp)]),
     "ins_poisson_cg_bordered": (C.c_int, [vp, C.c_int]),
+    "ins_poisson_fdm_create": (C.c_int, [vp, C.POINTER(c_double_p), C.POINTER(c_double_p), C.POINTER(vp)]),
     "ins_poisson_destroy": (C.c_int, [vp]),
     "ins_poisson_solve_f64": (C.c_int, [vp, vp, vp]),
     "ins_poisson_last_info": (C.c_int, [vp, C.POINTER(C.c_int64), c_double_p]),

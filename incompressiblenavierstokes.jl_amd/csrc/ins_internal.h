@@ -93,7 +93,14 @@ struct ins_grid {
   double* red_host = nullptr;  // pinned
 };
 
-enum PoissonKind { POISSON_SPECTRAL = 0, POISSON_CG = 1 };
+enum PoissonKind { POISSON_SPECTRAL = 0, POISSON_CG = 1, POISSON_FDM = 2 };
+
+// fast-diagonalisation direct solver (ins_fdm.hip)
+struct ins_fdm;
+int ins_fdm_create(int D, const int n[3], const double* const V[3], const double* const lam[3], int singular, ins_fdm** out);
+int ins_fdm_destroy(ins_fdm* F);
+int ins_fdm_solve(ins_fdm* F, hipStream_t s);
+double* ins_fdm_buffer(ins_fdm* F);
 
 struct ins_poisson {
   PoissonKind kind;
@@ -123,6 +130,8 @@ struct ins_poisson {
   long long ndof = 0;
   long long last_iter = 0;
   double last_res = 0;
+  // fdm (psolver_direct)
+  ins_fdm* fdm = nullptr;
 };
 
 struct ins_rk {

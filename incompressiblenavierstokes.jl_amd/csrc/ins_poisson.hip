@@ -573,12 +573,65 @@ extern "C" int ins_poisson_destroy(ins_poisson_t* ps) {
   if (ps->L) (void)hipFree(ps->L);
   if (ps->q) (void)hipFree(ps->q);
   if (ps->dinv) (void)hipFree(ps->dinv);
+  if (ps->fdm) (void)ins_fdm_destroy(ps->fdm);
   delete ps;
   return INS_OK;
 }
 
+// psolver_direct: pack Ip -> FDM solve (ins_fdm.hip) -> unpack                     pressure.jl:101-154
+static int fdm_solve(ins_poisson* ps, double* p, hipStream_t s) {
+  const GridDev& g = ps->grid->g;
+  double* buf = ins_fdm_buffer(ps->fdm);
+  dim3 block(64, 4, 1), grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), g.D == 3 ? ps->np[2] : 1);
+  if (g.D == 2)
+    hipLaunchKernelGGL((k_pack<2, true>), grid, block, 0, s, g, p, buf, ps->np[0], ps->np[1]);
+  else
+    hipLaunchKernelGGL((k_pack<3, true>), grid, block, 0, s, g, p, buf, ps->np[0], ps->np[1]);
+  INS_LAUNCH_CHECK();
+  int rc = ins_fdm_solve(ps->fdm, s);
+  if (rc) return rc;
+  if (g.D == 2)
+    hipLaunchKernelGGL((k_pack<2, false>), grid, block, 0, s, g, p, buf, ps->np[0], ps->np[1]);
+  else
+    hipLaunchKernelGGL((k_pack<3, false>), grid, block, 0, s, g, p, buf, ps->np[0], ps->np[1]);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+extern "C" int ins_poisson_fdm_create(const ins_grid_t* G, const double* const* V, const double* const* lam, ins_poisson_t** out) {
+  INS_REQUIRE(G && V && lam && out, "null argument");
+  const GridDev& g = G->g;
+  int n[3] = {1, 1, 1};
+  bool singular = true;
+  for (int a = 0; a < g.D; ++a) {
+    INS_REQUIRE(g.bc[a][0] != INS_BC_HALO && g.bc[a][1] != INS_BC_HALO, "psolver_direct on a slab grid is not implemented");
+    INS_REQUIRE(V[a] && lam[a], "null eigen-decomposition");
+    n[a] = g.ip_hi[a] - g.ip_lo[a];
+    if (g.bc[a][0] == INS_BC_PRESSURE || g.bc[a][1] == INS_BC_PRESSURE) singular = false;
+  }
+  ins_poisson* ps = new ins_poisson();
+  ps->kind = POISSON_FDM;
+  ps->grid = G;
+  ps->singular = singular;
+  ps->ndof = (long long)n[0] * n[1] * n[2];
+  for (int a = 0; a < 3; ++a) ps->np[a] = n[a];
+  const double* Vp[3] = {V[0], V[1], g.D == 3 ? V[2] : nullptr};
+  const double* lp[3] = {lam[0], lam[1], g.D == 3 ? lam[2] : nullptr};
+  int rc = ins_fdm_create(g.D, n, Vp, lp, singular ? 1 : 0, &ps->fdm);
+  if (rc) {
+    delete ps;
+    return rc;
+  }
+  *out = ps;
+  return INS_OK;
+}
+
 int ins_k_poisson_solve(ins_poisson* ps, double* p, hipStream_t s) {
-  return ps->kind == POISSON_SPECTRAL ? spectral_solve(ps, p, s) : cg_solve(ps, p, s);
+  switch (ps->kind) {
+    case POISSON_SPECTRAL: return spectral_solve(ps, p, s);
+    case POISSON_FDM: return fdm_solve(ps, p, s);
+    default: return cg_solve(ps, p, s);
+  }
 }
 
 extern "C" int ins_poisson_solve_f64(ins_poisson_t* ps, double* p, void* stream) {

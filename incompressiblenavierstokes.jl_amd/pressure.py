@@ -70,24 +70,88 @@ class psolver_cg(_PSolver):
             _lib.call("ins_poisson_cg_bordered", self._handle, 1)
 
 
-def psolver_direct(setup):
-    """pressure.jl:101-154.  The reference's CPU method factorises `laplacian_mat` with SuiteSparse and
-    its GPU method needs cuDSS (ext/IncompressibleNavierStokesCUDSSExt.jl); a device sparse direct solver
-    is out of this round's scope — non-periodic problems use `psolver_cg`."""
-    raise NotImplementedError(
-        "psolver_direct has no MI355X implementation yet; use psolver_cg(setup) (tight reltol for direct-solver accuracy)"
-    )
+def _laplacian_1d(setup, a):
+    """The 1-D factor Tα of `laplacian!` (operators.jl:328-350) on Ip[α]: Ω/Δα · ((p₊-p)/Δu[I] - (p-p₋)/Δu[I-1]) with
+    the reference's branch order for the first/last volume; ghost pressures of the `else` branch follow
+    apply_bc_p! (boundary_conditions.jl:186-215: periodic wrap, Neumann copy for Dirichlet/Symmetric, 0 for Pressure)."""
+    from .boundary_conditions import DirichletBC, PressureBC
+
+    g = setup.grid
+    lo, hi = g.Ip[a]
+    n = hi - lo
+    du = g.Δu[a]
+    bl, br = setup.boundary_conditions[a]
+    T = np.zeros((n, n))
+    for i in range(n):
+        cr, cl = 1.0 / du[lo + i], 1.0 / du[lo + i - 1]
+        first, last = i == 0, i == n - 1
+        right = left = True  # which one-sided differences survive
+        ghost_r = ghost_l = None  # column the ghost value aliases, None = 0 (PressureBC)
+        if first and isinstance(bl, PressureBC):
+            pass
+        elif last and isinstance(br, PressureBC):
+            pass
+        elif first and isinstance(bl, DirichletBC):
+            left = False
+        elif last and isinstance(br, DirichletBC):
+            right = False
+        else:
+            if first:
+                ghost_l = n - 1 if isinstance(bl, PeriodicBC) else i
+            if last:
+                ghost_r = 0 if isinstance(br, PeriodicBC) else i
+        if right:
+            T[i, i] -= cr
+            j = i + 1 if not last else ghost_r
+            if j is not None:
+                T[i, j] += cr
+        if left:
+            T[i, i] -= cl
+            j = i - 1 if not first else ghost_l
+            if j is not None:
+                T[i, j] += cl
+    return T
+
+
+class psolver_direct(_PSolver):
+    """Create direct Poisson solver from setup (pressure.jl:101-154).
+
+    The reference factorises `laplacian_mat(setup)` (SuiteSparse on the CPU, cuDSS on CUDA) — bordered with the
+    constant vector when no side is a PressureBC (pressure.jl:133-140).  On the tensor-product grids of this
+    package that matrix is Σα Tα ⊗ (⊗β≠α Dβ), so the same system is solved directly by fast diagonalisation:
+    the generalised eigenpairs Tα Vα = Dα Vα Λα are computed here once (host, O(N³) per direction, like the
+    reference's factorisation step) and every solve is six fp64 GEMMs on the device (csrc/ins_fdm.hip)."""
+
+    kind = "direct"
+
+    def __init__(self, setup):
+        super().__init__(setup)
+        g = setup.grid
+        D = g.dimension
+        self._V, self._lam = [], []
+        for a in range(D):
+            lo, hi = g.Ip[a]
+            T = _laplacian_1d(setup, a)
+            if not np.allclose(T, T.T, rtol=1e-13, atol=0):
+                raise ValueError("psolver_direct: the 1-D Laplacian factor is not symmetric")
+            dm = 1.0 / np.sqrt(g.Δ[a][lo:hi])
+            lam, W = np.linalg.eigh(dm[:, None] * T * dm[None, :])  # D^-1/2 T D^-1/2 = W Λ Wᵀ
+            self._V.append(np.asfortranarray(dm[:, None] * W))  # Vα = D^-1/2 W,  VαᵀDαVα = I
+            self._lam.append(np.ascontiguousarray(lam))
+        dp = C.POINTER(C.c_double)
+        Vp = (dp * 3)(*[v.ctypes.data_as(dp) for v in self._V])
+        lp = (dp * 3)(*[v.ctypes.data_as(dp) for v in self._lam])
+        _lib.call("ins_poisson_fdm_create", setup.handle, Vp, lp, C.byref(self._handle))
 
 
 def default_psolver(setup):
-    """Get default Poisson solver from setup (pressure.jl:85-98); the non-spectral branch returns
-    `psolver_cg(reltol=1e-12, bordered=True)`: the same linear system the direct solver factorises."""
+    """Get default Poisson solver from setup (pressure.jl:85-98)."""
     g = setup.grid
     isperiodic = all(isinstance(a, PeriodicBC) and isinstance(b, PeriodicBC) for a, b in setup.boundary_conditions)
     isuniform = all(np.allclose(d, d[0], rtol=math.sqrt(np.finfo(np.float64).eps), atol=0) for d in g.Δ)
     if isperiodic and isuniform:
         return psolver_spectral(setup)
-    return psolver_cg(setup, reltol=1e-12, bordered=True)
+    return psolver_direct(setup)
 
 
 def poisson_(psolver, f):

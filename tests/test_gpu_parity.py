@@ -141,11 +141,47 @@ def test_pressure_solvers_known_answer(ins, oracle):
     pe = ins.from_numpy(sp, p_exact)
     lap = ins.laplacian(pe, sp)
     ip = tuple(slice(lo, hi) for lo, hi in g.Ip)
-    for mk in (ins.psolver_cg, ins.psolver_spectral):
+    for mk in (ins.psolver_direct, ins.psolver_cg, ins.psolver_spectral):  # test/psolvers.jl:21-30
         got = ins.to_numpy(ins.apply_bc_p(ins.poisson(mk(sp), lap), 0.0, sp))
         assert np.allclose(got[ip], p_exact[ip], rtol=math.sqrt(o.EPS), atol=1e-9)
-    with pytest.raises(NotImplementedError):
-        ins.psolver_direct(sp)
+
+
+def _channel(o):
+    x = (np.linspace(0.0, 2.0, 9), o.tanh_grid(0.0, 1.0, 6, 1.5), o.stretched_grid(0.0, 1.0, 5, 1.2))
+    bcs = ((o.PeriodicBC(), o.PeriodicBC()), (o.DirichletBC(), o.DirichletBC()), (o.SymmetricBC(), o.PressureBC()))
+    return o.make_setup(x, bcs, Re=100.0)
+
+
+@pytest.mark.parametrize("geom", ["dirichlet2d", "dirichlet3d", "mixed3d", "periodic2d", "periodic3d", "channel3d"])
+@pytest.mark.parametrize("consistent", [True, False])
+def test_direct_matches_oracle_direct(ins, oracle, geom, consistent):
+    """psolver_direct (fast diagonalisation on rocBLAS) against the oracle's sparse-LU factorisation of laplacian_mat,
+    including right-hand sides outside the range of a singular L (the bordered system, pressure.jl:133-140)."""
+    o = oracle
+    so = _channel(o) if geom == "channel3d" else GEOMS[geom](o)
+    sp = mirror(ins, so, o)
+    g = so.grid
+    if consistent:
+        u_h = o.apply_bc_u(fx.randn_field(g.N + (g.D,), 8), 0.0, so)
+        f = o.scalewithvolume(o.divergence(u_h, so), so)
+    else:
+        f = fx.randn_field(g.N, 9)
+    want = o.poisson(o.psolver_direct(so), f)
+    solver = ins.psolver_direct(sp)
+    assert solver.kind == "direct"
+    got = ins.to_numpy(ins.poisson(solver, ins.from_numpy(sp, f)))
+    ip = tuple(slice(lo, hi) for lo, hi in g.Ip)
+    assert rell2(got[ip], want[ip]) < POISSON_TOL
+    mask = np.ones(g.N, bool)
+    mask[ip] = False
+    assert np.array_equal(got[mask], f[mask])  # only view(p, Ip) is written (pressure.jl:150)
+    # and it really solves L p = f - mean(f)·[singular] with the device Laplacian
+    pb = ins.apply_bc_p(ins.from_numpy(sp, got), 0.0, sp)
+    res = ins.to_numpy(ins.laplacian(pb, sp))[ip] - f[ip]
+    singular = not any(isinstance(b, o.PressureBC) for side in so.boundary_conditions for b in side)
+    if singular:
+        res += f[ip].mean()
+    assert np.abs(res).max() < 1e-10 * max(np.abs(f[ip]).max(), 1.0)
 
 
 @pytest.mark.parametrize("n", [(16, 16), (12, 20, 8), (64, 32, 16)])
@@ -205,11 +241,11 @@ def test_project_matches_oracle(ins, oracle, geom):
     u_h = o.apply_bc_u(fx.randn_field(g.N + (g.D,), 12), 0.0, so)
     periodic = geom.startswith("periodic")
     pso = o.psolver_spectral(so) if periodic else o.psolver_direct(so)
-    psp = ins.psolver_spectral(sp) if periodic else ins.psolver_cg(sp, reltol=1e-13)
+    psp = ins.psolver_spectral(sp) if periodic else ins.psolver_direct(sp)
     want_u = o.project_(u_h.copy(order="F"), so, pso, o.scalarfield(so))
     u, p = ins.from_numpy(sp, u_h), ins.scalarfield(sp)
     ins.project_(u, sp, psp, p)
-    tol = POISSON_TOL if periodic else 1e-8
+    tol = POISSON_TOL
     assert rell2(ins.to_numpy(u), want_u) < tol
     ins.apply_bc_u_(u, 0.0, sp)
     if periodic:
@@ -256,7 +292,7 @@ def test_rk44_tgv3d_64_ten_steps(ins, oracle):
 
 
 def test_rk44_dirichlet_cavity_matches_oracle(ins, oracle):
-    """Config-5-shaped problem at test size: stretched grid, lid-driven Dirichlet walls, periodic z, CG."""
+    """Config-5-shaped problem at test size: stretched grid, lid-driven Dirichlet walls, periodic z, default (direct) solver."""
     o = oracle
     lid = (1.0, 0.2, 0.0)
     x = (o.cosine_grid(0.0, 1.0, 12), o.cosine_grid(0.0, 1.0, 10), np.linspace(-0.2, 0.2, 9))
@@ -264,11 +300,15 @@ def test_rk44_dirichlet_cavity_matches_oracle(ins, oracle):
     sp = ins.Setup(x=x, boundary_conditions=((ins.DirichletBC(), ins.DirichletBC()), (ins.DirichletBC(), ins.DirichletBC(lid)),
                                              (ins.PeriodicBC(), ins.PeriodicBC())), Re=100.0)
     pso, psp = o.psolver_direct(so), ins.default_psolver(sp)
-    assert psp.kind == "cg"
+    assert psp.kind == "direct"
     u0 = o.apply_bc_u_(o.vectorfield(so), 0.0, so)
     st = o.solve_unsteady(so, (0.0, 0.02), u0, psolver=pso, dt=0.005)
     (u, _, t), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 0.02), ustart=ins.from_numpy(sp, u0), psolver=psp, Δt=0.005)
-    assert rell2(ins.to_numpy(u), st["u"]) < 1e-8
+    assert rell2(ins.to_numpy(u), st["u"]) < STEP_TOL
+    # the bordered CG variant solves the same system (slower): agrees to its tolerance
+    (u2, _, _), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 0.02), ustart=ins.from_numpy(sp, u0),
+                                       psolver=ins.psolver_cg(sp, reltol=1e-12, bordered=True), Δt=0.005)
+    assert rell2(ins.to_numpy(u2), st["u"]) < 1e-8
 
 
 def test_timestep_inplace_equals_outofplace(ins, oracle):
