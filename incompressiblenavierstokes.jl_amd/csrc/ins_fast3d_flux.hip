@@ -481,12 +481,20 @@ static int launch_flux_any(const ins_grid* G, const double* u, double* F, const 
   return INS_ERR_INVALID;
 }
 
+// 64-outputs-per-wavefront specialisation for periodic, exactly-uniform boxes (ins_flux64.hip)
+bool ins_flux64_supported(const ins_grid* G);
+int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, const RkEpi* epi, const double* pI, int corr_mode, hipStream_t s);
+
 int ins_k_momentum_flux3d(const ins_grid* G, double visc, const double* u, double* F, bool zero_shell, hipStream_t s) {
-  int rc = ins_flux3d_prepare(G, visc, s);
-  if (rc) return rc;
-  RkEpi epi;
-  memset(&epi, 0, sizeof(epi));
-  if ((rc = launch_flux_any<false>(G, u, F, epi, nullptr, 0, s))) return rc;
+  int rc;
+  if (ins_flux64_supported(G)) {
+    if ((rc = ins_k_flux64(G, visc, u, F, nullptr, nullptr, 0, s))) return rc;
+  } else {
+    if ((rc = ins_flux3d_prepare(G, visc, s))) return rc;
+    RkEpi epi;
+    memset(&epi, 0, sizeof(epi));
+    if ((rc = launch_flux_any<false>(G, u, F, epi, nullptr, 0, s))) return rc;
+  }
   if (zero_shell) {
     const GridDev& g = G->g;
     const long long total = 2LL * ((long long)g.N[0] * g.N[1] + (long long)g.N[0] * g.N[2] + (long long)g.N[1] * g.N[2]);
@@ -498,6 +506,7 @@ int ins_k_momentum_flux3d(const ins_grid* G, double visc, const double* u, doubl
 
 // K1 + K6: k_i = momentum(u_in) (stored when epi.write_k) and the stage velocity u* (interior) in one pass.
 int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s) {
+  if (ins_flux64_supported(G)) return ins_k_flux64(G, visc, u_in, k_out, &epi, nullptr, 0, s);
   int rc = ins_flux3d_prepare(G, visc, s);
   if (rc) return rc;
   return launch_flux_any<true>(G, u_in, k_out, epi, nullptr, 0, s);
@@ -507,6 +516,7 @@ int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, 
 // projection's gradient-subtract is applied in registers (periodic, exactly-uniform grids).
 int ins_k_momentum_rk_fused_corr(const ins_grid* G, double visc, const double* ustar_prev, const double* pI, double* k_out, const RkEpi& epi,
                                  hipStream_t s) {
+  if (ins_flux64_supported(G)) return ins_k_flux64(G, visc, ustar_prev, k_out, &epi, pI, 1, s);
   int rc = ins_flux3d_prepare(G, visc, s);
   if (rc) return rc;
   return launch_flux_any<true>(G, ustar_prev, k_out, epi, pI, 1, s);
@@ -515,6 +525,7 @@ int ins_k_momentum_rk_fused_corr(const ins_grid* G, double visc, const double* u
 // Slab flavour: z neighbours from ghost planes; p_ext = [1 plane below | local planes | 2 planes above] (unpadded in x, y).
 int ins_k_momentum_rk_fused_corr_slab(const ins_grid* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out,
                                       const RkEpi& epi, hipStream_t s) {
+  if (ins_flux64_supported(G)) return ins_k_flux64(G, visc, ustar_prev, k_out, &epi, p_ext, 2, s);
   int rc = ins_flux3d_prepare(G, visc, s);
   if (rc) return rc;
   return launch_flux_any<true>(G, ustar_prev, k_out, epi, p_ext, 2, s);

@@ -1,0 +1,453 @@
+// K1 (flux form, 64 outputs per wavefront) — the periodic / exactly-uniform specialisation of ins_fast3d_flux.hip
+// (convection_diffusion_kernel! + fill!(F, 0), operators.jl:647-690, 971; optional RK epilogue and in-register
+// pressure correction exactly as documented there).
+//
+// ins_fast3d_flux.hip spends lanes 0 and 63 of every wavefront on halo columns, so a 256-wide row needs 5 wavefronts
+// (62+62+62+62+8) and a 512-wide row 9.  Here all 64 lanes produce output:
+//   * the two halo columns (x0-1 and x0+64) of ALL R+2 rows arrive in ONE extra load per component and plane, rows
+//     packed across lanes (lanes 0..7: left column, lanes 16..23: right column);
+//   * `v_readlane` moves a packed halo value to an SGPR; it enters the wave shift as the DPP `old` operand, i.e. the value
+//     lane 63 (wave_shl) or lane 0 (wave_shr) keeps when it has no source lane;
+//   * lane 0 has no left neighbour to take the left-face x-fluxes from: they are evaluated from the halo scalars (three
+//     more flux evaluations per row, wave-wide; the kernel is memory-bound);
+//   * with the pressure correction (CORR) the packed halo columns are corrected in packed form from a packed load of the
+//     four pressure columns x0-1, x0, x0+64, x0+65 (DPP row shifts inside the 16-lane rows).
+// So every column of u is loaded once per (R+2)-row window and a 256 (512) wide row takes exactly 4 (8) wavefronts.
+// Everything else (R+2 register rows, z-march with carried z-flux, 3-buffer plane prefetch, k-major XCD-partitioned tile
+// order) is the scheme of ins_fast3d_flux.hip.  Addressing: wave-uniform row bases (SGPR) + one 32-bit lane offset, so the
+// loads use the saddr form and no 64-bit address registers; the grid enters as 12 scalars instead of the GridDev tables.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "ins_internal.h"
+
+namespace {
+
+struct Dir {
+  double vs, vo, rs, ro;  // ν/Δ (α == β), ν/Δu (α != β), 1/Δu, 1/Δ  — the constant metric record of one direction
+};
+
+struct FluxArgs {
+  const double* u;
+  const double* pI;
+  double* F;
+  long long sc;  // component stride (elements)
+  int N0, N1, N2;
+  int zc, ntx, nty, ntz;
+  Dir X, Y, Z;
+  RkEpi epi;
+};
+
+__device__ __forceinline__ double rdlane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_old(double old, double v) {  // lanes without a source lane keep `old`
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double next_h(double v, double h) { return dpp_old<0x130>(h, v); }  // lane l <- l+1, lane 63 <- h
+__device__ __forceinline__ double prev_h(double v, double h) { return dpp_old<0x138>(h, v); }  // lane l <- l-1, lane 0  <- h
+
+// Buffer addressing: descriptor (4 SGPRs) = one plane of one array, soffset (SGPR) = row start, voffset (VGPR) = column.
+// All plane / row arithmetic runs on the scalar unit; a lane holds one 32-bit offset for every load and store it issues.
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t plane_rsrc(const double* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ double ldb(rsrc_t r, unsigned voff, unsigned soff) {
+  const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ void stb(rsrc_t r, unsigned voff, unsigned soff, double x) {
+  v2u v;
+  v.x = (unsigned)__double2loint(x);
+  v.y = (unsigned)__double2hiint(x);
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+
+// Face flux with the uniform half weights ¼: ν(up - uc)/Δb - ½(uc + up)·½(ub0 + ub1)
+__device__ __forceinline__ double flux(double uc, double up, double ub0, double ub1, double vd) {
+  const double uba = 0.25 * (ub0 + ub1);
+  return (up - uc) * vd - (uc + up) * uba;
+}
+
+__device__ __forceinline__ int wrapi(int q, int n) {  // q in [-n, 2n) -> [0, n)
+  return q < 0 ? q + n : (q >= n ? q - n : q);
+}
+
+template <int R>
+struct Plane {
+  double v[3][R + 2];
+  double h[3];  // packed halo columns: lane r = row r of column x0-1, lane 16+r = row r of column x0+64
+};
+
+// XW wavefronts side by side in x, 4/XW stacked in y.  CORR as in ins_fast3d_flux.hip: 0 = `u` has valid ghost volumes;
+// 1 = `u` is the previous stage's uncorrected u* (interior only), pI its unpadded pressure, every neighbour through the
+// periodic image; 2 = z-slab: x, y periodic images, z through exchanged ghost planes, pI = [1 | nzl | 2] extended buffer.
+template <int R, int XW, bool FUSE, int CORR, bool SKEL = false>
+__global__ __launch_bounds__(256) void k_flux64(FluxArgs a) {
+  static_assert(R + 3 <= 8, "packed halo rows live in 8-lane groups");
+  int txi, tyi, tzi;
+  {
+    const int nty_local = (a.nty + 7) >> 3;
+    int seq = (int)(blockIdx.x >> 3);
+    if (seq >= a.ntx * nty_local * a.ntz) return;
+    txi = seq % a.ntx;
+    seq /= a.ntx;
+    tyi = (int)(blockIdx.x & 7) * nty_local + seq % nty_local;
+    tzi = seq / nty_local;
+    if (tyi >= a.nty) return;
+  }
+  const int lane = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int wx = wave % XW, wy = wave / XW;
+  const int N0 = a.N0, N1 = a.N1, N2 = a.N2;
+  const int n0 = N0 - 2, n1 = N1 - 2, n2 = N2 - 2;
+  const int x0 = (txi * XW + wx) * 64;  // interior (0-based) column of lane 0
+  if (x0 >= n0) return;                 // no barriers in this kernel: safe
+  const int jb0 = (tyi * (4 / XW) + wy) * R;  // interior row of the first output row
+  if (jb0 >= n1) return;
+  const int k0 = 1 + tzi * a.zc;               // padded plane index of the first output plane
+  const int k1 = min(k0 + a.zc, N2 - 1);
+  const long long sz = (long long)N0 * N1;
+  const int ci = x0 + lane;
+  const bool xout = ci < n0;
+  const Dir X = a.X, Y = a.Y, Z = a.Z;
+
+  // padded row / column of a (possibly out-of-range) interior index
+  auto prow_of = [&](int jr) { return CORR ? wrapi(jr, n1) + 1 : min(jr + 1, N1 - 1); };
+  auto pcol_of = [&](int c) { return CORR ? wrapi(c, n0) + 1 : min(c + 1, N0 - 1); };
+
+  // ---- wave-uniform row starts (elements inside a plane) and per-lane byte offsets --------------------------------------
+  unsigned urow[R + 2];  // u: byte offset of the padded row inside a plane
+  unsigned qrow[R + 3];  // p: byte offset of the interior row inside an unpadded plane (CORR)
+#pragma unroll
+  for (int rr = 0; rr < R + 2; ++rr) urow[rr] = (unsigned)(prow_of(jb0 - 1 + rr) * N0) * 8u;
+  if (CORR) {
+#pragma unroll
+    for (int rr = 0; rr < R + 3; ++rr) qrow[rr] = (unsigned)((prow_of(jb0 - 1 + rr) - 1) * n0) * 8u;
+  }
+  const unsigned ubytes = (unsigned)sz * 8u, qbytes = (unsigned)(n0 * n1) * 8u;
+  const unsigned ucol = (unsigned)pcol_of(ci) * 8u;            // main lanes: own column
+  const unsigned qcol = CORR ? (unsigned)(pcol_of(ci) - 1) * 8u : 0u;
+  unsigned uhoff, qhoff = 0;  // packed halo loads: in-plane byte offset of this lane's (row, column)
+  {
+    const int r = lane & 7, grp = (lane >> 3) & 3;
+    const int ru = r <= R + 1 ? r : 0;
+    const int colu = (grp == 2) ? pcol_of(x0 + 64) : pcol_of(x0 - 1);
+    uhoff = (unsigned)(prow_of(jb0 - 1 + ru) * N0 + colu) * 8u;
+    if (CORR) {
+      const int rq = r <= R + 2 ? r : 0;
+      const int cq = grp == 0 ? x0 - 1 : (grp == 1 ? x0 : (grp == 2 ? x0 + 64 : x0 + 65));
+      qhoff = (unsigned)((prow_of(jb0 - 1 + rq) - 1) * n0 + (pcol_of(cq) - 1)) * 8u;
+    }
+  }
+
+  auto uplane = [&](int kk) {  // padded plane index -> plane actually read
+    return CORR == 1 ? wrapi(kk - 1, n2) + 1 : (CORR == 2 ? min(kk, N2 - 1) : kk);
+  };
+  auto load_plane = [&](Plane<R>& P, int kk) {
+    const double* base = a.u + (long long)uplane(kk) * sz;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const rsrc_t rs = plane_rsrc(base + c * a.sc, ubytes);
+#pragma unroll
+      for (int rr = 0; rr < R + 2; ++rr) P.v[c][rr] = ldb(rs, ucol, urow[rr]);
+      P.h[c] = ldb(rs, uhoff, 0);
+    }
+  };
+  auto load_p = [&](double (&P)[R + 3], double& PH, int kk) {
+    const rsrc_t rs = plane_rsrc(a.pI + (long long)(CORR == 2 ? min(kk, N2) : wrapi(kk - 1, n2)) * n0 * n1, qbytes);
+#pragma unroll
+    for (int rr = 0; rr < R + 3; ++rr) P[rr] = ldb(rs, qcol, qrow[rr]);
+    PH = ldb(rs, qhoff, 0);
+  };
+  // u = u* - ∇p (applypressure!, operators.jl:225-233) for one register plane and its packed halo columns
+  auto correct = [&](Plane<R>& P, const double (&Pc)[R + 3], double PHc, const double (&Pn)[R + 3], double PHn) {
+#pragma unroll
+    for (int rr = 0; rr < R + 2; ++rr) {
+      const double pc = Pc[rr];
+      P.v[0][rr] -= (next_h(pc, rdlane(PHc, 16 + rr)) - pc) * X.rs;
+      P.v[1][rr] -= (Pc[rr + 1] - pc) * Y.rs;
+      P.v[2][rr] -= (Pn[rr] - pc) * Z.rs;
+    }
+    P.h[0] -= (dpp_old<0x108>(PHc, PHc) - PHc) * X.rs;  // row_shl:8 — p of the next column, same row
+    P.h[1] -= (dpp_old<0x101>(PHc, PHc) - PHc) * Y.rs;  // row_shl:1 — p of the next row, same column
+    P.h[2] -= (PHn - PHc) * Z.rs;
+  };
+
+  double zprev[3][R];
+  auto zflux0 = [&](const Plane<R>& C, const Plane<R>& Nx) {  // upper-face z-fluxes of the plane below the chunk
+#pragma unroll
+    for (int rr = 1; rr <= R; ++rr) {
+      const double Wc = C.v[2][rr];
+      zprev[0][rr - 1] = flux(C.v[0][rr], Nx.v[0][rr], Wc, next_h(Wc, rdlane(C.h[2], 16 + rr)), Z.vo);
+      zprev[1][rr - 1] = flux(C.v[1][rr], Nx.v[1][rr], Wc, C.v[2][rr + 1], Z.vo);
+      zprev[2][rr - 1] = flux(Wc, Nx.v[2][rr], Wc, Nx.v[2][rr], Z.vs);
+    }
+  };
+
+  auto emit = [&](int rr, int k, double fu, double fv, double fw, double Uc, double Vc, double Wc) {
+    const long long pk = (long long)k * sz;
+        const int j = jb0 + rr - 1;  // interior row
+    if (xout && j < n1) {
+      const unsigned rowb = (unsigned)((j + 1) * N0) * 8u;  // wave-uniform
+      const unsigned co = (unsigned)(ci + 1) * 8u;
+      if (FUSE) {
+        double su, sv, sw;
+        if (a.epi.ustart) {
+          const double* b = a.epi.ustart + pk;
+          su = ldb(plane_rsrc(b, ubytes), co, rowb);
+          sv = ldb(plane_rsrc(b + a.sc, ubytes), co, rowb);
+          sw = ldb(plane_rsrc(b + 2 * a.sc, ubytes), co, rowb);
+        } else {
+          su = Uc;
+          sv = Vc;
+          sw = Wc;
+        }
+        for (int q = 0; q < a.epi.n; ++q) {
+          const double* kq = a.epi.k[q] + pk;
+          const double cq = a.epi.coef[q];
+          su += cq * ldb(plane_rsrc(kq, ubytes), co, rowb);
+          sv += cq * ldb(plane_rsrc(kq + a.sc, ubytes), co, rowb);
+          sw += cq * ldb(plane_rsrc(kq + 2 * a.sc, ubytes), co, rowb);
+        }
+        su += a.epi.coef_self * fu;
+        sv += a.epi.coef_self * fv;
+        sw += a.epi.coef_self * fw;
+        double* o = a.epi.ustar + pk;
+        stb(plane_rsrc(o, ubytes), co, rowb, su);
+        stb(plane_rsrc(o + a.sc, ubytes), co, rowb, sv);
+        stb(plane_rsrc(o + 2 * a.sc, ubytes), co, rowb, sw);
+      }
+      if (!FUSE || a.epi.write_k) {
+        double* o = a.F + pk;
+        stb(plane_rsrc(o, ubytes), co, rowb, fu);
+        stb(plane_rsrc(o + a.sc, ubytes), co, rowb, fv);
+        stb(plane_rsrc(o + 2 * a.sc, ubytes), co, rowb, fw);
+      }
+    }
+    };
+
+  auto body = [&](const Plane<R>& C, const Plane<R>& Nx, int k) {
+    double fyu_o = 0, fyv_o = 0, fyw_o = 0;
+#pragma unroll
+    for (int rr = 0; rr <= R; ++rr) {
+      const double Uc = C.v[0][rr], Vc = C.v[1][rr], Wc = C.v[2][rr];
+      if (SKEL) {  // timing experiment: same loads, stores and epilogue, trivial arithmetic (tools/scan_flux64.sh)
+        if (rr >= 1) {
+          const double fu = Uc + C.v[0][rr - 1] + C.v[0][rr + 1] + Nx.v[0][rr] + zprev[0][rr - 1] + C.h[0];
+          const double fv = Vc + C.v[1][rr - 1] + C.v[1][rr + 1] + Nx.v[1][rr] + zprev[1][rr - 1] + C.h[1];
+          const double fw = Wc + C.v[2][rr - 1] + C.v[2][rr + 1] + Nx.v[2][rr] + zprev[2][rr - 1] + C.h[2];
+          emit(rr, k, fu, fv, fw, Uc, Vc, Wc);
+        }
+        continue;
+      }
+      const double Vn = next_h(Vc, rdlane(C.h[1], 16 + rr));
+      // y-fluxes through the face between rows rr and rr+1
+      const double fyu = flux(Uc, C.v[0][rr + 1], Vc, Vn, Y.vo);
+      const double fyv = flux(Vc, C.v[1][rr + 1], Vc, C.v[1][rr + 1], Y.vs);
+      const double fyw = flux(Wc, C.v[2][rr + 1], Vc, Nx.v[1][rr], Y.vo);
+      if (rr >= 1) {
+        const double Un = next_h(Uc, rdlane(C.h[0], 16 + rr)), Wn = next_h(Wc, rdlane(C.h[2], 16 + rr));
+        const double fxu = flux(Uc, Un, Uc, Un, X.vs);
+        const double fxv = flux(Vc, Vn, Uc, C.v[0][rr + 1], X.vo);
+        const double fxw = flux(Wc, Wn, Uc, Nx.v[0][rr], X.vo);
+        // left-face fluxes of lane 0 from the halo column x0-1 (all other lanes take their left neighbour's right face)
+        const double sU = rdlane(C.h[0], rr), sV = rdlane(C.h[1], rr), sW = rdlane(C.h[2], rr);
+        const double sUu = rdlane(C.h[0], rr + 1), sUn = rdlane(Nx.h[0], rr);
+        const double lxu = flux(sU, Uc, sU, Uc, X.vs);
+        const double lxv = flux(sV, Vc, sU, sUu, X.vo);
+        const double lxw = flux(sW, Wc, sU, sUn, X.vo);
+        double fu = (fxu - prev_h(fxu, lxu)) * X.rs;
+        double fv = (fxv - prev_h(fxv, lxv)) * X.ro;
+        double fw = (fxw - prev_h(fxw, lxw)) * X.ro;
+        fu += (fyu - fyu_o) * Y.ro;
+        fv += (fyv - fyv_o) * Y.rs;
+        fw += (fyw - fyw_o) * Y.ro;
+        const double zu = flux(Uc, Nx.v[0][rr], Wc, Wn, Z.vo);
+        const double zv = flux(Vc, Nx.v[1][rr], Wc, C.v[2][rr + 1], Z.vo);
+        const double zw = flux(Wc, Nx.v[2][rr], Wc, Nx.v[2][rr], Z.vs);
+        fu += (zu - zprev[0][rr - 1]) * Z.ro;
+        fv += (zv - zprev[1][rr - 1]) * Z.ro;
+        fw += (zw - zprev[2][rr - 1]) * Z.rs;
+        zprev[0][rr - 1] = zu;
+        zprev[1][rr - 1] = zv;
+        zprev[2][rr - 1] = zw;
+        emit(rr, k, fu, fv, fw, Uc, Vc, Wc);
+      }
+      fyu_o = fyu;
+      fyv_o = fyv;
+      fyw_o = fyw;
+    }
+  };
+
+  Plane<R> A, B, Cc;
+  if (!CORR) {
+    load_plane(A, k0 - 1);
+    load_plane(B, k0);
+    load_plane(Cc, min(k0 + 1, N2 - 1));
+    zflux0(A, B);
+    int k = k0;
+    // 3-buffer rotation (static register indices): compute plane k from (cur, next) while plane k+2 is in flight
+    while (true) {
+      load_plane(A, min(k + 2, N2 - 1));
+      body(B, Cc, k);
+      if (++k >= k1) break;
+      load_plane(B, min(k + 2, N2 - 1));
+      body(Cc, A, k);
+      if (++k >= k1) break;
+      load_plane(Cc, min(k + 2, N2 - 1));
+      body(A, B, k);
+      if (++k >= k1) break;
+    }
+  } else {
+    // invariant at the top of iteration k: cur = corrected plane k, nxt = RAW plane k+1, Pa = p(k+1), Pb = p(k+2)
+    double Pa[R + 3], Pb[R + 3], Ha, Hb;
+    load_p(Pa, Ha, k0 - 1);
+    load_p(Pb, Hb, k0);
+    load_plane(A, k0 - 1);
+    load_plane(B, k0);
+    correct(A, Pa, Ha, Pb, Hb);
+    load_p(Pa, Ha, k0 + 1);
+    correct(B, Pb, Hb, Pa, Ha);
+    load_plane(Cc, k0 + 1);
+    load_p(Pb, Hb, k0 + 2);
+    zflux0(A, B);
+    int k = k0;
+    while (true) {
+      correct(Cc, Pa, Ha, Pb, Hb);  // plane k+1 with p(k+1), p(k+2)
+      load_plane(A, k + 2);
+      load_p(Pa, Ha, k + 3);
+      body(B, Cc, k);
+      if (++k >= k1) break;
+      correct(A, Pb, Hb, Pa, Ha);
+      load_plane(B, k + 2);
+      load_p(Pb, Hb, k + 3);
+      body(Cc, A, k);
+      if (++k >= k1) break;
+      correct(B, Pa, Ha, Pb, Hb);
+      load_plane(Cc, k + 2);
+      load_p(Pa, Ha, k + 3);
+      body(A, B, k);
+      if (++k >= k1) break;
+      // second half of the period-6 rotation (the two p buffers have swapped roles)
+      correct(Cc, Pb, Hb, Pa, Ha);
+      load_plane(A, k + 2);
+      load_p(Pb, Hb, k + 3);
+      body(B, Cc, k);
+      if (++k >= k1) break;
+      correct(A, Pa, Ha, Pb, Hb);
+      load_plane(B, k + 2);
+      load_p(Pa, Ha, k + 3);
+      body(Cc, A, k);
+      if (++k >= k1) break;
+      correct(B, Pb, Hb, Pa, Ha);
+      load_plane(Cc, k + 2);
+      load_p(Pb, Hb, k + 3);
+      body(A, B, k);
+      if (++k >= k1) break;
+    }
+  }
+}
+
+int env_int(const char* name) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+}
+const int g_disable = env_int("INS_DISABLE_FLUX64");
+const int g_rows = env_int("INS_FLUX64_ROWS");
+const int g_rows_corr = env_int("INS_FLUX64_ROWS_CORR");
+const int g_zchunk = env_int("INS_FLUX64_ZC");
+const int g_xw = env_int("INS_FLUX64_XW");
+const int g_skel = env_int("INS_FLUX64_SKEL");  // timing experiment only: wrong results by design
+
+Dir make_dir(const ins_grid* G, int d, double visc) {
+  // the constant record ins_fast3d_flux.hip's UNIFORM kernels read (index 1): same fp64 operations, on the host
+  const double dxu = G->desc.dxu[d][1], dx1 = G->desc.dx[d][1], dx2 = G->desc.dx[d][2];
+  Dir r;
+  r.vs = visc * (dx2 > 2 * INS_EPS ? 1.0 / dx2 : 0.0);
+  r.vo = visc * (dxu > 2 * INS_EPS ? 1.0 / dxu : 0.0);
+  r.rs = 1.0 / dxu;
+  r.ro = 1.0 / dx1;
+  return r;
+}
+
+template <int R, int XW, bool FUSE>
+int launch(const ins_grid* G, FluxArgs& a, int corr_mode, hipStream_t s) {
+  const GridDev& g = G->g;
+  a.ntx = cdiv(g.N[0] - 2, 64 * XW);
+  a.nty = cdiv(g.N[1] - 2, (4 / XW) * R);
+  a.ntz = cdiv(g.N[2] - 2, a.zc);
+  const unsigned nb = (unsigned)(8LL * a.ntx * ((a.nty + 7) / 8) * a.ntz);
+  const dim3 block(64, 4, 1);
+  if (g_skel && corr_mode == 0 && R == 4)
+    hipLaunchKernelGGL((k_flux64<4, XW, FUSE, 0, true>), dim3(nb), block, 0, s, a);
+  else if (corr_mode == 0)
+    hipLaunchKernelGGL((k_flux64<R, XW, FUSE, 0>), dim3(nb), block, 0, s, a);
+  else if constexpr (FUSE) {
+    if (corr_mode == 1)
+      hipLaunchKernelGGL((k_flux64<R, XW, true, 1>), dim3(nb), block, 0, s, a);
+    else
+      hipLaunchKernelGGL((k_flux64<R, XW, true, 2>), dim3(nb), block, 0, s, a);
+  } else {
+    ins_set_error("in-kernel pressure correction needs the fused epilogue");
+    return INS_ERR_UNSUPPORTED;
+  }
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+}  // namespace
+
+// 3-D, every interior volume a DOF (all-periodic box or periodic slab), bitwise-constant metric records, room for the
+// periodic wrap of a full wavefront window.
+bool ins_flux64_supported(const ins_grid* G) {
+  const GridDev& g = G->g;
+  return !g_disable && g.D == 3 && G->all_dof && G->uniform_exact && g.N[0] - 2 >= 66 && g.N[1] - 2 >= 8 && g.N[2] - 2 >= 4;
+}
+
+// corr_mode 0: u has valid ghost volumes.  1 / 2: see k_flux64.  fuse: RK epilogue `epi`.
+int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, const RkEpi* epi, const double* pI, int corr_mode, hipStream_t s) {
+  const GridDev& g = G->g;
+  FluxArgs a;
+  memset(&a, 0, sizeof(a));
+  a.u = u;
+  a.pI = pI;
+  a.F = F;
+  a.sc = g.sc;
+  a.N0 = g.N[0];
+  a.N1 = g.N[1];
+  a.N2 = g.N[2];
+  a.zc = g_zchunk ? g_zchunk : (g.N[2] >= 384 ? 8 : 4);
+  a.X = make_dir(G, 0, visc);
+  a.Y = make_dir(G, 1, visc);
+  a.Z = make_dir(G, 2, visc);
+  if (epi) a.epi = *epi;
+  const int waves_x = cdiv(g.N[0] - 2, 64);
+  const int xw = g_xw ? g_xw : (waves_x >= 4 ? 4 : (waves_x >= 2 ? 2 : 1));
+  int rows = corr_mode ? (g_rows_corr ? g_rows_corr : 2) : (g_rows ? g_rows : 4);
+  rows = std::min(std::max(rows, 2), 4);
+#define INS_F64_CASE(RR, FUSE)                                            \
+  if (rows == RR) {                                                       \
+    if (xw == 4) return launch<RR, 4, FUSE>(G, a, corr_mode, s);          \
+    if (xw == 2) return launch<RR, 2, FUSE>(G, a, corr_mode, s);          \
+    return launch<RR, 1, FUSE>(G, a, corr_mode, s);                       \
+  }
+  if (epi) {
+    INS_F64_CASE(2, true)
+    INS_F64_CASE(3, true)
+    INS_F64_CASE(4, true)
+  } else {
+    INS_F64_CASE(2, false)
+    INS_F64_CASE(3, false)
+    INS_F64_CASE(4, false)
+  }
+#undef INS_F64_CASE
+  return INS_ERR_INVALID;
+}

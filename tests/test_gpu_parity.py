@@ -481,3 +481,45 @@ def test_full_size_512_decaying_turbulence_properties(ins):
     assert 0 < e1 < e0
     (w2, _, _), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 5e-4), ustart=u, psolver=ps, Δt=2.5e-4)
     assert torch.equal(w, w2) and float(u.sum()) == chk0  # deterministic, and ustart untouched (docopy)
+
+
+# ------------------------------------------------------------------ K1, 64 outputs per wavefront (csrc/ins_flux64.hip)
+def exact_box(o, n, Re=500.0):
+    """Periodic box whose coordinates are exact binary fractions: the metric records are bitwise constant, which is
+    what selects the constant-record kernels."""
+    return o.make_setup(tuple(np.arange(ni + 1) * 2.0**-6 for ni in n), Re=Re)
+
+
+# x: one full + one partial wavefront / two full / 3 full + partial / minimum width; y, z: ragged against R and the z-chunk
+FLUX64_BOXES = [(96, 9, 7), (128, 16, 12), (200, 8, 5), (66, 10, 4), (130, 13, 9)]
+
+
+@pytest.mark.parametrize("n", FLUX64_BOXES)
+def test_flux64_momentum_matches_oracle(ins, oracle, n):
+    from ins_amd import _lib
+
+    o = oracle
+    so = exact_box(o, n)
+    sp = mirror(ins, so, o)
+    assert _lib.load().ins_grid_is_uniform_exact(sp.handle)
+    u_h = o.apply_bc_u(fx.randn_field(so.grid.N + (3,), 21), 0.0, so)
+    got = ins.to_numpy(ins.momentum_(ins.from_numpy(sp, fx.randn_field(so.grid.N + (3,), 22)), ins.from_numpy(sp, u_h), None, 0.0, sp))
+    assert relmax(got, o.momentum(u_h, None, 0.0, so)) < OP_TOL
+
+
+@pytest.mark.parametrize("n", [(96, 10, 8), (128, 16, 12), (200, 8, 6), (66, 10, 4), (130, 14, 10)])  # even: spectral solver
+@pytest.mark.parametrize("method", ["RK44", "Wray3"])
+def test_flux64_rk_steps_match_oracle(ins, oracle, n, method):
+    """Fused stage kernels: first stage (RK epilogue) and the in-register pressure correction of the later stages, on boxes
+    whose last wavefront is partial and whose periodic images cross wavefront borders."""
+    o = oracle
+    so = exact_box(o, n)
+    sp = mirror(ins, so, o)
+    pso, psp = o.psolver_spectral(so), ins.psolver_spectral(sp)
+    u0 = o.random_field(so, kp=2, seed=5, psolver=pso)
+    mo, mp_ = getattr(o, method)(), getattr(ins.RKMethods, method)()
+    st = o.solve_unsteady(so, (0.0, 0.02), u0, method=mo, psolver=pso, dt=0.01)
+    (u, _, t), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 0.02), ustart=ins.from_numpy(sp, u0), method=mp_, psolver=psp, Δt=0.01)
+    assert rell2(ins.to_numpy(u), st["u"]) < STEP_TOL
+    assert ins.max_abs_divergence(u, sp) < 1e-10
+    del psp, sp
