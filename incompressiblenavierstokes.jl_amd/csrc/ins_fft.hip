@@ -138,7 +138,7 @@ struct PackMap {
 };
 
 template <int LOGN, int TK, bool INVERSE, bool PACKED>
-__global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kxn, const double2* __restrict__ tw_g, PackMap pm) {
+__global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kxn, int kxs, const double2* __restrict__ tw_g, PackMap pm) {
   constexpr int N = 1 << LOGN;
   extern __shared__ double2 lds_dyn[];
   double2* buf = lds_dyn;          // [N][TK]
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kx
   const int col = t % TK;
   const int kx = blockIdx.x * TK + col;
   const bool live = kx < kxn;
-  double2* base = data + (long long)blockIdx.y * N * kxn + kx;
+  double2* base = data + (long long)blockIdx.y * N * kxs + kx;  // kxs = row stride (>= kxn; a multiple of 8 keeps tiles line-aligned)
   // packed address of (row r, this kx, this plane)
   long long pbase = 0, prow = 0, pq = 0;
   if (PACKED) {
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kx
   constexpr int RPT = 256 / TK;
   for (int r = t / TK; r < N; r += RPT) {
     double2 v = make_double2(0.0, 0.0);
-    if (live) v = (PACKED && INVERSE) ? pm.packed[paddr(r)] : base[(long long)r * kxn];
+    if (live) v = (PACKED && INVERSE) ? pm.packed[paddr(r)] : base[(long long)r * kxs];
     buf[r * TK + col] = v;
   }
   __syncthreads();
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kx
       if (PACKED && !INVERSE)
         pm.packed[paddr(r)] = buf[r * TK + col];
       else
-        base[(long long)r * kxn] = buf[r * TK + col];
+        base[(long long)r * kxs] = buf[r * TK + col];
     }
 }
 
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kx
 // ------------------------------------------------------------------------------------------------------------
 template <int LOGN, int NP, int SRC>
 __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restrict__ src, double2* __restrict__ out, int n1,
-                                              const double2* __restrict__ tw_g) {
+                                              const double2* __restrict__ tw_g, int kxs) {
   constexpr int N = 1 << LOGN;
   constexpr int KXN = N / 2 + 1;
   extern __shared__ double2 lds_dyn[];
@@ -235,9 +235,9 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
     const double2 zm = buf[p * N + pos_of_freq<LOGN>((N - s) & (N - 1))];
     const double2 a = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
     const double2 b = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
-    const long long o = s + (long long)KXN * (j + (long long)n1 * kz);
+    const long long o = s + (long long)kxs * (j + (long long)n1 * kz);
     out[o] = a;
-    out[o + KXN] = b;  // row j + 1 (n1 is even)
+    out[o + kxs] = b;  // row j + 1 (n1 is even)
   }
 }
 
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
 // ------------------------------------------------------------------------------------------------------------
 template <int LOGN, int NP>
 __global__ __launch_bounds__(256) void k_xinv(const double2* __restrict__ in, double* __restrict__ pI, int n1,
-                                              const double2* __restrict__ tw_g) {
+                                              const double2* __restrict__ tw_g, int kxs) {
   constexpr int N = 1 << LOGN;
   constexpr int KXN = N / 2 + 1;
   extern __shared__ double2 lds_dyn[];
@@ -261,9 +261,9 @@ __global__ __launch_bounds__(256) void k_xinv(const double2* __restrict__ in, do
     const int j = j0 + 2 * p;
     double2 a = make_double2(0.0, 0.0), b = a;
     if (j < n1) {
-      const long long o = s + (long long)KXN * (j + (long long)n1 * kz);
+      const long long o = s + (long long)kxs * (j + (long long)n1 * kz);
       a = in[o];
-      b = in[o + KXN];
+      b = in[o + kxs];
     }
     if (s == 0 || s == N / 2) {  // C2R semantics: DC and Nyquist bins are real
       a.y = 0.0;
@@ -289,7 +289,7 @@ int set_lds(K kernel, size_t lds) {
 }
 
 template <int LOGN>
-int launch_y(double2* data, int kxn, int nplanes, const double2* tw, bool inverse, const PackMap* pm, hipStream_t s) {
+int launch_y(double2* data, int kxn, int kxs, int nplanes, const double2* tw, bool inverse, const PackMap* pm, hipStream_t s) {
   constexpr int N = 1 << LOGN;
   constexpr int TK = N <= 256 ? 16 : (N == 512 ? 8 : 4);  // 256-B segments per row where LDS allows (<= 80 KB tiles)
   constexpr size_t lds = ((size_t)N * TK + N) * sizeof(double2);
@@ -299,7 +299,7 @@ int launch_y(double2* data, int kxn, int nplanes, const double2* tw, bool invers
   do {                                                                                                          \
     int rc = set_lds(&k_yfft<LOGN, TK, INV, PK>, lds);                                                          \
     if (rc) return rc;                                                                                          \
-    hipLaunchKernelGGL((k_yfft<LOGN, TK, INV, PK>), grid, dim3(256), lds, s, data, kxn, tw, pm ? *pm : none);   \
+    hipLaunchKernelGGL((k_yfft<LOGN, TK, INV, PK>), grid, dim3(256), lds, s, data, kxn, kxs, tw, pm ? *pm : none);   \
   } while (0)
   if (pm) {
     if (inverse)
@@ -318,28 +318,28 @@ int launch_y(double2* data, int kxn, int nplanes, const double2* tw, bool invers
 }
 
 template <int LOGN>
-int launch_xfwd(const GridDev& g, const double* src, int from_u, double2* out, int n1, int n2, const double2* tw, hipStream_t s) {
+int launch_xfwd(const GridDev& g, const double* src, int from_u, double2* out, int n1, int n2, const double2* tw, int kxs, hipStream_t s) {
   constexpr int N = 1 << LOGN;
   constexpr int NP = N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N);
   constexpr size_t lds = ((size_t)NP * N + N) * sizeof(double2);
   dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
   if (from_u == 2)
-    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 2>), grid, dim3(256), lds, s, g, src, out, n1, tw);
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 2>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs);
   else if (from_u)
-    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 1>), grid, dim3(256), lds, s, g, src, out, n1, tw);
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 1>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs);
   else
-    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 0>), grid, dim3(256), lds, s, g, src, out, n1, tw);
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 0>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
 
 template <int LOGN>
-int launch_xinv(const double2* in, double* pI, int n1, int n2, const double2* tw, hipStream_t s) {
+int launch_xinv(const double2* in, double* pI, int n1, int n2, const double2* tw, int kxs, hipStream_t s) {
   constexpr int N = 1 << LOGN;
   constexpr int NP = N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N);
   constexpr size_t lds = ((size_t)NP * N + N) * sizeof(double2);
   dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
-  hipLaunchKernelGGL((k_xinv<LOGN, NP>), grid, dim3(256), lds, s, in, pI, n1, tw);
+  hipLaunchKernelGGL((k_xinv<LOGN, NP>), grid, dim3(256), lds, s, in, pI, n1, tw, kxs);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -387,28 +387,31 @@ void ins_ownfft_permute_symbol(int n, const double* ay, double* out) {
 }
 
 int ins_k_ownfft_xfwd(const ins_grid* G, const double* src, int from_u, double* phat, int n0, int n1, int n2, const double* tw,
-                      hipStream_t s) {
+                      hipStream_t s, int kxs) {
+  if (kxs <= 0) kxs = n0 / 2 + 1;
   static const GridDev no_grid{};  // SRC = 0 never touches the grid
   const GridDev& g = G ? G->g : no_grid;
   double2* out = reinterpret_cast<double2*>(phat);
   const double2* w = reinterpret_cast<const double2*>(tw);
-#define CALL(LG) launch_xfwd<LG>(g, src, from_u, out, n1, n2, w, s)
+#define CALL(LG) launch_xfwd<LG>(g, src, from_u, out, n1, n2, w, kxs, s)
   INS_POW2_SWITCH(n0, CALL)
 #undef CALL
 }
 
-int ins_k_ownfft_xinv(const double* phat, double* pI, int n0, int n1, int n2, const double* tw, hipStream_t s) {
+int ins_k_ownfft_xinv(const double* phat, double* pI, int n0, int n1, int n2, const double* tw, hipStream_t s, int kxs) {
+  if (kxs <= 0) kxs = n0 / 2 + 1;
   const double2* in = reinterpret_cast<const double2*>(phat);
   const double2* w = reinterpret_cast<const double2*>(tw);
-#define CALL(LG) launch_xinv<LG>(in, pI, n1, n2, w, s)
+#define CALL(LG) launch_xinv<LG>(in, pI, n1, n2, w, kxs, s)
   INS_POW2_SWITCH(n0, CALL)
 #undef CALL
 }
 
-int ins_k_ownfft_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s) {
+int ins_k_ownfft_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s, int kxs) {
+  if (kxs <= 0) kxs = kxn;
   double2* d = reinterpret_cast<double2*>(phat);
   const double2* w = reinterpret_cast<const double2*>(tw);
-#define CALL(LG) launch_y<LG>(d, kxn, n2, w, inverse, nullptr, s)
+#define CALL(LG) launch_y<LG>(d, kxn, kxs, n2, w, inverse, nullptr, s)
   INS_POW2_SWITCH(n1, CALL)
 #undef CALL
 }
@@ -419,7 +422,7 @@ int ins_k_ownfft_y_packed(double* phat, double* packed, int kxn, int n1, int nzl
   double2* d = reinterpret_cast<double2*>(phat);
   const double2* w = reinterpret_cast<const double2*>(tw);
   PackMap pm{reinterpret_cast<double2*>(packed), nyl, nzl, cw};
-#define CALL(LG) launch_y<LG>(d, kxn, nzl, w, inverse, &pm, s)
+#define CALL(LG) launch_y<LG>(d, kxn, kxn, nzl, w, inverse, &pm, s)
   INS_POW2_SWITCH(n1, CALL)
 #undef CALL
 }

@@ -24,8 +24,13 @@
 
 namespace {
 
+// The constant metric record of one direction.  The uniform half weights ¼ = ½·½ of the convective flux are folded into the
+// constants (4× the diffusion coefficients, ¼× the width reciprocals): power-of-two scalings, so every result is bitwise
+// what the unscaled expression gives, and twelve multiplications per cell disappear.
 struct Dir {
-  double vs, vo, rs, ro;  // ν/Δ (α == β), ν/Δu (α != β), 1/Δu, 1/Δ  — the constant metric record of one direction
+  double vs, vo;  // 4ν/Δ (α == β), 4ν/Δu (α != β)
+  double rs, ro;  // ¼/Δu, ¼/Δ
+  double gs;      // 1/Δu (pressure gradient, CORR)
 };
 
 struct FluxArgs {
@@ -70,10 +75,9 @@ __device__ __forceinline__ void stb(rsrc_t r, unsigned voff, unsigned soff, doub
   __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
 
-// Face flux with the uniform half weights ¼: ν(up - uc)/Δb - ½(uc + up)·½(ub0 + ub1)
-__device__ __forceinline__ double flux(double uc, double up, double ub0, double ub1, double vd) {
-  const double uba = 0.25 * (ub0 + ub1);
-  return (up - uc) * vd - (uc + up) * uba;
+// 4 × face flux:  4ν(up - uc)/Δb - (uc + up)(ub0 + ub1)        [ν(up - uc)/Δb - ½(uc + up)·½(ub0 + ub1), times 4]
+__device__ __forceinline__ double flux(double uc, double up, double ub0, double ub1, double vd4) {
+  return (up - uc) * vd4 - (uc + up) * (ub0 + ub1);
 }
 
 __device__ __forceinline__ int wrapi(int q, int n) {  // q in [-n, 2n) -> [0, n)
@@ -90,8 +94,8 @@ struct Plane {
 // 1 = `u` is the previous stage's uncorrected u* (interior only), pI its unpadded pressure, every neighbour through the
 // periodic image; 2 = z-slab: x, y periodic images, z through exchanged ghost planes, pI = [1 | nzl | 2] extended buffer.
 template <int R, int XW, bool FUSE, int CORR, bool SKEL = false>
-__global__ __launch_bounds__(256) void k_flux64(FluxArgs a) {
-  static_assert(R + 3 <= 8, "packed halo rows live in 8-lane groups");
+__global__ __launch_bounds__(256, 2) void k_flux64(FluxArgs a) {
+  static_assert(R + 2 + (CORR ? 1 : 0) <= 8, "packed halo rows live in 8-lane groups");
   int txi, tyi, tzi;
   {
     const int nty_local = (a.nty + 7) >> 3;
@@ -172,13 +176,13 @@ __global__ __launch_bounds__(256) void k_flux64(FluxArgs a) {
 #pragma unroll
     for (int rr = 0; rr < R + 2; ++rr) {
       const double pc = Pc[rr];
-      P.v[0][rr] -= (next_h(pc, rdlane(PHc, 16 + rr)) - pc) * X.rs;
-      P.v[1][rr] -= (Pc[rr + 1] - pc) * Y.rs;
-      P.v[2][rr] -= (Pn[rr] - pc) * Z.rs;
+      P.v[0][rr] -= (next_h(pc, rdlane(PHc, 16 + rr)) - pc) * X.gs;
+      P.v[1][rr] -= (Pc[rr + 1] - pc) * Y.gs;
+      P.v[2][rr] -= (Pn[rr] - pc) * Z.gs;
     }
-    P.h[0] -= (dpp_old<0x108>(PHc, PHc) - PHc) * X.rs;  // row_shl:8 — p of the next column, same row
-    P.h[1] -= (dpp_old<0x101>(PHc, PHc) - PHc) * Y.rs;  // row_shl:1 — p of the next row, same column
-    P.h[2] -= (PHn - PHc) * Z.rs;
+    P.h[0] -= (dpp_old<0x108>(PHc, PHc) - PHc) * X.gs;  // row_shl:8 — p of the next column, same row
+    P.h[1] -= (dpp_old<0x101>(PHc, PHc) - PHc) * Y.gs;  // row_shl:1 — p of the next row, same column
+    P.h[2] -= (PHn - PHc) * Z.gs;
   };
 
   double zprev[3][R];
@@ -234,33 +238,45 @@ __global__ __launch_bounds__(256) void k_flux64(FluxArgs a) {
     }
     };
 
-  auto body = [&](const Plane<R>& C, const Plane<R>& Nx, int k) {
+  // One output plane.  C = plane k, Nx = plane k+1 (both complete, corrected).  As soon as a row of C has been consumed its
+  // registers are re-loaded with the same row of plane `kload` (= k+2, the next plane this buffer has to hold), so the
+  // prefetch of plane k+2 is in flight during the whole of plane k without a third register plane.
+  auto body = [&](Plane<R>& C, const Plane<R>& Nx, int k, int kload) {
+    const double* nb = a.u + (long long)uplane(kload) * sz;
+    const rsrc_t n0r = plane_rsrc(nb, ubytes), n1r = plane_rsrc(nb + a.sc, ubytes), n2r = plane_rsrc(nb + 2 * a.sc, ubytes);
+    const double ch0 = C.h[0], ch1 = C.h[1], ch2 = C.h[2];
     double fyu_o = 0, fyv_o = 0, fyw_o = 0;
 #pragma unroll
     for (int rr = 0; rr <= R; ++rr) {
       const double Uc = C.v[0][rr], Vc = C.v[1][rr], Wc = C.v[2][rr];
       if (SKEL) {  // timing experiment: same loads, stores and epilogue, trivial arithmetic (tools/scan_flux64.sh)
         if (rr >= 1) {
-          const double fu = Uc + C.v[0][rr - 1] + C.v[0][rr + 1] + Nx.v[0][rr] + zprev[0][rr - 1] + C.h[0];
-          const double fv = Vc + C.v[1][rr - 1] + C.v[1][rr + 1] + Nx.v[1][rr] + zprev[1][rr - 1] + C.h[1];
-          const double fw = Wc + C.v[2][rr - 1] + C.v[2][rr + 1] + Nx.v[2][rr] + zprev[2][rr - 1] + C.h[2];
+          const double fu = Uc + fyu_o + C.v[0][rr + 1] + Nx.v[0][rr] + zprev[0][rr - 1] + ch0;
+          const double fv = Vc + fyv_o + C.v[1][rr + 1] + Nx.v[1][rr] + zprev[1][rr - 1] + ch1;
+          const double fw = Wc + fyw_o + C.v[2][rr + 1] + Nx.v[2][rr] + zprev[2][rr - 1] + ch2;
           emit(rr, k, fu, fv, fw, Uc, Vc, Wc);
         }
+        fyu_o = Uc;
+        fyv_o = Vc;
+        fyw_o = Wc;
+        C.v[0][rr] = ldb(n0r, ucol, urow[rr]);
+        C.v[1][rr] = ldb(n1r, ucol, urow[rr]);
+        C.v[2][rr] = ldb(n2r, ucol, urow[rr]);
         continue;
       }
-      const double Vn = next_h(Vc, rdlane(C.h[1], 16 + rr));
+      const double Vn = next_h(Vc, rdlane(ch1, 16 + rr));
       // y-fluxes through the face between rows rr and rr+1
       const double fyu = flux(Uc, C.v[0][rr + 1], Vc, Vn, Y.vo);
       const double fyv = flux(Vc, C.v[1][rr + 1], Vc, C.v[1][rr + 1], Y.vs);
       const double fyw = flux(Wc, C.v[2][rr + 1], Vc, Nx.v[1][rr], Y.vo);
       if (rr >= 1) {
-        const double Un = next_h(Uc, rdlane(C.h[0], 16 + rr)), Wn = next_h(Wc, rdlane(C.h[2], 16 + rr));
+        const double Un = next_h(Uc, rdlane(ch0, 16 + rr)), Wn = next_h(Wc, rdlane(ch2, 16 + rr));
         const double fxu = flux(Uc, Un, Uc, Un, X.vs);
         const double fxv = flux(Vc, Vn, Uc, C.v[0][rr + 1], X.vo);
         const double fxw = flux(Wc, Wn, Uc, Nx.v[0][rr], X.vo);
         // left-face fluxes of lane 0 from the halo column x0-1 (all other lanes take their left neighbour's right face)
-        const double sU = rdlane(C.h[0], rr), sV = rdlane(C.h[1], rr), sW = rdlane(C.h[2], rr);
-        const double sUu = rdlane(C.h[0], rr + 1), sUn = rdlane(Nx.h[0], rr);
+        const double sU = rdlane(ch0, rr), sV = rdlane(ch1, rr), sW = rdlane(ch2, rr);
+        const double sUu = rdlane(ch0, rr + 1), sUn = rdlane(Nx.h[0], rr);
         const double lxu = flux(sU, Uc, sU, Uc, X.vs);
         const double lxv = flux(sV, Vc, sU, sUu, X.vo);
         const double lxw = flux(sW, Wc, sU, sUn, X.vo);
@@ -284,26 +300,31 @@ __global__ __launch_bounds__(256) void k_flux64(FluxArgs a) {
       fyu_o = fyu;
       fyv_o = fyv;
       fyw_o = fyw;
+      // row rr of plane k is dead: its registers receive plane `kload`
+      C.v[0][rr] = ldb(n0r, ucol, urow[rr]);
+      C.v[1][rr] = ldb(n1r, ucol, urow[rr]);
+      C.v[2][rr] = ldb(n2r, ucol, urow[rr]);
     }
+    C.v[0][R + 1] = ldb(n0r, ucol, urow[R + 1]);
+    C.v[1][R + 1] = ldb(n1r, ucol, urow[R + 1]);
+    C.v[2][R + 1] = ldb(n2r, ucol, urow[R + 1]);
+    C.h[0] = ldb(n0r, uhoff, 0);
+    C.h[1] = ldb(n1r, uhoff, 0);
+    C.h[2] = ldb(n2r, uhoff, 0);
   };
 
-  Plane<R> A, B, Cc;
+  // Two register planes.  Loads past the chunk re-read plane k1 / p(k1+1) (cache hits) instead of branching.
+  Plane<R> P0, P1;
   if (!CORR) {
-    load_plane(A, k0 - 1);
-    load_plane(B, k0);
-    load_plane(Cc, min(k0 + 1, N2 - 1));
-    zflux0(A, B);
+    load_plane(P0, k0 - 1);
+    load_plane(P1, k0);
+    zflux0(P0, P1);
+    load_plane(P0, min(k0 + 1, k1));
     int k = k0;
-    // 3-buffer rotation (static register indices): compute plane k from (cur, next) while plane k+2 is in flight
     while (true) {
-      load_plane(A, min(k + 2, N2 - 1));
-      body(B, Cc, k);
+      body(P1, P0, k, min(k + 2, k1));
       if (++k >= k1) break;
-      load_plane(B, min(k + 2, N2 - 1));
-      body(Cc, A, k);
-      if (++k >= k1) break;
-      load_plane(Cc, min(k + 2, N2 - 1));
-      body(A, B, k);
+      body(P0, P1, k, min(k + 2, k1));
       if (++k >= k1) break;
     }
   } else {
@@ -311,46 +332,23 @@ __global__ __launch_bounds__(256) void k_flux64(FluxArgs a) {
     double Pa[R + 3], Pb[R + 3], Ha, Hb;
     load_p(Pa, Ha, k0 - 1);
     load_p(Pb, Hb, k0);
-    load_plane(A, k0 - 1);
-    load_plane(B, k0);
-    correct(A, Pa, Ha, Pb, Hb);
+    load_plane(P0, k0 - 1);
+    load_plane(P1, k0);
+    correct(P0, Pa, Ha, Pb, Hb);
     load_p(Pa, Ha, k0 + 1);
-    correct(B, Pb, Hb, Pa, Ha);
-    load_plane(Cc, k0 + 1);
-    load_p(Pb, Hb, k0 + 2);
-    zflux0(A, B);
+    correct(P1, Pb, Hb, Pa, Ha);
+    zflux0(P0, P1);
+    load_plane(P0, min(k0 + 1, k1));
+    load_p(Pb, Hb, min(k0 + 2, k1 + 1));
     int k = k0;
     while (true) {
-      correct(Cc, Pa, Ha, Pb, Hb);  // plane k+1 with p(k+1), p(k+2)
-      load_plane(A, k + 2);
-      load_p(Pa, Ha, k + 3);
-      body(B, Cc, k);
+      correct(P0, Pa, Ha, Pb, Hb);  // plane k+1 with p(k+1), p(k+2)
+      load_p(Pa, Ha, min(k + 3, k1 + 1));
+      body(P1, P0, k, min(k + 2, k1));
       if (++k >= k1) break;
-      correct(A, Pb, Hb, Pa, Ha);
-      load_plane(B, k + 2);
-      load_p(Pb, Hb, k + 3);
-      body(Cc, A, k);
-      if (++k >= k1) break;
-      correct(B, Pa, Ha, Pb, Hb);
-      load_plane(Cc, k + 2);
-      load_p(Pa, Ha, k + 3);
-      body(A, B, k);
-      if (++k >= k1) break;
-      // second half of the period-6 rotation (the two p buffers have swapped roles)
-      correct(Cc, Pb, Hb, Pa, Ha);
-      load_plane(A, k + 2);
-      load_p(Pb, Hb, k + 3);
-      body(B, Cc, k);
-      if (++k >= k1) break;
-      correct(A, Pa, Ha, Pb, Hb);
-      load_plane(B, k + 2);
-      load_p(Pa, Ha, k + 3);
-      body(Cc, A, k);
-      if (++k >= k1) break;
-      correct(B, Pb, Hb, Pa, Ha);
-      load_plane(Cc, k + 2);
-      load_p(Pb, Hb, k + 3);
-      body(A, B, k);
+      correct(P1, Pb, Hb, Pa, Ha);
+      load_p(Pb, Hb, min(k + 3, k1 + 1));
+      body(P0, P1, k, min(k + 2, k1));
       if (++k >= k1) break;
     }
   }
@@ -360,21 +358,23 @@ int env_int(const char* name) {
   const char* v = getenv(name);
   return v ? atoi(v) : 0;
 }
-const int g_disable = env_int("INS_DISABLE_FLUX64");
-const int g_rows = env_int("INS_FLUX64_ROWS");
-const int g_rows_corr = env_int("INS_FLUX64_ROWS_CORR");
-const int g_zchunk = env_int("INS_FLUX64_ZC");
-const int g_xw = env_int("INS_FLUX64_XW");
-const int g_skel = env_int("INS_FLUX64_SKEL");  // timing experiment only: wrong results by design
+int g_disable = env_int("INS_DISABLE_FLUX64");
+int g_rows = env_int("INS_FLUX64_ROWS");
+int g_rows_corr = env_int("INS_FLUX64_ROWS_CORR");
+int g_zchunk = env_int("INS_FLUX64_ZC");
+int g_xw = env_int("INS_FLUX64_XW");
+int g_lds = env_int("INS_FLUX64_LDS");    // experiment: dynamic LDS bytes per workgroup (caps workgroups per CU)
+int g_skel = env_int("INS_FLUX64_SKEL");  // timing experiment only: wrong results by design
 
 Dir make_dir(const ins_grid* G, int d, double visc) {
   // the constant record ins_fast3d_flux.hip's UNIFORM kernels read (index 1): same fp64 operations, on the host
   const double dxu = G->desc.dxu[d][1], dx1 = G->desc.dx[d][1], dx2 = G->desc.dx[d][2];
   Dir r;
-  r.vs = visc * (dx2 > 2 * INS_EPS ? 1.0 / dx2 : 0.0);
-  r.vo = visc * (dxu > 2 * INS_EPS ? 1.0 / dxu : 0.0);
-  r.rs = 1.0 / dxu;
-  r.ro = 1.0 / dx1;
+  r.vs = 4.0 * (visc * (dx2 > 2 * INS_EPS ? 1.0 / dx2 : 0.0));
+  r.vo = 4.0 * (visc * (dxu > 2 * INS_EPS ? 1.0 / dxu : 0.0));
+  r.gs = 1.0 / dxu;
+  r.rs = 0.25 * r.gs;
+  r.ro = 0.25 * (1.0 / dx1);
   return r;
 }
 
@@ -386,17 +386,17 @@ int launch(const ins_grid* G, FluxArgs& a, int corr_mode, hipStream_t s) {
   a.ntz = cdiv(g.N[2] - 2, a.zc);
   const unsigned nb = (unsigned)(8LL * a.ntx * ((a.nty + 7) / 8) * a.ntz);
   const dim3 block(64, 4, 1);
-  if (g_skel && corr_mode == 0 && R == 4)
-    hipLaunchKernelGGL((k_flux64<4, XW, FUSE, 0, true>), dim3(nb), block, 0, s, a);
+  if (g_skel && corr_mode == 0)
+    hipLaunchKernelGGL((k_flux64<R, XW, FUSE, 0, true>), dim3(nb), block, (size_t)g_lds, s, a);
   else if (corr_mode == 0)
-    hipLaunchKernelGGL((k_flux64<R, XW, FUSE, 0>), dim3(nb), block, 0, s, a);
-  else if constexpr (FUSE) {
+    hipLaunchKernelGGL((k_flux64<R, XW, FUSE, 0>), dim3(nb), block, (size_t)g_lds, s, a);
+  else if constexpr (FUSE && R <= 5) {
     if (corr_mode == 1)
-      hipLaunchKernelGGL((k_flux64<R, XW, true, 1>), dim3(nb), block, 0, s, a);
+      hipLaunchKernelGGL((k_flux64<R, XW, true, 1>), dim3(nb), block, (size_t)g_lds, s, a);
     else
-      hipLaunchKernelGGL((k_flux64<R, XW, true, 2>), dim3(nb), block, 0, s, a);
+      hipLaunchKernelGGL((k_flux64<R, XW, true, 2>), dim3(nb), block, (size_t)g_lds, s, a);
   } else {
-    ins_set_error("in-kernel pressure correction needs the fused epilogue");
+    ins_set_error("in-kernel pressure correction needs the fused epilogue and <= 5 rows per thread");
     return INS_ERR_UNSUPPORTED;
   }
   INS_LAUNCH_CHECK();
@@ -404,6 +404,18 @@ int launch(const ins_grid* G, FluxArgs& a, int corr_mode, hipStream_t s) {
 }
 
 }  // namespace
+
+// Tuning knobs for experiments in one process on one allocation (not part of the public ABI); -1 keeps a value.
+extern "C" void ins_tune_flux64(int disable, int rows, int rows_corr, int zchunk, int xw, int skel, int burst_unused, int lds) {
+  if (disable >= 0) g_disable = disable;
+  if (rows >= 0) g_rows = rows;
+  if (rows_corr >= 0) g_rows_corr = rows_corr;
+  if (zchunk >= 0) g_zchunk = zchunk;
+  if (xw >= 0) g_xw = xw;
+  if (skel >= 0) g_skel = skel;
+  (void)burst_unused;
+  if (lds >= 0) g_lds = lds;
+}
 
 // 3-D, every interior volume a DOF (all-periodic box or periodic slab), bitwise-constant metric records, room for the
 // periodic wrap of a full wavefront window.
@@ -424,7 +436,10 @@ int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, con
   a.N0 = g.N[0];
   a.N1 = g.N[1];
   a.N2 = g.N[2];
-  a.zc = g_zchunk ? g_zchunk : (g.N[2] >= 384 ? 8 : 4);
+  // z-chunk: every chunk re-reads two planes from HBM ((zc+2)/zc read amplification, measured with FETCH_SIZE), so chunks are
+  // as long as the tile count allows; 32 keeps >= 1024 workgroups at 256^3 (profiles/r01f_k1_traffic.txt)
+  const int n2 = g.N[2] - 2;
+  a.zc = g_zchunk ? g_zchunk : (n2 >= 128 ? 32 : (n2 >= 64 ? 16 : (n2 >= 32 ? 8 : 4)));
   a.X = make_dir(G, 0, visc);
   a.Y = make_dir(G, 1, visc);
   a.Z = make_dir(G, 2, visc);
@@ -432,7 +447,7 @@ int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, con
   const int waves_x = cdiv(g.N[0] - 2, 64);
   const int xw = g_xw ? g_xw : (waves_x >= 4 ? 4 : (waves_x >= 2 ? 2 : 1));
   int rows = corr_mode ? (g_rows_corr ? g_rows_corr : 2) : (g_rows ? g_rows : 4);
-  rows = std::min(std::max(rows, 2), 4);
+  rows = std::min(std::max(rows, 2), corr_mode ? 5 : 6);
 #define INS_F64_CASE(RR, FUSE)                                            \
   if (rows == RR) {                                                       \
     if (xw == 4) return launch<RR, 4, FUSE>(G, a, corr_mode, s);          \
@@ -443,10 +458,14 @@ int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, con
     INS_F64_CASE(2, true)
     INS_F64_CASE(3, true)
     INS_F64_CASE(4, true)
+    INS_F64_CASE(5, true)
+    INS_F64_CASE(6, true)
   } else {
     INS_F64_CASE(2, false)
     INS_F64_CASE(3, false)
     INS_F64_CASE(4, false)
+    INS_F64_CASE(5, false)
+    INS_F64_CASE(6, false)
   }
 #undef INS_F64_CASE
   return INS_ERR_INVALID;

@@ -118,6 +118,7 @@ struct ins_poisson {
   hipStream_t plan_stream = nullptr;
   bool zfused = false;      // 3-D: batched 2-D (x,y) plans + the fused z kernel (ins_zsolve.hip)
   bool ownfft = false;      // 3-D power-of-two box: all five passes are own LDS kernels (ins_fft.hip), no rocFFT
+  int kxs = 0;              // ownfft: row stride of phat (kmax[0] rounded up to 8 complex = 128 B)
   double* tw = nullptr;     // z twiddles
   double* tw_x = nullptr;   // x / y twiddles (ownfft)
   double* tw_y = nullptr;
@@ -189,14 +190,16 @@ void ins_fft_solver_released();
 bool ins_zsolve_supported(int nz);
 bool ins_ownfft_supported(const int np[3]);
 void ins_ownfft_permute_symbol(int n, const double* ay, double* out);
-int ins_k_ownfft_xfwd(const ins_grid* G, const double* src, int from_u, double* phat, int n0, int n1, int n2, const double* tw, hipStream_t s);
-int ins_k_ownfft_xinv(const double* phat, double* pI, int n0, int n1, int n2, const double* tw, hipStream_t s);
-int ins_k_ownfft_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s);
+// kxs: row stride of phat in complex elements (0 = dense, n0/2+1); a multiple of 8 keeps the y/z tiles 128-B aligned
+int ins_k_ownfft_xfwd(const ins_grid* G, const double* src, int from_u, double* phat, int n0, int n1, int n2, const double* tw, hipStream_t s,
+                      int kxs = 0);
+int ins_k_ownfft_xinv(const double* phat, double* pI, int n0, int n1, int n2, const double* tw, hipStream_t s, int kxs = 0);
+int ins_k_ownfft_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s, int kxs = 0);
 int ins_k_ownfft_y_packed(double* phat, double* packed, int kxn, int n1, int nzl, int nyl, int cw, const double* tw, bool inverse,
                           hipStream_t s);
 int ins_zsolve_twiddles(int nz, double** out);
 int ins_k_zsolve(double* data, int nz, long long nl, const double* ax, int kxn, const double* ay, const double* az, const double* tw,
-                 double inv_n, bool zero_mean, hipStream_t s);
+                 double inv_n, bool zero_mean, hipStream_t s, int kxs = 0);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }

@@ -332,11 +332,16 @@ extern "C" int ins_poisson_spectral_create(const ins_grid_t* G, ins_poisson_t** 
     ins_poisson_destroy(ps);
     return code;
   };
-  if (hipMalloc(&ps->pI, nreal * sizeof(double)) != hipSuccess || hipMalloc(&ps->phat, ncplx * sizeof(hipfftDoubleComplex)) != hipSuccess) {
+  ps->ownfft = D == 3 && ins_ownfft_supported(ps->np);
+  if (ps->ownfft) {  // rows of phat padded to whole 128-B lines: the y / z tiles then never straddle a line (profiles/r01f_pmc_traffic.json)
+    ps->kxs = getenv("INS_PHAT_DENSE") ? ps->kmax[0] : ((ps->kmax[0] + 7) & ~7);
+    ncplx = (long long)ps->kxs * ps->kmax[1] * ps->kmax[2];
+  }
+  if (hipMalloc(&ps->pI, nreal * sizeof(double)) != hipSuccess || hipMalloc(&ps->phat, ncplx * sizeof(hipfftDoubleComplex)) != hipSuccess ||
+      hipMemset(ps->phat, 0, ncplx * sizeof(hipfftDoubleComplex)) != hipSuccess) {
     ins_set_error("hipMalloc(pI/phat) failed for %lld cells", nreal);
     return fail(INS_ERR_HIP);
   }
-  ps->ownfft = D == 3 && ins_ownfft_supported(ps->np);
   // ahat[α][k] = 4 Ω sinpi(k/Np[α])² / Δx[α]²                                      pressure.jl:305-311
   for (int a = 0; a < D; ++a) {
     std::vector<double> ah(ps->kmax[a]);
@@ -378,15 +383,15 @@ extern "C" int ins_poisson_spectral_create(const ins_grid_t* G, ins_poisson_t** 
 
 // pI -> pI through the five own passes; from_u != nullptr: the right-hand side Ω·div(u) is formed inside pass 1
 static int ownfft_transform(ins_poisson* ps, const double* from_u, hipStream_t s) {
-  const int n0 = ps->np[0], n1 = ps->np[1], n2 = ps->np[2], kxn = ps->kmax[0];
+  const int n0 = ps->np[0], n1 = ps->np[1], n2 = ps->np[2], kxn = ps->kmax[0], kxs = ps->kxs;
   double* ph = reinterpret_cast<double*>(ps->phat);
   int rc;
-  if ((rc = ins_k_ownfft_xfwd(ps->grid, from_u ? from_u : ps->pI, from_u != nullptr, ph, n0, n1, n2, ps->tw_x, s))) return rc;
-  if ((rc = ins_k_ownfft_y(ph, kxn, n1, n2, ps->tw_y, false, s))) return rc;
+  if ((rc = ins_k_ownfft_xfwd(ps->grid, from_u ? from_u : ps->pI, from_u != nullptr, ph, n0, n1, n2, ps->tw_x, s, kxs))) return rc;
+  if ((rc = ins_k_ownfft_y(ph, kxn, n1, n2, ps->tw_y, false, s, kxs))) return rc;
   const double inv_n = 1.0 / ((double)n0 * n1 * n2);
-  if ((rc = ins_k_zsolve(ph, n2, (long long)kxn * n1, ps->ahat[0], kxn, ps->ahat[1], ps->ahat[2], ps->tw, inv_n, true, s))) return rc;
-  if ((rc = ins_k_ownfft_y(ph, kxn, n1, n2, ps->tw_y, true, s))) return rc;
-  return ins_k_ownfft_xinv(ph, ps->pI, n0, n1, n2, ps->tw_x, s);
+  if ((rc = ins_k_zsolve(ph, n2, (long long)kxs * n1, ps->ahat[0], kxn, ps->ahat[1], ps->ahat[2], ps->tw, inv_n, true, s, kxs))) return rc;
+  if ((rc = ins_k_ownfft_y(ph, kxn, n1, n2, ps->tw_y, true, s, kxs))) return rc;
+  return ins_k_ownfft_xinv(ph, ps->pI, n0, n1, n2, ps->tw_x, s, kxs);
 }
 
 static int spectral_transform(ins_poisson* ps, hipStream_t s) {

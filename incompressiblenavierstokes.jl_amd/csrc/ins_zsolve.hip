@@ -52,7 +52,7 @@ __device__ __forceinline__ int freq_of_pos(int p) {
 template <int LOGN, int TK>
 __global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long long nl, const double* __restrict__ ax, int kxn,
                                                 const double* __restrict__ ay, const double* __restrict__ az,
-                                                const double2* __restrict__ tw_g, double inv_n, int zero_mean) {
+                                                const double2* __restrict__ tw_g, double inv_n, int zero_mean, int kxs) {
   constexpr int N = 1 << LOGN;
   constexpr bool ODD = LOGN & 1;
   extern __shared__ double2 lds_dyn[];  // dynamic: tiles above 64 KB need the opt-in limit
@@ -62,13 +62,15 @@ __global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long
   const long long l0 = (long long)blockIdx.x * TK;
   const int col = t % TK;
   const long long line = l0 + col;
-  const bool live = line < nl;
+  // lines are (ky, kx) pairs stored with row stride kxs >= kxn; the padding columns hold nothing
+  const int lkx = (int)(line % kxs);
+  const bool live = line < nl && lkx < kxn;
   for (int m = t; m < N; m += 256) tw[m] = tw_g[m];
   constexpr int RPT = 256 / TK;  // z-rows covered by one sweep of the workgroup
   for (int r = t / TK; r < N; r += RPT) buf[r * TK + col] = live ? data[(long long)r * nl + line] : make_double2(0.0, 0.0);
   // 1/((âx + ây) + âz): the (x,y) part of the symbol is fixed per line
   double axy = 1.0;
-  if (live) axy = ax[(int)(line % kxn)] + ay[(int)(line / kxn)];
+  if (live) axy = ax[lkx] + ay[(int)(line / kxs)];
   const bool mean_line = zero_mean && line == 0;
   __syncthreads();
 
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long
 
 template <int LOGN, int TK>
 int launch_zsolve(double2* data, long long nl, const double* ax, int kxn, const double* ay, const double* az, const double2* tw,
-                  double inv_n, bool zero_mean, hipStream_t s) {
+                  double inv_n, bool zero_mean, hipStream_t s, int kxs) {
   const unsigned nb = (unsigned)((nl + TK - 1) / TK);
   constexpr size_t lds = ((size_t)(1 << LOGN) * TK + (1 << LOGN)) * sizeof(double2);
   static bool attr_set = false;
@@ -166,7 +168,7 @@ int launch_zsolve(double2* data, long long nl, const double* ax, int kxn, const 
     INS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_zsolve<LOGN, TK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_zsolve<LOGN, TK>), dim3(nb), dim3(256), lds, s, data, nl, ax, kxn, ay, az, tw, inv_n, zero_mean ? 1 : 0);
+  hipLaunchKernelGGL((k_zsolve<LOGN, TK>), dim3(nb), dim3(256), lds, s, data, nl, ax, kxn, ay, az, tw, inv_n, zero_mean ? 1 : 0, kxs);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -207,19 +209,20 @@ int ins_zsolve_twiddles(int nz, double** out) {
   return INS_OK;
 }
 
-// data[kz][line] (line = ky*kxn + kx, nl lines), in place.
+// data[kz][line] (line = ky*kxs + kx, nl = kxs * nky lines of which kx < kxn are live), in place.  kxs <= 0: kxs = kxn.
 int ins_k_zsolve(double* data, int nz, long long nl, const double* ax, int kxn, const double* ay, const double* az, const double* tw,
-                 double inv_n, bool zero_mean, hipStream_t s) {
+                 double inv_n, bool zero_mean, hipStream_t s, int kxs) {
+  if (kxs <= 0) kxs = kxn;
   double2* d = reinterpret_cast<double2*>(data);
   const double2* w = reinterpret_cast<const double2*>(tw);
   switch (nz) {
-    case 16: return launch_zsolve<4, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s);
-    case 32: return launch_zsolve<5, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s);
-    case 64: return launch_zsolve<6, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s);
-    case 128: return launch_zsolve<7, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s);
-    case 256: return launch_zsolve<8, 8>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s);
-    case 512: return launch_zsolve<9, 8>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s);    // 72 KB tile
-    case 1024: return launch_zsolve<10, 4>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s);  // 80 KB tile
+    case 16: return launch_zsolve<4, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+    case 32: return launch_zsolve<5, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+    case 64: return launch_zsolve<6, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+    case 128: return launch_zsolve<7, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+    case 256: return launch_zsolve<8, 8>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+    case 512: return launch_zsolve<9, 8>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);    // 72 KB tile
+    case 1024: return launch_zsolve<10, 4>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);  // 80 KB tile
   }
   ins_set_error("ins_k_zsolve: unsupported nz = %d", nz);
   return INS_ERR_UNSUPPORTED;

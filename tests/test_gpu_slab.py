@@ -21,7 +21,7 @@ def rell2(a, b):
     return float(np.sqrt(np.sum((a - b) ** 2)) / np.sqrt(np.sum(b**2)))
 
 
-@pytest.mark.parametrize("n", [(64, 32, 16), (70, 24, 20)])
+@pytest.mark.parametrize("n", [(64, 32, 16), (70, 24, 20), (128, 16, 16)])  # last: 64-wide K1 (ins_flux64.hip), CORR = 2
 def test_one_rank_slab_equals_single_gpu_path(oracle, n):
     _need_gpu()
     import ins_amd as ins
@@ -80,7 +80,7 @@ def _worker(rank, world, port, n, nsteps, out_dir, chunks=1):
 
 
 @pytest.mark.parametrize("world,n,chunks", [(2, (66, 16, 24), 1), (4, (66, 16, 24), 1), (2, (64, 16, 32), 1), (4, (64, 32, 32), 1),
-                                            (2, (64, 16, 32), 4), (2, (66, 16, 32), 3)])
+                                            (2, (64, 16, 32), 4), (2, (66, 16, 32), 3), (2, (128, 16, 32), 4)])
 def test_multi_rank_slab_on_one_gpu_matches_oracle(tmp_path, oracle, world, n, chunks):
     """(66,16,24): rocFFT x/y + rocFFT z; power-of-two boxes: own x/y passes with the digit-reversed ky order split
     across ranks + the fused z kernel."""

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM-side traffic from two rocprofv3 counter passes of the same command (FETCH_SIZE and WRITE_SIZE, collected
+separately as MI355X_MICROARCH.md prescribes; FETCH_SIZE is doubled: gfx950 rule):
+    tools/pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv out.json "<command>" "<grid>"
+Kernels are grouped by a short name derived from the mangled symbol (template arguments kept for the flux kernels)."""
+import csv, json, re, sys, collections
+
+def short(name):
+    m = re.search(r"(k_flux64|k_momentum_flux)I([A-Za-z0-9_]*?)EEv", name)
+    if m:
+        args = re.findall(r"L[ib]([0-9]+)E", m.group(2))
+        if m.group(1) == "k_flux64":  # <R, XW, FUSE, CORR, SKEL>
+            r, xw, fuse, corr = args[:4]
+            return f"k_flux64<R={r},XW={xw},FUSE={fuse},CORR={corr}>"
+        return f"k_momentum_flux<{','.join(args)}>"
+    m = re.search(r"\d+(k_[a-z0-9_]+)", name)
+    return m.group(1) if m else name[:60]
+
+def collect(path, counter):
+    acc = collections.defaultdict(list)
+    for row in csv.DictReader(open(path)):
+        if row["Counter_Name"] == counter:
+            acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+    return acc
+
+fe, wr = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+out = {"command": sys.argv[4], "grid": sys.argv[5], "note": "KB counters; hbm_read_GB = 2 x FETCH_SIZE (gfx950), per launch averages", "per_kernel": {}}
+for k in sorted(set(fe) | set(wr)):
+    f, w = fe.get(k, [0.0]), wr.get(k, [0.0])
+    rd, wt = 2 * sum(f) / len(f) * 1024 / 1e9, sum(w) / len(w) * 1024 / 1e9
+    if rd + wt < 1e-3:
+        continue
+    out["per_kernel"][k] = {"launches": len(f), "hbm_read_GB": rd, "hbm_write_GB": wt, "hbm_total_GB": rd + wt}
+stage = [v for k, v in out["per_kernel"].items() if k.startswith("k_flux64") and "FUSE=1" in k]
+if stage:
+    n = sum(v["launches"] for v in stage)
+    out["per_kernel"]["stage kernel, RK44 step average"] = {"hbm_total_GB": sum(v["hbm_total_GB"] * v["launches"] for v in stage) / n, "launches": n}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+for k, v in out["per_kernel"].items():
+    print(f"{k:50s} {json.dumps(v)}")
