@@ -164,10 +164,17 @@ __global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kx
   };
   for (int m = t; m < N; m += 256) tw[m] = tw_g[m];
   constexpr int RPT = 256 / TK;
-  for (int r = t / TK; r < N; r += RPT) {
-    double2 v = make_double2(0.0, 0.0);
-    if (live) v = (PACKED && INVERSE) ? pm.packed[paddr(r)] : base[(long long)r * kxs];
-    buf[r * TK + col] = v;
+  constexpr int NIT = N / RPT;  // rows per work-item: all its loads are issued before the first LDS write
+  {
+    double2 v[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) {
+      const int r = t / TK + q * RPT;
+      v[q] = make_double2(0.0, 0.0);
+      if (live) v[q] = (PACKED && INVERSE) ? pm.packed[paddr(r)] : base[(long long)r * kxs];
+    }
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) buf[(t / TK + q * RPT) * TK + col] = v[q];
   }
   __syncthreads();
   if (INVERSE)
@@ -175,7 +182,9 @@ __global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kx
   else
     fft_dif<LOGN, TK, TK, 1, false>(buf, tw, t);
   if (live)
-    for (int r = t / TK; r < N; r += RPT) {
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) {
+      const int r = t / TK + q * RPT;
       if (PACKED && !INVERSE)
         pm.packed[paddr(r)] = buf[r * TK + col];
       else
@@ -200,13 +209,18 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
   const int j0 = blockIdx.x * 2 * NP;
   for (int m = t; m < N; m += 256) tw[m] = tw_g[m];
   double* bufd = reinterpret_cast<double*>(buf);
-  for (int idx = t; idx < 2 * NP * N; idx += 256) {
-    const int row = idx / N, i = idx - row * N;
-    const int j = j0 + row;
-    double v = 0.0;
-    if (j < n1) {
+  // every work-item owns NIT (row, column) points; all their loads are issued (clamped rows, no branches) before the first
+  // LDS write, so one round trip to HBM covers the whole tile instead of one per row
+  constexpr int NIT = (2 * NP * N) / 256;
+  {
+    double v[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) {
+      const int idx = t + 256 * q;
+      const int row = idx / N, i = idx - row * N;
+      const int j = min(j0 + row, n1 - 1);
       if (SRC == 0) {
-        v = src[i + (long long)N * (j + (long long)n1 * kz)];
+        v[q] = src[i + (long long)N * (j + (long long)n1 * kz)];
       } else {
         // Ω · div(u*) at interior cell (i, j, kz): periodic wrap instead of ghost reads (k_div_to_pI<3, true>)
         const int I0 = i + 1, I1 = j + 1, I2 = kz + 1;
@@ -219,10 +233,15 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
         d += (src[g.sc + c] - src[g.sc + cy]) * g.rdx[1][I1];
         d += (src[2 * g.sc + c] - src[2 * g.sc + cz]) * g.rdx[2][I2];
         const double om = g.dx[0][I0] * g.dx[1][I1] * g.dx[2][I2];
-        v = d * om;
+        v[q] = d * om;
       }
     }
-    bufd[2 * ((row >> 1) * N + i) + (row & 1)] = v;
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) {
+      const int idx = t + 256 * q;
+      const int row = idx / N, i = idx - row * N;
+      bufd[2 * ((row >> 1) * N + i) + (row & 1)] = (j0 + row < n1) ? v[q] : 0.0;
+    }
   }
   __syncthreads();
   fft_dif<LOGN, NP, 1, N, true>(buf, tw, t);
@@ -256,21 +275,32 @@ __global__ __launch_bounds__(256) void k_xinv(const double2* __restrict__ in, do
   const int kz = blockIdx.y;
   const int j0 = blockIdx.x * 2 * NP;
   for (int m = t; m < N; m += 256) tw[m] = tw_g[m];
-  for (int idx = t; idx < NP * KXN; idx += 256) {
-    const int p = idx / KXN, s = idx - p * KXN;
-    const int j = j0 + 2 * p;
-    double2 a = make_double2(0.0, 0.0), b = a;
-    if (j < n1) {
+  constexpr int NIT = (NP * KXN + 255) / 256;  // all loads first (clamped, branch-free), then the LDS scatter
+  {
+    double2 av[NIT], bv[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) {
+      const int idx = min(t + 256 * q, NP * KXN - 1);
+      const int p = idx / KXN, s = idx - p * KXN;
+      const int j = min(j0 + 2 * p, n1 - 2);
       const long long o = s + (long long)kxs * (j + (long long)n1 * kz);
-      a = in[o];
-      b = in[o + kxs];
+      av[q] = in[o];
+      bv[q] = in[o + kxs];
     }
-    if (s == 0 || s == N / 2) {  // C2R semantics: DC and Nyquist bins are real
-      a.y = 0.0;
-      b.y = 0.0;
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) {
+      const int idx = t + 256 * q;
+      if (idx >= NP * KXN) break;
+      const int p = idx / KXN, s = idx - p * KXN;
+      double2 a = av[q], b = bv[q];
+      if (j0 + 2 * p >= n1) a = b = make_double2(0.0, 0.0);
+      if (s == 0 || s == N / 2) {  // C2R semantics: DC and Nyquist bins are real
+        a.y = 0.0;
+        b.y = 0.0;
+      }
+      buf[p * N + pos_of_freq<LOGN>(s)] = make_double2(a.x - b.y, a.y + b.x);
+      if (s != 0 && s != N / 2) buf[p * N + pos_of_freq<LOGN>(N - s)] = make_double2(a.x + b.y, b.x - a.y);
     }
-    buf[p * N + pos_of_freq<LOGN>(s)] = make_double2(a.x - b.y, a.y + b.x);
-    if (s != 0 && s != N / 2) buf[p * N + pos_of_freq<LOGN>(N - s)] = make_double2(a.x + b.y, b.x - a.y);
   }
   __syncthreads();
   fft_dit<LOGN, NP, 1, N, true>(buf, tw, t);

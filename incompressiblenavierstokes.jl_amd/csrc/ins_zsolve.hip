@@ -67,7 +67,14 @@ __global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long
   const bool live = line < nl && lkx < kxn;
   for (int m = t; m < N; m += 256) tw[m] = tw_g[m];
   constexpr int RPT = 256 / TK;  // z-rows covered by one sweep of the workgroup
-  for (int r = t / TK; r < N; r += RPT) buf[r * TK + col] = live ? data[(long long)r * nl + line] : make_double2(0.0, 0.0);
+  constexpr int NIT = N / RPT;  // all loads of a work-item in flight before the first LDS write
+  {
+    double2 v[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) v[q] = live ? data[(long long)(t / TK + q * RPT) * nl + line] : make_double2(0.0, 0.0);
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) buf[(t / TK + q * RPT) * TK + col] = v[q];
+  }
   // 1/((âx + ây) + âz): the (x,y) part of the symbol is fixed per line
   double axy = 1.0;
   if (live) axy = ax[lkx] + ay[(int)(line / kxs)];
@@ -155,7 +162,8 @@ __global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long
     __syncthreads();
   }
   if (live)
-    for (int r = t / TK; r < N; r += RPT) data[(long long)r * nl + line] = buf[r * TK + col];
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) data[(long long)(t / TK + q * RPT) * nl + line] = buf[(t / TK + q * RPT) * TK + col];
 }
 
 template <int LOGN, int TK>
