@@ -182,7 +182,7 @@ def main():
         k1_512["frac"] = k1_512["achieved"] / HBM_PEAK_GBS
         del u5, F5, s5
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")
+    tfile = os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")
     if n == 256 and os.path.exists(tfile):  # PMC counters cannot be read in-process: committed rocprofv3 --pmc result
         try:
             traffic = json.load(open(tfile))["per_kernel"]["stage kernel, RK44 step average"]["hbm_total_GB"] * 1e9
@@ -208,7 +208,7 @@ def main():
         "config": {"workload": f"TaylorGreenVortex3D {n}^3 periodic fp64, RK44 + spectral Poisson, dt=1e-3, Re=1e3",
                    "grid": [n, n, n], "decomposition": "single GPU"},
         "roofline": {
-            "kernel": "k_momentum_flux FUSE[/CORR] (K1+K6: momentum-RHS stencil + RK stage combination; stages >= 2 also apply "
+            "kernel": "k_flux64 FUSE[/CORR] (K1+K6: momentum-RHS stencil + RK stage combination; stages >= 2 also apply "
                       "the previous projection's gradient-subtract in registers)",
             "bound": "hbm",
             "achieved": k1_gbs,
@@ -216,14 +216,14 @@ def main():
             "unit": "GB/s",
             "frac": k1_gbs / HBM_PEAK_GBS,
             "traffic": traffic,
-            "traffic_note": "B per launch, HBM FETCH(x2 gfx950)+WRITE from rocprofv3 --pmc, profiles/r01d_pmc_traffic.json",
+            "traffic_note": "B per launch, HBM FETCH(x2 gfx950)+WRITE from rocprofv3 --pmc, profiles/r01f_pmc_traffic.json",
             "bytes_per_cell": fused_bytes_per_cell,
             "bytes_per_cell_by_stage": stage_bytes,
             "avg_launch_ms": k1_avg_ms,
             "launches": k1_n.value,
         },
         "roofline_k1": {
-            "kernel": "k_momentum_flux (K1: momentum-RHS stencil alone, ins_momentum_f64)",
+            "kernel": "k_flux64 (K1: momentum-RHS stencil alone, ins_momentum_f64)",
             "bound": "hbm",
             "achieved": k1_plain_gbs,
             "peak": HBM_PEAK_GBS,

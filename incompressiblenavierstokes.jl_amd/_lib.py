@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libinship.so")
+LIB_PATH = os.environ.get("INS_HIP_LIB") or os.path.join(_HERE, "libinship.so")  # INS_HIP_LIB: A/B builds (tools/)
 
 INS_BC_PERIODIC, INS_BC_DIRICHLET, INS_BC_SYMMETRIC, INS_BC_PRESSURE, INS_BC_HALO = range(5)
 

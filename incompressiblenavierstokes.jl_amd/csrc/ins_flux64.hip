@@ -196,38 +196,55 @@ __global__ __launch_bounds__(256, 2) void k_flux64(FluxArgs a) {
     }
   };
 
-  auto emit = [&](int rr, int k, double fu, double fv, double fw, double Uc, double Vc, double Wc) {
+  // output rows of this wavefront (clamped: rows / columns past the box are computed but never stored)
+  unsigned orow[R];
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) orow[rr] = (unsigned)((min(jb0 + rr, n1 - 1) + 1) * N0) * 8u;
+  const unsigned ocol = (unsigned)(min(ci, n0 - 1) + 1) * 8u;
+
+  // RK epilogue, first half: s = ustart + Σ_q coef_q k_q for all R rows of plane k.  Issued at the top of the plane so the
+  // loads fly during the flux arithmetic (they used to sit right before the stores: one exposed round trip per row).
+  auto epi_load = [&](const Plane<R>& C, int k, double (&sacc)[3][R]) {
     const long long pk = (long long)k * sz;
-        const int j = jb0 + rr - 1;  // interior row
+    if (a.epi.ustart) {
+      const double* b = a.epi.ustart + pk;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const rsrc_t rs = plane_rsrc(b + c * a.sc, ubytes);
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) sacc[c][rr] = ldb(rs, ocol, orow[rr]);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) sacc[c][rr] = C.v[c][rr + 1];
+    }
+    for (int q = 0; q < a.epi.n; ++q) {
+      const double* kq = a.epi.k[q] + pk;
+      const double cq = a.epi.coef[q];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const rsrc_t rs = plane_rsrc(kq + c * a.sc, ubytes);
+        double kv[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) kv[rr] = ldb(rs, ocol, orow[rr]);
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) sacc[c][rr] += cq * kv[rr];
+      }
+    }
+  };
+  // second half: u* = s + coef_self f, and k_i = f when a later stage needs it
+  auto emit = [&](int rr, int k, double fu, double fv, double fw, double s0, double s1, double s2) {
+    const long long pk = (long long)k * sz;
+    const int j = jb0 + rr - 1;  // interior row
     if (xout && j < n1) {
-      const unsigned rowb = (unsigned)((j + 1) * N0) * 8u;  // wave-uniform
-      const unsigned co = (unsigned)(ci + 1) * 8u;
+      const unsigned rowb = orow[rr - 1], co = ocol;
       if (FUSE) {
-        double su, sv, sw;
-        if (a.epi.ustart) {
-          const double* b = a.epi.ustart + pk;
-          su = ldb(plane_rsrc(b, ubytes), co, rowb);
-          sv = ldb(plane_rsrc(b + a.sc, ubytes), co, rowb);
-          sw = ldb(plane_rsrc(b + 2 * a.sc, ubytes), co, rowb);
-        } else {
-          su = Uc;
-          sv = Vc;
-          sw = Wc;
-        }
-        for (int q = 0; q < a.epi.n; ++q) {
-          const double* kq = a.epi.k[q] + pk;
-          const double cq = a.epi.coef[q];
-          su += cq * ldb(plane_rsrc(kq, ubytes), co, rowb);
-          sv += cq * ldb(plane_rsrc(kq + a.sc, ubytes), co, rowb);
-          sw += cq * ldb(plane_rsrc(kq + 2 * a.sc, ubytes), co, rowb);
-        }
-        su += a.epi.coef_self * fu;
-        sv += a.epi.coef_self * fv;
-        sw += a.epi.coef_self * fw;
         double* o = a.epi.ustar + pk;
-        stb(plane_rsrc(o, ubytes), co, rowb, su);
-        stb(plane_rsrc(o + a.sc, ubytes), co, rowb, sv);
-        stb(plane_rsrc(o + 2 * a.sc, ubytes), co, rowb, sw);
+        stb(plane_rsrc(o, ubytes), co, rowb, s0 + a.epi.coef_self * fu);
+        stb(plane_rsrc(o + a.sc, ubytes), co, rowb, s1 + a.epi.coef_self * fv);
+        stb(plane_rsrc(o + 2 * a.sc, ubytes), co, rowb, s2 + a.epi.coef_self * fw);
       }
       if (!FUSE || a.epi.write_k) {
         double* o = a.F + pk;
@@ -236,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void k_flux64(FluxArgs a) {
         stb(plane_rsrc(o + 2 * a.sc, ubytes), co, rowb, fw);
       }
     }
-    };
+  };
 
   // One output plane.  C = plane k, Nx = plane k+1 (both complete, corrected).  As soon as a row of C has been consumed its
   // registers are re-loaded with the same row of plane `kload` (= k+2, the next plane this buffer has to hold), so the
@@ -245,6 +262,8 @@ __global__ __launch_bounds__(256, 2) void k_flux64(FluxArgs a) {
     const double* nb = a.u + (long long)uplane(kload) * sz;
     const rsrc_t n0r = plane_rsrc(nb, ubytes), n1r = plane_rsrc(nb + a.sc, ubytes), n2r = plane_rsrc(nb + 2 * a.sc, ubytes);
     const double ch0 = C.h[0], ch1 = C.h[1], ch2 = C.h[2];
+    double sacc[3][R];
+    if (FUSE) epi_load(C, k, sacc);
     double fyu_o = 0, fyv_o = 0, fyw_o = 0;
 #pragma unroll
     for (int rr = 0; rr <= R; ++rr) {
@@ -254,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void k_flux64(FluxArgs a) {
           const double fu = Uc + fyu_o + C.v[0][rr + 1] + Nx.v[0][rr] + zprev[0][rr - 1] + ch0;
           const double fv = Vc + fyv_o + C.v[1][rr + 1] + Nx.v[1][rr] + zprev[1][rr - 1] + ch1;
           const double fw = Wc + fyw_o + C.v[2][rr + 1] + Nx.v[2][rr] + zprev[2][rr - 1] + ch2;
-          emit(rr, k, fu, fv, fw, Uc, Vc, Wc);
+          emit(rr, k, fu, fv, fw, FUSE ? sacc[0][rr - 1] : 0.0, FUSE ? sacc[1][rr - 1] : 0.0, FUSE ? sacc[2][rr - 1] : 0.0);
         }
         fyu_o = Uc;
         fyv_o = Vc;
@@ -295,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void k_flux64(FluxArgs a) {
         zprev[0][rr - 1] = zu;
         zprev[1][rr - 1] = zv;
         zprev[2][rr - 1] = zw;
-        emit(rr, k, fu, fv, fw, Uc, Vc, Wc);
+        emit(rr, k, fu, fv, fw, FUSE ? sacc[0][rr - 1] : 0.0, FUSE ? sacc[1][rr - 1] : 0.0, FUSE ? sacc[2][rr - 1] : 0.0);
       }
       fyu_o = fyu;
       fyv_o = fyv;

@@ -12,6 +12,7 @@
 //     digit-reversed in, natural order out.  No reordering pass is ever needed.
 // nz must be a power of two in [8, 1024]; other sizes keep the rocFFT path.
 #include <cmath>
+#include <cstdlib>
 
 #include "ins_internal.h"
 

@@ -6,15 +6,10 @@ Kernels are grouped by a short name derived from the mangled symbol (template ar
 import csv, json, re, sys, collections
 
 def short(name):
-    m = re.search(r"(k_flux64|k_momentum_flux)I([A-Za-z0-9_]*?)EEv", name)
+    m = re.search(r"(k_[a-z0-9_]+)(<[^>(]*>)?", name)  # demangled: (anonymous namespace)::k_flux64<2, 4, true, 1, false>(...)
     if m:
-        args = re.findall(r"L[ib]([0-9]+)E", m.group(2))
-        if m.group(1) == "k_flux64":  # <R, XW, FUSE, CORR, SKEL>
-            r, xw, fuse, corr = args[:4]
-            return f"k_flux64<R={r},XW={xw},FUSE={fuse},CORR={corr}>"
-        return f"k_momentum_flux<{','.join(args)}>"
-    m = re.search(r"\d+(k_[a-z0-9_]+)", name)
-    return m.group(1) if m else name[:60]
+        return m.group(1) + (m.group(2) or "").replace(" ", "")
+    return name[:60]
 
 def collect(path, counter):
     acc = collections.defaultdict(list)
@@ -31,7 +26,7 @@ for k in sorted(set(fe) | set(wr)):
     if rd + wt < 1e-3:
         continue
     out["per_kernel"][k] = {"launches": len(f), "hbm_read_GB": rd, "hbm_write_GB": wt, "hbm_total_GB": rd + wt}
-stage = [v for k, v in out["per_kernel"].items() if k.startswith("k_flux64") and "FUSE=1" in k]
+stage = [v for k, v in out["per_kernel"].items() if re.match(r"k_flux64<\d+,\d+,true,", k)]  # <R, XW, FUSE, CORR, SKEL>
 if stage:
     n = sum(v["launches"] for v in stage)
     out["per_kernel"]["stage kernel, RK44 step average"] = {"hbm_total_GB": sum(v["hbm_total_GB"] * v["launches"] for v in stage) / n, "launches": n}
