@@ -223,6 +223,15 @@ int ins_slab_fft_xy_inverse_only(ins_slab_fft_t* fft, double* work, double* pI, 
  * chunk width cw (chunk c = kx in [c*cw, min((c+1)*cw, nx/2+1))), so no pack / unpack pass exists; with from_u != 0 the
  * right-hand side Ω·div(u) is formed inside the x pass from the slab's velocity (`src` = u on `grid`, z via ghost planes). */
 int ins_slab_fft_is_own(const ins_slab_fft_t* fft);
+/* Transpose-free distributed solve (csrc/ins_ztri.hip): after the local (x, y) transforms the z direction of
+ * pressure.jl:326-341 is one periodic tridiagonal system per (kx, ky) line — the circulant matrix the reference's z-FFT
+ * diagonalises — solved across ranks by the partition method; ranks exchange two complex numbers per line instead of the
+ * two all-to-all transposes.  Sequence on every rank:  ztri_forward -> all-gather of `edge` (ztri_edge_elems doubles per
+ * rank, rank-major) -> ztri_finish.  `from_u` != 0: src is the slab's u* and Ω·div(u*) is formed inside the x pass
+ * (power-of-two boxes); else src is pI (divergence! + scalewithvolume! already applied).  Works with one rank as well. */
+int ins_slab_ztri_edge_elems(const ins_slab_fft_t* S, int64_t* doubles);
+int ins_slab_ztri_forward(ins_slab_fft_t* S, const ins_grid_t* grid, const double* src, int from_u, double* work, double* edge, void* stream);
+int ins_slab_ztri_finish(ins_slab_fft_t* S, double* work, const double* edges_all, double* pI, void* stream);
 int ins_slab_fft_forward_packed(ins_slab_fft_t* fft, const ins_grid_t* grid, const double* src, int from_u, double* work, double* sendbuf,
                                 int cw, void* stream);
 int ins_slab_fft_inverse_packed(ins_slab_fft_t* fft, double* recvbuf, double* work, double* pI, int cw, void* stream);

@@ -90,6 +90,9 @@ SIGNATURES = {
     "ins_slab_fft_unpack_chunk": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     "ins_slab_fft_xy_inverse_only": (C.c_int, [vp, vp, vp, vp]),
     "ins_slab_fft_is_own": (C.c_int, [vp]),
+    "ins_slab_ztri_edge_elems": (C.c_int, [vp, C.POINTER(C.c_int64)]),
+    "ins_slab_ztri_forward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp]),
+    "ins_slab_ztri_finish": (C.c_int, [vp, vp, vp, vp, vp]),
     "ins_slab_fft_forward_packed": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp]),
     "ins_slab_fft_inverse_packed": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
 }

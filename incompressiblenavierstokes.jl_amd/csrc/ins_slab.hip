@@ -24,7 +24,16 @@ struct ins_slab_fft {
   bool ownfft = false;                                  // power-of-two box: own x / y passes too (ins_fft.hip), no rocFFT
   double *tw_x = nullptr, *tw_y = nullptr;
   const ins_grid* dummy_grid = nullptr;
+  // transpose-free z solve (ins_ztri.hip): every ky in storage order, Ω/Δz², interface values (L_{r-1}, F_{r+1}) per line
+  double* ay_full = nullptr;
+  double cz = 0.0;
+  double* ztri_bc = nullptr;
 };
+
+int ins_k_ztri_forward(double* work, int kxn, int kxs, int n1, int m, int nranks, int rank, const double* ax, const double* ay, double c,
+                       double scale, double* edge, hipStream_t s);
+int ins_k_ztri_finish(double* work, int kxn, int kxs, int n1, int m, int nranks, int rank, const double* ax, const double* ay, double c,
+                      const double* edges_all, double* bc, hipStream_t s);
 
 namespace {
 
@@ -141,21 +150,25 @@ extern "C" int ins_slab_fft_create(const int32_t np[3], const double h[3], int r
     const double sn = std::sin(M_PI * ((double)k / np[a]));
     return 4 * om * sn * sn / (h[a] * h[a]);
   };
-  std::vector<double> ax(S->kxn), ay(S->nyl), az(np[2]);
+  std::vector<double> ax(S->kxn), ay(S->nyl), az(np[2]), ayf(np[1]);
   for (int k = 0; k < S->kxn; ++k) ax[k] = symbol(0, k);
   S->ownfft = ins_ownfft_supported(np);
+  S->cz = om / (h[2] * h[2]);
   if (S->ownfft) {  // the own y pass leaves ky in digit-reversed storage order: slice the permuted symbol vector
-    std::vector<double> full(np[1]), perm(np[1]);
+    std::vector<double> full(np[1]);
     for (int k = 0; k < np[1]; ++k) full[k] = symbol(1, k);
-    ins_ownfft_permute_symbol(np[1], full.data(), perm.data());
-    for (int k = 0; k < S->nyl; ++k) ay[k] = perm[rank * S->nyl + k];
+    ins_ownfft_permute_symbol(np[1], full.data(), ayf.data());
+    for (int k = 0; k < S->nyl; ++k) ay[k] = ayf[rank * S->nyl + k];
   } else {
+    for (int k = 0; k < np[1]; ++k) ayf[k] = symbol(1, k);
     for (int k = 0; k < S->nyl; ++k) ay[k] = symbol(1, rank * S->nyl + k);
   }
   for (int k = 0; k < np[2]; ++k) az[k] = symbol(2, k);
   bool ok = hipMalloc(&S->ax, ax.size() * 8) == hipSuccess && hipMalloc(&S->ay, ay.size() * 8) == hipSuccess &&
-            hipMalloc(&S->az, az.size() * 8) == hipSuccess;
-  ok = ok && hipMemcpy(S->ax, ax.data(), ax.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMalloc(&S->az, az.size() * 8) == hipSuccess && hipMalloc(&S->ay_full, ayf.size() * 8) == hipSuccess &&
+            hipMalloc(&S->ztri_bc, (size_t)4 * S->kxn * np[1] * 8) == hipSuccess;
+  ok = ok && hipMemcpy(S->ay_full, ayf.data(), ayf.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(S->ax, ax.data(), ax.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
        hipMemcpy(S->ay, ay.data(), ay.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
        hipMemcpy(S->az, az.data(), az.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) {
@@ -217,6 +230,8 @@ extern "C" int ins_slab_fft_destroy(ins_slab_fft_t* S) {
   if (S->ax) (void)hipFree(S->ax);
   if (S->ay) (void)hipFree(S->ay);
   if (S->az) (void)hipFree(S->az);
+  if (S->ay_full) (void)hipFree(S->ay_full);
+  if (S->ztri_bc) (void)hipFree(S->ztri_bc);
   delete S;
   return INS_OK;
 }
@@ -344,6 +359,41 @@ extern "C" int ins_slab_fft_inverse_packed(ins_slab_fft_t* S, double* recvbuf, d
 }
 
 extern "C" int ins_slab_fft_is_own(const ins_slab_fft_t* S) { return S && S->ownfft; }
+
+// ---- transpose-free solve: the z direction as distributed tridiagonal systems (ins_ztri.hip) ----------------------------------
+// Per rank the exchange buffer holds [yF (lines) | yL (lines) | the singular line's nzl local values], complex, lines = kxn * ny.
+extern "C" int ins_slab_ztri_edge_elems(const ins_slab_fft_t* S, int64_t* doubles) {
+  INS_REQUIRE(S && doubles, "null argument");
+  *doubles = 2 * (2 * (int64_t)S->kxn * S->np[1] + S->nzl);
+  return INS_OK;
+}
+
+// x / y forward transforms of the local planes (from_u: Ω·div(u) formed inside the x pass, own passes only; else src = pI),
+// then the forward elimination along z in place on `work` and this rank's interface data -> `edge`.
+extern "C" int ins_slab_ztri_forward(ins_slab_fft_t* S, const ins_grid_t* G, const double* src, int from_u, double* work, double* edge, void* stream) {
+  INS_REQUIRE(S && src && work && edge, "null argument");
+  INS_REQUIRE(S->nzl >= 2, "the tridiagonal z solve needs >= 2 local planes");
+  hipStream_t s = as_stream(stream);
+  int rc;
+  if (from_u) {
+    INS_REQUIRE(S->ownfft, "forming the right-hand side inside the x pass needs a power-of-two box");
+    INS_REQUIRE(G && G->g.D == 3 && G->g.N[0] == S->np[0] + 2 && G->g.N[1] == S->np[1] + 2 && G->g.N[2] == S->nzl + 2, "grid does not match the slab");
+    if ((rc = ins_k_ownfft_xfwd(G, src, 2, work, S->np[0], S->np[1], S->nzl, S->tw_x, s))) return rc;
+    if ((rc = ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s))) return rc;
+  } else if ((rc = slab_xy_forward(S, const_cast<double*>(src), work, s)))
+    return rc;
+  const double scale = -1.0 / ((double)S->np[0] * S->np[1]);
+  return ins_k_ztri_forward(work, S->kxn, S->kxn, S->np[1], S->nzl, S->nranks, S->rank, S->ax, S->ay_full, S->cz, scale, edge, s);
+}
+
+// edges_all = the all-gathered edge buffers (rank-major).  Interface solve, back substitution, inverse y / x transforms -> pI.
+extern "C" int ins_slab_ztri_finish(ins_slab_fft_t* S, double* work, const double* edges_all, double* pI, void* stream) {
+  INS_REQUIRE(S && work && edges_all && pI, "null argument");
+  hipStream_t s = as_stream(stream);
+  int rc = ins_k_ztri_finish(work, S->kxn, S->kxn, S->np[1], S->nzl, S->nranks, S->rank, S->ax, S->ay_full, S->cz, edges_all, S->ztri_bc, s);
+  if (rc) return rc;
+  return slab_xy_inverse(S, work, pI, s);
+}
 
 /* 1 when kx chunks are supported (power-of-two nz -> fused z kernel). */
 extern "C" int ins_slab_fft_can_chunk(const ins_slab_fft_t* S) { return S && S->tw != nullptr; }

@@ -1,0 +1,266 @@
+// Distributed z solve of the spectral Poisson solver WITHOUT transposes (pressure.jl:289-351 restated).
+//
+// After the (x, y) transforms of a z-slab the Poisson problem decouples into one periodic tridiagonal system per (kx, ky) line,
+//     (âx + ây) p_k + c (2 p_k - p_{k+1} - p_{k-1}) = g_k,      c = Ω/Δz²,   g = -f̂ / (nx ny),   k = 0..nz-1 (periodic),
+// whose circulant matrix is exactly what the reference's z-FFT diagonalises (eigenvalues âx + ây + 4c sin²(π kz/nz) = âx+ây+âz).
+// The FFT route needs the whole line on one rank: two all-to-all transposes of the full half spectrum per solve (135 MB per rank
+// and transpose at 256³ per rank — more than a stage's compute over one xGMI link).  Here each rank keeps its nzl planes and the
+// lines are solved by the partition (SPIKE) method; ranks exchange TWO complex numbers per line (one small all-gather):
+//
+//   1. forward elimination of the local block A_r = tridiag(-c, d, -c) (d = âx+ây+2c) on g, in place, and in the same sweep the two
+//      numbers yF = (A_r⁻¹ g)_first, yL = (A_r⁻¹ g)_last as dot products with the spikes A_r⁻¹ e_first, A_r⁻¹ e_last;
+//   2. all-gather of (yF, yL) [host: torch.distributed]; every rank solves the 2P x 2P interface system per line — it is
+//      block-circulant (all local blocks are equal), so a P-point DFT over ranks reduces it to P independent 2x2 systems;
+//   3. back substitution with the two interface values (p_last of the rank below, p_first of the rank above) folded in.
+// The blocks are symmetric Toeplitz, so pivots, spikes and the eliminated boundary columns have closed forms in the decaying
+// root r of r + 1/r = d/c; nothing but the field itself is stored.  Two streaming passes (read + write each) replace the fused
+// z-FFT pass of the single-GPU path.  The (0,0) line is singular (d = 2c): its nz values are gathered with the interface data and
+// solved by two prefix sums with the reference's gauge (zero mean, pressure.jl:336-341).
+#include <cmath>
+
+#include "ins_internal.h"
+
+namespace {
+
+struct ZtriArgs {
+  double2* data;       // [m][n1][kxs]  (work array after the x / y transforms)
+  int kxn, kxs, n1, m; // live kx, row stride, rows, local planes
+  int nranks, rank;
+  const double* ax;    // [kxn]
+  const double* ay;    // [n1]  (storage order of ky)
+  double c, scale;     // Ω/Δz², -1/(nx ny)
+};
+
+struct LineConst {
+  double lnr, r, r2, D, rm1;  // ln r, r, r², 1 - r^(2m+2), r^(m+1)
+};
+
+__device__ __forceinline__ LineConst line_const(double s, int m) {  // s = (âx + ây)/c = d/c - 2 > 0
+  LineConst L;
+  const double sq = sqrt(s * (4.0 + s));
+  L.lnr = -log1p(0.5 * (s + sq));  // r = 2 / (s + 2 + sq): the decaying root, without cancellation
+  L.r = exp(L.lnr);
+  L.r2 = L.r * L.r;
+  L.D = -expm1((2.0 * m + 2.0) * L.lnr);
+  L.rm1 = exp((m + 1.0) * L.lnr);
+  return L;
+}
+
+__device__ __forceinline__ double2 operator*(double a, double2 v) { return make_double2(a * v.x, a * v.y); }
+__device__ __forceinline__ double2 operator+(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// ---- pass 1: forward elimination + spike dot products -------------------------------------------------------------------
+// pivots 1/den_k = (r/c)(1 - E_k)/(1 - E_k r²), E_k = r^(2k+2);  gp_k = (g_k + c gp_{k-1}) / den_k
+// spikes v_k = (r^(k+1) - r^(m+1) r^(m-k)) / (1 - r^(2m+2)) = c (A_r⁻¹ e_0)_k,  w_k = v_{m-1-k}
+__global__ __launch_bounds__(256) void k_ztri_fwd(ZtriArgs a, double2* __restrict__ edge, double2* __restrict__ line0) {
+  const int kx = blockIdx.x * 64 + threadIdx.x, ky = blockIdx.y * 4 + threadIdx.y;
+  if (kx >= a.kxn || ky >= a.n1) return;
+  const long long lines = (long long)a.kxn * a.n1, l = kx + (long long)a.kxn * ky;
+  const long long ps = (long long)a.kxs * a.n1;
+  double2* x = a.data + kx + (long long)a.kxs * ky;
+  const double sxy = a.ax[kx] + a.ay[ky];
+  if (sxy == 0.0) {  // the singular line: hand the scaled right-hand side to the gather, leave the rest to k_ztri_line0
+    for (int k = 0; k < a.m; ++k) line0[k] = a.scale * x[k * ps];
+    edge[l] = edge[lines + l] = make_double2(0.0, 0.0);
+    return;
+  }
+  const LineConst L = line_const(sxy / a.c, a.m);
+  const double rc = L.r / a.c, idc = 1.0 / (L.D * a.c);
+  double E = L.r2, pa = L.r;
+  double2 gp = make_double2(0.0, 0.0), accF = gp, accL = gp;
+#pragma unroll 8
+  for (int k = 0; k < a.m; ++k) {
+    const double2 g = a.scale * x[k * ps];
+    const double inv = rc * (1.0 - E) / (1.0 - E * L.r2);
+    gp = inv * (g + a.c * gp);
+    x[k * ps] = gp;
+    const double pb = exp((a.m - k) * L.lnr);  // r^(m-k)
+    accF = accF + ((pa - L.rm1 * pb) * idc) * g;
+    accL = accL + ((pb - L.rm1 * pa) * idc) * g;
+    E *= L.r2;
+    pa *= L.r;
+  }
+  edge[l] = accF;
+  edge[lines + l] = accL;
+}
+
+// ---- interface: block-circulant 2P x 2P system per line, by a DFT over ranks ---------------------------------------------
+//   F_r - α L_{r-1} - β F_{r+1} = yF_r,   L_r - β L_{r-1} - α F_{r+1} = yL_r,   α = v_0, β = v_{m-1}
+// edges_all: [rank][ per-rank block of `stride` complex: yF[lines], yL[lines], line0[m] ];  out bc: [2][lines] = (L_{r-1}, F_{r+1})
+constexpr int ZTRI_MAX_RANKS = 16;
+__global__ __launch_bounds__(256) void k_ztri_iface(ZtriArgs a, const double2* __restrict__ edges_all, long long stride, double2* __restrict__ bc) {
+  const int kx = blockIdx.x * 64 + threadIdx.x, ky = blockIdx.y * 4 + threadIdx.y;
+  if (kx >= a.kxn || ky >= a.n1) return;
+  const long long lines = (long long)a.kxn * a.n1, l = kx + (long long)a.kxn * ky;
+  const double sxy = a.ax[kx] + a.ay[ky];
+  if (sxy == 0.0) {
+    bc[l] = bc[lines + l] = make_double2(0.0, 0.0);
+    return;
+  }
+  const LineConst L = line_const(sxy / a.c, a.m);
+  const double alpha = L.r * (-expm1(2.0 * a.m * L.lnr)) / L.D;
+  const double beta = exp(a.m * L.lnr) * (1.0 - L.r2) / L.D;
+  const int P = a.nranks;
+  double2 yF[ZTRI_MAX_RANKS], yL[ZTRI_MAX_RANKS];
+  for (int q = 0; q < P; ++q) {
+    yF[q] = edges_all[q * stride + l];
+    yL[q] = edges_all[q * stride + lines + l];
+  }
+  double2 Lprev = make_double2(0.0, 0.0), Fnext = Lprev;
+  const int rp = (a.rank + P - 1) % P, rn = (a.rank + 1) % P;
+  for (int j = 0; j < P; ++j) {
+    double2 hF = make_double2(0.0, 0.0), hL = hF;
+    for (int q = 0; q < P; ++q) {  // forward DFT over ranks: e^{-iθ_j q}
+      double sn, cs;
+      sincospi(-2.0 * (double)((j * q) % P) / P, &sn, &cs);
+      const double2 w = make_double2(cs, sn);
+      hF = hF + cmul(w, yF[q]);
+      hL = hL + cmul(w, yL[q]);
+    }
+    double sn, cs;
+    sincospi(2.0 * (double)j / P, &sn, &cs);
+    const double2 ep = make_double2(cs, sn), em = make_double2(cs, -sn);  // e^{+iθ}, e^{-iθ}
+    // [ 1 - β e^{+iθ}    -α e^{-iθ} ] [F̂]   [ŷF]
+    // [   -α e^{+iθ}   1 - β e^{-iθ} ] [L̂] = [ŷL]
+    const double2 a11 = make_double2(1.0 - beta * ep.x, -beta * ep.y), a22 = make_double2(1.0 - beta * em.x, -beta * em.y);
+    const double2 a12 = (-alpha) * em, a21 = (-alpha) * ep;
+    const double det = 1.0 - 2.0 * beta * cs + beta * beta - alpha * alpha;  // a11 a22 - a12 a21 (real)
+    const double2 Fh = (1.0 / det) * (cmul(a22, hF) + (-1.0) * cmul(a12, hL));
+    const double2 Lh = (1.0 / det) * (cmul(a11, hL) + (-1.0) * cmul(a21, hF));
+    double s2, c2;
+    sincospi(2.0 * (double)((j * rp) % P) / P, &s2, &c2);
+    Lprev = Lprev + cmul(make_double2(c2, s2), Lh);
+    sincospi(2.0 * (double)((j * rn) % P) / P, &s2, &c2);
+    Fnext = Fnext + cmul(make_double2(c2, s2), Fh);
+  }
+  bc[l] = (1.0 / P) * Lprev;
+  bc[lines + l] = (1.0 / P) * Fnext;
+}
+
+// ---- pass 2: back substitution with the interface values folded in -------------------------------------------------------
+// g̃ = g + c L_{r-1} e_0 + c F_{r+1} e_{m-1}  =>  gp̃_k = gp_k + c L φ_k (+ c F /den_{m-1} at k = m-1),  φ_k = r^(k+1)(1-r²)/(c(1-E_k r²))
+// p_{m-1} = gp̃_{m-1},  p_k = gp̃_k + (c/den_k) p_{k+1}
+__global__ __launch_bounds__(256) void k_ztri_bwd(ZtriArgs a, const double2* __restrict__ bc) {
+  const int kx = blockIdx.x * 64 + threadIdx.x, ky = blockIdx.y * 4 + threadIdx.y;
+  if (kx >= a.kxn || ky >= a.n1) return;
+  const long long lines = (long long)a.kxn * a.n1, l = kx + (long long)a.kxn * ky;
+  const long long ps = (long long)a.kxs * a.n1;
+  double2* x = a.data + kx + (long long)a.kxs * ky;
+  const double sxy = a.ax[kx] + a.ay[ky];
+  if (sxy == 0.0) return;  // k_ztri_line0
+  const LineConst L = line_const(sxy / a.c, a.m);
+  const double2 Lp = bc[l], Fn = bc[lines + l];
+  const double omr2 = 1.0 - L.r2;
+  double2 p = make_double2(0.0, 0.0);
+#pragma unroll 8
+  for (int k = a.m - 1; k >= 0; --k) {
+    const double pa = exp((k + 1.0) * L.lnr);  // r^(k+1)
+    const double q = 1.0 / (1.0 - pa * pa * L.r2);
+    const double cinv = L.r * (1.0 - pa * pa) * q;  // c / den_k
+    double2 v = x[k * ps] + (pa * omr2 * q) * Lp;    // + c L φ_k
+    if (k == a.m - 1) v = v + cinv * Fn;
+    p = v + cinv * p;
+    x[k * ps] = p;
+  }
+}
+
+// ---- the singular line: -c (p_{k+1} - 2 p_k + p_{k-1}) = g_k - mean(g), periodic over N = P m, mean(p) = 0 -----------------
+// q_k = p_{k+1} - p_k = q_0 - S_k,  S_k = Σ_{j=1..k} h_j,  h = (g - ḡ)/c;   p_k = p_0 + k q_0 - T_k,  T_k = Σ_{j<k} S_j;
+// periodicity: q_0 = T_N / N;  gauge: p_0 = -(1/N) Σ_k (k q_0 - T_k).   One wavefront, chunks per lane, shuffle scans.
+__device__ __forceinline__ double2 wave_sum(double2 v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    v.x += __shfl_xor(v.x, off, 64);
+    v.y += __shfl_xor(v.y, off, 64);
+  }
+  return v;
+}
+__device__ __forceinline__ double2 wave_excl_scan(double2 v, int lane) {  // exclusive prefix sum over lanes
+  double2 inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double tx = __shfl_up(inc.x, off, 64), ty = __shfl_up(inc.y, off, 64);
+    if (lane >= off) {
+      inc.x += tx;
+      inc.y += ty;
+    }
+  }
+  return make_double2(inc.x - v.x, inc.y - v.y);
+}
+
+__global__ __launch_bounds__(64) void k_ztri_line0(ZtriArgs a, const double2* __restrict__ edges_all, long long stride, long long line0_off) {
+  const int lane = threadIdx.x;
+  const int P = a.nranks, m = a.m, N = P * m;
+  const int C = (N + 63) / 64, s = min(lane * C, N), e = min(s + C, N);
+  auto g_at = [&](int k) { return edges_all[(long long)(k / m) * stride + line0_off + (k % m)]; };
+  const double ic = 1.0 / a.c, iN = 1.0 / N;
+  double2 sum = make_double2(0.0, 0.0);
+  for (int k = s; k < e; ++k) sum = sum + g_at(k);
+  const double2 gbar = iN * wave_sum(sum);
+  auto h_at = [&](int k) {
+    const double2 g = g_at(k);
+    return make_double2((g.x - gbar.x) * ic, (g.y - gbar.y) * ic);
+  };
+  const double2 h0 = h_at(0);
+  // chunk sums of h -> H base;  S_j = H_j - h_0 (inclusive prefix minus the j = 0 term)
+  double2 A = make_double2(0.0, 0.0);
+  for (int k = s; k < e; ++k) A = A + h_at(k);
+  const double2 Hbase = wave_excl_scan(A, lane);
+  double2 B = make_double2(0.0, 0.0), H = Hbase;
+  for (int k = s; k < e; ++k) {
+    H = H + h_at(k);
+    B = B + make_double2(H.x - h0.x, H.y - h0.y);
+  }
+  const double2 Tbase = wave_excl_scan(B, lane);  // T_s = Σ_{j<s} S_j
+  const double2 q0 = iN * wave_sum(B);            // T_N / N
+  double2 Cs = make_double2(0.0, 0.0), T = Tbase;
+  H = Hbase;
+  for (int k = s; k < e; ++k) {
+    Cs = Cs + make_double2(k * q0.x - T.x, k * q0.y - T.y);
+    H = H + h_at(k);
+    T = T + make_double2(H.x - h0.x, H.y - h0.y);
+  }
+  const double2 p0 = (-iN) * wave_sum(Cs);
+  const long long ps = (long long)a.kxs * a.n1;
+  const int k0 = a.rank * m;
+  T = Tbase;
+  H = Hbase;
+  for (int k = s; k < e; ++k) {
+    if (k >= k0 && k < k0 + m) a.data[(long long)(k - k0) * ps] = make_double2(p0.x + k * q0.x - T.x, p0.y + k * q0.y - T.y);
+    H = H + h_at(k);
+    T = T + make_double2(H.x - h0.x, H.y - h0.y);
+  }
+}
+
+}  // namespace
+
+// launched by ins_slab.hip (which owns the slab handle): all on stream s
+int ins_k_ztri_forward(double* work, int kxn, int kxs, int n1, int m, int nranks, int rank, const double* ax, const double* ay, double c,
+                       double scale, double* edge, hipStream_t s) {
+  ZtriArgs a{reinterpret_cast<double2*>(work), kxn, kxs, n1, m, nranks, rank, ax, ay, c, scale};
+  const long long lines = (long long)kxn * n1;
+  double2* e = reinterpret_cast<double2*>(edge);
+  dim3 block(64, 4), grid(cdiv(kxn, 64), cdiv(n1, 4));
+  hipLaunchKernelGGL(k_ztri_fwd, grid, block, 0, s, a, e, e + 2 * lines);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+int ins_k_ztri_finish(double* work, int kxn, int kxs, int n1, int m, int nranks, int rank, const double* ax, const double* ay, double c,
+                      const double* edges_all, double* bc, hipStream_t s) {
+  if (nranks > ZTRI_MAX_RANKS) {
+    ins_set_error("tridiagonal z solve: at most %d ranks", ZTRI_MAX_RANKS);
+    return INS_ERR_UNSUPPORTED;
+  }
+  ZtriArgs a{reinterpret_cast<double2*>(work), kxn, kxs, n1, m, nranks, rank, ax, ay, c, 0.0};
+  const long long lines = (long long)kxn * n1, stride = 2 * lines + m;
+  const double2* ea = reinterpret_cast<const double2*>(edges_all);
+  double2* b = reinterpret_cast<double2*>(bc);
+  dim3 block(64, 4), grid(cdiv(kxn, 64), cdiv(n1, 4));
+  hipLaunchKernelGGL(k_ztri_iface, grid, block, 0, s, a, ea, stride, b);
+  hipLaunchKernelGGL(k_ztri_bwd, grid, block, 0, s, a, (const double2*)b);
+  hipLaunchKernelGGL(k_ztri_line0, dim3(1), dim3(64), 0, s, a, ea, stride, 2 * lines);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}

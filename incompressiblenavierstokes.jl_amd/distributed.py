@@ -6,8 +6,15 @@ The reference has no multi-device code; this module distributes exactly the refe
 
     rank r owns interior z-planes [r*nz/P, (r+1)*nz/P) (+ one ghost plane per side); x, y stay whole.
     per stage:  halo(u)  ->  K1+K6 (k_i, u*)  ->  halo(w-plane of u*)  ->  K2 (Ω div u* -> pI)
-                -> 2-D FFT(x,y) + pack -> all-to-all -> z-FFT / symbol / inverse z-FFT -> all-to-all
-                -> unpack + inverse 2-D FFT -> halo(first p plane) -> K4 (u* -= ∇p, x/y ghost images)
+                -> 2-D FFT(x,y)
+                   zsolve = "tridiag" (default for > 1 rank): forward elimination along z + interface data
+                      -> all-gather (2 complex numbers per (kx, ky) line) -> back substitution     [csrc/ins_ztri.hip]
+                   zsolve = "fft": pack -> all-to-all -> z-FFT / symbol / inverse z-FFT -> all-to-all -> unpack
+                -> inverse 2-D FFT -> halo(first p plane) -> K4 (u* -= ∇p, x/y ghost images)
+
+The z direction of the spectral solve is a periodic tridiagonal system per (kx, ky) line (the circulant matrix the z-FFT
+diagonalises).  Solving it across ranks by the partition method moves ~1 MB per rank and solve instead of the whole half
+spectrum twice (135 MB per rank and transpose at 256^3 per rank), which is what xGMI's point-to-point links cannot hide.
 
 `SlabStepper` holds only index bookkeeping and communication; the rank-local numerics come from a
 `kernels` object: `HipSlabKernels` below (libinship, the product) — tests inject a CPU implementation to
@@ -99,6 +106,18 @@ class SlabComm:
             self.all_to_all(recv, send)
             return SlabComm._Done()
         return dist.all_to_all_single(recv, send, group=self.group2 if which else self.group, async_op=True)
+
+    def all_gather(self, out, inp):
+        """out[r*len(inp):(r+1)*len(inp)] = rank r's inp."""
+        if self.world == 1:
+            out.copy_(inp)
+            return
+        if self._stage(inp):
+            ho = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(ho, inp.cpu(), group=self.group)
+            out.copy_(ho)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.group)
 
     def barrier(self):
         if self.world > 1:
@@ -242,6 +261,25 @@ class HipSlabKernels:
     def fft_inverse_packed(self, recvbuf, work, pI, cw):
         _lib.call("ins_slab_fft_inverse_packed", self._fft, self._p(recvbuf), self._p(work), self._p(pI), cw, self.setup.stream)
 
+    # transpose-free z solve (csrc/ins_ztri.hip)
+    def supports_ztri(self):
+        return self.layout.nzl >= 2 and self.layout.world <= 16
+
+    def ztri_edge(self, ranks=1):
+        n = C.c_int64()
+        _lib.call("ins_slab_ztri_edge_elems", self._fft, C.byref(n))
+        return torch.zeros(n.value * ranks, dtype=torch.float64, device=self.device)
+
+    def ztri_forward(self, src, from_u, work, edge):
+        """(x, y) transforms of the local planes (from_u: Ω·div(u) formed inside the x pass), forward elimination along z in
+        place on `work`, this rank's interface data -> edge."""
+        s = self.setup
+        ptr = s.ptr(src, True) if from_u else self._p(src)
+        _lib.call("ins_slab_ztri_forward", self._fft, s.handle, ptr, 1 if from_u else 0, self._p(work), self._p(edge), s.stream)
+
+    def ztri_finish(self, work, edges_all, pI):
+        _lib.call("ins_slab_ztri_finish", self._fft, self._p(work), self._p(edges_all), self._p(pI), self.setup.stream)
+
     def applypressure(self, u, pI, p_top):
         s = self.setup
         _lib.call("ins_slab_applypressure_f64", s.handle, s.ptr(u, True), self._p(pI), self._p(p_top), s.stream)
@@ -254,8 +292,19 @@ class SlabStepper:
     """Explicit Runge-Kutta stepping of a periodic box decomposed into z-slabs
     (step_explicit_runge_kutta.jl:4-59 distributed; same arithmetic in the same order on every cell)."""
 
-    def __init__(self, method, layout, kernels, comm, chunks=1):
+    def __init__(self, method, layout, kernels, comm, chunks=1, zsolve=None):
         self.method, self.lay, self.k, self.comm = method, layout, kernels, comm
+        # z direction of the Poisson solve: "tridiag" = distributed tridiagonal systems, one small all-gather per solve;
+        # "fft" = two all-to-all transposes around the z-FFT.  Default: tridiag as soon as there is more than one rank
+        # (on one rank the fused z-FFT pass is one HBM pass instead of two).
+        import os
+
+        zsolve = zsolve or os.environ.get("INS_SLAB_ZSOLVE") or ("tridiag" if comm.world > 1 else "fft")
+        if zsolve not in ("tridiag", "fft"):
+            raise ValueError("zsolve must be 'tridiag' or 'fft'")
+        if zsolve == "tridiag" and not bool(getattr(kernels, "supports_ztri", lambda: False)()):
+            zsolve = "fft"
+        self.zsolve = zsolve
         # kx-chunks of the half spectrum for the pipelined transposes (1 = one all-to-all each way)
         chunks = max(1, min(int(chunks), layout.kxn)) if kernels.can_chunk() else 1
         self.cw = -(-layout.kxn // chunks)  # uniform chunk width (the last chunk may be narrower)
@@ -276,6 +325,9 @@ class SlabStepper:
         self.bufa = kernels.cplx()
         self.bufb = kernels.cplx()
         self.p_top = kernels.real()[: layout.n[0] * layout.n[1]].clone()
+        if self.zsolve == "tridiag":
+            self.edge = kernels.ztri_edge()
+            self.edges_all = kernels.ztri_edge(comm.world)
         self.n = 0
 
     # -- exchanges ---------------------------------------------------------------------------
@@ -314,6 +366,18 @@ class SlabStepper:
         """apply=False: solve only (pI <- p); the gradient-subtract is left to the next stage's stencil kernel."""
         K = self.k
         self.halo_u(u, comps=(2,), down_only=True)  # divergence needs w[I - e_z] only (operators.jl:122)
+        if self.zsolve == "tridiag":
+            if self.packed:  # power-of-two box: Ω·div(u) formed inside the x pass
+                K.ztri_forward(u, True, self.work, self.edge)
+            else:
+                K.divergence(u, self.pI)
+                K.ztri_forward(self.pI, False, self.work, self.edge)
+            self.comm.all_gather(self.edges_all, self.edge)
+            K.ztri_finish(self.work, self.edges_all, self.pI)
+            if apply:
+                self.halo_p()
+                K.applypressure(u, self.pI, self.p_top)
+            return u
         if self.packed:
             # power-of-two box: [K2 + x pass] -> y pass straight into the send buffer -> chunked transposes around the
             # z pass -> y pass straight out of the receive buffer -> x pass: no divergence / pack / unpack passes

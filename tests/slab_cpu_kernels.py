@@ -192,6 +192,99 @@ class OracleSlabKernels:
             self.unpack_chunk(recvbuf[per_kx * k0 : per_kx * (k0 + kc)], work, k0, kc)
         self.fft_xy_inverse(work, pI)
 
+    # ---- transpose-free z solve: independent numpy restatement of csrc/ins_ztri.hip's contract ------------------------
+    # (dense per-line Thomas with explicit pivots, explicit spikes from two more Thomas solves, dense 2P x 2P interface
+    #  systems, np.fft for the singular line — none of the closed forms the HIP kernels use)
+    def supports_ztri(self):
+        return self.layout.nzl >= 2
+
+    def _ztri_setup(self):
+        lay = self.layout
+        ny = lay.n[1]
+        om = self.cell_volume
+        self.cz = om / self.h[2] ** 2
+        ayf = 4 * om * np.sin(np.pi * (np.arange(ny) / ny)) ** 2 / self.h[1] ** 2
+        self.dline = ayf[:, None] + self.ax[None, :] + 2 * self.cz  # d = âx + ây + 2c, [ky][kx]
+        self.lines = ny * lay.kxn
+
+    def ztri_edge(self, ranks=1):
+        if not hasattr(self, "lines"):
+            self._ztri_setup()
+        return torch.zeros(2 * (2 * self.lines + self.layout.nzl) * ranks, dtype=torch.float64)
+
+    def _thomas(self, g):
+        """A_r^{-1} g for every line: g [m][ky][kx] complex, A_r = tridiag(-c, d, -c)."""
+        m, c, d = g.shape[0], self.cz, self.dline
+        cp = np.zeros((m,) + d.shape)
+        gp = np.zeros_like(g)
+        den = d.copy()
+        gp[0] = g[0] / den
+        for k in range(1, m):
+            cp[k - 1] = -c / den
+            den = d + c * cp[k - 1]
+            gp[k] = (g[k] + c * gp[k - 1]) / den
+        y = np.zeros_like(g)
+        y[m - 1] = gp[m - 1]
+        for k in range(m - 2, -1, -1):
+            y[k] = gp[k] - cp[k] * y[k + 1]
+        return y
+
+    def ztri_forward(self, src, from_u, work, edge):
+        lay = self.layout
+        if not hasattr(self, "lines"):
+            self._ztri_setup()
+        pI = src
+        if from_u:
+            pI = self.real()
+            self.divergence(src, pI)
+        a = pI.numpy().reshape(lay.nzl, lay.n[1], lay.n[0])
+        g = -np.fft.rfftn(a, axes=(1, 2))  # [kzl][ky][kx]; numpy's irfftn carries the 1/(nx ny) the HIP passes fold into g
+        e = self._c(edge)
+        e[2 * self.lines :] = g[:, 0, 0]
+        g[:, 0, 0] = 0.0
+        y = self._thomas(g)
+        self._c(work)[...] = y.reshape(-1)  # the stand-in keeps y = A_r^{-1} g (the HIP kernel keeps the half-eliminated field)
+        e[: self.lines] = y[0].reshape(-1)
+        e[self.lines : 2 * self.lines] = y[-1].reshape(-1)
+
+    def ztri_finish(self, work, edges_all, pI):
+        lay = self.layout
+        P, m, c = lay.world, lay.nzl, self.cz
+        ny, kxn = lay.n[1], lay.kxn
+        ea = self._c(edges_all).reshape(P, 2 * self.lines + m)
+        yF = ea[:, : self.lines].reshape(P, ny, kxn)
+        yL = ea[:, self.lines : 2 * self.lines].reshape(P, ny, kxn)
+        e0 = np.zeros((m, ny, kxn), dtype=complex)
+        e0[0] = c
+        v = self._thomas(e0).real  # c A_r^{-1} e_first
+        w = v[::-1]                # c A_r^{-1} e_last (symmetric Toeplitz)
+        # interface: unknowns z = [F_0, L_0, F_1, L_1, ...]
+        M = np.zeros((ny, kxn, 2 * P, 2 * P))
+        rhs = np.zeros((ny, kxn, 2 * P), dtype=complex)
+        for r in range(P):
+            rp, rn = (r - 1) % P, (r + 1) % P
+            M[..., 2 * r, 2 * r] += 1.0
+            M[..., 2 * r, 2 * rp + 1] += -v[0]
+            M[..., 2 * r, 2 * rn] += -w[0]
+            M[..., 2 * r + 1, 2 * r + 1] += 1.0
+            M[..., 2 * r + 1, 2 * rp + 1] += -v[m - 1]
+            M[..., 2 * r + 1, 2 * rn] += -w[m - 1]
+            rhs[..., 2 * r] = yF[r]
+            rhs[..., 2 * r + 1] = yL[r]
+        M[0, 0] = np.eye(2 * P)  # the singular line is handled below
+        z = np.linalg.solve(M, rhs[..., None])[..., 0]
+        Lprev = z[..., 2 * ((lay.rank - 1) % P) + 1]
+        Fnext = z[..., 2 * ((lay.rank + 1) % P)]
+        y = self._c(work).reshape(m, ny, kxn)
+        p = y + Lprev[None] * v + Fnext[None] * w
+        # singular line: periodic 1-D Poisson over all nz values, zero mean (pressure.jl:336-341)
+        g0 = ea[:, 2 * self.lines :].reshape(-1)
+        gh = np.fft.fft(g0)
+        gh[1:] /= self.az[1:]
+        gh[0] = 0.0
+        p[:, 0, 0] = np.fft.ifft(gh)[lay.rank * m : (lay.rank + 1) * m]
+        pI.numpy()[...] = np.fft.irfftn(p, s=(ny, lay.n[0]), axes=(1, 2)).reshape(-1)
+
     def applypressure(self, u, pI, p_top):
         lay = self.layout
         nx, ny = lay.n[0], lay.n[1]

@@ -17,7 +17,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, nsteps, method_name, out_dir, chunks=1, own=False):
+def _worker(rank, world, port, n, nsteps, method_name, out_dir, chunks=1, own=False, zsolve="fft"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -32,7 +32,8 @@ def _worker(rank, world, port, n, nsteps, method_name, out_dir, chunks=1, own=Fa
         K = OracleSlabKernels(lay, Re=500.0, own=own)
         comm = ins.SlabComm(group2=dist.new_group(ranks=list(range(world))) if chunks > 1 else None)
         method = getattr(ins.RKMethods, method_name)()
-        st = ins.SlabStepper(method, lay, K, comm, chunks=chunks)
+        st = ins.SlabStepper(method, lay, K, comm, chunks=chunks, zsolve=zsolve)
+        assert st.zsolve == zsolve
         assert len(st.chunks) == min(chunks, lay.kxn) and st.packed == own and st.inkernel == (own and len(method.b) > 1)
         u = K.from_global(u0)
         for _ in range(nsteps):
@@ -44,14 +45,18 @@ def _worker(rank, world, port, n, nsteps, method_name, out_dir, chunks=1, own=Fa
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("method_name,chunks,own", [("RK44", 1, False), ("Wray3", 1, False), ("FE11", 1, False), ("RK44", 3, False),
-                                                    ("RK44", 1, True), ("RK44", 3, True), ("Wray3", 2, True), ("FE11", 1, True)])
-def test_slab_stepper_two_ranks_matches_single_domain(tmp_path, oracle, method_name, chunks, own):
-    """chunks > 1: the transposes pipelined over kx-chunks on two process groups; own: the packed-pass branch."""
+@pytest.mark.parametrize("method_name,chunks,own,zsolve,world",
+                         [("RK44", 1, False, "fft", 2), ("Wray3", 1, False, "fft", 2), ("FE11", 1, False, "fft", 2), ("RK44", 3, False, "fft", 2),
+                          ("RK44", 1, True, "fft", 2), ("RK44", 3, True, "fft", 2), ("Wray3", 2, True, "fft", 2), ("FE11", 1, True, "fft", 2),
+                          ("RK44", 1, False, "tridiag", 2), ("RK44", 1, True, "tridiag", 2), ("Wray3", 1, True, "tridiag", 2),
+                          ("FE11", 1, False, "tridiag", 2), ("RK44", 1, True, "tridiag", 3)])
+def test_slab_stepper_two_ranks_matches_single_domain(tmp_path, oracle, method_name, chunks, own, zsolve, world):
+    """chunks > 1: the transposes pipelined over kx-chunks on two process groups; own: the packed-pass branch;
+    zsolve = tridiag: no transposes, the z direction as distributed tridiagonal systems (one all-gather per solve)."""
     o = oracle
-    n, world, nsteps = (12, 8, 12), 2, 2
+    n, nsteps = (12, 6 * (world // 2 + world % 2) if world == 3 else 8, 12), 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, nsteps, method_name, str(tmp_path), chunks, own), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, nsteps, method_name, str(tmp_path), chunks, own, zsolve), nprocs=world, join=True)
     x = tuple(np.linspace(0.0, 1.0, ni + 1) for ni in n)
     so = o.make_setup(x, Re=500.0)
     ps = o.psolver_spectral(so)

@@ -21,8 +21,11 @@ def rell2(a, b):
     return float(np.sqrt(np.sum((a - b) ** 2)) / np.sqrt(np.sum(b**2)))
 
 
+@pytest.mark.parametrize("zsolve", ["fft", "tridiag"])
 @pytest.mark.parametrize("n", [(64, 32, 16), (70, 24, 20), (128, 16, 16)])  # last: 64-wide K1 (ins_flux64.hip), CORR = 2
-def test_one_rank_slab_equals_single_gpu_path(oracle, n):
+def test_one_rank_slab_equals_single_gpu_path(oracle, n, zsolve):
+    """zsolve = tridiag: the distributed tridiagonal z solve (csrc/ins_ztri.hip) with one rank is the whole periodic line —
+    it must reproduce the z-FFT solve of the single-GPU path."""
     _need_gpu()
     import ins_amd as ins
 
@@ -40,11 +43,12 @@ def test_one_rank_slab_equals_single_gpu_path(oracle, n):
     gc.collect()
     lay = ins.SlabLayout(n, 1, 0)
     K = ins.HipSlabKernels(lay, Re=800.0)
-    st = ins.SlabStepper(ins.RKMethods.RK44(), lay, K, ins.SlabComm())
+    st = ins.SlabStepper(ins.RKMethods.RK44(), lay, K, ins.SlabComm(), zsolve=zsolve)
+    assert st.zsolve == zsolve
     u = K.from_global(u0)
     for _ in range(2):
         st.step_(u, 0.01)
-    assert rell2(ins.to_numpy(u), uref) < 1e-12
+    assert rell2(ins.to_numpy(u), uref) < (1e-12 if zsolve == "fft" else 1e-11)
     assert st.max_abs_divergence(u) < 1e-10
 
 
@@ -54,7 +58,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, nsteps, out_dir, chunks=1):
+def _worker(rank, world, port, n, nsteps, out_dir, chunks=1, zsolve="fft"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -67,7 +71,8 @@ def _worker(rank, world, port, n, nsteps, out_dir, chunks=1):
         u0 = o.random_field(so, kp=2, seed=7)
         lay = ins.SlabLayout(n, world, rank)
         K = ins.HipSlabKernels(lay, Re=500.0, device="cuda:0")
-        st = ins.SlabStepper(ins.RKMethods.RK44(), lay, K, ins.SlabComm(), chunks=chunks)
+        st = ins.SlabStepper(ins.RKMethods.RK44(), lay, K, ins.SlabComm(), chunks=chunks, zsolve=zsolve)
+        assert st.zsolve == zsolve
         u = K.from_global(u0)
         for _ in range(nsteps):
             st.step_(u, 0.01)
@@ -79,15 +84,17 @@ def _worker(rank, world, port, n, nsteps, out_dir, chunks=1):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,chunks", [(2, (66, 16, 24), 1), (4, (66, 16, 24), 1), (2, (64, 16, 32), 1), (4, (64, 32, 32), 1),
-                                            (2, (64, 16, 32), 4), (2, (66, 16, 32), 3), (2, (128, 16, 32), 4)])
-def test_multi_rank_slab_on_one_gpu_matches_oracle(tmp_path, oracle, world, n, chunks):
+@pytest.mark.parametrize("world,n,chunks,zsolve", [(2, (66, 16, 24), 1, "fft"), (4, (66, 16, 24), 1, "fft"), (2, (64, 16, 32), 1, "fft"),
+                                                   (4, (64, 32, 32), 1, "fft"), (2, (64, 16, 32), 4, "fft"), (2, (66, 16, 32), 3, "fft"),
+                                                   (2, (128, 16, 32), 4, "fft"), (2, (64, 16, 32), 1, "tridiag"), (4, (64, 32, 32), 1, "tridiag"),
+                                                   (2, (66, 16, 24), 1, "tridiag"), (3, (128, 18, 24), 1, "tridiag"), (2, (128, 16, 32), 1, "tridiag")])
+def test_multi_rank_slab_on_one_gpu_matches_oracle(tmp_path, oracle, world, n, chunks, zsolve):
     """(66,16,24): rocFFT x/y + rocFFT z; power-of-two boxes: own x/y passes with the digit-reversed ky order split
     across ranks + the fused z kernel."""
     _need_gpu()
     o = oracle
     nsteps = 2
-    mp.spawn(_worker, args=(world, _free_port(), n, nsteps, str(tmp_path), chunks), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, nsteps, str(tmp_path), chunks, zsolve), nprocs=world, join=True)
     x = tuple(np.linspace(0.0, 1.0, ni + 1) for ni in n)
     so = o.make_setup(x, Re=500.0)
     ps = o.psolver_spectral(so)
