@@ -53,36 +53,58 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_doub
 // ---- pass 1: forward elimination + spike dot products -------------------------------------------------------------------
 // pivots 1/den_k = (r/c)(1 - E_k)/(1 - E_k r²), E_k = r^(2k+2);  gp_k = (g_k + c gp_{k-1}) / den_k
 // spikes v_k = (r^(k+1) - r^(m+1) r^(m-k)) / (1 - r^(2m+2)) = c (A_r⁻¹ e_0)_k,  w_k = v_{m-1-k}
-__global__ __launch_bounds__(256) void k_ztri_fwd(ZtriArgs a, double2* __restrict__ edge, double2* __restrict__ line0) {
-  const int kx = blockIdx.x * 64 + threadIdx.x, ky = blockIdx.y * 4 + threadIdx.y;
+// One work-item per REAL component of a line (re and im obey the same real recurrence): twice the parallelism of one per line,
+// which matters because a slab has only kxn·ny lines and every one is a serial march over the local planes.
+__global__ __launch_bounds__(256) void k_ztri_fwd(ZtriArgs a, double* __restrict__ edge, double* __restrict__ line0) {
+  const int t = blockIdx.x * 64 + threadIdx.x, ky = blockIdx.y * 4 + threadIdx.y;
+  const int kx = t >> 1;
   if (kx >= a.kxn || ky >= a.n1) return;
-  const long long lines = (long long)a.kxn * a.n1, l = kx + (long long)a.kxn * ky;
-  const long long ps = (long long)a.kxs * a.n1;
-  double2* x = a.data + kx + (long long)a.kxs * ky;
+  const long long lines2 = 2LL * a.kxn * a.n1, l2 = t + 2LL * a.kxn * ky;
+  const long long ps = 2LL * a.kxs * a.n1;
+  double* x = reinterpret_cast<double*>(a.data) + t + 2LL * a.kxs * ky;
   const double sxy = a.ax[kx] + a.ay[ky];
   if (sxy == 0.0) {  // the singular line: hand the scaled right-hand side to the gather, leave the rest to k_ztri_line0
-    for (int k = 0; k < a.m; ++k) line0[k] = a.scale * x[k * ps];
-    edge[l] = edge[lines + l] = make_double2(0.0, 0.0);
+    for (int k = 0; k < a.m; ++k) line0[2 * k + (t & 1)] = a.scale * x[k * ps];
+    edge[l2] = edge[lines2 + l2] = 0.0;
     return;
   }
   const LineConst L = line_const(sxy / a.c, a.m);
   const double rc = L.r / a.c, idc = 1.0 / (L.D * a.c);
   double E = L.r2, pa = L.r;
-  double2 gp = make_double2(0.0, 0.0), accF = gp, accL = gp;
-#pragma unroll 8
-  for (int k = 0; k < a.m; ++k) {
-    const double2 g = a.scale * x[k * ps];
-    const double inv = rc * (1.0 - E) / (1.0 - E * L.r2);
-    gp = inv * (g + a.c * gp);
-    x[k * ps] = gp;
-    const double pb = exp((a.m - k) * L.lnr);  // r^(m-k)
-    accF = accF + ((pa - L.rm1 * pb) * idc) * g;
-    accL = accL + ((pb - L.rm1 * pa) * idc) * g;
-    E *= L.r2;
-    pa *= L.r;
+  double gp = 0.0, accF = 0.0, accL = 0.0;
+  const double rinv = 1.0 / L.r;
+  // 16-plane chunks, double-buffered in registers: the loads of chunk c+1 are issued before the stores of chunk c (the compiler
+  // may not move a load above a store to the same array, and a load-compute-store chain per plane costs one HBM round trip each)
+  constexpr int CH = 16;
+  double buf[CH], nxt[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) buf[j] = x[(long long)min(j, a.m - 1) * ps];
+  for (int k0 = 0; k0 < a.m; k0 += CH) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) nxt[j] = x[(long long)min(k0 + CH + j, a.m - 1) * ps];
+    // r^(m-k) by a running product re-seeded from exp() every chunk: r >= ~0.1 on these grids, so a seed that underflows
+    // cannot become significant within 16 steps, and the product never has to climb out of an underflow
+    double pb = exp((a.m - k0) * L.lnr);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int k = k0 + j;
+      if (k < a.m) {
+        const double g = a.scale * buf[j];
+        const double inv = rc * (1.0 - E) / (1.0 - E * L.r2);
+        gp = inv * (g + a.c * gp);
+        x[k * ps] = gp;
+        accF += ((pa - L.rm1 * pb) * idc) * g;
+        accL += ((pb - L.rm1 * pa) * idc) * g;
+        E *= L.r2;
+        pa *= L.r;
+        pb *= rinv;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) buf[j] = nxt[j];
   }
-  edge[l] = accF;
-  edge[lines + l] = accL;
+  edge[l2] = accF;
+  edge[lines2 + l2] = accL;
 }
 
 // ---- interface: block-circulant 2P x 2P system per line, by a DFT over ranks ---------------------------------------------
@@ -141,27 +163,43 @@ __global__ __launch_bounds__(256) void k_ztri_iface(ZtriArgs a, const double2* _
 // ---- pass 2: back substitution with the interface values folded in -------------------------------------------------------
 // g̃ = g + c L_{r-1} e_0 + c F_{r+1} e_{m-1}  =>  gp̃_k = gp_k + c L φ_k (+ c F /den_{m-1} at k = m-1),  φ_k = r^(k+1)(1-r²)/(c(1-E_k r²))
 // p_{m-1} = gp̃_{m-1},  p_k = gp̃_k + (c/den_k) p_{k+1}
-__global__ __launch_bounds__(256) void k_ztri_bwd(ZtriArgs a, const double2* __restrict__ bc) {
-  const int kx = blockIdx.x * 64 + threadIdx.x, ky = blockIdx.y * 4 + threadIdx.y;
+__global__ __launch_bounds__(256) void k_ztri_bwd(ZtriArgs a, const double* __restrict__ bc) {
+  const int t = blockIdx.x * 64 + threadIdx.x, ky = blockIdx.y * 4 + threadIdx.y;
+  const int kx = t >> 1;
   if (kx >= a.kxn || ky >= a.n1) return;
-  const long long lines = (long long)a.kxn * a.n1, l = kx + (long long)a.kxn * ky;
-  const long long ps = (long long)a.kxs * a.n1;
-  double2* x = a.data + kx + (long long)a.kxs * ky;
+  const long long lines2 = 2LL * a.kxn * a.n1, l2 = t + 2LL * a.kxn * ky;
+  const long long ps = 2LL * a.kxs * a.n1;
+  double* x = reinterpret_cast<double*>(a.data) + t + 2LL * a.kxs * ky;
   const double sxy = a.ax[kx] + a.ay[ky];
   if (sxy == 0.0) return;  // k_ztri_line0
   const LineConst L = line_const(sxy / a.c, a.m);
-  const double2 Lp = bc[l], Fn = bc[lines + l];
+  const double Lp = bc[l2], Fn = bc[lines2 + l2];
   const double omr2 = 1.0 - L.r2;
-  double2 p = make_double2(0.0, 0.0);
-#pragma unroll 8
-  for (int k = a.m - 1; k >= 0; --k) {
-    const double pa = exp((k + 1.0) * L.lnr);  // r^(k+1)
-    const double q = 1.0 / (1.0 - pa * pa * L.r2);
-    const double cinv = L.r * (1.0 - pa * pa) * q;  // c / den_k
-    double2 v = x[k * ps] + (pa * omr2 * q) * Lp;    // + c L φ_k
-    if (k == a.m - 1) v = v + cinv * Fn;
-    p = v + cinv * p;
-    x[k * ps] = p;
+  double p = 0.0;
+  const double rinv = 1.0 / L.r;
+  constexpr int CH = 16;  // double-buffered 16-plane chunks, see k_ztri_fwd
+  double buf[CH], nxt[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) buf[j] = x[(long long)max(a.m - 1 - j, 0) * ps];
+  for (int k0 = a.m - 1; k0 >= 0; k0 -= CH) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) nxt[j] = x[(long long)max(k0 - CH - j, 0) * ps];
+    double pa = exp((k0 + 1.0) * L.lnr);  // r^(k+1), running product re-seeded every chunk
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int k = k0 - j;
+      if (k >= 0) {
+        const double q = 1.0 / (1.0 - pa * pa * L.r2);
+        const double cinv = L.r * (1.0 - pa * pa) * q;  // c / den_k
+        double v = buf[j] + (pa * omr2 * q) * Lp;        // + c L φ_k
+        if (k == a.m - 1) v += cinv * Fn;
+        p = v + cinv * p;
+        x[k * ps] = p;
+        pa *= rinv;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) buf[j] = nxt[j];
   }
 }
 
@@ -240,9 +278,8 @@ int ins_k_ztri_forward(double* work, int kxn, int kxs, int n1, int m, int nranks
                        double scale, double* edge, hipStream_t s) {
   ZtriArgs a{reinterpret_cast<double2*>(work), kxn, kxs, n1, m, nranks, rank, ax, ay, c, scale};
   const long long lines = (long long)kxn * n1;
-  double2* e = reinterpret_cast<double2*>(edge);
-  dim3 block(64, 4), grid(cdiv(kxn, 64), cdiv(n1, 4));
-  hipLaunchKernelGGL(k_ztri_fwd, grid, block, 0, s, a, e, e + 2 * lines);
+  dim3 block(64, 4), grid(cdiv(2 * kxn, 64), cdiv(n1, 4));  // one work-item per real component
+  hipLaunchKernelGGL(k_ztri_fwd, grid, block, 0, s, a, edge, edge + 4 * lines);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -259,7 +296,7 @@ int ins_k_ztri_finish(double* work, int kxn, int kxs, int n1, int m, int nranks,
   double2* b = reinterpret_cast<double2*>(bc);
   dim3 block(64, 4), grid(cdiv(kxn, 64), cdiv(n1, 4));
   hipLaunchKernelGGL(k_ztri_iface, grid, block, 0, s, a, ea, stride, b);
-  hipLaunchKernelGGL(k_ztri_bwd, grid, block, 0, s, a, (const double2*)b);
+  hipLaunchKernelGGL(k_ztri_bwd, dim3(cdiv(2 * kxn, 64), cdiv(n1, 4)), block, 0, s, a, (const double*)bc);
   hipLaunchKernelGGL(k_ztri_line0, dim3(1), dim3(64), 0, s, a, ea, stride, 2 * lines);
   INS_LAUNCH_CHECK();
   return INS_OK;
