@@ -49,9 +49,11 @@ def run_distributed(args, ins):
         n = (args.n, args.n, args.n * world)
     lay = ins.SlabLayout(n, world, rank)
     K = ins.HipSlabKernels(lay, Re=1000.0, device=dev)
-    # second communicator so that back-transposes of finished kx-chunks run beside forward ones (full-duplex xGMI links)
+    # zsolve (INS_SLAB_ZSOLVE): "tridiag" (default for > 1 rank) needs no transposes; "fft" pipelines them over kx-chunks on a second
+    # communicator so that back-transposes of finished chunks run beside forward ones (full-duplex xGMI links)
+    zs = os.environ.get("INS_SLAB_ZSOLVE") or ("tridiag" if world > 1 else "fft")
     nchunks = int(os.environ.get("INS_SLAB_CHUNKS", "4"))
-    g2 = dist.new_group(ranks=list(range(world))) if nchunks > 1 else None
+    g2 = dist.new_group(ranks=list(range(world))) if (nchunks > 1 and zs == "fft") else None
     comm = ins.SlabComm(group2=g2)
     st = ins.SlabStepper(ins.RKMethods.RK44(), lay, K, comm, chunks=nchunks)
     u = K.vector()
@@ -90,8 +92,10 @@ def run_distributed(args, ins):
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"TaylorGreenVortex3D {n[0]}x{n[1]}x{n[2]} periodic fp64, RK44 + distributed spectral Poisson, dt=1e-3, Re=1e3",
-                       "grid": list(n), "decomposition": f"z-slabs x{world} (256^3 cells per GPU), RCCL halo + all-to-all transposes"},
-            "check": {"max_abs_div_times_dx": div * (1.0 / n[0]), "finite": finite, "backend": backend, "kx_chunks": len(st.chunks)},
+                       "grid": list(n), "decomposition": f"z-slabs x{world} (256^3 cells per GPU), RCCL halo planes + "
+                                        + ("one all-gather of interface values per solve (distributed tridiagonal z solve)" if st.zsolve == "tridiag"
+                                           else "all-to-all transposes around the z-FFT")},
+            "check": {"max_abs_div_times_dx": div * (1.0 / n[0]), "finite": finite, "backend": backend, "zsolve": st.zsolve, "kx_chunks": len(st.chunks)},
         }
         print(json.dumps(out))
     dist.destroy_process_group()

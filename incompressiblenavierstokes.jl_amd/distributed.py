@@ -85,6 +85,15 @@ class SlabComm:
             for (t, _), (h, _) in zip(recvs, hr):
                 t.copy_(h)
 
+    def exchange_async(self, sends, recvs):
+        """Like exchange(), but returns the outstanding requests (RCCL: the transfer runs beside later kernels of the current
+        stream; `wait()` orders the stream after it).  Staged / single-rank modes complete immediately."""
+        if self.world == 1 or any(self._stage(t) for t, _ in sends):
+            self.exchange(sends, recvs)
+            return []
+        ops = [dist.P2POp(dist.isend, t, d, self.group) for t, d in sends] + [dist.P2POp(dist.irecv, t, s, self.group) for t, s in recvs]
+        return dist.batch_isend_irecv(ops)
+
     def all_to_all(self, recv, send):
         if self.world == 1:
             recv.copy_(send)
@@ -346,6 +355,15 @@ class SlabStepper:
                 recvs.append((K.plane(u, c, lay.nzl + 1), lay.next))
         self.comm.exchange(sends, recvs)
 
+    def halo_u_rest_async(self, u):
+        """Every ghost plane of halo_u(u) except the downward w plane (which halo_u(u, comps=(2,), down_only=True) moved
+        already), started asynchronously: the stage velocity u* is final once the stencil kernel has run, so these planes can
+        travel while the Poisson solve computes."""
+        lay, K = self.lay, self.k
+        sends = [(K.plane(u, c, lay.nzl), lay.next) for c in (0, 1)] + [(K.plane(u, c, 1), lay.prev) for c in (0, 1, 2)]
+        recvs = [(K.plane(u, c, 0), lay.prev) for c in (0, 1)] + [(K.plane(u, c, lay.nzl + 1), lay.next) for c in (0, 1, 2)]
+        return self.comm.exchange_async(sends, recvs)
+
     def halo_p(self):
         """First local pI plane -> previous rank's `p_top`."""
         lay, K = self.lay, self.k
@@ -362,10 +380,11 @@ class SlabStepper:
         self.comm.exchange(sends, recvs)
 
     # -- projection (pressure.jl:69-82 on slabs) ---------------------------------------------------
-    def project_(self, u, apply=True):
+    def project_(self, u, apply=True, w_halo_done=False):
         """apply=False: solve only (pI <- p); the gradient-subtract is left to the next stage's stencil kernel."""
         K = self.k
-        self.halo_u(u, comps=(2,), down_only=True)  # divergence needs w[I - e_z] only (operators.jl:122)
+        if not w_halo_done:
+            self.halo_u(u, comps=(2,), down_only=True)  # divergence needs w[I - e_z] only (operators.jl:122)
         if self.zsolve == "tridiag":
             if self.packed:  # power-of-two box: Ω·div(u) formed inside the x pass
                 K.ztri_forward(u, True, self.work, self.edge)
@@ -451,11 +470,17 @@ class SlabStepper:
             else:
                 K.stage_momentum(u_in, self.ku[i] if write_k else None, None if i == 0 else u, out, coefs, ks, Δt * A[i, i])
             if self.inkernel and not last:
-                self.project_(out, apply=False)
+                # u* is final here (its correction happens inside the next stencil kernel): the w plane the divergence needs
+                # goes first, the other five ghost planes travel while the Poisson solve runs
+                self.halo_u(out, comps=(2,), down_only=True)
+                pending = self.halo_u_rest_async(out)
+                self.project_(out, apply=False, w_halo_done=True)
                 self.halo_p_ext()
+                for req in pending:
+                    req.wait()
             else:
                 self.project_(out)
-            self.halo_u(out)  # z ghost planes for the next stencil (x/y ghosts: K4 images, or periodic addressing in-kernel)
+                self.halo_u(out)  # z ghost planes for the next stencil (x/y ghosts: K4 images, or periodic addressing in-kernel)
             u_in = out
         if ns == 1:
             u.copy_(self.ub[0])
