@@ -46,6 +46,12 @@ __device__ __forceinline__ LineConst line_const(double s, int m) {  // s = (âx 
   return L;
 }
 
+// reciprocal: hardware estimate + one Newton step (the quotient feeds a recurrence that is itself only accurate to rounding)
+__device__ __forceinline__ double frcp(double x) {
+  const double y = __builtin_amdgcn_rcp(x);
+  return y * (2.0 - x * y);
+}
+
 __device__ __forceinline__ double2 operator*(double a, double2 v) { return make_double2(a * v.x, a * v.y); }
 __device__ __forceinline__ double2 operator+(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -56,10 +62,11 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_doub
 // One work-item per REAL component of a line (re and im obey the same real recurrence): twice the parallelism of one per line,
 // which matters because a slab has only kxn·ny lines and every one is a serial march over the local planes.
 __global__ __launch_bounds__(256) void k_ztri_fwd(ZtriArgs a, double* __restrict__ edge, double* __restrict__ line0) {
-  const int t = blockIdx.x * 64 + threadIdx.x, ky = blockIdx.y * 4 + threadIdx.y;
+  // flat index over (ky, kx, re/im): a 256-wide workgroup reads 2 KB of consecutive memory per plane
+  const long long lines2 = 2LL * a.kxn * a.n1, l2 = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (l2 >= lines2) return;
+  const int ky = (int)(l2 / (2 * a.kxn)), t = (int)(l2 - (long long)ky * 2 * a.kxn);
   const int kx = t >> 1;
-  if (kx >= a.kxn || ky >= a.n1) return;
-  const long long lines2 = 2LL * a.kxn * a.n1, l2 = t + 2LL * a.kxn * ky;
   const long long ps = 2LL * a.kxs * a.n1;
   double* x = reinterpret_cast<double*>(a.data) + t + 2LL * a.kxs * ky;
   const double sxy = a.ax[kx] + a.ay[ky];
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256) void k_ztri_fwd(ZtriArgs a, double* __restrict
   const LineConst L = line_const(sxy / a.c, a.m);
   const double rc = L.r / a.c, idc = 1.0 / (L.D * a.c);
   double E = L.r2, pa = L.r;
-  double gp = 0.0, accF = 0.0, accL = 0.0;
+  double gp = 0.0, SA = 0.0, SB = 0.0;  // Σ r^(k+1) g_k, Σ r^(m-k) g_k
   const double rinv = 1.0 / L.r;
   // 16-plane chunks, double-buffered in registers: the loads of chunk c+1 are issued before the stores of chunk c (the compiler
   // may not move a load above a store to the same array, and a load-compute-store chain per plane costs one HBM round trip each)
@@ -90,11 +97,11 @@ __global__ __launch_bounds__(256) void k_ztri_fwd(ZtriArgs a, double* __restrict
       const int k = k0 + j;
       if (k < a.m) {
         const double g = a.scale * buf[j];
-        const double inv = rc * (1.0 - E) / (1.0 - E * L.r2);
+        const double inv = rc * (1.0 - E) * frcp(1.0 - E * L.r2);
         gp = inv * (g + a.c * gp);
         x[k * ps] = gp;
-        accF += ((pa - L.rm1 * pb) * idc) * g;
-        accL += ((pb - L.rm1 * pa) * idc) * g;
+        SA += pa * g;
+        SB += pb * g;
         E *= L.r2;
         pa *= L.r;
         pb *= rinv;
@@ -103,8 +110,8 @@ __global__ __launch_bounds__(256) void k_ztri_fwd(ZtriArgs a, double* __restrict
 #pragma unroll
     for (int j = 0; j < CH; ++j) buf[j] = nxt[j];
   }
-  edge[l2] = accF;
-  edge[lines2 + l2] = accL;
+  edge[l2] = idc * (SA - L.rm1 * SB);           // Σ v_k g_k / c
+  edge[lines2 + l2] = idc * (SB - L.rm1 * SA);  // Σ w_k g_k / c
 }
 
 // ---- interface: block-circulant 2P x 2P system per line, by a DFT over ranks ---------------------------------------------
@@ -164,10 +171,11 @@ __global__ __launch_bounds__(256) void k_ztri_iface(ZtriArgs a, const double2* _
 // g̃ = g + c L_{r-1} e_0 + c F_{r+1} e_{m-1}  =>  gp̃_k = gp_k + c L φ_k (+ c F /den_{m-1} at k = m-1),  φ_k = r^(k+1)(1-r²)/(c(1-E_k r²))
 // p_{m-1} = gp̃_{m-1},  p_k = gp̃_k + (c/den_k) p_{k+1}
 __global__ __launch_bounds__(256) void k_ztri_bwd(ZtriArgs a, const double* __restrict__ bc) {
-  const int t = blockIdx.x * 64 + threadIdx.x, ky = blockIdx.y * 4 + threadIdx.y;
+  // flat index over (ky, kx, re/im): a 256-wide workgroup reads 2 KB of consecutive memory per plane
+  const long long lines2 = 2LL * a.kxn * a.n1, l2 = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (l2 >= lines2) return;
+  const int ky = (int)(l2 / (2 * a.kxn)), t = (int)(l2 - (long long)ky * 2 * a.kxn);
   const int kx = t >> 1;
-  if (kx >= a.kxn || ky >= a.n1) return;
-  const long long lines2 = 2LL * a.kxn * a.n1, l2 = t + 2LL * a.kxn * ky;
   const long long ps = 2LL * a.kxs * a.n1;
   double* x = reinterpret_cast<double*>(a.data) + t + 2LL * a.kxs * ky;
   const double sxy = a.ax[kx] + a.ay[ky];
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(256) void k_ztri_bwd(ZtriArgs a, const double* __re
     for (int j = 0; j < CH; ++j) {
       const int k = k0 - j;
       if (k >= 0) {
-        const double q = 1.0 / (1.0 - pa * pa * L.r2);
+        const double q = frcp(1.0 - pa * pa * L.r2);
         const double cinv = L.r * (1.0 - pa * pa) * q;  // c / den_k
         double v = buf[j] + (pa * omr2 * q) * Lp;        // + c L φ_k
         if (k == a.m - 1) v += cinv * Fn;
@@ -278,8 +286,7 @@ int ins_k_ztri_forward(double* work, int kxn, int kxs, int n1, int m, int nranks
                        double scale, double* edge, hipStream_t s) {
   ZtriArgs a{reinterpret_cast<double2*>(work), kxn, kxs, n1, m, nranks, rank, ax, ay, c, scale};
   const long long lines = (long long)kxn * n1;
-  dim3 block(64, 4), grid(cdiv(2 * kxn, 64), cdiv(n1, 4));  // one work-item per real component
-  hipLaunchKernelGGL(k_ztri_fwd, grid, block, 0, s, a, edge, edge + 4 * lines);
+  hipLaunchKernelGGL(k_ztri_fwd, dim3(cdiv(2 * lines, 256)), dim3(256), 0, s, a, edge, edge + 4 * lines);  // one work-item per real component
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -296,7 +303,7 @@ int ins_k_ztri_finish(double* work, int kxn, int kxs, int n1, int m, int nranks,
   double2* b = reinterpret_cast<double2*>(bc);
   dim3 block(64, 4), grid(cdiv(kxn, 64), cdiv(n1, 4));
   hipLaunchKernelGGL(k_ztri_iface, grid, block, 0, s, a, ea, stride, b);
-  hipLaunchKernelGGL(k_ztri_bwd, dim3(cdiv(2 * kxn, 64), cdiv(n1, 4)), block, 0, s, a, (const double*)bc);
+  hipLaunchKernelGGL(k_ztri_bwd, dim3(cdiv(2 * lines, 256)), dim3(256), 0, s, a, (const double*)bc);
   hipLaunchKernelGGL(k_ztri_line0, dim3(1), dim3(64), 0, s, a, ea, stride, 2 * lines);
   INS_LAUNCH_CHECK();
   return INS_OK;
