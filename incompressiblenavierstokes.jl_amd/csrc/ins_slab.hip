@@ -28,6 +28,7 @@ struct ins_slab_fft {
   double* ay_full = nullptr;
   double cz = 0.0;
   double* ztri_bc = nullptr;
+  int kxs = 0;  // row stride of `work` on the transpose-free route: kxn rounded up to whole 128-B lines with the own passes
 };
 
 int ins_k_ztri_forward(double* work, int kxn, int kxs, int n1, int m, int nranks, int rank, const double* ax, const double* ay, double c,
@@ -154,6 +155,7 @@ extern "C" int ins_slab_fft_create(const int32_t np[3], const double h[3], int r
   for (int k = 0; k < S->kxn; ++k) ax[k] = symbol(0, k);
   S->ownfft = ins_ownfft_supported(np);
   S->cz = om / (h[2] * h[2]);
+  S->kxs = S->ownfft ? ((S->kxn + 7) & ~7) : S->kxn;
   if (S->ownfft) {  // the own y pass leaves ky in digit-reversed storage order: slice the permuted symbol vector
     std::vector<double> full(np[1]);
     for (int k = 0; k < np[1]; ++k) full[k] = symbol(1, k);
@@ -239,7 +241,7 @@ extern "C" int ins_slab_fft_destroy(ins_slab_fft_t* S) {
 extern "C" int ins_slab_fft_sizes(const ins_slab_fft_t* S, int64_t* real_elems, int64_t* complex_elems) {
   INS_REQUIRE(S && real_elems && complex_elems, "null argument");
   *real_elems = (int64_t)S->np[0] * S->np[1] * S->nzl;
-  *complex_elems = (int64_t)S->kxn * S->np[1] * S->nzl;  // == kxn * nyl * nz
+  *complex_elems = (int64_t)S->kxs * S->np[1] * S->nzl;  // >= kxn * nyl * nz, the transposed buffers of the FFT route
   return INS_OK;
 }
 
@@ -378,21 +380,26 @@ extern "C" int ins_slab_ztri_forward(ins_slab_fft_t* S, const ins_grid_t* G, con
   if (from_u) {
     INS_REQUIRE(S->ownfft, "forming the right-hand side inside the x pass needs a power-of-two box");
     INS_REQUIRE(G && G->g.D == 3 && G->g.N[0] == S->np[0] + 2 && G->g.N[1] == S->np[1] + 2 && G->g.N[2] == S->nzl + 2, "grid does not match the slab");
-    if ((rc = ins_k_ownfft_xfwd(G, src, 2, work, S->np[0], S->np[1], S->nzl, S->tw_x, s))) return rc;
-    if ((rc = ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s))) return rc;
+    if ((rc = ins_k_ownfft_xfwd(G, src, 2, work, S->np[0], S->np[1], S->nzl, S->tw_x, s, S->kxs))) return rc;
+    if ((rc = ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s, S->kxs))) return rc;
+  } else if (S->ownfft) {
+    if ((rc = ins_k_ownfft_xfwd(nullptr, src, 0, work, S->np[0], S->np[1], S->nzl, S->tw_x, s, S->kxs))) return rc;
+    if ((rc = ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s, S->kxs))) return rc;
   } else if ((rc = slab_xy_forward(S, const_cast<double*>(src), work, s)))
     return rc;
   const double scale = -1.0 / ((double)S->np[0] * S->np[1]);
-  return ins_k_ztri_forward(work, S->kxn, S->kxn, S->np[1], S->nzl, S->nranks, S->rank, S->ax, S->ay_full, S->cz, scale, edge, s);
+  return ins_k_ztri_forward(work, S->kxn, S->kxs, S->np[1], S->nzl, S->nranks, S->rank, S->ax, S->ay_full, S->cz, scale, edge, s);
 }
 
 // edges_all = the all-gathered edge buffers (rank-major).  Interface solve, back substitution, inverse y / x transforms -> pI.
 extern "C" int ins_slab_ztri_finish(ins_slab_fft_t* S, double* work, const double* edges_all, double* pI, void* stream) {
   INS_REQUIRE(S && work && edges_all && pI, "null argument");
   hipStream_t s = as_stream(stream);
-  int rc = ins_k_ztri_finish(work, S->kxn, S->kxn, S->np[1], S->nzl, S->nranks, S->rank, S->ax, S->ay_full, S->cz, edges_all, S->ztri_bc, s);
+  int rc = ins_k_ztri_finish(work, S->kxn, S->kxs, S->np[1], S->nzl, S->nranks, S->rank, S->ax, S->ay_full, S->cz, edges_all, S->ztri_bc, s);
   if (rc) return rc;
-  return slab_xy_inverse(S, work, pI, s);
+  if (!S->ownfft) return slab_xy_inverse(S, work, pI, s);
+  if ((rc = ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, true, s, S->kxs))) return rc;
+  return ins_k_ownfft_xinv(work, pI, S->np[0], S->np[1], S->nzl, S->tw_x, s, S->kxs);
 }
 
 /* 1 when kx chunks are supported (power-of-two nz -> fused z kernel). */
