@@ -452,12 +452,8 @@ static int launch_flux(const ins_grid* G, const double* u, double* F, const RkEp
     hipLaunchKernelGGL((k_momentum_flux<R, true, false, XW, FUSE, 0>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
   else if (!masked)
     hipLaunchKernelGGL((k_momentum_flux<R, false, false, XW, FUSE, 0>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
-  else if (!FUSE)
-    hipLaunchKernelGGL((k_momentum_flux<RC, false, true, XW, false, 0>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
-  else {
-    ins_set_error("fused RK epilogue needs an all-periodic grid");
-    return INS_ERR_UNSUPPORTED;
-  }
+  else  // masked: the epilogue leaves u* = ustart (+ 0) on volumes that are no DOF, apply_bc_u! sets them afterwards as always
+    hipLaunchKernelGGL((k_momentum_flux<RC, false, true, XW, FUSE, 0>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }

@@ -11,6 +11,7 @@
 #include <rocblas/rocblas.h>
 
 #include <cmath>
+#include <vector>
 
 #include "ins_internal.h"
 
@@ -21,49 +22,67 @@ struct ins_fdm {
   double* V[3] = {nullptr, nullptr, nullptr};    // n[a] x n[a], column-major, Dα-orthonormal eigenvectors
   double* lam[3] = {nullptr, nullptr, nullptr};  // eigenvalues (<= 0)
   double *a = nullptr, *b = nullptr;             // two n0*n1*n2 work arrays
-  double* sums = nullptr;                        // partial sums for the mean shift
+  double* sums = nullptr;                        // [0..4095] block partials of Σ p, [4096] mean(f), [4097] mean(p)
+  double* ones[3] = {nullptr, nullptr, nullptr};  // Vαᵀ 1: (Vx⊗Vy⊗Vz)ᵀ 1 = ones_x ⊗ ones_y ⊗ ones_z
+  long long null_index = 0;                      // storage index of the null mode (λx = λy = λz = 0)
+  double null_scale = 1.0;                       // V₀ = null_scale · 1  =>  Σ f = q[null] / null_scale
   bool singular = true;
   double lam_tol = 0.0;
 };
 
 namespace {
 
-// q /= (λx + λy + λz), null mode -> 0
+// Singular systems (no PressureBC side) are handled in eigen-space, where both gauges are rank-one:
+//   mean(f) removal:  f - m·1  <=>  q - m·(Vᵀ1),  Vᵀ1 = ox ⊗ oy ⊗ oz,  and  Σ f = q[null] / null_scale  (V₀ is the constant vector);
+//   mean(p) = (Vᵀ1)ᵀ q' / n, accumulated while q' is written — so no pass over f or p is spent on either.
+__global__ void k_fdm_null(const double* __restrict__ q, long long null_index, double inv, double* __restrict__ sums) {
+  sums[4096] = q[null_index] * inv;  // mean(f)
+}
+
+// q' = (q - mean(f)·ox oy oz) / (λx + λy + λz), null mode -> 0; block partials of Σ ox oy oz q'
 __global__ __launch_bounds__(256) void k_fdm_scale(double* __restrict__ q, const double* __restrict__ lx, const double* __restrict__ ly,
-                                                   const double* __restrict__ lz, int n0, int n1, int n2, double tol) {
+                                                   const double* __restrict__ lz, const double* __restrict__ ox, const double* __restrict__ oy,
+                                                   const double* __restrict__ oz, int n0, int n1, int n2, double tol, int singular,
+                                                   double* __restrict__ sums) {
+  __shared__ double lds[4];
   const long long total = (long long)n0 * n1 * n2;
+  const double mf = singular ? sums[4096] : 0.0;
+  double acc = 0.0;
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
     const int i = (int)(t % n0);
     const long long r = t / n0;
     const int j = (int)(r % n1), k = (int)(r / n1);
     double lam = lx[i] + ly[j];
     if (lz) lam += lz[k];
-    q[t] = (fabs(lam) <= tol) ? 0.0 : q[t] / lam;
+    double v = q[t];
+    if (singular) {
+      double o = ox[i] * oy[j];
+      if (oz) o *= oz[k];
+      v = (fabs(lam) <= tol) ? 0.0 : (v - mf * o) / lam;
+      acc += o * v;
+    } else {
+      v /= lam;
+    }
+    q[t] = v;
+  }
+  if (singular) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
   }
 }
 
-__global__ __launch_bounds__(256) void k_fdm_partial_sum(const double* __restrict__ p, long long n, double* __restrict__ partial) {
+__global__ __launch_bounds__(256) void k_fdm_mean(double* __restrict__ sums, int nblk, double inv_n) {
   __shared__ double lds[4];
   double acc = 0.0;
-  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) acc += p[t];
+  for (int b = threadIdx.x; b < nblk; b += 256) acc += sums[b];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
-}
-
-// p -= mean, mean from the per-block partial sums (no host round trip)
-__global__ __launch_bounds__(256) void k_fdm_shift(double* __restrict__ p, long long n, const double* __restrict__ partial, int nblk) {
-  __shared__ double mean;
-  if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[b];
-    mean = s / (double)n;
-  }
-  __syncthreads();
-  const double m = mean;
-  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) p[t] -= m;
+  if (threadIdx.x == 0) sums[4097] = (lds[0] + lds[1] + lds[2] + lds[3]) * inv_n;  // mean(p), subtracted by the consumer
 }
 
 #define INS_BLAS_TRY(expr)                                                                     \
@@ -83,6 +102,7 @@ int ins_fdm_destroy(ins_fdm* F) {
   for (int a = 0; a < 3; ++a) {
     if (F->V[a]) (void)hipFree(F->V[a]);
     if (F->lam[a]) (void)hipFree(F->lam[a]);
+    if (F->ones[a]) (void)hipFree(F->ones[a]);
   }
   if (F->a) (void)hipFree(F->a);
   if (F->b) (void)hipFree(F->b);
@@ -106,8 +126,20 @@ int ins_fdm_create(int D, const int n[3], const double* const V[3], const double
          hipMemcpy(F->V[a], V[a], (size_t)n[a] * n[a] * 8, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(F->lam[a], lam[a], (size_t)n[a] * 8, hipMemcpyHostToDevice) == hipSuccess;
     for (int i = 0; i < n[a]; ++i) lmax = std::fmax(lmax, std::fabs(lam[a][i]));
+    // Vαᵀ 1 and the null mode of this direction (largest eigenvalue, ~0 when the system is singular)
+    std::vector<double> o(n[a], 0.0);
+    int inull = 0;
+    for (int j = 0; j < n[a]; ++j) {
+      for (int i = 0; i < n[a]; ++i) o[j] += V[a][i + (size_t)n[a] * j];
+      if (std::fabs(lam[a][j]) < std::fabs(lam[a][inull])) inull = j;
+    }
+    F->null_index += (long long)inull * (a == 0 ? 1 : (a == 1 ? n[0] : (long long)n[0] * n[1]));
+    F->null_scale *= V[a][(size_t)n[a] * inull];
+    ok = ok && hipMalloc(&F->ones[a], (size_t)n[a] * 8) == hipSuccess &&
+         hipMemcpy(F->ones[a], o.data(), (size_t)n[a] * 8, hipMemcpyHostToDevice) == hipSuccess;
   }
-  ok = ok && hipMalloc(&F->a, total * 8) == hipSuccess && hipMalloc(&F->b, total * 8) == hipSuccess && hipMalloc(&F->sums, 1024 * 8) == hipSuccess;
+  ok = ok && hipMalloc(&F->a, total * 8) == hipSuccess && hipMalloc(&F->b, total * 8) == hipSuccess && hipMalloc(&F->sums, 4098 * 8) == hipSuccess &&
+       hipMemset(F->sums, 0, 4098 * 8) == hipSuccess;
   if (!ok) {
     ins_set_error("ins_fdm_create: allocation / upload failed");
     ins_fdm_destroy(F);
@@ -126,13 +158,7 @@ int ins_fdm_solve(ins_fdm* F, hipStream_t s) {
   INS_BLAS_TRY(rocblas_set_stream(F->h, s));
   INS_BLAS_TRY(rocblas_set_pointer_mode(F->h, rocblas_pointer_mode_host));
   double *x = F->a, *y = F->b;
-  const int nblk = (int)std::min<long long>((total + 255) / 256, 1024);
-  const unsigned nshift = (unsigned)std::min<long long>((total + 255) / 256, 4096);
-  if (F->singular) {  // bordered system: L p = f - mean(f) e  (λ = e'f / e'e), which makes the right-hand side solvable
-    hipLaunchKernelGGL(k_fdm_partial_sum, dim3(nblk), dim3(256), 0, s, F->a, total, F->sums);
-    hipLaunchKernelGGL(k_fdm_shift, dim3(nshift), dim3(256), 0, s, F->a, total, F->sums, nblk);
-    INS_LAUNCH_CHECK();
-  }
+  const int nblk = (int)std::min<long long>((total + 255) / 256, 4096);
   // forward: q = (Vxᵀ ⊗ Vyᵀ ⊗ Vzᵀ) f
   INS_BLAS_TRY(rocblas_dgemm(F->h, rocblas_operation_transpose, rocblas_operation_none, n0, n1 * n2, n0, &one, F->V[0], n0, x, n0, &zero, y, n0));
   INS_BLAS_TRY(rocblas_dgemm_strided_batched(F->h, rocblas_operation_none, rocblas_operation_none, n0, n1, n1, &one, y, n0, n01, F->V[1], n1, 0,
@@ -143,8 +169,10 @@ int ins_fdm_solve(ins_fdm* F, hipStream_t s) {
     std::swap(x, y);
   }
   // x holds Vᵀf
-  hipLaunchKernelGGL(k_fdm_scale, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, s, x, F->lam[0], F->lam[1],
-                     F->D == 3 ? F->lam[2] : nullptr, n0, n1, n2, F->lam_tol);
+  if (F->singular) hipLaunchKernelGGL(k_fdm_null, dim3(1), dim3(1), 0, s, x, F->null_index, 1.0 / (F->null_scale * (double)total), F->sums);
+  hipLaunchKernelGGL(k_fdm_scale, dim3(nblk), dim3(256), 0, s, x, F->lam[0], F->lam[1], F->D == 3 ? F->lam[2] : nullptr, F->ones[0], F->ones[1],
+                     F->D == 3 ? F->ones[2] : nullptr, n0, n1, n2, F->lam_tol, F->singular ? 1 : 0, F->sums);
+  if (F->singular) hipLaunchKernelGGL(k_fdm_mean, dim3(1), dim3(256), 0, s, F->sums, nblk, 1.0 / (double)total);
   INS_LAUNCH_CHECK();
   // backward: p = (Vx ⊗ Vy ⊗ Vz) q
   if (F->D == 3) {
@@ -157,12 +185,10 @@ int ins_fdm_solve(ins_fdm* F, hipStream_t s) {
   INS_BLAS_TRY(rocblas_dgemm(F->h, rocblas_operation_none, rocblas_operation_none, n0, n1 * n2, n0, &one, F->V[0], n0, y, n0, &zero, x, n0));
   // x is F->a when D == 3 (two swaps) ... keep the result in F->a in every case
   if (x != F->a) INS_HIP_TRY(hipMemcpyAsync(F->a, x, total * 8, hipMemcpyDeviceToDevice, s));
-  if (F->singular) {  // e'p = 0, the bordered system's constraint (pressure.jl:133-140)
-    hipLaunchKernelGGL(k_fdm_partial_sum, dim3(nblk), dim3(256), 0, s, F->a, total, F->sums);
-    hipLaunchKernelGGL(k_fdm_shift, dim3(nshift), dim3(256), 0, s, F->a, total, F->sums, nblk);
-    INS_LAUNCH_CHECK();
-  }
   return INS_OK;
 }
 
 double* ins_fdm_buffer(ins_fdm* F) { return F->a; }
+
+// device scalar mean(p[Ip]) of the last solve: the consumer of the buffer subtracts it (e'p = 0, pressure.jl:133-140); nullptr when L is regular
+const double* ins_fdm_mean(ins_fdm* F) { return F->singular ? F->sums + 4097 : nullptr; }

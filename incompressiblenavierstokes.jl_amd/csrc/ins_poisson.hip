@@ -5,6 +5,7 @@
 //   project : for the spectral solver the ghost strip / re-pad copies, scalewithvolume! and the periodic
 //             apply_bc_p! are folded into the divergence and gradient kernels.
 #include <cmath>
+#include <cstdlib>
 
 #include "ins_internal.h"
 
@@ -36,7 +37,8 @@ __global__ __launch_bounds__(256) void k_div_to_pI(GridDev g, const double* __re
 
 // copyto!(pI, view(p, Ip))  /  copyto!(view(p, Ip), pI)                        pressure.jl:320, 347
 template <int D, bool PACK>
-__global__ __launch_bounds__(256) void k_pack(GridDev g, double* __restrict__ p, double* __restrict__ pI, int n0, int n1) {
+__global__ __launch_bounds__(256) void k_pack(GridDev g, double* __restrict__ p, double* __restrict__ pI, int n0, int n1,
+                                              const double* __restrict__ shift = nullptr) {
   const int ii = blockIdx.x * 64 + threadIdx.x;
   const int jj = blockIdx.y * 4 + threadIdx.y;
   const int kk = D == 3 ? (int)blockIdx.z : 0;
@@ -46,7 +48,62 @@ __global__ __launch_bounds__(256) void k_pack(GridDev g, double* __restrict__ p,
   if (PACK)
     pI[q] = p[c];
   else
-    p[c] = pI[q];
+    p[c] = shift ? pI[q] - *shift : pI[q];
+}
+
+// psolver_direct inside project!: copyto!(view(p, Ip), pI) - mean + apply_bc_p! + applypressure! in one pass over the box
+// Ip grown by one ghost layer (pressure.jl:150, boundary_conditions.jl:306-318 / 388 / 445-453 / 497-502, operators.jl:225-233).
+// Ghost values follow apply_bc_p!'s rules composed over the directions: periodic image, copy of the adjacent volume (Symmetric),
+// zero (Pressure); volumes behind a Dirichlet side are left untouched as in the reference (never read: no velocity DOF touches them).
+__device__ __forceinline__ int map_p(int I, int lo, int hi, int bcl, int bcr) {  // -> offset in [0, hi-lo), -1: zero, -2: untouched
+  if (I >= lo && I < hi) return I - lo;
+  const bool left = I < lo;
+  const int bc = left ? bcl : bcr;
+  if (bc == INS_BC_PERIODIC) return left ? hi - lo - 1 : 0;
+  if (bc == INS_BC_SYMMETRIC) return left ? 0 : hi - lo - 1;
+  if (bc == INS_BC_PRESSURE) return -1;
+  return -2;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_unpack_grad_bc(GridDev g, double* __restrict__ u, double* __restrict__ p, const double* __restrict__ pI,
+                                                        int n0, int n1, const double* __restrict__ shift) {
+  const int I0 = g.ip_lo[0] - 1 + blockIdx.x * 64 + threadIdx.x;
+  const int I1 = g.ip_lo[1] - 1 + blockIdx.y * 4 + threadIdx.y;
+  const int I2 = D == 3 ? g.ip_lo[2] - 1 + (int)blockIdx.z : 0;
+  if (I0 > g.ip_hi[0] || I1 > g.ip_hi[1]) return;
+  const int I[3] = {I0, I1, I2};
+  const long long qs[3] = {1, n0, (long long)n0 * n1};
+  int w[3] = {0, 0, 0};
+  bool zero = false, skip = false;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    w[a] = map_p(I[a], g.ip_lo[a], g.ip_hi[a], g.bc[a][0], g.bc[a][1]);
+    zero = zero || w[a] == -1;
+    skip = skip || w[a] == -2;
+  }
+  if (skip) return;
+  const double sh = shift ? *shift : 0.0;
+  long long q = 0;
+#pragma unroll
+  for (int a = 0; a < D; ++a) q += (long long)(w[a] < 0 ? 0 : w[a]) * qs[a];
+  const double pc = zero ? 0.0 : pI[q] - sh;
+  const long long c = I[0] + I[1] * g.sx[1] + I[2] * g.sx[2];
+  p[c] = pc;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    bool dof = true;
+#pragma unroll
+    for (int b = 0; b < D; ++b) dof = dof && I[b] >= g.iu_lo[a][b] && I[b] < g.iu_hi[a][b];
+    if (!dof) continue;
+    const int wn = map_p(I[a] + 1, g.ip_lo[a], g.ip_hi[a], g.bc[a][0], g.bc[a][1]);
+    bool zn = wn == -1;
+#pragma unroll
+    for (int b = 0; b < D; ++b) zn = zn || (b != a && w[b] == -1);
+    const long long qn = q + (long long)((wn < 0 ? 0 : wn) - (w[a] < 0 ? 0 : w[a])) * qs[a];  // direction a replaced, the others kept
+    const double pn = zn ? 0.0 : pI[qn] - sh;
+    u[a * g.sc + c] -= (pn - pc) * g.rdxu[a][I[a]];
+  }
 }
 
 // K3: phat = -phat / (ax + ay + az) * (1/prod(Np));  phat[0] = 0                 pressure.jl:326-341
@@ -595,10 +652,11 @@ static int fdm_solve(ins_poisson* ps, double* p, hipStream_t s) {
   INS_LAUNCH_CHECK();
   int rc = ins_fdm_solve(ps->fdm, s);
   if (rc) return rc;
+  const double* shift = ins_fdm_mean(ps->fdm);  // e'p = 0 of the bordered system, applied while unpacking
   if (g.D == 2)
-    hipLaunchKernelGGL((k_pack<2, false>), grid, block, 0, s, g, p, buf, ps->np[0], ps->np[1]);
+    hipLaunchKernelGGL((k_pack<2, false>), grid, block, 0, s, g, p, buf, ps->np[0], ps->np[1], shift);
   else
-    hipLaunchKernelGGL((k_pack<3, false>), grid, block, 0, s, g, p, buf, ps->np[0], ps->np[1]);
+    hipLaunchKernelGGL((k_pack<3, false>), grid, block, 0, s, g, p, buf, ps->np[0], ps->np[1], shift);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -668,6 +726,24 @@ int ins_k_project(const ins_grid* G, ins_poisson* ps, double* u, double* p, hipS
       hipLaunchKernelGGL(k_grad_from_pI<2>, gridp, block, 0, s, g, u, p, ps->pI, ps->np[0], ps->np[1], 1);
     else
       hipLaunchKernelGGL(k_grad_from_pI<3>, gridp, block, 0, s, g, u, p, ps->pI, ps->np[0], ps->np[1], ps->np[2]);
+    INS_LAUNCH_CHECK();
+    return INS_OK;
+  }
+  if (ps->kind == POISSON_FDM && !getenv("INS_DISABLE_FDM_FUSED")) {
+    // direct solver: Ω·div(u) straight into the solver's buffer, and copy-back - mean + apply_bc_p! + applypressure! in one pass
+    double* buf = ins_fdm_buffer(ps->fdm);
+    dim3 block(64, 4, 1), grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), g.D == 3 ? ps->np[2] : 1);
+    if (g.D == 2)
+      hipLaunchKernelGGL(k_div_to_pI<2>, grid, block, 0, s, g, u, buf, ps->np[0], ps->np[1]);
+    else
+      hipLaunchKernelGGL(k_div_to_pI<3>, grid, block, 0, s, g, u, buf, ps->np[0], ps->np[1]);
+    INS_LAUNCH_CHECK();
+    if ((rc = ins_fdm_solve(ps->fdm, s))) return rc;
+    dim3 gridp(cdiv(ps->np[0] + 2, 64), cdiv(ps->np[1] + 2, 4), g.D == 3 ? ps->np[2] + 2 : 1);
+    if (g.D == 2)
+      hipLaunchKernelGGL(k_unpack_grad_bc<2>, gridp, block, 0, s, g, u, p, (const double*)buf, ps->np[0], ps->np[1], ins_fdm_mean(ps->fdm));
+    else
+      hipLaunchKernelGGL(k_unpack_grad_bc<3>, gridp, block, 0, s, g, u, p, (const double*)buf, ps->np[0], ps->np[1], ins_fdm_mean(ps->fdm));
     INS_LAUNCH_CHECK();
     return INS_OK;
   }

@@ -233,9 +233,57 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
     INS_HIP_TRY(hipMemcpy(dplanes, planes, 18 * sizeof(double*), hipMemcpyHostToDevice));
   }
   int rc;
+  const int ns = rk->nstage;
+  // 3-D grids with the flux kernel and time-independent boundary data: K6 runs as K1's epilogue (no k_combine pass, no
+  // snapshot copy: the caller's u is ustart for the whole step and the stage velocities ping-pong in two library buffers,
+  // as on the periodic path).  Every non-interior volume of a stage buffer is (re)written by apply_bc_u! before it is read.
+  static const bool no_fuse_np = getenv("INS_DISABLE_FUSED_RK") != nullptr;
+  if (!no_fuse_np && !planes && ins_fast3d_supported(G)) {
+    const size_t vbytes = (size_t)nvec * sizeof(double);
+    for (int b = 0; b < 2; ++b)
+      if (!rk->ub[b]) {
+        INS_HIP_TRY(hipMalloc(&rk->ub[b], vbytes));
+        INS_HIP_TRY(hipMemcpyAsync(rk->ub[b], u, vbytes, hipMemcpyDeviceToDevice, s));  // once: volumes no kernel ever writes
+      }
+    double* cur = u;
+    for (int i = 0; i < ns; ++i) {
+      if ((rc = ins_k_apply_bc_u(G, cur, 0, nullptr, s))) return rc;           // :19
+      double* out = (i == ns - 1 && ns > 1) ? u : rk->ub[i & 1];
+      RkEpi epi;
+      memset(&epi, 0, sizeof(epi));
+      for (int j = 0; j < i; ++j) {
+        const double coef = dt * rk->A[i * ns + j];
+        if (coef == 0.0) continue;
+        epi.coef[epi.n] = coef;
+        epi.k[epi.n] = rk->ku[j];
+        ++epi.n;
+      }
+      epi.coef_self = dt * rk->A[i * ns + i];
+      epi.ustart = (i == 0) ? nullptr : u;
+      epi.ustar = out;
+      for (int i2 = i + 1; i2 < ns; ++i2)
+        if (rk->A[i2 * ns + i] != 0.0) epi.write_k = 1;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (rk->profiling) {
+        INS_HIP_TRY(hipEventCreate(&e0));
+        INS_HIP_TRY(hipEventCreate(&e1));
+        INS_HIP_TRY(hipEventRecord(e0, s));
+      }
+      if ((rc = ins_k_momentum_rk_fused(G, visc, cur, rk->ku[i], epi, s))) return rc;   // :21, :35-38
+      if (rk->profiling) {
+        INS_HIP_TRY(hipEventRecord(e1, s));
+        rk->prof_events.push_back(e0);
+        rk->prof_events.push_back(e1);
+      }
+      cur = out;
+      if ((rc = ins_k_apply_bc_u(G, cur, 0, nullptr, s))) return rc;           // :48
+      if ((rc = ins_k_project(G, rk->ps, cur, rk->p, s))) return rc;            // :49
+    }
+    if (ns == 1) INS_HIP_TRY(hipMemcpyAsync(u, rk->ub[0], vbytes, hipMemcpyDeviceToDevice, s));
+    return ins_k_apply_bc_u(G, u, 0, nullptr, s);                              // :55
+  }
   // copyto!(ustart, u)                                                   step_explicit_runge_kutta.jl:14
   INS_HIP_TRY(hipMemcpyAsync(rk->ustart, u, nvec * sizeof(double), hipMemcpyDeviceToDevice, s));
-  const int ns = rk->nstage;
   for (int i = 0; i < ns; ++i) {
     if ((rc = ins_k_apply_bc_u(G, u, 0, dplanes, s))) return rc;             // :19
     hipEvent_t e0 = nullptr, e1 = nullptr;
