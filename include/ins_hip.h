@@ -192,6 +192,11 @@ int ins_stage_momentum_f64(const ins_grid_t* grid, double visc, const double* u_
 int ins_stage_momentum_corr_f64(const ins_grid_t* grid, double visc, const double* ustar_prev, const double* p_ext, double* k_out,
                                 const double* ustart, double* ustar, int nterms, const double* coefs, const double* const* ks,
                                 double coef_self, void* stream);
+/* The same stage in two launches so that a halo exchange can run beside the first: part = 1 runs the z-chunks that read no ghost
+ * plane of ustar_prev / p_ext, part = 2 the remaining ones (part = 0: everything, = ins_stage_momentum_corr_f64). */
+int ins_stage_momentum_corr_part_f64(const ins_grid_t* grid, double visc, const double* ustar_prev, const double* p_ext, double* k_out,
+                                     const double* ustart, double* ustar, int nterms, const double* coefs, const double* const* ks,
+                                     double coef_self, int part, void* stream);
 /* pI[nx,ny,nzl] = Ω·divergence(u) on the slab interior (operators.jl:117-125, 81-95; pressure.jl:320): x, y via
  * periodic wrap, z via the ghost plane. */
 int ins_slab_divergence_f64(const ins_grid_t* grid, const double* u, double* pI, void* stream);
@@ -232,6 +237,9 @@ int ins_slab_fft_is_own(const ins_slab_fft_t* fft);
 int ins_slab_ztri_edge_elems(const ins_slab_fft_t* S, int64_t* doubles);
 int ins_slab_ztri_forward(ins_slab_fft_t* S, const ins_grid_t* grid, const double* src, int from_u, double* work, double* edge, void* stream);
 int ins_slab_ztri_finish(ins_slab_fft_t* S, double* work, const double* edges_all, double* pI, void* stream);
+/* x pass of ins_slab_ztri_forward (from_u = 1) for local planes [kz0, kz0 + nkz) only; follow with ins_slab_ztri_forward(from_u = 2).
+ * Planes >= 1 read no ghost plane of u, so they can run while the w plane below the slab is still in flight. */
+int ins_slab_xfwd_planes(ins_slab_fft_t* S, const ins_grid_t* grid, const double* u, double* work, int kz0, int nkz, void* stream);
 int ins_slab_fft_forward_packed(ins_slab_fft_t* fft, const ins_grid_t* grid, const double* src, int from_u, double* work, double* sendbuf,
                                 int cw, void* stream);
 int ins_slab_fft_inverse_packed(ins_slab_fft_t* fft, double* recvbuf, double* work, double* pI, int cw, void* stream);

@@ -75,6 +75,7 @@ SIGNATURES = {
     "ins_rk_stage_force": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
     "ins_stage_momentum_f64": (C.c_int, [vp, C.c_double, vp, vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), C.c_double, vp]),
     "ins_stage_momentum_corr_f64": (C.c_int, [vp, C.c_double, vp, vp, vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), C.c_double, vp]),
+    "ins_stage_momentum_corr_part_f64": (C.c_int, [vp, C.c_double, vp, vp, vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), C.c_double, C.c_int, vp]),
     "ins_slab_divergence_f64": (C.c_int, [vp, vp, vp, vp]),
     "ins_slab_applypressure_f64": (C.c_int, [vp, vp, vp, vp, vp]),
     "ins_slab_fft_create": (C.c_int, [C.POINTER(C.c_int32), c_double_p, C.c_int, C.c_int, C.POINTER(vp)]),
@@ -93,6 +94,7 @@ SIGNATURES = {
     "ins_slab_ztri_edge_elems": (C.c_int, [vp, C.POINTER(C.c_int64)]),
     "ins_slab_ztri_forward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp]),
     "ins_slab_ztri_finish": (C.c_int, [vp, vp, vp, vp, vp]),
+    "ins_slab_xfwd_planes": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "ins_slab_fft_forward_packed": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp]),
     "ins_slab_fft_inverse_packed": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
 }

@@ -479,7 +479,8 @@ static int launch_flux_any(const ins_grid* G, const double* u, double* F, const 
 
 // 64-outputs-per-wavefront specialisation for periodic, exactly-uniform boxes (ins_flux64.hip)
 bool ins_flux64_supported(const ins_grid* G);
-int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, const RkEpi* epi, const double* pI, int corr_mode, hipStream_t s);
+int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, const RkEpi* epi, const double* pI, int corr_mode, hipStream_t s,
+                 int part = 0);
 
 int ins_k_momentum_flux3d(const ins_grid* G, double visc, const double* u, double* F, bool zero_shell, hipStream_t s) {
   int rc;
@@ -521,9 +522,12 @@ int ins_k_momentum_rk_fused_corr(const ins_grid* G, double visc, const double* u
 }
 
 // Slab flavour: z neighbours from ghost planes; p_ext = [1 plane below | local planes | 2 planes above] (unpadded in x, y).
+// part (z-chunk subsets, see ins_flux64.hip): 1 = chunks that need no ghost plane, 2 = the rest, 0 = all.  Grids the 64-wide kernel does
+// not take run everything in part 2 (and part 0).
 int ins_k_momentum_rk_fused_corr_slab(const ins_grid* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out,
-                                      const RkEpi& epi, hipStream_t s) {
-  if (ins_flux64_supported(G)) return ins_k_flux64(G, visc, ustar_prev, k_out, &epi, p_ext, 2, s);
+                                      const RkEpi& epi, hipStream_t s, int part) {
+  if (ins_flux64_supported(G)) return ins_k_flux64(G, visc, ustar_prev, k_out, &epi, p_ext, 2, s, part);
+  if (part == 1) return INS_OK;
   int rc = ins_flux3d_prepare(G, visc, s);
   if (rc) return rc;
   return launch_flux_any<true>(G, ustar_prev, k_out, epi, p_ext, 2, s);

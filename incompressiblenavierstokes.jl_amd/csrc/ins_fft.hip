@@ -198,14 +198,14 @@ __global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kx
 // ------------------------------------------------------------------------------------------------------------
 template <int LOGN, int NP, int SRC>
 __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restrict__ src, double2* __restrict__ out, int n1,
-                                              const double2* __restrict__ tw_g, int kxs) {
+                                              const double2* __restrict__ tw_g, int kxs, int kz0) {
   constexpr int N = 1 << LOGN;
   constexpr int KXN = N / 2 + 1;
   extern __shared__ double2 lds_dyn[];
   double2* buf = lds_dyn;          // [NP][N]
   double2* tw = lds_dyn + NP * N;  // [N]
   const int t = threadIdx.x;
-  const int kz = blockIdx.y;       // interior plane index
+  const int kz = kz0 + blockIdx.y;  // interior plane index (kz0: first plane of this launch)
   const int j0 = blockIdx.x * 2 * NP;
   for (int m = t; m < N; m += 256) tw[m] = tw_g[m];
   double* bufd = reinterpret_cast<double*>(buf);
@@ -348,17 +348,17 @@ int launch_y(double2* data, int kxn, int kxs, int nplanes, const double2* tw, bo
 }
 
 template <int LOGN>
-int launch_xfwd(const GridDev& g, const double* src, int from_u, double2* out, int n1, int n2, const double2* tw, int kxs, hipStream_t s) {
+int launch_xfwd(const GridDev& g, const double* src, int from_u, double2* out, int n1, int n2, const double2* tw, int kxs, hipStream_t s, int kz0) {
   constexpr int N = 1 << LOGN;
   constexpr int NP = N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N);
   constexpr size_t lds = ((size_t)NP * N + N) * sizeof(double2);
   dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
   if (from_u == 2)
-    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 2>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs);
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 2>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0);
   else if (from_u)
-    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 1>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs);
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 1>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0);
   else
-    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 0>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs);
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 0>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -417,13 +417,13 @@ void ins_ownfft_permute_symbol(int n, const double* ay, double* out) {
 }
 
 int ins_k_ownfft_xfwd(const ins_grid* G, const double* src, int from_u, double* phat, int n0, int n1, int n2, const double* tw,
-                      hipStream_t s, int kxs) {
+                      hipStream_t s, int kxs, int kz0) {
   if (kxs <= 0) kxs = n0 / 2 + 1;
   static const GridDev no_grid{};  // SRC = 0 never touches the grid
   const GridDev& g = G ? G->g : no_grid;
   double2* out = reinterpret_cast<double2*>(phat);
   const double2* w = reinterpret_cast<const double2*>(tw);
-#define CALL(LG) launch_xfwd<LG>(g, src, from_u, out, n1, n2, w, kxs, s)
+#define CALL(LG) launch_xfwd<LG>(g, src, from_u, out, n1, n2, w, kxs, s, kz0)
   INS_POW2_SWITCH(n0, CALL)
 #undef CALL
 }

@@ -40,6 +40,9 @@ struct FluxArgs {
   long long sc;  // component stride (elements)
   int N0, N1, N2;
   int zc, ntx, nty, ntz;
+  // plane range of this launch: chunk t covers [k_lo + t zc, min(.. + zc, k_hi)); kB > 0: two chunks, [k_lo, k_lo + zc) and [kB, kB + zc)
+  // (the host runs the planes that read no ghost plane beside the halo exchange, then the two thin boundary ranges)
+  int k_lo, k_hi, kB;
   Dir X, Y, Z;
   RkEpi epi;
 };
@@ -116,8 +119,8 @@ __global__ __launch_bounds__(256, 2) void k_flux64(FluxArgs a) {
   if (x0 >= n0) return;                 // no barriers in this kernel: safe
   const int jb0 = (tyi * (4 / XW) + wy) * R;  // interior row of the first output row
   if (jb0 >= n1) return;
-  const int k0 = 1 + tzi * a.zc;               // padded plane index of the first output plane
-  const int k1 = min(k0 + a.zc, N2 - 1);
+  const int k0 = a.kB ? (tzi ? a.kB : a.k_lo) : a.k_lo + tzi * a.zc;  // padded plane index of the first output plane
+  const int k1 = a.kB ? k0 + a.zc : min(k0 + a.zc, a.k_hi);
   const long long sz = (long long)N0 * N1;
   const int ci = x0 + lane;
   const bool xout = ci < n0;
@@ -398,12 +401,9 @@ Dir make_dir(const ins_grid* G, int d, double visc) {
 }
 
 template <int R, int XW, bool FUSE>
-int launch(const ins_grid* G, FluxArgs& a, int corr_mode, hipStream_t s) {
-  const GridDev& g = G->g;
-  a.ntx = cdiv(g.N[0] - 2, 64 * XW);
-  a.nty = cdiv(g.N[1] - 2, (4 / XW) * R);
-  a.ntz = cdiv(g.N[2] - 2, a.zc);
+int launch_range(const ins_grid* G, FluxArgs& a, int corr_mode, hipStream_t s) {
   const unsigned nb = (unsigned)(8LL * a.ntx * ((a.nty + 7) / 8) * a.ntz);
+  if (nb == 0) return INS_OK;
   const dim3 block(64, 4, 1);
   if (g_skel && corr_mode == 0)
     hipLaunchKernelGGL((k_flux64<R, XW, FUSE, 0, true>), dim3(nb), block, (size_t)g_lds, s, a);
@@ -420,6 +420,32 @@ int launch(const ins_grid* G, FluxArgs& a, int corr_mode, hipStream_t s) {
   }
   INS_LAUNCH_CHECK();
   return INS_OK;
+}
+
+// part 0: every plane; 1: the planes that read no ghost plane, [1 + ZB, nzl + 1 - ZB); 2: the two boundary ranges of ZB planes
+constexpr int ZB = 4;
+template <int R, int XW, bool FUSE>
+int launch(const ins_grid* G, FluxArgs& a, int corr_mode, int part, hipStream_t s) {
+  const GridDev& g = G->g;
+  a.ntx = cdiv(g.N[0] - 2, 64 * XW);
+  a.nty = cdiv(g.N[1] - 2, (4 / XW) * R);
+  const int nzl = g.N[2] - 2;
+  a.k_lo = 1;
+  a.k_hi = nzl + 1;
+  a.kB = 0;
+  if (part != 0 && nzl <= 2 * ZB) {  // too thin to split: everything in part 2
+    if (part == 1) return INS_OK;
+    part = 0;
+  }
+  if (part == 1) {
+    a.k_lo = 1 + ZB;
+    a.k_hi = nzl + 1 - ZB;
+  } else if (part == 2) {
+    a.zc = ZB;
+    a.kB = nzl + 1 - ZB;
+  }
+  a.ntz = part == 2 ? 2 : cdiv(a.k_hi - a.k_lo, a.zc);
+  return launch_range<R, XW, FUSE>(G, a, corr_mode, s);
 }
 
 }  // namespace
@@ -444,7 +470,8 @@ bool ins_flux64_supported(const ins_grid* G) {
 }
 
 // corr_mode 0: u has valid ghost volumes.  1 / 2: see k_flux64.  fuse: RK epilogue `epi`.
-int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, const RkEpi* epi, const double* pI, int corr_mode, hipStream_t s) {
+int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, const RkEpi* epi, const double* pI, int corr_mode, hipStream_t s,
+                 int part) {
   const GridDev& g = G->g;
   FluxArgs a;
   memset(&a, 0, sizeof(a));
@@ -469,9 +496,9 @@ int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, con
   rows = std::min(std::max(rows, 2), corr_mode ? 5 : 6);
 #define INS_F64_CASE(RR, FUSE)                                            \
   if (rows == RR) {                                                       \
-    if (xw == 4) return launch<RR, 4, FUSE>(G, a, corr_mode, s);          \
-    if (xw == 2) return launch<RR, 2, FUSE>(G, a, corr_mode, s);          \
-    return launch<RR, 1, FUSE>(G, a, corr_mode, s);                       \
+    if (xw == 4) return launch<RR, 4, FUSE>(G, a, corr_mode, part, s);    \
+    if (xw == 2) return launch<RR, 2, FUSE>(G, a, corr_mode, part, s);    \
+    return launch<RR, 1, FUSE>(G, a, corr_mode, part, s);                 \
   }
   if (epi) {
     INS_F64_CASE(2, true)

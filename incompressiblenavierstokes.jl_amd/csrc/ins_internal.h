@@ -178,7 +178,7 @@ int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, 
 int ins_k_momentum_rk_fused_corr(const ins_grid* G, double visc, const double* ustar_prev, const double* pI, double* k_out, const RkEpi& epi,
                                  hipStream_t s);
 int ins_k_momentum_rk_fused_corr_slab(const ins_grid* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out,
-                                      const RkEpi& epi, hipStream_t s);
+                                      const RkEpi& epi, hipStream_t s, int part = 0);
 int ins_k_project_periodic_solve_only(const ins_grid* G, ins_poisson* ps, const double* u, hipStream_t s);
 int ins_k_poisson_solve(ins_poisson* ps, double* p, hipStream_t s);
 // blocking reductions over an index box of a scalar field; op: 0 sum(a*b), 1 max|a|, 2 min(a)
@@ -192,8 +192,9 @@ bool ins_zsolve_supported(int nz);
 bool ins_ownfft_supported(const int np[3]);
 void ins_ownfft_permute_symbol(int n, const double* ay, double* out);
 // kxs: row stride of phat in complex elements (0 = dense, n0/2+1); a multiple of 8 keeps the y/z tiles 128-B aligned
+// n2 planes starting at interior plane kz0
 int ins_k_ownfft_xfwd(const ins_grid* G, const double* src, int from_u, double* phat, int n0, int n1, int n2, const double* tw, hipStream_t s,
-                      int kxs = 0);
+                      int kxs = 0, int kz0 = 0);
 int ins_k_ownfft_xinv(const double* phat, double* pI, int n0, int n1, int n2, const double* tw, hipStream_t s, int kxs = 0);
 int ins_k_ownfft_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s, int kxs = 0);
 int ins_k_ownfft_y_packed(double* phat, double* packed, int kxn, int n1, int nzl, int nyl, int cw, const double* tw, bool inverse,

@@ -377,7 +377,10 @@ extern "C" int ins_slab_ztri_forward(ins_slab_fft_t* S, const ins_grid_t* G, con
   INS_REQUIRE(S->nzl >= 2, "the tridiagonal z solve needs >= 2 local planes");
   hipStream_t s = as_stream(stream);
   int rc;
-  if (from_u) {
+  if (from_u == 2) {  // x pass already done plane range by plane range (ins_slab_xfwd_planes)
+    INS_REQUIRE(S->ownfft, "forming the right-hand side inside the x pass needs a power-of-two box");
+    if ((rc = ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s, S->kxs))) return rc;
+  } else if (from_u) {
     INS_REQUIRE(S->ownfft, "forming the right-hand side inside the x pass needs a power-of-two box");
     INS_REQUIRE(G && G->g.D == 3 && G->g.N[0] == S->np[0] + 2 && G->g.N[1] == S->np[1] + 2 && G->g.N[2] == S->nzl + 2, "grid does not match the slab");
     if ((rc = ins_k_ownfft_xfwd(G, src, 2, work, S->np[0], S->np[1], S->nzl, S->tw_x, s, S->kxs))) return rc;
@@ -389,6 +392,17 @@ extern "C" int ins_slab_ztri_forward(ins_slab_fft_t* S, const ins_grid_t* G, con
     return rc;
   const double scale = -1.0 / ((double)S->np[0] * S->np[1]);
   return ins_k_ztri_forward(work, S->kxn, S->kxs, S->np[1], S->nzl, S->nranks, S->rank, S->ax, S->ay_full, S->cz, scale, edge, s);
+}
+
+// The x pass of ins_slab_ztri_forward (from_u = 1) for local planes [kz0, kz0 + nkz) only: planes >= 1 need no ghost plane of u, so they
+// can be transformed while the w plane below the slab is still travelling; call ins_slab_ztri_forward with from_u = 2 afterwards.
+extern "C" int ins_slab_xfwd_planes(ins_slab_fft_t* S, const ins_grid_t* G, const double* u, double* work, int kz0, int nkz, void* stream) {
+  INS_REQUIRE(S && G && u && work, "null argument");
+  INS_REQUIRE(S->ownfft, "forming the right-hand side inside the x pass needs a power-of-two box");
+  INS_REQUIRE(G->g.D == 3 && G->g.N[0] == S->np[0] + 2 && G->g.N[1] == S->np[1] + 2 && G->g.N[2] == S->nzl + 2, "grid does not match the slab");
+  INS_REQUIRE(kz0 >= 0 && nkz >= 0 && kz0 + nkz <= S->nzl, "bad plane range");
+  if (nkz == 0) return INS_OK;
+  return ins_k_ownfft_xfwd(G, u, 2, work, S->np[0], S->np[1], nkz, S->tw_x, as_stream(stream), S->kxs, kz0);
 }
 
 // edges_all = the all-gathered edge buffers (rank-major).  Interface solve, back substitution, inverse y / x transforms -> pI.
@@ -442,9 +456,24 @@ extern "C" int ins_slab_applypressure_f64(const ins_grid_t* G, double* u, const 
 // Stage kernel with the PREVIOUS stage's projection applied in registers (k_momentum_flux<..., CORR = 2>): `ustar_prev` is that
 // stage's uncorrected velocity with valid z-ghost planes, `p_ext` = [1 plane below | nzl local planes | 2 planes above] of its
 // pressure (unpadded in x, y).  Exactly-uniform slabs only.
+static int stage_momentum_corr(const ins_grid_t* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out, const double* ustart,
+                               double* ustar, int nterms, const double* coefs, const double* const* ks, double coef_self, int part, void* stream);
+
 extern "C" int ins_stage_momentum_corr_f64(const ins_grid_t* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out,
                                            const double* ustart, double* ustar, int nterms, const double* coefs, const double* const* ks,
                                            double coef_self, void* stream) {
+  return stage_momentum_corr(G, visc, ustar_prev, p_ext, k_out, ustart, ustar, nterms, coefs, ks, coef_self, 0, stream);
+}
+
+extern "C" int ins_stage_momentum_corr_part_f64(const ins_grid_t* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out,
+                                                const double* ustart, double* ustar, int nterms, const double* coefs, const double* const* ks,
+                                                double coef_self, int part, void* stream) {
+  INS_REQUIRE(part >= 0 && part <= 2, "part must be 0 (all), 1 (interior z-chunks) or 2 (boundary z-chunks)");
+  return stage_momentum_corr(G, visc, ustar_prev, p_ext, k_out, ustart, ustar, nterms, coefs, ks, coef_self, part, stream);
+}
+
+static int stage_momentum_corr(const ins_grid_t* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out, const double* ustart,
+                               double* ustar, int nterms, const double* coefs, const double* const* ks, double coef_self, int part, void* stream) {
   int rc = check_slab_grid(G);
   if (rc) return rc;
   INS_REQUIRE(ustar_prev && p_ext && ustar && ustart, "null argument");
@@ -464,7 +493,7 @@ extern "C" int ins_stage_momentum_corr_f64(const ins_grid_t* G, double visc, con
   epi.ustar = ustar;
   epi.write_k = k_out != nullptr;
   static double* dummy = nullptr;
-  return ins_k_momentum_rk_fused_corr_slab(G, visc, ustar_prev, p_ext, k_out ? k_out : dummy, epi, as_stream(stream));
+  return ins_k_momentum_rk_fused_corr_slab(G, visc, ustar_prev, p_ext, k_out ? k_out : dummy, epi, as_stream(stream), part);
 }
 
 extern "C" int ins_stage_momentum_f64(const ins_grid_t* G, double visc, const double* u_in, double* k_out, const double* ustart,

@@ -218,13 +218,22 @@ class HipSlabKernels:
         n0, n1 = self.layout.n[0], self.layout.n[1]
         return torch.zeros(self.real_elems + 3 * n0 * n1, dtype=torch.float64, device=self.device)
 
-    def stage_momentum_corr(self, ustar_prev, p_ext, k_out, ustart, ustar, coefs, ks, coef_self):
+    def stage_momentum_corr(self, ustar_prev, p_ext, k_out, ustart, ustar, coefs, ks, coef_self, part=0):
+        """part 1: the z-chunks that read no ghost plane (can run beside the halo exchange); part 2: the rest; 0: everything."""
         s = self.setup
         n = len(coefs)
         carr = (C.c_double * max(n, 1))(*coefs)
         karr = (C.c_void_p * max(n, 1))(*[k.data_ptr() for k in ks])
-        _lib.call("ins_stage_momentum_corr_f64", s.handle, 1.0 / s.Re, s.ptr(ustar_prev, True), self._p(p_ext),
-                  s.ptr(k_out, True) if k_out is not None else None, s.ptr(ustart, True), s.ptr(ustar, True), n, carr, karr, float(coef_self), s.stream)
+        _lib.call("ins_stage_momentum_corr_part_f64", s.handle, 1.0 / s.Re, s.ptr(ustar_prev, True), self._p(p_ext),
+                  s.ptr(k_out, True) if k_out is not None else None, s.ptr(ustart, True), s.ptr(ustar, True), n, carr, karr, float(coef_self),
+                  int(part), s.stream)
+
+    # stage_momentum_corr(part=...) and xfwd_planes exist: SlabStepper overlaps exchanges with them (INS_SLAB_NO_SPLIT=1: A/B switch)
+    splits_stage = not bool(__import__("os").environ.get("INS_SLAB_NO_SPLIT"))
+
+    def xfwd_planes(self, u, work, kz0, nkz):
+        s = self.setup
+        _lib.call("ins_slab_xfwd_planes", self._fft, s.handle, s.ptr(u, True), self._p(work), int(kz0), int(nkz), s.stream)
 
     def divergence(self, u, pI):
         s = self.setup
@@ -280,11 +289,11 @@ class HipSlabKernels:
         return torch.zeros(n.value * ranks, dtype=torch.float64, device=self.device)
 
     def ztri_forward(self, src, from_u, work, edge):
-        """(x, y) transforms of the local planes (from_u: Ω·div(u) formed inside the x pass), forward elimination along z in
-        place on `work`, this rank's interface data -> edge."""
+        """(x, y) transforms of the local planes (from_u = 1: Ω·div(u) formed inside the x pass; 2: the x pass was done by
+        xfwd_planes), forward elimination along z in place on `work`, this rank's interface data -> edge."""
         s = self.setup
         ptr = s.ptr(src, True) if from_u else self._p(src)
-        _lib.call("ins_slab_ztri_forward", self._fft, s.handle, ptr, 1 if from_u else 0, self._p(work), self._p(edge), s.stream)
+        _lib.call("ins_slab_ztri_forward", self._fft, s.handle, ptr, int(from_u), self._p(work), self._p(edge), s.stream)
 
     def ztri_finish(self, work, edges_all, pI):
         _lib.call("ins_slab_ztri_finish", self._fft, self._p(work), self._p(edges_all), self._p(pI), self.setup.stream)
@@ -369,7 +378,7 @@ class SlabStepper:
         lay, K = self.lay, self.k
         self.comm.exchange([(K.p_plane(self.pI, 0), lay.prev)], [(self.p_top, lay.next)])
 
-    def halo_p_ext(self):
+    def halo_p_ext(self, wait=True):
         """Ghost planes of the extended pressure buffer: my last plane -> next rank's `below`; my first two planes ->
         previous rank's two `above` planes."""
         lay, K = self.lay, self.k
@@ -377,16 +386,32 @@ class SlabStepper:
         pX, nzl = self.pX, lay.nzl
         sends = [(pX[plane * nzl : plane * (nzl + 1)], lay.next), (pX[plane : plane * 3], lay.prev)]
         recvs = [(pX[0:plane], lay.prev), (pX[plane * (nzl + 1) : plane * (nzl + 3)], lay.next)]
-        self.comm.exchange(sends, recvs)
+        if wait:
+            self.comm.exchange(sends, recvs)
+            return []
+        return self.comm.exchange_async(sends, recvs)
 
     # -- projection (pressure.jl:69-82 on slabs) ---------------------------------------------------
-    def project_(self, u, apply=True, w_halo_done=False):
+    def project_(self, u, apply=True, w_halo_done=False, rest_async=False):
         """apply=False: solve only (pI <- p); the gradient-subtract is left to the next stage's stencil kernel."""
         K = self.k
-        if not w_halo_done:
+        split = self.zsolve == "tridiag" and self.packed and not w_halo_done and bool(getattr(K, "splits_stage", False)) and self.lay.nzl >= 2
+        if split:
+            # the w plane below the slab travels while the x pass transforms the planes that do not need it
+            lay = self.lay
+            pend = self.comm.exchange_async([(K.plane(u, 2, lay.nzl), lay.next)], [(K.plane(u, 2, 0), lay.prev)])
+            K.xfwd_planes(u, self.work, 1, lay.nzl - 1)
+            for req in pend:
+                req.wait()
+            if rest_async:  # u is final (apply=False callers): its other ghost planes travel during the rest of the solve
+                self._rest = self.halo_u_rest_async(u)
+            K.xfwd_planes(u, self.work, 0, 1)
+        elif not w_halo_done:
             self.halo_u(u, comps=(2,), down_only=True)  # divergence needs w[I - e_z] only (operators.jl:122)
         if self.zsolve == "tridiag":
-            if self.packed:  # power-of-two box: Ω·div(u) formed inside the x pass
+            if split:
+                K.ztri_forward(u, 2, self.work, self.edge)
+            elif self.packed:  # power-of-two box: Ω·div(u) formed inside the x pass
                 K.ztri_forward(u, True, self.work, self.edge)
             else:
                 K.divergence(u, self.pI)
@@ -454,6 +479,8 @@ class SlabStepper:
         K.fill_xy_ghosts(u)
         self.halo_u(u)
         u_in = u
+        pending, p_pending = [], []
+        split = bool(getattr(K, "splits_stage", False))
         for i in range(ns):
             out = u if (i == ns - 1 and ns > 1) else self.ub[i & 1]
             coefs, ks = [], []
@@ -465,19 +492,33 @@ class SlabStepper:
             write_k = any(A[i2, i] != 0.0 for i2 in range(i + 1, ns))
             last = i == ns - 1
             if self.inkernel and i > 0:
-                # previous stage's projection applied in registers from (u*, p) — no K4 pass for that stage
-                K.stage_momentum_corr(u_in, self.pX, self.ku[i] if write_k else None, u, out, coefs, ks, Δt * A[i, i])
+                # previous stage's projection applied in registers from (u*, p) — no K4 pass for that stage.  The z-chunks that read
+                # no ghost plane run while the ghost planes of p (and the last of u*) are still arriving.
+                kw = self.ku[i] if write_k else None
+                if split:
+                    K.stage_momentum_corr(u_in, self.pX, kw, u, out, coefs, ks, Δt * A[i, i], part=1)
+                for req in pending + p_pending:
+                    req.wait()
+                pending, p_pending = [], []
+                if split:
+                    K.stage_momentum_corr(u_in, self.pX, kw, u, out, coefs, ks, Δt * A[i, i], part=2)
+                else:
+                    K.stage_momentum_corr(u_in, self.pX, kw, u, out, coefs, ks, Δt * A[i, i])
             else:
                 K.stage_momentum(u_in, self.ku[i] if write_k else None, None if i == 0 else u, out, coefs, ks, Δt * A[i, i])
             if self.inkernel and not last:
                 # u* is final here (its correction happens inside the next stencil kernel): the w plane the divergence needs
                 # goes first, the other five ghost planes travel while the Poisson solve runs
-                self.halo_u(out, comps=(2,), down_only=True)
-                pending = self.halo_u_rest_async(out)
-                self.project_(out, apply=False, w_halo_done=True)
-                self.halo_p_ext()
-                for req in pending:
-                    req.wait()
+                if split and self.zsolve == "tridiag" and self.packed:
+                    # project_ moves the w plane itself beside the x pass and starts the other five planes right behind it
+                    self._rest = None
+                    self.project_(out, apply=False, rest_async=True)
+                    pending = self._rest if self._rest is not None else self.halo_u_rest_async(out)
+                else:
+                    self.halo_u(out, comps=(2,), down_only=True)
+                    pending = self.halo_u_rest_async(out)
+                    self.project_(out, apply=False, w_halo_done=True)
+                p_pending = self.halo_p_ext(wait=not split)
             else:
                 self.project_(out)
                 self.halo_u(out)  # z ghost planes for the next stencil (x/y ghosts: K4 images, or periodic addressing in-kernel)
