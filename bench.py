@@ -137,15 +137,22 @@ def main():
     cells = float(n) ** 3
     value = cells / (ms_per_step * 1e-3) / 1e6
     k1_avg_ms = k1_ms.value / max(k1_n.value, 1)
-    # compulsory bytes per cell of the fused stage kernel: R u_in + (R ustart, not for stage 1) + R k_j (non-zero a_ij)
-    # + W u* + (W k_i when a later stage needs it)                       step_explicit_runge_kutta.jl:35-38
-    A = method.A
+    # compulsory bytes per cell of the fused stage kernel                  step_explicit_runge_kutta.jl:35-38
+    #   k-basis:              R u_in + (R ustart, not for stage 1) + R k_j (non-zero a_ij) + W u* + (W k_i when a later stage needs it)
+    #   stage-velocity basis: R u_in + (R ustart) + R V_m (non-zero β_im) + W u*       (csrc/ins_rk.hip; no stage force is stored)
+    A = np.asarray(method.A, dtype=float)
     ns = len(method.b)
+    inkernel = ns > 1 and not os.environ.get("INS_DISABLE_INKERNEL_CORR")
+    vbasis = inkernel and not os.environ.get("INS_RK_KEEP_K") and all(A[i, i] != 0.0 for i in range(ns))
     stage_bytes = []
     for i in range(ns):
-        nk = sum(1 for j in range(i) if A[i, j] != 0.0)
-        wk = any(A[i2, i] != 0.0 for i2 in range(i + 1, ns))
-        inkernel_p = 8 if (i > 0 and ns > 1 and not os.environ.get("INS_DISABLE_INKERNEL_CORR")) else 0  # stages >= 2 also read p
+        inkernel_p = 8 if (i > 0 and inkernel) else 0  # stages >= 2 also read p
+        if vbasis:
+            beta = np.linalg.solve(A[:i, :i].T, A[i, :i]) if i else np.zeros(0)
+            nk, wk = int(np.count_nonzero(beta)), False
+        else:
+            nk = sum(1 for j in range(i) if A[i, j] != 0.0)
+            wk = any(A[i2, i] != 0.0 for i2 in range(i + 1, ns))
         stage_bytes.append(24 * (1 + (1 if i > 0 else 0) + nk + 1 + (1 if wk else 0)) + inkernel_p)
     fused_bytes_per_cell = float(np.mean(stage_bytes))
     k1_gbs = fused_bytes_per_cell * cells / (k1_avg_ms * 1e-3) / 1e9
@@ -233,7 +240,8 @@ def main():
             "avg_launch_ms": k1_plain_ms,
         },
         "roofline_k1_512": k1_512,
-        "step_bandwidth": {"design_bytes_per_cell": 1104, "achieved_GBs": 1104 * cells / (ms_per_step * 1e-3) / 1e9},
+        "step_bandwidth": {"design_bytes_per_cell": 448 + int(sum(stage_bytes)), "achieved_GBs": (448 + sum(stage_bytes)) * cells / (ms_per_step * 1e-3) / 1e9,
+                           "note": "per cell and step: 4 Poisson solves x (32 + 16 + 16 + 16 + 16) B + 64 B final K4 + the stage kernels"},
         "check": {"max_abs_div_times_dx": div / n, "kinetic_energy": energy},
     }
     if not args.no_cpu_baseline:

@@ -251,9 +251,10 @@ __global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __r
         if (FUSE) {
           double su, sv, sw;
           if (epi.ustart) {
-            su = epi.ustart[c];
-            sv = epi.ustart[c + g.sc];
-            sw = epi.ustart[c + 2 * g.sc];
+            const double c0 = 1.0 + epi.c0m1;  // exactly 1 in the k-basis
+            su = c0 * epi.ustart[c];
+            sv = c0 * epi.ustart[c + g.sc];
+            sw = c0 * epi.ustart[c + 2 * g.sc];
           } else {
             su = Uc;
             sv = Vc;

@@ -211,11 +211,12 @@ __global__ __launch_bounds__(256, 2) void k_flux64(FluxArgs a) {
     const long long pk = (long long)k * sz;
     if (a.epi.ustart) {
       const double* b = a.epi.ustart + pk;
+      const double c0 = 1.0 + a.epi.c0m1;  // exactly 1 in the k-basis
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const rsrc_t rs = plane_rsrc(b + c * a.sc, ubytes);
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) sacc[c][rr] = ldb(rs, ocol, orow[rr]);
+        for (int rr = 0; rr < R; ++rr) sacc[c][rr] = c0 * ldb(rs, ocol, orow[rr]);
       }
     } else {
 #pragma unroll

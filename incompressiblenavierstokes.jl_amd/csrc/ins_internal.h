@@ -145,6 +145,7 @@ struct ins_rk {
   std::vector<double*> ku;
   double* p = nullptr;
   double* ub[2] = {nullptr, nullptr};  // ping-pong stage velocities of the fused path
+  std::vector<double*> vb;             // all uncorrected stage velocities V_0..V_{s-2} (stage-velocity basis, ins_rk.hip)
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;  // (start, stop) pairs around momentum launches
 };
@@ -158,6 +159,7 @@ struct RkEpi {
   double coef[INS_MAX_STAGES];
   const double* k[INS_MAX_STAGES];
   double coef_self;         // Δt A[i,i]
+  double c0m1;              // ustart enters as (1 + c0m1)·ustart; 0 in the k-basis, -Σ coef in the stage-velocity basis (ins_rk.hip)
   const double* ustart;     // nullptr: ustart is the stencil input itself (first stage)
   double* ustar;            // stage velocity out (interior volumes only)
 };

@@ -102,6 +102,8 @@ extern "C" int ins_rk_destroy(ins_rk_t* rk) {
   if (rk->p) (void)hipFree(rk->p);
   for (double* k : rk->ku)
     if (k) (void)hipFree(k);
+  for (double* v : rk->vb)
+    if (v && v != rk->ub[0] && v != rk->ub[1]) (void)hipFree(v);
   for (double* b : rk->ub)
     if (b) (void)hipFree(b);
   for (hipEvent_t e : rk->prof_events) (void)hipEventDestroy(e);
@@ -167,23 +169,60 @@ static int rk_step_fused_periodic(ins_rk* rk, double visc, double* u, double dt,
   // the projection's gradient-subtract in registers (k_momentum_flux<..., CORR>), so K4 runs for the last stage only.
   static const bool no_corr = getenv("INS_DISABLE_INKERNEL_CORR") != nullptr;
   const bool inkernel = !no_corr && G->uniform_exact && ns > 1 && G->g.N[0] >= 8 && G->g.N[1] >= 8 && G->g.N[2] >= 8;
+  // Stage-velocity basis.  With in-kernel correction the UNCORRECTED stage velocities V_m = ustart + Δt Σ_{j<=m} A[m,j] k_j stay in
+  // memory anyway (they are the next stencil's input), and when every A[m,m] != 0 they span the same space as {ustart, k_j}:
+  //   V_i = (1 - Σ_m β_im) ustart + Σ_{m<i} β_im V_m + Δt A[i,i] k_i,     β_i · A[0:i,0:i] = A[i,0:i].
+  // So no k_j is ever written or read: RK44 moves 336 instead of 432 B per cell and step through the stage kernels (β_3 = (1/3, 2/3, 1/3),
+  // all other β = 0).  Algebraically the reference's combination (step_explicit_runge_kutta.jl:35-38); rounding differs at the 1e-16 level.
+  // INS_RK_KEEP_K=1 restores the k-basis (and fills the ku cache arrays, which this basis leaves untouched).
+  static const bool keep_k = getenv("INS_RK_KEEP_K") != nullptr;
+  bool vbasis = inkernel && !keep_k;
+  for (int i = 0; vbasis && i < ns; ++i) vbasis = rk->A[i * ns + i] != 0.0;
+  if (vbasis && (int)rk->vb.size() < ns - 1) {
+    rk->vb.resize(ns - 1, nullptr);
+    for (int m = 0; m < ns - 1; ++m)
+      if (!rk->vb[m]) {
+        if (m < 2 && rk->ub[m]) {
+          rk->vb[m] = rk->ub[m];
+          continue;
+        }
+        INS_HIP_TRY(hipMalloc(&rk->vb[m], vbytes));
+        INS_HIP_TRY(hipMemsetAsync(rk->vb[m], 0, vbytes, s));
+      }
+  }
   const double* in = u;
   for (int i = 0; i < ns; ++i) {
-    double* out = (i == ns - 1 && ns > 1) ? u : rk->ub[i & 1];
+    double* out = (i == ns - 1 && ns > 1) ? u : (vbasis ? rk->vb[i] : rk->ub[i & 1]);
     RkEpi epi;
     memset(&epi, 0, sizeof(epi));
-    for (int j = 0; j < i; ++j) {
-      const double coef = dt * rk->A[i * ns + j];
-      if (coef == 0.0) continue;
-      epi.coef[epi.n] = coef;
-      epi.k[epi.n] = rk->ku[j];
-      ++epi.n;
+    if (vbasis) {
+      double beta[INS_MAX_STAGES];
+      for (int m = i - 1; m >= 0; --m) {  // β_i · A[0:i,0:i] = A[i,0:i], A lower triangular
+        double v = rk->A[i * ns + m];
+        for (int j = m + 1; j < i; ++j) v -= beta[j] * rk->A[j * ns + m];
+        beta[m] = v / rk->A[m * ns + m];
+      }
+      for (int m = 0; m < i; ++m) {
+        if (beta[m] == 0.0) continue;
+        epi.coef[epi.n] = beta[m];
+        epi.k[epi.n] = rk->vb[m];
+        epi.c0m1 -= beta[m];
+        ++epi.n;
+      }
+    } else {
+      for (int j = 0; j < i; ++j) {
+        const double coef = dt * rk->A[i * ns + j];
+        if (coef == 0.0) continue;
+        epi.coef[epi.n] = coef;
+        epi.k[epi.n] = rk->ku[j];
+        ++epi.n;
+      }
+      for (int i2 = i + 1; i2 < ns; ++i2)
+        if (rk->A[i2 * ns + i] != 0.0) epi.write_k = 1;
     }
     epi.coef_self = dt * rk->A[i * ns + i];
     epi.ustart = (i == 0) ? nullptr : u;
     epi.ustar = out;
-    for (int i2 = i + 1; i2 < ns; ++i2)
-      if (rk->A[i2 * ns + i] != 0.0) epi.write_k = 1;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (rk->profiling) {
       INS_HIP_TRY(hipEventCreate(&e0));

@@ -457,7 +457,8 @@ extern "C" int ins_slab_applypressure_f64(const ins_grid_t* G, double* u, const 
 // stage's uncorrected velocity with valid z-ghost planes, `p_ext` = [1 plane below | nzl local planes | 2 planes above] of its
 // pressure (unpadded in x, y).  Exactly-uniform slabs only.
 static int stage_momentum_corr(const ins_grid_t* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out, const double* ustart,
-                               double* ustar, int nterms, const double* coefs, const double* const* ks, double coef_self, int part, void* stream);
+                               double* ustar, int nterms, const double* coefs, const double* const* ks, double coef_self, int part, void* stream,
+                               double c0m1 = 0.0);
 
 extern "C" int ins_stage_momentum_corr_f64(const ins_grid_t* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out,
                                            const double* ustart, double* ustar, int nterms, const double* coefs, const double* const* ks,
@@ -467,13 +468,14 @@ extern "C" int ins_stage_momentum_corr_f64(const ins_grid_t* G, double visc, con
 
 extern "C" int ins_stage_momentum_corr_part_f64(const ins_grid_t* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out,
                                                 const double* ustart, double* ustar, int nterms, const double* coefs, const double* const* ks,
-                                                double coef_self, int part, void* stream) {
+                                                double coef_self, double c0m1, int part, void* stream) {
   INS_REQUIRE(part >= 0 && part <= 2, "part must be 0 (all), 1 (interior z-chunks) or 2 (boundary z-chunks)");
-  return stage_momentum_corr(G, visc, ustar_prev, p_ext, k_out, ustart, ustar, nterms, coefs, ks, coef_self, part, stream);
+  return stage_momentum_corr(G, visc, ustar_prev, p_ext, k_out, ustart, ustar, nterms, coefs, ks, coef_self, part, stream, c0m1);
 }
 
 static int stage_momentum_corr(const ins_grid_t* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out, const double* ustart,
-                               double* ustar, int nterms, const double* coefs, const double* const* ks, double coef_self, int part, void* stream) {
+                               double* ustar, int nterms, const double* coefs, const double* const* ks, double coef_self, int part, void* stream,
+                               double c0m1) {
   int rc = check_slab_grid(G);
   if (rc) return rc;
   INS_REQUIRE(ustar_prev && p_ext && ustar && ustart, "null argument");
@@ -488,6 +490,7 @@ static int stage_momentum_corr(const ins_grid_t* G, double visc, const double* u
     epi.coef[q] = coefs[q];
     epi.k[q] = ks[q];
   }
+  epi.c0m1 = c0m1;
   epi.coef_self = coef_self;
   epi.ustart = ustart;
   epi.ustar = ustar;

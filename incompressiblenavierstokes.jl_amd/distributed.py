@@ -21,6 +21,7 @@ spectrum twice (135 MB per rank and transpose at 256^3 per rank), which is what 
 rehearse the communication pattern under gloo without a GPU.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -218,15 +219,16 @@ class HipSlabKernels:
         n0, n1 = self.layout.n[0], self.layout.n[1]
         return torch.zeros(self.real_elems + 3 * n0 * n1, dtype=torch.float64, device=self.device)
 
-    def stage_momentum_corr(self, ustar_prev, p_ext, k_out, ustart, ustar, coefs, ks, coef_self, part=0):
-        """part 1: the z-chunks that read no ghost plane (can run beside the halo exchange); part 2: the rest; 0: everything."""
+    def stage_momentum_corr(self, ustar_prev, p_ext, k_out, ustart, ustar, coefs, ks, coef_self, part=0, c0m1=0.0):
+        """part 1: the planes that read no ghost plane (can run beside the halo exchange); part 2: the rest; 0: everything.
+        c0m1 != 0: `ks` are earlier uncorrected stage velocities (stage-velocity basis, see SlabStepper)."""
         s = self.setup
         n = len(coefs)
         carr = (C.c_double * max(n, 1))(*coefs)
         karr = (C.c_void_p * max(n, 1))(*[k.data_ptr() for k in ks])
         _lib.call("ins_stage_momentum_corr_part_f64", s.handle, 1.0 / s.Re, s.ptr(ustar_prev, True), self._p(p_ext),
                   s.ptr(k_out, True) if k_out is not None else None, s.ptr(ustart, True), s.ptr(ustar, True), n, carr, karr, float(coef_self),
-                  int(part), s.stream)
+                  float(c0m1), int(part), s.stream)
 
     # stage_momentum_corr(part=...) and xfwd_planes exist: SlabStepper overlaps exchanges with them (INS_SLAB_NO_SPLIT=1: A/B switch)
     splits_stage = not bool(__import__("os").environ.get("INS_SLAB_NO_SPLIT"))
@@ -315,8 +317,6 @@ class SlabStepper:
         # z direction of the Poisson solve: "tridiag" = distributed tridiagonal systems, one small all-gather per solve;
         # "fft" = two all-to-all transposes around the z-FFT.  Default: tridiag as soon as there is more than one rank
         # (on one rank the fused z-FFT pass is one HBM pass instead of two).
-        import os
-
         zsolve = zsolve or os.environ.get("INS_SLAB_ZSOLVE") or ("tridiag" if comm.world > 1 else "fft")
         if zsolve not in ("tridiag", "fft"):
             raise ValueError("zsolve must be 'tridiag' or 'fft'")
@@ -329,9 +329,20 @@ class SlabStepper:
         self.chunks = [(k0, min(self.cw, layout.kxn - k0)) for k0 in range(0, layout.kxn, self.cw)]
         self.packed = bool(getattr(kernels, "is_own", lambda: False)())
         ns = len(method.b)
-        self.ku = [kernels.vector() for _ in range(ns)]
-        self.ub = [kernels.vector(), kernels.vector()]
         self.inkernel = bool(getattr(kernels, "supports_inkernel", lambda: False)()) and len(method.b) > 1
+        # Stage-velocity basis (csrc/ins_rk.hip): with in-kernel correction the uncorrected stage velocities V_m stay in memory as the
+        # next stencil's input, and V_i = (1 - Σβ) ustart + Σ_{m<i} β_im V_m + Δt A[i,i] k_i with β_i A[0:i,0:i] = A[i,0:i] — no stage force
+        # is written or read (RK44: 336 instead of 432 B per cell and step through the stage kernels).
+        A = np.asarray(method.A, dtype=float)
+        self.vbasis = (self.inkernel and bool(getattr(kernels, "splits_stage", False)) and all(A[i, i] != 0.0 for i in range(ns))
+                       and not os.environ.get("INS_RK_KEEP_K"))
+        if self.vbasis:
+            self.vb = [kernels.vector() for _ in range(ns - 1)]
+            self.beta = [np.linalg.solve(A[:i, :i].T, A[i, :i]) if i else np.zeros(0) for i in range(ns)]
+            self.ku, self.ub = [], []
+        else:
+            self.ku = [kernels.vector() for _ in range(ns)]
+            self.ub = [kernels.vector(), kernels.vector()]
         plane = layout.n[0] * layout.n[1]
         if self.inkernel:  # pI lives inside the extended buffer so that its ghost planes can be exchanged in place
             self.pX = kernels.pext()
@@ -482,26 +493,35 @@ class SlabStepper:
         pending, p_pending = [], []
         split = bool(getattr(K, "splits_stage", False))
         for i in range(ns):
-            out = u if (i == ns - 1 and ns > 1) else self.ub[i & 1]
-            coefs, ks = [], []
-            for j in range(i):
-                cf = Δt * A[i, j]
-                if cf != 0.0:
-                    coefs.append(cf)
-                    ks.append(self.ku[j])
-            write_k = any(A[i2, i] != 0.0 for i2 in range(i + 1, ns))
+            coefs, ks, c0m1 = [], [], 0.0
+            if self.vbasis:
+                out = u if i == ns - 1 else self.vb[i]
+                for m in range(i):
+                    if self.beta[i][m] != 0.0:
+                        coefs.append(float(self.beta[i][m]))
+                        ks.append(self.vb[m])
+                        c0m1 -= float(self.beta[i][m])
+                write_k = False
+            else:
+                out = u if (i == ns - 1 and ns > 1) else self.ub[i & 1]
+                for j in range(i):
+                    cf = Δt * A[i, j]
+                    if cf != 0.0:
+                        coefs.append(cf)
+                        ks.append(self.ku[j])
+                write_k = any(A[i2, i] != 0.0 for i2 in range(i + 1, ns))
             last = i == ns - 1
             if self.inkernel and i > 0:
                 # previous stage's projection applied in registers from (u*, p) — no K4 pass for that stage.  The z-chunks that read
                 # no ghost plane run while the ghost planes of p (and the last of u*) are still arriving.
                 kw = self.ku[i] if write_k else None
                 if split:
-                    K.stage_momentum_corr(u_in, self.pX, kw, u, out, coefs, ks, Δt * A[i, i], part=1)
+                    K.stage_momentum_corr(u_in, self.pX, kw, u, out, coefs, ks, Δt * A[i, i], part=1, c0m1=c0m1)
                 for req in pending + p_pending:
                     req.wait()
                 pending, p_pending = [], []
                 if split:
-                    K.stage_momentum_corr(u_in, self.pX, kw, u, out, coefs, ks, Δt * A[i, i], part=2)
+                    K.stage_momentum_corr(u_in, self.pX, kw, u, out, coefs, ks, Δt * A[i, i], part=2, c0m1=c0m1)
                 else:
                     K.stage_momentum_corr(u_in, self.pX, kw, u, out, coefs, ks, Δt * A[i, i])
             else:
