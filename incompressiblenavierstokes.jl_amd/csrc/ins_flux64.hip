@@ -385,6 +385,7 @@ int g_disable = env_int("INS_DISABLE_FLUX64");
 int g_rows = env_int("INS_FLUX64_ROWS");
 int g_rows_corr = env_int("INS_FLUX64_ROWS_CORR");
 int g_zchunk = env_int("INS_FLUX64_ZC");
+int g_zchunk_corr = env_int("INS_FLUX64_ZC_CORR");
 int g_xw = env_int("INS_FLUX64_XW");
 int g_lds = env_int("INS_FLUX64_LDS");    // experiment: dynamic LDS bytes per workgroup (caps workgroups per CU)
 int g_skel = env_int("INS_FLUX64_SKEL");  // timing experiment only: wrong results by design
@@ -484,9 +485,11 @@ int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, con
   a.N1 = g.N[1];
   a.N2 = g.N[2];
   // z-chunk: every chunk re-reads two planes from HBM ((zc+2)/zc read amplification, measured with FETCH_SIZE), so chunks are
-  // as long as the tile count allows; 32 keeps >= 1024 workgroups at 256^3 (profiles/r01f_k1_traffic.txt)
+  // as long as the tile count allows (profiles/r01f_k1_traffic.txt; 64 planes at 256^3: 2.93 -> 2.89 ms per step, one workgroup per CU
+  // for the 4-row kernels and still the fastest)
   const int n2 = g.N[2] - 2;
-  a.zc = g_zchunk ? g_zchunk : (n2 >= 128 ? 32 : (n2 >= 64 ? 16 : (n2 >= 32 ? 8 : 4)));
+  const bool small_plane = (long long)(g.N[0] - 2) * (g.N[1] - 2) <= 256LL * 256;  // 512^2 planes: 32 planes measured faster than 64 (24.0 vs 24.8 ms/step)
+  a.zc = (corr_mode && g_zchunk_corr) ? g_zchunk_corr : (g_zchunk ? g_zchunk : (n2 >= 256 && small_plane ? 64 : (n2 >= 128 ? 32 : (n2 >= 64 ? 16 : (n2 >= 32 ? 8 : 4)))));
   a.X = make_dir(G, 0, visc);
   a.Y = make_dir(G, 1, visc);
   a.Z = make_dir(G, 2, visc);

@@ -16,11 +16,10 @@ u = ins.vectorfield(setup); u.copy_(torch.randn(u.shape, dtype=torch.float64, de
 F = ins.vectorfield(setup)
 # (label, disable, rows, zc, skel, burst, lds)
 variants = [("old62", 1, 0, 0, 0, 0, 0)]
-for r in (4, 5, 6):
-    for zc in (8, 16):
+for r in (2, 3, 4):
+    for zc in (8, 16, 32, 64):
         variants.append((f"f64 R{r} zc{zc}", 0, r, zc, 0, 0, 0))
-variants += [("skel R4 zc8", 0, 4, 8, 1, 0, 0), ("skel R6 zc8", 0, 6, 8, 1, 0, 0),
-             ("f64 R4 zc8 lds70k", 0, 4, 8, 0, 0, 70000), ("f64 R4 zc32", 0, 4, 32, 0, 0, 0)]
+variants += [("skel R4 zc32", 0, 4, 32, 1, 0, 0), ("f64 R4 zc32 lds70k", 0, 4, 32, 0, 0, 70000), ("f64 R2 zc32 lds50k", 0, 2, 32, 0, 0, 50000)]
 times = {v[0]: [] for v in variants}
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for rep in range(6):
