@@ -118,14 +118,25 @@ class SlabComm:
         return dist.all_to_all_single(recv, send, group=self.group2 if which else self.group, async_op=True)
 
     def all_gather(self, out, inp):
-        """out[r*len(inp):(r+1)*len(inp)] = rank r's inp."""
+        """out[r*len(inp):(r+1)*len(inp)] = rank r's inp.
+        On RCCL the gather is done as direct sends to every peer in one group call: xGMI is a full mesh of point-to-point links,
+        so each ~1 MB block crosses exactly one link and all links work at once, instead of the P-1 dependent hops of a ring
+        (INS_SLAB_GATHER=collective selects all_gather_into_tensor)."""
         if self.world == 1:
             out.copy_(inp)
             return
+        n = inp.numel()
         if self._stage(inp):
             ho = torch.empty(out.shape, dtype=out.dtype)
             dist.all_gather_into_tensor(ho, inp.cpu(), group=self.group)
             out.copy_(ho)
+        elif (os.environ.get("INS_SLAB_GATHER") or ("p2p" if self.backend == "nccl" else "collective")) == "p2p":
+            out[self.rank * n : (self.rank + 1) * n].copy_(inp)
+            peers = [(self.rank + d) % self.world for d in range(1, self.world)]
+            ops = [dist.P2POp(dist.isend, inp, q, self.group) for q in peers]
+            ops += [dist.P2POp(dist.irecv, out[q * n : (q + 1) * n], q, self.group) for q in reversed(peers)]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
         else:
             dist.all_gather_into_tensor(out, inp, group=self.group)
 

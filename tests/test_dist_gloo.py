@@ -49,12 +49,17 @@ def _worker(rank, world, port, n, nsteps, method_name, out_dir, chunks=1, own=Fa
                          [("RK44", 1, False, "fft", 2), ("Wray3", 1, False, "fft", 2), ("FE11", 1, False, "fft", 2), ("RK44", 3, False, "fft", 2),
                           ("RK44", 1, True, "fft", 2), ("RK44", 3, True, "fft", 2), ("Wray3", 2, True, "fft", 2), ("FE11", 1, True, "fft", 2),
                           ("RK44", 1, False, "tridiag", 2), ("RK44", 1, True, "tridiag", 2), ("Wray3", 1, True, "tridiag", 2),
-                          ("FE11", 1, False, "tridiag", 2), ("RK44", 1, True, "tridiag", 3)])
+                          ("FE11", 1, False, "tridiag", 2), ("RK44", 1, True, "tridiag", 3), ("RK44", 1, True, "tridiag-p2p", 3)])
 def test_slab_stepper_two_ranks_matches_single_domain(tmp_path, oracle, method_name, chunks, own, zsolve, world):
     """chunks > 1: the transposes pipelined over kx-chunks on two process groups; own: the packed-pass branch;
     zsolve = tridiag: no transposes, the z direction as distributed tridiagonal systems (one all-gather per solve)."""
     o = oracle
     n, nsteps = (12, 6 * (world // 2 + world % 2) if world == 3 else 8, 12), 2
+    if zsolve.endswith("-p2p"):  # the interface gather as direct sends to every peer (the RCCL default) instead of the collective
+        zsolve = "tridiag"
+        os.environ["INS_SLAB_GATHER"] = "p2p"
+    else:
+        os.environ.pop("INS_SLAB_GATHER", None)
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n, nsteps, method_name, str(tmp_path), chunks, own, zsolve), nprocs=world, join=True)
     x = tuple(np.linspace(0.0, 1.0, ni + 1) for ni in n)
