@@ -240,6 +240,14 @@ int ins_slab_fft_is_own(const ins_slab_fft_t* fft);
 int ins_slab_ztri_edge_elems(const ins_slab_fft_t* S, int64_t* doubles);
 int ins_slab_ztri_forward(ins_slab_fft_t* S, const ins_grid_t* grid, const double* src, int from_u, double* work, double* edge, void* stream);
 int ins_slab_ztri_finish(ins_slab_fft_t* S, double* work, const double* edges_all, double* pI, void* stream);
+/* The same solve with the kxn·ny lines cut into `nchunks` ranges, so that the gather of one range travels while the next range is swept:
+ * ztri_transform -> for each c: ztri_sweep_forward(c) + gather of its edge buffer (ztri_chunk gives range and size) -> for each c:
+ * ztri_sweep_backward(c) -> ztri_inverse.  forward / finish above are the one-range forms. */
+int ins_slab_ztri_chunk(const ins_slab_fft_t* S, int c, int nchunks, int64_t* line_lo, int64_t* line_cnt, int64_t* edge_doubles);
+int ins_slab_ztri_transform(ins_slab_fft_t* S, const ins_grid_t* grid, const double* src, int from_u, double* work, void* stream);
+int ins_slab_ztri_sweep_forward(ins_slab_fft_t* S, double* work, double* edge, int c, int nchunks, void* stream);
+int ins_slab_ztri_sweep_backward(ins_slab_fft_t* S, double* work, const double* edges_all, int c, int nchunks, void* stream);
+int ins_slab_ztri_inverse(ins_slab_fft_t* S, double* work, double* pI, void* stream);
 /* x pass of ins_slab_ztri_forward (from_u = 1) for local planes [kz0, kz0 + nkz) only; follow with ins_slab_ztri_forward(from_u = 2).
  * Planes >= 1 read no ghost plane of u, so they can run while the w plane below the slab is still in flight. */
 int ins_slab_xfwd_planes(ins_slab_fft_t* S, const ins_grid_t* grid, const double* u, double* work, int kz0, int nkz, void* stream);

@@ -95,6 +95,11 @@ SIGNATURES = {
     "ins_slab_ztri_forward": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp]),
     "ins_slab_ztri_finish": (C.c_int, [vp, vp, vp, vp, vp]),
     "ins_slab_xfwd_planes": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "ins_slab_ztri_chunk": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ins_slab_ztri_transform": (C.c_int, [vp, vp, vp, C.c_int, vp, vp]),
+    "ins_slab_ztri_sweep_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
+    "ins_slab_ztri_sweep_backward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
+    "ins_slab_ztri_inverse": (C.c_int, [vp, vp, vp, vp]),
     "ins_slab_fft_forward_packed": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp]),
     "ins_slab_fft_inverse_packed": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
 }

@@ -9,6 +9,7 @@
 //   solve_z    : 1-D FFT along z, divide by the Laplacian symbol (mean mode zeroed, 1/prod(Np) folded in), inverse
 //   (all-to-all back)
 //   inverse_xy : unpack, 2-D C2R per plane -> pI
+#include <algorithm>
 #include <cmath>
 
 #include "ins_internal.h"
@@ -32,9 +33,9 @@ struct ins_slab_fft {
 };
 
 int ins_k_ztri_forward(double* work, int kxn, int kxs, int n1, int m, int nranks, int rank, const double* ax, const double* ay, double c,
-                       double scale, double* edge, hipStream_t s);
+                       double scale, double* edge, long long l_lo, long long l_cnt, hipStream_t s);
 int ins_k_ztri_finish(double* work, int kxn, int kxs, int n1, int m, int nranks, int rank, const double* ax, const double* ay, double c,
-                      const double* edges_all, double* bc, hipStream_t s);
+                      const double* edges_all, long long stride, double* bc, long long l_lo, long long l_cnt, hipStream_t s);
 
 namespace {
 
@@ -363,35 +364,95 @@ extern "C" int ins_slab_fft_inverse_packed(ins_slab_fft_t* S, double* recvbuf, d
 extern "C" int ins_slab_fft_is_own(const ins_slab_fft_t* S) { return S && S->ownfft; }
 
 // ---- transpose-free solve: the z direction as distributed tridiagonal systems (ins_ztri.hip) ----------------------------------
-// Per rank the exchange buffer holds [yF (lines) | yL (lines) | the singular line's nzl local values], complex, lines = kxn * ny.
-extern "C" int ins_slab_ztri_edge_elems(const ins_slab_fft_t* S, int64_t* doubles) {
-  INS_REQUIRE(S && doubles, "null argument");
-  *doubles = 2 * (2 * (int64_t)S->kxn * S->np[1] + S->nzl);
+// The kxn·ny lines can be cut into `nchunks` ranges so that the gather of one range travels while the next range is swept.
+// Per rank the exchange buffer of a range holds [yF (cnt) | yL (cnt) | the singular line's nzl local values (range 0 only)], complex.
+static void ztri_range(const ins_slab_fft* S, int c, int nchunks, long long* lo, long long* cnt) {
+  const long long lines = (long long)S->kxn * S->np[1];
+  long long per = (lines + nchunks - 1) / nchunks;
+  per = (per + 127) / 128 * 128;  // whole 256-thread workgroups of re/im components
+  *lo = std::min(lines, (long long)c * per);
+  *cnt = std::min(per, lines - *lo);
+}
+
+extern "C" int ins_slab_ztri_chunk(const ins_slab_fft_t* S, int c, int nchunks, int64_t* line_lo, int64_t* line_cnt, int64_t* edge_doubles) {
+  INS_REQUIRE(S && nchunks >= 1 && c >= 0 && c < nchunks, "bad chunk");
+  long long lo, cnt;
+  ztri_range(S, c, nchunks, &lo, &cnt);
+  if (line_lo) *line_lo = lo;
+  if (line_cnt) *line_cnt = cnt;
+  if (edge_doubles) *edge_doubles = 2 * (2 * cnt + (c == 0 ? S->nzl : 0));
   return INS_OK;
 }
 
-// x / y forward transforms of the local planes (from_u: Ω·div(u) formed inside the x pass, own passes only; else src = pI),
-// then the forward elimination along z in place on `work` and this rank's interface data -> `edge`.
-extern "C" int ins_slab_ztri_forward(ins_slab_fft_t* S, const ins_grid_t* G, const double* src, int from_u, double* work, double* edge, void* stream) {
-  INS_REQUIRE(S && src && work && edge, "null argument");
+extern "C" int ins_slab_ztri_edge_elems(const ins_slab_fft_t* S, int64_t* doubles) {
+  INS_REQUIRE(S && doubles, "null argument");
+  return ins_slab_ztri_chunk(S, 0, 1, nullptr, nullptr, doubles);
+}
+
+// (x, y) forward transforms of the local planes into `work` (from_u = 1: Ω·div(u) formed inside the x pass, own passes only; 2: the x
+// pass was done by ins_slab_xfwd_planes; 0: src = pI).
+extern "C" int ins_slab_ztri_transform(ins_slab_fft_t* S, const ins_grid_t* G, const double* src, int from_u, double* work, void* stream) {
+  INS_REQUIRE(S && src && work, "null argument");
   INS_REQUIRE(S->nzl >= 2, "the tridiagonal z solve needs >= 2 local planes");
   hipStream_t s = as_stream(stream);
   int rc;
   if (from_u == 2) {  // x pass already done plane range by plane range (ins_slab_xfwd_planes)
     INS_REQUIRE(S->ownfft, "forming the right-hand side inside the x pass needs a power-of-two box");
-    if ((rc = ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s, S->kxs))) return rc;
-  } else if (from_u) {
+    return ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s, S->kxs);
+  }
+  if (from_u) {
     INS_REQUIRE(S->ownfft, "forming the right-hand side inside the x pass needs a power-of-two box");
     INS_REQUIRE(G && G->g.D == 3 && G->g.N[0] == S->np[0] + 2 && G->g.N[1] == S->np[1] + 2 && G->g.N[2] == S->nzl + 2, "grid does not match the slab");
     if ((rc = ins_k_ownfft_xfwd(G, src, 2, work, S->np[0], S->np[1], S->nzl, S->tw_x, s, S->kxs))) return rc;
-    if ((rc = ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s, S->kxs))) return rc;
-  } else if (S->ownfft) {
+    return ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s, S->kxs);
+  }
+  if (S->ownfft) {
     if ((rc = ins_k_ownfft_xfwd(nullptr, src, 0, work, S->np[0], S->np[1], S->nzl, S->tw_x, s, S->kxs))) return rc;
-    if ((rc = ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s, S->kxs))) return rc;
-  } else if ((rc = slab_xy_forward(S, const_cast<double*>(src), work, s)))
-    return rc;
+    return ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s, S->kxs);
+  }
+  return slab_xy_forward(S, const_cast<double*>(src), work, s);
+}
+
+// forward elimination along z of line range c (in place on `work`) and this rank's interface data of the range -> edge
+extern "C" int ins_slab_ztri_sweep_forward(ins_slab_fft_t* S, double* work, double* edge, int c, int nchunks, void* stream) {
+  INS_REQUIRE(S && work && edge && nchunks >= 1 && c >= 0 && c < nchunks, "bad argument");
+  long long lo, cnt;
+  ztri_range(S, c, nchunks, &lo, &cnt);
   const double scale = -1.0 / ((double)S->np[0] * S->np[1]);
-  return ins_k_ztri_forward(work, S->kxn, S->kxs, S->np[1], S->nzl, S->nranks, S->rank, S->ax, S->ay_full, S->cz, scale, edge, s);
+  return ins_k_ztri_forward(work, S->kxn, S->kxs, S->np[1], S->nzl, S->nranks, S->rank, S->ax, S->ay_full, S->cz, scale, edge, lo, cnt, as_stream(stream));
+}
+
+// edges_all = the gathered edge buffers of range c (rank-major): interface solve + back substitution of the range
+extern "C" int ins_slab_ztri_sweep_backward(ins_slab_fft_t* S, double* work, const double* edges_all, int c, int nchunks, void* stream) {
+  INS_REQUIRE(S && work && edges_all && nchunks >= 1 && c >= 0 && c < nchunks, "bad argument");
+  long long lo, cnt;
+  ztri_range(S, c, nchunks, &lo, &cnt);
+  const long long stride = 2 * cnt + (c == 0 ? S->nzl : 0);
+  return ins_k_ztri_finish(work, S->kxn, S->kxs, S->np[1], S->nzl, S->nranks, S->rank, S->ax, S->ay_full, S->cz, edges_all, stride,
+                           S->ztri_bc + 4 * lo, lo, cnt, as_stream(stream));
+}
+
+// inverse y / x transforms of `work` -> pI
+extern "C" int ins_slab_ztri_inverse(ins_slab_fft_t* S, double* work, double* pI, void* stream) {
+  INS_REQUIRE(S && work && pI, "null argument");
+  hipStream_t s = as_stream(stream);
+  if (!S->ownfft) return slab_xy_inverse(S, work, pI, s);
+  int rc = ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, true, s, S->kxs);
+  if (rc) return rc;
+  return ins_k_ownfft_xinv(work, pI, S->np[0], S->np[1], S->nzl, S->tw_x, s, S->kxs);
+}
+
+// one-range forms
+extern "C" int ins_slab_ztri_forward(ins_slab_fft_t* S, const ins_grid_t* G, const double* src, int from_u, double* work, double* edge, void* stream) {
+  INS_REQUIRE(edge, "null argument");
+  int rc = ins_slab_ztri_transform(S, G, src, from_u, work, stream);
+  return rc ? rc : ins_slab_ztri_sweep_forward(S, work, edge, 0, 1, stream);
+}
+
+extern "C" int ins_slab_ztri_finish(ins_slab_fft_t* S, double* work, const double* edges_all, double* pI, void* stream) {
+  INS_REQUIRE(pI, "null argument");
+  int rc = ins_slab_ztri_sweep_backward(S, work, edges_all, 0, 1, stream);
+  return rc ? rc : ins_slab_ztri_inverse(S, work, pI, stream);
 }
 
 // The x pass of ins_slab_ztri_forward (from_u = 1) for local planes [kz0, kz0 + nkz) only: planes >= 1 need no ghost plane of u, so they
@@ -403,17 +464,6 @@ extern "C" int ins_slab_xfwd_planes(ins_slab_fft_t* S, const ins_grid_t* G, cons
   INS_REQUIRE(kz0 >= 0 && nkz >= 0 && kz0 + nkz <= S->nzl, "bad plane range");
   if (nkz == 0) return INS_OK;
   return ins_k_ownfft_xfwd(G, u, 2, work, S->np[0], S->np[1], nkz, S->tw_x, as_stream(stream), S->kxs, kz0);
-}
-
-// edges_all = the all-gathered edge buffers (rank-major).  Interface solve, back substitution, inverse y / x transforms -> pI.
-extern "C" int ins_slab_ztri_finish(ins_slab_fft_t* S, double* work, const double* edges_all, double* pI, void* stream) {
-  INS_REQUIRE(S && work && edges_all && pI, "null argument");
-  hipStream_t s = as_stream(stream);
-  int rc = ins_k_ztri_finish(work, S->kxn, S->kxs, S->np[1], S->nzl, S->nranks, S->rank, S->ax, S->ay_full, S->cz, edges_all, S->ztri_bc, s);
-  if (rc) return rc;
-  if (!S->ownfft) return slab_xy_inverse(S, work, pI, s);
-  if ((rc = ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, true, s, S->kxs))) return rc;
-  return ins_k_ownfft_xinv(work, pI, S->np[0], S->np[1], S->nzl, S->tw_x, s, S->kxs);
 }
 
 /* 1 when kx chunks are supported (power-of-two nz -> fused z kernel). */

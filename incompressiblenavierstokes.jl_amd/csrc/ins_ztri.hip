@@ -61,10 +61,11 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_doub
 // spikes v_k = (r^(k+1) - r^(m+1) r^(m-k)) / (1 - r^(2m+2)) = c (A_r⁻¹ e_0)_k,  w_k = v_{m-1-k}
 // One work-item per REAL component of a line (re and im obey the same real recurrence): twice the parallelism of one per line,
 // which matters because a slab has only kxn·ny lines and every one is a serial march over the local planes.
-__global__ __launch_bounds__(256) void k_ztri_fwd(ZtriArgs a, double* __restrict__ edge, double* __restrict__ line0) {
-  // flat index over (ky, kx, re/im): a 256-wide workgroup reads 2 KB of consecutive memory per plane
-  const long long lines2 = 2LL * a.kxn * a.n1, l2 = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (l2 >= lines2) return;
+__global__ __launch_bounds__(256) void k_ztri_fwd(ZtriArgs a, double* __restrict__ edge, double* __restrict__ line0, long long l_lo, long long l_cnt) {
+  // flat index over (ky, kx, re/im) of the line range of this launch: a 256-wide workgroup reads 2 KB of consecutive memory per plane
+  const long long r2 = (long long)blockIdx.x * 256 + threadIdx.x;  // component index inside the range
+  if (r2 >= 2 * l_cnt) return;
+  const long long lines2 = 2 * l_cnt, l2 = 2 * l_lo + r2;
   const int ky = (int)(l2 / (2 * a.kxn)), t = (int)(l2 - (long long)ky * 2 * a.kxn);
   const int kx = t >> 1;
   const long long ps = 2LL * a.kxs * a.n1;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void k_ztri_fwd(ZtriArgs a, double* __restrict
   const double sxy = a.ax[kx] + a.ay[ky];
   if (sxy == 0.0) {  // the singular line: hand the scaled right-hand side to the gather, leave the rest to k_ztri_line0
     for (int k = 0; k < a.m; ++k) line0[2 * k + (t & 1)] = a.scale * x[k * ps];
-    edge[l2] = edge[lines2 + l2] = 0.0;
+    edge[r2] = edge[lines2 + r2] = 0.0;
     return;
   }
   const LineConst L = line_const(sxy / a.c, a.m);
@@ -110,18 +111,21 @@ __global__ __launch_bounds__(256) void k_ztri_fwd(ZtriArgs a, double* __restrict
 #pragma unroll
     for (int j = 0; j < CH; ++j) buf[j] = nxt[j];
   }
-  edge[l2] = idc * (SA - L.rm1 * SB);           // Σ v_k g_k / c
-  edge[lines2 + l2] = idc * (SB - L.rm1 * SA);  // Σ w_k g_k / c
+  edge[r2] = idc * (SA - L.rm1 * SB);           // Σ v_k g_k / c
+  edge[lines2 + r2] = idc * (SB - L.rm1 * SA);  // Σ w_k g_k / c
 }
 
 // ---- interface: block-circulant 2P x 2P system per line, by a DFT over ranks ---------------------------------------------
 //   F_r - α L_{r-1} - β F_{r+1} = yF_r,   L_r - β L_{r-1} - α F_{r+1} = yL_r,   α = v_0, β = v_{m-1}
 // edges_all: [rank][ per-rank block of `stride` complex: yF[lines], yL[lines], line0[m] ];  out bc: [2][lines] = (L_{r-1}, F_{r+1})
 constexpr int ZTRI_MAX_RANKS = 16;
-__global__ __launch_bounds__(256) void k_ztri_iface(ZtriArgs a, const double2* __restrict__ edges_all, long long stride, double2* __restrict__ bc) {
-  const int kx = blockIdx.x * 64 + threadIdx.x, ky = blockIdx.y * 4 + threadIdx.y;
-  if (kx >= a.kxn || ky >= a.n1) return;
-  const long long lines = (long long)a.kxn * a.n1, l = kx + (long long)a.kxn * ky;
+__global__ __launch_bounds__(256) void k_ztri_iface(ZtriArgs a, const double2* __restrict__ edges_all, long long stride, double2* __restrict__ bc,
+                                                    long long l_lo, long long l_cnt) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= l_cnt) return;
+  const long long lines = l_cnt, l = r;  // edges_all / bc are indexed inside the range
+  const long long lg = l_lo + r;
+  const int ky = (int)(lg / a.kxn), kx = (int)(lg - (long long)ky * a.kxn);
   const double sxy = a.ax[kx] + a.ay[ky];
   if (sxy == 0.0) {
     bc[l] = bc[lines + l] = make_double2(0.0, 0.0);
@@ -170,10 +174,11 @@ __global__ __launch_bounds__(256) void k_ztri_iface(ZtriArgs a, const double2* _
 // ---- pass 2: back substitution with the interface values folded in -------------------------------------------------------
 // g̃ = g + c L_{r-1} e_0 + c F_{r+1} e_{m-1}  =>  gp̃_k = gp_k + c L φ_k (+ c F /den_{m-1} at k = m-1),  φ_k = r^(k+1)(1-r²)/(c(1-E_k r²))
 // p_{m-1} = gp̃_{m-1},  p_k = gp̃_k + (c/den_k) p_{k+1}
-__global__ __launch_bounds__(256) void k_ztri_bwd(ZtriArgs a, const double* __restrict__ bc) {
-  // flat index over (ky, kx, re/im): a 256-wide workgroup reads 2 KB of consecutive memory per plane
-  const long long lines2 = 2LL * a.kxn * a.n1, l2 = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (l2 >= lines2) return;
+__global__ __launch_bounds__(256) void k_ztri_bwd(ZtriArgs a, const double* __restrict__ bc, long long l_lo, long long l_cnt) {
+  // flat index over (ky, kx, re/im) of the line range of this launch: a 256-wide workgroup reads 2 KB of consecutive memory per plane
+  const long long r2 = (long long)blockIdx.x * 256 + threadIdx.x;  // component index inside the range
+  if (r2 >= 2 * l_cnt) return;
+  const long long lines2 = 2 * l_cnt, l2 = 2 * l_lo + r2;
   const int ky = (int)(l2 / (2 * a.kxn)), t = (int)(l2 - (long long)ky * 2 * a.kxn);
   const int kx = t >> 1;
   const long long ps = 2LL * a.kxs * a.n1;
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(256) void k_ztri_bwd(ZtriArgs a, const double* __re
   const double sxy = a.ax[kx] + a.ay[ky];
   if (sxy == 0.0) return;  // k_ztri_line0
   const LineConst L = line_const(sxy / a.c, a.m);
-  const double Lp = bc[l2], Fn = bc[lines2 + l2];
+  const double Lp = bc[r2], Fn = bc[lines2 + r2];  // bc of this range: [L (cnt)][F (cnt)]
   const double omr2 = 1.0 - L.r2;
   double p = 0.0;
   const double rinv = 1.0 / L.r;
@@ -282,29 +287,30 @@ __global__ __launch_bounds__(64) void k_ztri_line0(ZtriArgs a, const double2* __
 }  // namespace
 
 // launched by ins_slab.hip (which owns the slab handle): all on stream s
+// Line range [l_lo, l_lo + l_cnt) of the kxn·n1 lines.  edge: [yF (l_cnt) | yL (l_cnt) | the singular line's m values when the range holds line 0]
 int ins_k_ztri_forward(double* work, int kxn, int kxs, int n1, int m, int nranks, int rank, const double* ax, const double* ay, double c,
-                       double scale, double* edge, hipStream_t s) {
+                       double scale, double* edge, long long l_lo, long long l_cnt, hipStream_t s) {
   ZtriArgs a{reinterpret_cast<double2*>(work), kxn, kxs, n1, m, nranks, rank, ax, ay, c, scale};
-  const long long lines = (long long)kxn * n1;
-  hipLaunchKernelGGL(k_ztri_fwd, dim3(cdiv(2 * lines, 256)), dim3(256), 0, s, a, edge, edge + 4 * lines);  // one work-item per real component
+  if (l_cnt <= 0) return INS_OK;
+  hipLaunchKernelGGL(k_ztri_fwd, dim3(cdiv(2 * l_cnt, 256)), dim3(256), 0, s, a, edge, edge + 4 * l_cnt, l_lo, l_cnt);  // one work-item per real component
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
 
+// edges_all: the gathered edge buffers of this range, `stride` complex per rank; bc: scratch of 2·l_cnt complex
 int ins_k_ztri_finish(double* work, int kxn, int kxs, int n1, int m, int nranks, int rank, const double* ax, const double* ay, double c,
-                      const double* edges_all, double* bc, hipStream_t s) {
+                      const double* edges_all, long long stride, double* bc, long long l_lo, long long l_cnt, hipStream_t s) {
   if (nranks > ZTRI_MAX_RANKS) {
     ins_set_error("tridiagonal z solve: at most %d ranks", ZTRI_MAX_RANKS);
     return INS_ERR_UNSUPPORTED;
   }
+  if (l_cnt <= 0) return INS_OK;
   ZtriArgs a{reinterpret_cast<double2*>(work), kxn, kxs, n1, m, nranks, rank, ax, ay, c, 0.0};
-  const long long lines = (long long)kxn * n1, stride = 2 * lines + m;
   const double2* ea = reinterpret_cast<const double2*>(edges_all);
   double2* b = reinterpret_cast<double2*>(bc);
-  dim3 block(64, 4), grid(cdiv(kxn, 64), cdiv(n1, 4));
-  hipLaunchKernelGGL(k_ztri_iface, grid, block, 0, s, a, ea, stride, b);
-  hipLaunchKernelGGL(k_ztri_bwd, dim3(cdiv(2 * lines, 256)), dim3(256), 0, s, a, (const double*)bc);
-  hipLaunchKernelGGL(k_ztri_line0, dim3(1), dim3(64), 0, s, a, ea, stride, 2 * lines);
+  hipLaunchKernelGGL(k_ztri_iface, dim3(cdiv(l_cnt, 256)), dim3(256), 0, s, a, ea, stride, b, l_lo, l_cnt);
+  hipLaunchKernelGGL(k_ztri_bwd, dim3(cdiv(2 * l_cnt, 256)), dim3(256), 0, s, a, (const double*)bc, l_lo, l_cnt);
+  if (l_lo == 0) hipLaunchKernelGGL(k_ztri_line0, dim3(1), dim3(64), 0, s, a, ea, stride, 2 * l_cnt);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }

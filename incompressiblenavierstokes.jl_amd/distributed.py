@@ -140,6 +140,20 @@ class SlabComm:
         else:
             dist.all_gather_into_tensor(out, inp, group=self.group)
 
+    def all_gather_async(self, out, inp):
+        """all_gather whose transfer runs beside later kernels of the current stream; returns requests to wait() on ([] when it
+        completed synchronously: one rank, staged rehearsal or the collective route)."""
+        mode = os.environ.get("INS_SLAB_GATHER") or ("p2p" if self.backend == "nccl" else "collective")
+        if self.world == 1 or self._stage(inp) or mode != "p2p":
+            self.all_gather(out, inp)
+            return []
+        n = inp.numel()
+        out[self.rank * n : (self.rank + 1) * n].copy_(inp)
+        peers = [(self.rank + d) % self.world for d in range(1, self.world)]
+        ops = [dist.P2POp(dist.isend, inp, q, self.group) for q in peers]
+        ops += [dist.P2POp(dist.irecv, out[q * n : (q + 1) * n], q, self.group) for q in reversed(peers)]
+        return dist.batch_isend_irecv(ops)
+
     def barrier(self):
         if self.world > 1:
             dist.barrier(self.group)
@@ -311,6 +325,28 @@ class HipSlabKernels:
     def ztri_finish(self, work, edges_all, pI):
         _lib.call("ins_slab_ztri_finish", self._fft, self._p(work), self._p(edges_all), self._p(pI), self.setup.stream)
 
+    # the same solve with the lines cut into ranges (the gather of one range travels while the next range is swept)
+    ztri_chunked = True
+
+    def ztri_chunk_edge(self, c, nchunks, ranks=1):
+        n = C.c_int64()
+        _lib.call("ins_slab_ztri_chunk", self._fft, int(c), int(nchunks), None, None, C.byref(n))
+        return torch.zeros(n.value * ranks, dtype=torch.float64, device=self.device)
+
+    def ztri_transform(self, src, from_u, work):
+        s = self.setup
+        ptr = s.ptr(src, True) if from_u else self._p(src)
+        _lib.call("ins_slab_ztri_transform", self._fft, s.handle, ptr, int(from_u), self._p(work), s.stream)
+
+    def ztri_sweep_forward(self, work, edge, c, nchunks):
+        _lib.call("ins_slab_ztri_sweep_forward", self._fft, self._p(work), self._p(edge), int(c), int(nchunks), self.setup.stream)
+
+    def ztri_sweep_backward(self, work, edges_all, c, nchunks):
+        _lib.call("ins_slab_ztri_sweep_backward", self._fft, self._p(work), self._p(edges_all), int(c), int(nchunks), self.setup.stream)
+
+    def ztri_inverse(self, work, pI):
+        _lib.call("ins_slab_ztri_inverse", self._fft, self._p(work), self._p(pI), self.setup.stream)
+
     def applypressure(self, u, pI, p_top):
         s = self.setup
         _lib.call("ins_slab_applypressure_f64", s.handle, s.ptr(u, True), self._p(pI), self._p(p_top), s.stream)
@@ -366,8 +402,15 @@ class SlabStepper:
         self.bufb = kernels.cplx()
         self.p_top = kernels.real()[: layout.n[0] * layout.n[1]].clone()
         if self.zsolve == "tridiag":
-            self.edge = kernels.ztri_edge()
-            self.edges_all = kernels.ztri_edge(comm.world)
+            # line ranges of the interface gather (INS_SLAB_ZCHUNKS > 1: the gather of range c travels while range c+1 is swept).  Default 1:
+            # with direct sends the gather is ~1 MB over each link (tens of µs), about what the smaller launches cost (+0.08 ms per step at 2 ranges)
+            self.zchunks = int(os.environ.get("INS_SLAB_ZCHUNKS") or 1) if bool(getattr(kernels, "ztri_chunked", False)) else 1
+            if self.zchunks > 1:
+                self.edge_c = [kernels.ztri_chunk_edge(c, self.zchunks) for c in range(self.zchunks)]
+                self.edges_all_c = [kernels.ztri_chunk_edge(c, self.zchunks, comm.world) for c in range(self.zchunks)]
+            else:
+                self.edge = kernels.ztri_edge()
+                self.edges_all = kernels.ztri_edge(comm.world)
         self.n = 0
 
     # -- exchanges ---------------------------------------------------------------------------
@@ -432,14 +475,28 @@ class SlabStepper:
             self.halo_u(u, comps=(2,), down_only=True)  # divergence needs w[I - e_z] only (operators.jl:122)
         if self.zsolve == "tridiag":
             if split:
-                K.ztri_forward(u, 2, self.work, self.edge)
+                src, from_u = u, 2
             elif self.packed:  # power-of-two box: Ω·div(u) formed inside the x pass
-                K.ztri_forward(u, True, self.work, self.edge)
+                src, from_u = u, 1
             else:
                 K.divergence(u, self.pI)
-                K.ztri_forward(self.pI, False, self.work, self.edge)
-            self.comm.all_gather(self.edges_all, self.edge)
-            K.ztri_finish(self.work, self.edges_all, self.pI)
+                src, from_u = self.pI, 0
+            if self.zchunks > 1:
+                nc = self.zchunks
+                K.ztri_transform(src, from_u, self.work)
+                handles = []
+                for c in range(nc):
+                    K.ztri_sweep_forward(self.work, self.edge_c[c], c, nc)
+                    handles.append(self.comm.all_gather_async(self.edges_all_c[c], self.edge_c[c]))
+                for c in range(nc):
+                    for req in handles[c]:
+                        req.wait()
+                    K.ztri_sweep_backward(self.work, self.edges_all_c[c], c, nc)
+                K.ztri_inverse(self.work, self.pI)
+            else:
+                K.ztri_forward(src, from_u, self.work, self.edge)
+                self.comm.all_gather(self.edges_all, self.edge)
+                K.ztri_finish(self.work, self.edges_all, self.pI)
             if apply:
                 self.halo_p()
                 K.applypressure(u, self.pI, self.p_top)

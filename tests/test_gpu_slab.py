@@ -21,14 +21,17 @@ def rell2(a, b):
     return float(np.sqrt(np.sum((a - b) ** 2)) / np.sqrt(np.sum(b**2)))
 
 
-@pytest.mark.parametrize("zsolve", ["fft", "tridiag"])
+@pytest.mark.parametrize("zsolve", ["fft", "tridiag", "tridiag-3chunks"])
 @pytest.mark.parametrize("n", [(64, 32, 16), (70, 24, 20), (128, 16, 16)])  # last: 64-wide K1 (ins_flux64.hip), CORR = 2
-def test_one_rank_slab_equals_single_gpu_path(oracle, n, zsolve):
+def test_one_rank_slab_equals_single_gpu_path(oracle, n, zsolve, monkeypatch):
     """zsolve = tridiag: the distributed tridiagonal z solve (csrc/ins_ztri.hip) with one rank is the whole periodic line —
     it must reproduce the z-FFT solve of the single-GPU path."""
     _need_gpu()
     import ins_amd as ins
 
+    if zsolve == "tridiag-3chunks":  # the line ranges of the pipelined interface gather (the default with > 1 rank is 2)
+        zsolve = "tridiag"
+        monkeypatch.setenv("INS_SLAB_ZCHUNKS", "3")
     o = oracle
     x = tuple(np.linspace(0.0, 1.0, ni + 1) for ni in n)
     so = o.make_setup(x, Re=800.0)
@@ -87,13 +90,18 @@ def _worker(rank, world, port, n, nsteps, out_dir, chunks=1, zsolve="fft"):
 @pytest.mark.parametrize("world,n,chunks,zsolve", [(2, (66, 16, 24), 1, "fft"), (4, (66, 16, 24), 1, "fft"), (2, (64, 16, 32), 1, "fft"),
                                                    (4, (64, 32, 32), 1, "fft"), (2, (64, 16, 32), 4, "fft"), (2, (66, 16, 32), 3, "fft"),
                                                    (2, (128, 16, 32), 4, "fft"), (2, (64, 16, 32), 1, "tridiag"), (4, (64, 32, 32), 1, "tridiag"),
-                                                   (2, (66, 16, 24), 1, "tridiag"), (3, (128, 18, 24), 1, "tridiag"), (2, (128, 16, 32), 1, "tridiag")])
+                                                   (2, (66, 16, 24), 1, "tridiag"), (3, (128, 18, 24), 1, "tridiag"), (2, (128, 16, 32), 1, "tridiag"), (2, (64, 16, 32), 1, "tridiag-2ranges")])
 def test_multi_rank_slab_on_one_gpu_matches_oracle(tmp_path, oracle, world, n, chunks, zsolve):
     """(66,16,24): rocFFT x/y + rocFFT z; power-of-two boxes: own x/y passes with the digit-reversed ky order split
     across ranks + the fused z kernel."""
     _need_gpu()
     o = oracle
     nsteps = 2
+    if zsolve.endswith("-2ranges"):  # pipelined interface gather over two line ranges
+        zsolve = "tridiag"
+        os.environ["INS_SLAB_ZCHUNKS"] = "2"
+    else:
+        os.environ.pop("INS_SLAB_ZCHUNKS", None)
     mp.spawn(_worker, args=(world, _free_port(), n, nsteps, str(tmp_path), chunks, zsolve), nprocs=world, join=True)
     x = tuple(np.linspace(0.0, 1.0, ni + 1) for ni in n)
     so = o.make_setup(x, Re=500.0)
