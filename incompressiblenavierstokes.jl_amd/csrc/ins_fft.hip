@@ -75,9 +75,10 @@ __device__ __forceinline__ void fft_dif(double2* __restrict__ buf, const double2
       const double2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
       double2 y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
       if (L > 4) {
-        y1 = cmul(y1, tw[j * step]);
-        y2 = cmul(y2, tw[2 * j * step]);
-        y3 = cmul(y3, tw[3 * j * step]);
+        const double2 w1 = tw[j * step], w2 = cmul(w1, w1), w3 = cmul(w2, w1);  // one table read instead of three (LDS-bound stages)
+        y1 = cmul(y1, w1);
+        y2 = cmul(y2, w2);
+        y3 = cmul(y3, w3);
       }
       x[0] = cadd(t0, t2);
       x[Q * SR] = y1;
@@ -101,9 +102,10 @@ __device__ __forceinline__ void fft_dit(double2* __restrict__ buf, const double2
       double2* x = buf + c * SC + (g * L + j) * SR;
       double2 x0 = x[0], x1 = x[Q * SR], x2 = x[2 * Q * SR], x3 = x[3 * Q * SR];
       if (L > 4) {
-        x1 = cmulc(x1, tw[j * step]);
-        x2 = cmulc(x2, tw[2 * j * step]);
-        x3 = cmulc(x3, tw[3 * j * step]);
+        const double2 w1 = tw[j * step], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+        x1 = cmulc(x1, w1);
+        x2 = cmulc(x2, w2);
+        x3 = cmulc(x3, w3);
       }
       const double2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = mul_pi(csub(x1, x3));
       x[0] = cadd(t0, t2);

@@ -53,7 +53,7 @@ __device__ __forceinline__ int freq_of_pos(int p) {
 template <int LOGN, int TK>
 __global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long long nl, const double* __restrict__ ax, int kxn,
                                                 const double* __restrict__ ay, const double* __restrict__ az,
-                                                const double2* __restrict__ tw_g, double inv_n, int zero_mean, int kxs) {
+                                                const double2* __restrict__ tw_g, double inv_n, int zero_mean, int kxs, int skel) {
   constexpr int N = 1 << LOGN;
   constexpr bool ODD = LOGN & 1;
   extern __shared__ double2 lds_dyn[];  // dynamic: tiles above 64 KB need the opt-in limit
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long
 
   // ---------------- forward: DIF ----------------
   int L = N;
+  if (!skel) {  // skel: timing experiment (INS_ZSOLVE_SKEL): loads and stores only
   if (ODD) {
     for (int w = t; w < (N / 2) * TK; w += 256) {
       const int c = w % TK, j = w / TK;  // one group of length N
@@ -106,9 +107,10 @@ __global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long
       const double2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
       double2 y0 = cadd(t0, t2), y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
       if (!last) {
-        y1 = cmul(y1, tw[j * step]);
-        y2 = cmul(y2, tw[2 * j * step]);
-        y3 = cmul(y3, tw[3 * j * step]);
+        const double2 w1 = tw[j * step], w2 = cmul(w1, w1), w3 = cmul(w2, w1);  // one table read instead of three (LDS-bound stages)
+        y1 = cmul(y1, w1);
+        y2 = cmul(y2, w2);
+        y3 = cmul(y3, w3);
       } else {
         // last forward stage (j == 0, unit twiddles): apply the symbol right here.  Position p holds frequency
         // freq_of_pos(p); c is this thread's own column, so `axy` / `mean_line` are the right ones.
@@ -141,9 +143,10 @@ __global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long
       const int base = (g * L + j) * TK + c;
       double2 x0 = buf[base], x1 = buf[base + Q * TK], x2 = buf[base + 2 * Q * TK], x3 = buf[base + 3 * Q * TK];
       if (L > 4) {
-        x1 = cmulc(x1, tw[j * step]);
-        x2 = cmulc(x2, tw[2 * j * step]);
-        x3 = cmulc(x3, tw[3 * j * step]);
+        const double2 w1 = tw[j * step], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+        x1 = cmulc(x1, w1);
+        x2 = cmulc(x2, w2);
+        x3 = cmulc(x3, w3);
       }
       const double2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = mul_pi(csub(x1, x3));
       buf[base] = cadd(t0, t2);
@@ -162,6 +165,7 @@ __global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long
     }
     __syncthreads();
   }
+  }
   if (live)
 #pragma unroll
     for (int q = 0; q < NIT; ++q) data[(long long)(t / TK + q * RPT) * nl + line] = buf[(t / TK + q * RPT) * TK + col];
@@ -177,7 +181,7 @@ int launch_zsolve(double2* data, long long nl, const double* ax, int kxn, const 
     INS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_zsolve<LOGN, TK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_zsolve<LOGN, TK>), dim3(nb), dim3(256), lds, s, data, nl, ax, kxn, ay, az, tw, inv_n, zero_mean ? 1 : 0, kxs);
+  hipLaunchKernelGGL((k_zsolve<LOGN, TK>), dim3(nb), dim3(256), lds, s, data, nl, ax, kxn, ay, az, tw, inv_n, zero_mean ? 1 : 0, kxs, getenv("INS_ZSOLVE_SKEL") ? 1 : 0);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
