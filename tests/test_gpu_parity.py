@@ -232,10 +232,15 @@ def test_cg_matches_oracle_cg(ins, oracle, geom):
     assert rell2(got[ip], want[ip]) < 1e-6  # both stop at reltol sqrt(eps); they agree to that level
 
 
-@pytest.mark.parametrize("geom", ["periodic2d", "periodic3d", "dirichlet3d", "mixed3d"])
+def _mixed2d(o):  # Periodic x (Symmetric | Pressure): every ghost rule of apply_bc_p! in two dimensions
+    x = (np.linspace(0.0, 2.0, 11), o.tanh_grid(0.0, 1.0, 9, 1.4))
+    return o.make_setup(x, ((o.PeriodicBC(), o.PeriodicBC()), (o.SymmetricBC(), o.PressureBC())), Re=200.0)
+
+
+@pytest.mark.parametrize("geom", ["periodic2d", "periodic3d", "dirichlet2d", "dirichlet3d", "mixed2d", "mixed3d", "channel3d"])
 def test_project_matches_oracle(ins, oracle, geom):
     o = oracle
-    so = GEOMS[geom](o)
+    so = _mixed2d(o) if geom == "mixed2d" else (_channel(o) if geom == "channel3d" else GEOMS[geom](o))
     sp = mirror(ins, so, o)
     g = so.grid
     u_h = o.apply_bc_u(fx.randn_field(g.N + (g.D,), 12), 0.0, so)
