@@ -149,7 +149,7 @@ def main():
         inkernel_p = 8 if (i > 0 and inkernel) else 0  # stages >= 2 also read p
         if vbasis:
             beta = np.linalg.solve(A[:i, :i].T, A[i, :i]) if i else np.zeros(0)
-            nk, wk = int(np.count_nonzero(beta)), False
+            nk, wk = int(np.count_nonzero(beta[: max(i - 1, 0)])), False  # β[i-1] multiplies the stencil input itself: taken from registers
         else:
             nk = sum(1 for j in range(i) if A[i, j] != 0.0)
             wk = any(A[i2, i] != 0.0 for i2 in range(i + 1, ns))

@@ -91,6 +91,7 @@ template <int R>
 struct Plane {
   double v[3][R + 2];
   double h[3];  // packed halo columns: lane r = row r of column x0-1, lane 16+r = row r of column x0+64
+  double raw[3][R];  // CORR: the output rows before the pressure correction (a term of the stage-velocity basis, ins_rk.hip)
 };
 
 // XW wavefronts side by side in x, 4/XW stacked in y.  CORR as in ins_fast3d_flux.hip: 0 = `u` has valid ghost volumes;
@@ -176,6 +177,12 @@ __global__ __launch_bounds__(256, 2) void k_flux64(FluxArgs a) {
   };
   // u = u* - ∇p (applypressure!, operators.jl:225-233) for one register plane and its packed halo columns
   auto correct = [&](Plane<R>& P, const double (&Pc)[R + 3], double PHc, const double (&Pn)[R + 3], double PHn) {
+    if (a.epi.self_in != 0.0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) P.raw[c][rr] = P.v[c][rr + 1];
+    }
 #pragma unroll
     for (int rr = 0; rr < R + 2; ++rr) {
       const double pc = Pc[rr];
@@ -223,6 +230,12 @@ __global__ __launch_bounds__(256, 2) void k_flux64(FluxArgs a) {
       for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) sacc[c][rr] = C.v[c][rr + 1];
+    }
+    if (a.epi.self_in != 0.0) {  // the stencil input is itself a term: no second trip to memory for it
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) sacc[c][rr] += a.epi.self_in * (CORR ? C.raw[c][rr] : C.v[c][rr + 1]);
     }
     for (int q = 0; q < a.epi.n; ++q) {
       const double* kq = a.epi.k[q] + pk;

@@ -159,6 +159,7 @@ struct RkEpi {
   double coef[INS_MAX_STAGES];
   const double* k[INS_MAX_STAGES];
   double coef_self;         // Δt A[i,i]
+  double self_in;           // coefficient of the stencil input itself (its uncorrected value, taken from registers: ins_flux64.hip)
   double c0m1;              // ustart enters as (1 + c0m1)·ustart; 0 in the k-basis, -Σ coef in the stage-velocity basis (ins_rk.hip)
   const double* ustart;     // nullptr: ustart is the stencil input itself (first stage)
   double* ustar;            // stage velocity out (interior volumes only)

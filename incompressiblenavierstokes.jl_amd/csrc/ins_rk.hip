@@ -9,6 +9,7 @@ int ins_k_momentum_generic(const ins_grid* G, double visc, const double* u, doub
 int ins_k_momentum_fast3d(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s);
 int ins_k_momentum_fast3d_opts(const ins_grid* G, double visc, const double* u, double* F, bool zero_shell, hipStream_t s);
 bool ins_fast3d_supported(const ins_grid* G);
+bool ins_flux64_supported(const ins_grid* G);
 
 int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s);
 int ins_k_project_periodic_fused(const ins_grid* G, ins_poisson* ps, double* u, double* p, bool keep_p, hipStream_t s);
@@ -202,11 +203,16 @@ static int rk_step_fused_periodic(ins_rk* rk, double visc, double* u, double dt,
         for (int j = m + 1; j < i; ++j) v -= beta[j] * rk->A[j * ns + m];
         beta[m] = v / rk->A[m * ns + m];
       }
+      const bool flux64 = ins_flux64_supported(G);  // the 62-wide kernel has no register copy of the uncorrected input
       for (int m = 0; m < i; ++m) {
         if (beta[m] == 0.0) continue;
+        epi.c0m1 -= beta[m];
+        if (m == i - 1 && flux64) {  // V_{i-1} is this stage's stencil input
+          epi.self_in = beta[m];
+          continue;
+        }
         epi.coef[epi.n] = beta[m];
         epi.k[epi.n] = rk->vb[m];
-        epi.c0m1 -= beta[m];
         ++epi.n;
       }
     } else {
