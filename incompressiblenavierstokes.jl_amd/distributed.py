@@ -244,7 +244,7 @@ class HipSlabKernels:
         n0, n1 = self.layout.n[0], self.layout.n[1]
         return torch.zeros(self.real_elems + 3 * n0 * n1, dtype=torch.float64, device=self.device)
 
-    def stage_momentum_corr(self, ustar_prev, p_ext, k_out, ustart, ustar, coefs, ks, coef_self, part=0, c0m1=0.0):
+    def stage_momentum_corr(self, ustar_prev, p_ext, k_out, ustart, ustar, coefs, ks, coef_self, part=0, c0m1=0.0, self_in=0.0):
         """part 1: the planes that read no ghost plane (can run beside the halo exchange); part 2: the rest; 0: everything.
         c0m1 != 0: `ks` are earlier uncorrected stage velocities (stage-velocity basis, see SlabStepper)."""
         s = self.setup
@@ -253,10 +253,15 @@ class HipSlabKernels:
         karr = (C.c_void_p * max(n, 1))(*[k.data_ptr() for k in ks])
         _lib.call("ins_stage_momentum_corr_part_f64", s.handle, 1.0 / s.Re, s.ptr(ustar_prev, True), self._p(p_ext),
                   s.ptr(k_out, True) if k_out is not None else None, s.ptr(ustart, True), s.ptr(ustar, True), n, carr, karr, float(coef_self),
-                  float(c0m1), int(part), s.stream)
+                  float(c0m1), float(self_in), int(part), s.stream)
 
     # stage_momentum_corr(part=...) and xfwd_planes exist: SlabStepper overlaps exchanges with them (INS_SLAB_NO_SPLIT=1: A/B switch)
     splits_stage = not bool(__import__("os").environ.get("INS_SLAB_NO_SPLIT"))
+
+    def wide_stage_kernel(self):
+        """The 64-outputs-per-wavefront stage kernel runs on this slab: the stencil input can then be a term of the combination."""
+        return (bool(_lib.load().ins_grid_is_uniform_exact(self.setup.handle)) and self.layout.n[0] >= 66 and self.layout.n[1] >= 8
+                and self.layout.nzl >= 4 and not os.environ.get("INS_DISABLE_FLUX64"))
 
     def xfwd_planes(self, u, work, kz0, nkz):
         s = self.setup
@@ -383,6 +388,7 @@ class SlabStepper:
         A = np.asarray(method.A, dtype=float)
         self.vbasis = (self.inkernel and bool(getattr(kernels, "splits_stage", False)) and all(A[i, i] != 0.0 for i in range(ns))
                        and not os.environ.get("INS_RK_KEEP_K"))
+        self.wide = bool(getattr(kernels, "wide_stage_kernel", lambda: False)())
         if self.vbasis:
             self.vb = [kernels.vector() for _ in range(ns - 1)]
             self.beta = [np.linalg.solve(A[:i, :i].T, A[i, :i]) if i else np.zeros(0) for i in range(ns)]
@@ -561,14 +567,17 @@ class SlabStepper:
         pending, p_pending = [], []
         split = bool(getattr(K, "splits_stage", False))
         for i in range(ns):
-            coefs, ks, c0m1 = [], [], 0.0
+            coefs, ks, c0m1, self_in = [], [], 0.0, 0.0
             if self.vbasis:
                 out = u if i == ns - 1 else self.vb[i]
                 for m in range(i):
                     if self.beta[i][m] != 0.0:
+                        c0m1 -= float(self.beta[i][m])
+                        if m == i - 1 and self.wide:  # V_{i-1} is this stage's stencil input: taken from registers
+                            self_in = float(self.beta[i][m])
+                            continue
                         coefs.append(float(self.beta[i][m]))
                         ks.append(self.vb[m])
-                        c0m1 -= float(self.beta[i][m])
                 write_k = False
             else:
                 out = u if (i == ns - 1 and ns > 1) else self.ub[i & 1]
@@ -584,12 +593,12 @@ class SlabStepper:
                 # no ghost plane run while the ghost planes of p (and the last of u*) are still arriving.
                 kw = self.ku[i] if write_k else None
                 if split:
-                    K.stage_momentum_corr(u_in, self.pX, kw, u, out, coefs, ks, Δt * A[i, i], part=1, c0m1=c0m1)
+                    K.stage_momentum_corr(u_in, self.pX, kw, u, out, coefs, ks, Δt * A[i, i], part=1, c0m1=c0m1, self_in=self_in)
                 for req in pending + p_pending:
                     req.wait()
                 pending, p_pending = [], []
                 if split:
-                    K.stage_momentum_corr(u_in, self.pX, kw, u, out, coefs, ks, Δt * A[i, i], part=2, c0m1=c0m1)
+                    K.stage_momentum_corr(u_in, self.pX, kw, u, out, coefs, ks, Δt * A[i, i], part=2, c0m1=c0m1, self_in=self_in)
                 else:
                     K.stage_momentum_corr(u_in, self.pX, kw, u, out, coefs, ks, Δt * A[i, i])
             else:
