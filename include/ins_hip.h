@@ -157,6 +157,11 @@ int ins_rk_destroy(ins_rk_t* rk);
  * `planes` as in ins_apply_bc_u_f64 (time-independent Dirichlet data only; otherwise drive the stage loop
  * from the host with the operator-level calls). */
 int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, double dt, const double* const* planes, void* stream);
+/* The fixed-Δt loop of solve_unsteady (solver.jl:74-83 without processors): nsteps calls of timestep! with time-independent
+ * boundary data.  `u` is valid on entry and on return.  On the fused periodic path the projection's gradient-subtract of every step
+ * but the last is applied in registers by the next step's first stage kernel (same arithmetic per cell; the uncorrected intermediate
+ * fields are never visible); elsewhere this is exactly nsteps calls of ins_rk_step_f64. */
+int ins_rk_steps_f64(ins_rk_t* rk, double visc, double* u, double t, double dt, int nsteps, void* stream);
 /* Device pointers into the cache (valid until ins_rk_destroy): the stage pressure `p` and `ku[i]`. */
 /* K6 alone: out = base + Σ_q coefs[q]·ks[q] over whole vector fields, summed in index order — the stage-combination
  * broadcasts `u .= ustart; u .+= Δt A[i,j] ku[j]` (step_explicit_runge_kutta.jl:35-38) and LMWray3's state_copyto! /

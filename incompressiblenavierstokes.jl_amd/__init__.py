@@ -61,6 +61,7 @@ from .time_steppers import (
     runge_kutta_method,
     timestep,
     timestep_,
+    timesteps_,
 )
 
 _lib.load()  # fail loudly at import time if libinship.so is absent

@@ -258,6 +258,12 @@ __global__ __launch_bounds__(256, 2) void k_flux64(FluxArgs a) {
     if (xout && j < n1) {
       const unsigned rowb = orow[rr - 1], co = ocol;
       if (FUSE) {
+        if (CORR && a.epi.ustart_out) {  // chained steps: s is the corrected stencil input = this step's ustart (no term was added to it)
+          double* w = a.epi.ustart_out + pk;
+          stb(plane_rsrc(w, ubytes), co, rowb, s0);
+          stb(plane_rsrc(w + a.sc, ubytes), co, rowb, s1);
+          stb(plane_rsrc(w + 2 * a.sc, ubytes), co, rowb, s2);
+        }
         double* o = a.epi.ustar + pk;
         stb(plane_rsrc(o, ubytes), co, rowb, s0 + a.epi.coef_self * fu);
         stb(plane_rsrc(o + a.sc, ubytes), co, rowb, s1 + a.epi.coef_self * fv);

@@ -163,6 +163,7 @@ struct RkEpi {
   double c0m1;              // ustart enters as (1 + c0m1)·ustart; 0 in the k-basis, -Σ coef in the stage-velocity basis (ins_rk.hip)
   const double* ustart;     // nullptr: ustart is the stencil input itself (first stage)
   double* ustar;            // stage velocity out (interior volumes only)
+  double* ustart_out;       // optional (first stage of a chained step, ustart == nullptr): the corrected stencil input is stored here
 };
 
 

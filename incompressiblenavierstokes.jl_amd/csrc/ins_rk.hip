@@ -155,7 +155,9 @@ extern "C" int ins_rk_stage_force(const ins_rk_t* rk, int i, double** ku) {
 //   K4     u* -= ∇p on the interior + its periodic ghost images    (no apply_bc_u! launch)
 // Same arithmetic, in the same order, as the reference stage loop (step_explicit_runge_kutta.jl:17-50);
 // `ustart` is the caller's `u`, which stays untouched until the last stage writes the result into it.
-static int rk_step_fused_periodic(ins_rk* rk, double visc, double* u, double dt, hipStream_t s) {
+// chain: 0 = a whole step (u valid in, valid out); bit 1 = `u` holds the previous step's UNCORRECTED result and ps->pI its pressure
+// (the first stage corrects in registers and stores the corrected field as ustart); bit 2 = leave this step's result uncorrected in `u`.
+static int rk_step_fused_periodic(ins_rk* rk, double visc, double* u, double dt, hipStream_t s, int chain = 0) {
   const ins_grid* G = rk->grid;
   const int ns = rk->nstage;
   const size_t vbytes = (size_t)G->ncell * 3 * sizeof(double);
@@ -165,7 +167,8 @@ static int rk_step_fused_periodic(ins_rk* rk, double visc, double* u, double dt,
       INS_HIP_TRY(hipMemsetAsync(rk->ub[b], 0, vbytes, s));
     }
   int rc;
-  if ((rc = ins_k_apply_bc_u(G, u, 0, nullptr, s))) return rc;  // :19 (first stage; later ghosts come from K4)
+  const bool raw_in = chain & 1, raw_out = chain & 2;
+  if (!raw_in && (rc = ins_k_apply_bc_u(G, u, 0, nullptr, s))) return rc;  // :19 (first stage; later ghosts come from K4)
   // On exactly-uniform grids stages >= 2 read the previous stage's UNCORRECTED u* plus its pressure and apply
   // the projection's gradient-subtract in registers (k_momentum_flux<..., CORR>), so K4 runs for the last stage only.
   static const bool no_corr = getenv("INS_DISABLE_INKERNEL_CORR") != nullptr;
@@ -227,15 +230,16 @@ static int rk_step_fused_periodic(ins_rk* rk, double visc, double* u, double dt,
         if (rk->A[i2 * ns + i] != 0.0) epi.write_k = 1;
     }
     epi.coef_self = dt * rk->A[i * ns + i];
-    epi.ustart = (i == 0) ? nullptr : u;
+    epi.ustart = (i == 0) ? nullptr : (raw_in ? rk->ustart : u);  // raw_in: the corrected start field lives in the cache array
     epi.ustar = out;
+    if (i == 0 && raw_in) epi.ustart_out = rk->ustart;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (rk->profiling) {
       INS_HIP_TRY(hipEventCreate(&e0));
       INS_HIP_TRY(hipEventCreate(&e1));
       INS_HIP_TRY(hipEventRecord(e0, s));
     }
-    rc = (inkernel && i > 0) ? ins_k_momentum_rk_fused_corr(G, visc, in, rk->ps->pI, rk->ku[i], epi, s)
+    rc = (inkernel && (i > 0 || raw_in)) ? ins_k_momentum_rk_fused_corr(G, visc, in, rk->ps->pI, rk->ku[i], epi, s)
                              : ins_k_momentum_rk_fused(G, visc, in, rk->ku[i], epi, s);
     if (rc) return rc;
     if (rk->profiling) {
@@ -243,12 +247,37 @@ static int rk_step_fused_periodic(ins_rk* rk, double visc, double* u, double dt,
       rk->prof_events.push_back(e0);
       rk->prof_events.push_back(e1);
     }
-    rc = (inkernel && i < ns - 1) ? ins_k_project_periodic_solve_only(G, rk->ps, out, s)
-                                  : ins_k_project_periodic_fused(G, rk->ps, out, rk->p, i == ns - 1, s);
+    rc = (inkernel && (i < ns - 1 || raw_out)) ? ins_k_project_periodic_solve_only(G, rk->ps, out, s)
+                                               : ins_k_project_periodic_fused(G, rk->ps, out, rk->p, i == ns - 1, s);
     if (rc) return rc;
     in = out;
   }
   if (ns == 1) INS_HIP_TRY(hipMemcpyAsync(u, rk->ub[0], vbytes, hipMemcpyDeviceToDevice, s));
+  return INS_OK;
+}
+
+// nsteps steps of size dt with the final correction of every step but the last folded into the next step's first stage kernel
+// (same arithmetic per cell; the uncorrected intermediate results never become visible).  Falls back to single steps elsewhere.
+extern "C" int ins_rk_steps_f64(ins_rk_t* rk, double visc, double* u, double t, double dt, int nsteps, void* stream) {
+  INS_REQUIRE(rk && u && nsteps >= 0, "bad argument");
+  const ins_grid* G = rk->grid;
+  hipStream_t s = as_stream(stream);
+  const GridDev& g = G->g;
+  static const bool no_fuse = getenv("INS_DISABLE_FUSED_RK") != nullptr, no_corr = getenv("INS_DISABLE_INKERNEL_CORR") != nullptr,
+                    no_chain = getenv("INS_DISABLE_STEP_CHAIN") != nullptr;
+  bool ok = !no_fuse && !no_corr && !no_chain && g.D == 3 && G->all_periodic && G->all_dof && rk->ps->kind == POISSON_SPECTRAL && ins_fast3d_supported(G) &&
+            ins_flux64_supported(G) && G->uniform_exact && rk->nstage > 1 && g.N[0] >= 8 && g.N[1] >= 8 && g.N[2] >= 8;  // = in-kernel correction runs
+  if (!ok || nsteps < 2) {
+    for (int n = 0; n < nsteps; ++n) {
+      int rc = ins_rk_step_f64(rk, visc, u, t + n * dt, dt, nullptr, stream);
+      if (rc) return rc;
+    }
+    return INS_OK;
+  }
+  for (int n = 0; n < nsteps; ++n) {
+    int rc = rk_step_fused_periodic(rk, visc, u, dt, s, (n > 0 ? 1 : 0) | (n < nsteps - 1 ? 2 : 0));
+    if (rc) return rc;
+  }
   return INS_OK;
 }
 

@@ -4,7 +4,7 @@ import ctypes as C
 from . import _lib
 from .pressure import default_psolver
 from .setup import copyfield
-from .time_steppers import RKMethods, create_stepper, ode_method_cache, timestep_
+from .time_steppers import RKMethods, create_stepper, ode_method_cache, timestep_, timesteps_
 
 
 def get_state(stepper):
@@ -57,8 +57,12 @@ def solve_unsteady(*, setup, tlims, ustart, tempstart=None, method=None, psolver
     else:
         nstep = int(round((tend - tstart) / Δt))
         Δt = (tend - tstart) / nstep
-        for _ in range(nstep):
-            stepper = timestep_(method, stepper, Δt, θ=θ, cache=cache)
+        if not processors:  # nobody looks at the intermediate states: the whole loop is one native call
+            stepper = timesteps_(method, stepper, Δt, nstep, θ=θ, cache=cache)
             fire()
+        else:
+            for _ in range(nstep):
+                stepper = timestep_(method, stepper, Δt, θ=θ, cache=cache)
+                fire()
     outputs = {k: processors[k].finalize(initialized[k], lambda: state["value"]) for k in processors}
     return (stepper.u, None, stepper.t), outputs

@@ -179,6 +179,22 @@ def create_stepper(method, *, setup, psolver, u, temp=None, t=0.0, n=0):
     return SimpleNamespace(setup=setup, psolver=psolver, u=u, temp=temp, t=t, n=n)
 
 
+def timesteps_(method, stepper, Δt, nsteps, *, θ=None, cache):
+    """`nsteps` time steps of size Δt, in place: the fixed-Δt loop of solve_unsteady (solver.jl:74-83) as one native call
+    (`ins_rk_steps_f64`) when the boundary data is time-independent; otherwise `nsteps` calls of `timestep_`.
+    The stepper's `u` is valid on entry and on return (intermediate steps are not observable, as inside the reference's loop
+    without processors)."""
+    setup, psolver = stepper.setup, stepper.psolver
+    if (nsteps >= 1 and not isinstance(method, LMWray3) and not setup.needs_bc_planes and stepper.temp is None and setup.closure_model is None):
+        if cache.psolver is not psolver:
+            raise ValueError("cache was created for a different psolver")
+        _lib.call("ins_rk_steps_f64", cache.handle, 1.0 / setup.Re, setup.ptr(stepper.u, True), float(stepper.t), float(Δt), int(nsteps), setup.stream)
+        return create_stepper(method, setup=setup, psolver=psolver, u=stepper.u, temp=None, t=stepper.t + nsteps * method.c[-1] * Δt, n=stepper.n + nsteps)
+    for _ in range(nsteps):
+        stepper = timestep_(method, stepper, Δt, θ=θ, cache=cache)
+    return stepper
+
+
 def timestep_(method, stepper, Δt, *, θ=None, cache):
     """Perform one time step, in place (step_explicit_runge_kutta.jl:4-59).
 

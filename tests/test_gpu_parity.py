@@ -528,3 +528,32 @@ def test_flux64_rk_steps_match_oracle(ins, oracle, n, method):
     assert rell2(ins.to_numpy(u), st["u"]) < STEP_TOL
     assert ins.max_abs_divergence(u, sp) < 1e-10
     del psp, sp
+
+
+@pytest.mark.parametrize("n", [(128, 16, 12), (96, 10, 8), (66, 10, 4), (32, 32, 32)])
+def test_chained_steps_equal_single_steps(ins, oracle, n):
+    """`timesteps_` (ins_rk_steps_f64): on wide exact boxes the final correction of every step but the last is folded into the next
+    step's first stage kernel; the result must be what step-by-step `timestep_` gives (and the oracle); the last two boxes (too thin for
+    the in-kernel correction / too narrow for the 64-wide kernel) take the plain loop."""
+    o = oracle
+    so = exact_box(o, n)
+    sp = mirror(ins, so, o)
+    pso, psp = o.psolver_spectral(so), ins.psolver_spectral(sp)
+    u0 = o.random_field(so, kp=2, seed=9, psolver=pso)
+    m = ins.RKMethods.RK44()
+    cache = ins.ode_method_cache(m, sp, psp)
+    st1 = ins.create_stepper(m, setup=sp, psolver=psp, u=ins.from_numpy(sp, u0), t=0.0)
+    for _ in range(5):
+        st1 = ins.timestep_(m, st1, 0.01, cache=cache)
+    st2 = ins.create_stepper(m, setup=sp, psolver=psp, u=ins.from_numpy(sp, u0), t=0.0)
+    st2 = ins.timesteps_(m, st2, 0.01, 5, cache=cache)
+    assert st2.n == 5 and st2.t == pytest.approx(0.05)
+    a, b = ins.to_numpy(st1.u), ins.to_numpy(st2.u)
+    assert rell2(b, a) < 1e-13  # ghosts included
+    want = o.solve_unsteady(so, (0.0, 0.05), u0, psolver=pso, dt=0.01)["u"]
+    assert rell2(b, want) < STEP_TOL
+    assert ins.max_abs_divergence(st2.u, sp) < 1e-10
+    # and through solve_unsteady (no processors -> one native call)
+    (u3, _, t3), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 0.05), ustart=ins.from_numpy(sp, u0), psolver=psp, Δt=0.01)
+    assert rell2(ins.to_numpy(u3), a) < 1e-13
+    del psp, sp
