@@ -142,6 +142,15 @@ def main():
     k1_ms, k1_n = C.c_double(), C.c_int64()
     ins._lib.call("ins_rk_profile_read", cache.handle, C.byref(k1_ms), C.byref(k1_n))
     ins._lib.call("ins_rk_profile_enable", cache.handle, 0)
+    # for transparency: the same K steps as K separate timestep_ calls (u materialised after every step)
+    single_ms = None
+    if chained:
+        torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        for _ in range(args.steps):
+            stepper = ins.timestep_(method, stepper, dt, cache=cache)
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - ts0) * 1e3 / args.steps
 
     ms_per_step = (t1 - t0) * 1e3 / args.steps
     cells = float(n) ** 3
@@ -222,6 +231,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "ms_per_step_single_calls": single_ms,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
