@@ -61,13 +61,13 @@ def run_distributed(args, ins):
     st.project_(u)  # velocityfield(...; doproject = true)  (initializers.jl:38-42)
     st.halo_u(u)
     dt = 1e-3
-    for _ in range(args.warmup):
-        st.step_(u, dt)
+    # the fixed-Δt loop of solve_unsteady as on one GPU (bench.py): K steps per call, u valid before and after
+    if args.warmup:
+        st.steps_(u, dt, args.warmup)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st.step_(u, dt)
+    st.steps_(u, dt, args.steps)
     torch.cuda.synchronize()
     dist.barrier()
     t1 = time.perf_counter()

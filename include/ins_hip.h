@@ -202,10 +202,12 @@ int ins_stage_momentum_corr_f64(const ins_grid_t* grid, double visc, const doubl
  *   ustar = (1 + c0m1) ustart + Σ coefs[q] ks[q] + self_in ustar_prev + coef_self f ;
  * c0m1 = self_in = 0 with ks = stage forces is step_explicit_runge_kutta.jl:35-38; with ks = earlier UNCORRECTED stage velocities and
  * c0m1 = -(Σ coefs + self_in) it is the same combination in the stage-velocity basis (no stage force is stored or read,
- * csrc/ins_rk.hip).  self_in != 0 needs ins_slab_flux64 grids (x >= 66 cells, exactly uniform): see ins_grid_is_uniform_exact. */
+ * csrc/ins_rk.hip).  ustart = NULL (chained first stage: ustar_prev / p_ext are the PREVIOUS STEP's uncorrected result and pressure): the
+ * corrected input is the start field, nterms = 0, and it is also stored to ustart_out when given.  self_in != 0, ustart = NULL and
+ * ustart_out need the 64-wide stage kernel (x >= 66 cells, exactly uniform: ins_grid_is_uniform_exact). */
 int ins_stage_momentum_corr_part_f64(const ins_grid_t* grid, double visc, const double* ustar_prev, const double* p_ext, double* k_out,
                                      const double* ustart, double* ustar, int nterms, const double* coefs, const double* const* ks,
-                                     double coef_self, double c0m1, double self_in, int part, void* stream);
+                                     double coef_self, double c0m1, double self_in, double* ustart_out, int part, void* stream);
 /* pI[nx,ny,nzl] = Ω·divergence(u) on the slab interior (operators.jl:117-125, 81-95; pressure.jl:320): x, y via
  * periodic wrap, z via the ghost plane. */
 int ins_slab_divergence_f64(const ins_grid_t* grid, const double* u, double* pI, void* stream);

@@ -76,7 +76,7 @@ SIGNATURES = {
     "ins_rk_stage_force": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
     "ins_stage_momentum_f64": (C.c_int, [vp, C.c_double, vp, vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), C.c_double, vp]),
     "ins_stage_momentum_corr_f64": (C.c_int, [vp, C.c_double, vp, vp, vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), C.c_double, vp]),
-    "ins_stage_momentum_corr_part_f64": (C.c_int, [vp, C.c_double, vp, vp, vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), C.c_double, C.c_double, C.c_double, C.c_int, vp]),
+    "ins_stage_momentum_corr_part_f64": (C.c_int, [vp, C.c_double, vp, vp, vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), C.c_double, C.c_double, C.c_double, vp, C.c_int, vp]),
     "ins_slab_divergence_f64": (C.c_int, [vp, vp, vp, vp]),
     "ins_slab_applypressure_f64": (C.c_int, [vp, vp, vp, vp, vp]),
     "ins_slab_fft_create": (C.c_int, [C.POINTER(C.c_int32), c_double_p, C.c_int, C.c_int, C.POINTER(vp)]),

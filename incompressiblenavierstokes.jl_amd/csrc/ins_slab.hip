@@ -510,7 +510,7 @@ extern "C" int ins_slab_applypressure_f64(const ins_grid_t* G, double* u, const 
 // pressure (unpadded in x, y).  Exactly-uniform slabs only.
 static int stage_momentum_corr(const ins_grid_t* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out, const double* ustart,
                                double* ustar, int nterms, const double* coefs, const double* const* ks, double coef_self, int part, void* stream,
-                               double c0m1 = 0.0, double self_in = 0.0);
+                               double c0m1 = 0.0, double self_in = 0.0, double* ustart_out = nullptr);
 
 extern "C" int ins_stage_momentum_corr_f64(const ins_grid_t* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out,
                                            const double* ustart, double* ustar, int nterms, const double* coefs, const double* const* ks,
@@ -520,18 +520,19 @@ extern "C" int ins_stage_momentum_corr_f64(const ins_grid_t* G, double visc, con
 
 extern "C" int ins_stage_momentum_corr_part_f64(const ins_grid_t* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out,
                                                 const double* ustart, double* ustar, int nterms, const double* coefs, const double* const* ks,
-                                                double coef_self, double c0m1, double self_in, int part, void* stream) {
+                                                double coef_self, double c0m1, double self_in, double* ustart_out, int part, void* stream) {
   INS_REQUIRE(part >= 0 && part <= 2, "part must be 0 (all), 1 (interior z-chunks) or 2 (boundary z-chunks)");
-  INS_REQUIRE(self_in == 0.0 || ins_flux64_supported(G), "self_in needs the 64-wide stage kernel (ins_flux64.hip)");
-  return stage_momentum_corr(G, visc, ustar_prev, p_ext, k_out, ustart, ustar, nterms, coefs, ks, coef_self, part, stream, c0m1, self_in);
+  INS_REQUIRE((self_in == 0.0 && !ustart_out && ustart) || ins_flux64_supported(G), "self_in / ustart_out need the 64-wide stage kernel (ins_flux64.hip)");
+  INS_REQUIRE(ustart || (nterms == 0 && self_in == 0.0), "without ustart (chained first stage) there are no earlier terms");
+  return stage_momentum_corr(G, visc, ustar_prev, p_ext, k_out, ustart, ustar, nterms, coefs, ks, coef_self, part, stream, c0m1, self_in, ustart_out);
 }
 
 static int stage_momentum_corr(const ins_grid_t* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out, const double* ustart,
                                double* ustar, int nterms, const double* coefs, const double* const* ks, double coef_self, int part, void* stream,
-                               double c0m1, double self_in) {
+                               double c0m1, double self_in, double* ustart_out) {
   int rc = check_slab_grid(G);
   if (rc) return rc;
-  INS_REQUIRE(ustar_prev && p_ext && ustar && ustart, "null argument");
+  INS_REQUIRE(ustar_prev && p_ext && ustar, "null argument");
   INS_REQUIRE(G->uniform_exact, "in-kernel correction needs an exactly uniform grid");
   INS_REQUIRE(G->g.N[2] >= 4, "slab needs at least two local planes");
   INS_REQUIRE(nterms >= 0 && nterms <= INS_MAX_STAGES && (nterms == 0 || (coefs && ks)), "bad stage terms");
@@ -545,6 +546,7 @@ static int stage_momentum_corr(const ins_grid_t* G, double visc, const double* u
   }
   epi.c0m1 = c0m1;
   epi.self_in = self_in;
+  epi.ustart_out = ustart_out;
   epi.coef_self = coef_self;
   epi.ustart = ustart;
   epi.ustar = ustar;

@@ -244,7 +244,7 @@ class HipSlabKernels:
         n0, n1 = self.layout.n[0], self.layout.n[1]
         return torch.zeros(self.real_elems + 3 * n0 * n1, dtype=torch.float64, device=self.device)
 
-    def stage_momentum_corr(self, ustar_prev, p_ext, k_out, ustart, ustar, coefs, ks, coef_self, part=0, c0m1=0.0, self_in=0.0):
+    def stage_momentum_corr(self, ustar_prev, p_ext, k_out, ustart, ustar, coefs, ks, coef_self, part=0, c0m1=0.0, self_in=0.0, ustart_out=None):
         """part 1: the planes that read no ghost plane (can run beside the halo exchange); part 2: the rest; 0: everything.
         c0m1 != 0: `ks` are earlier uncorrected stage velocities (stage-velocity basis, see SlabStepper)."""
         s = self.setup
@@ -252,8 +252,8 @@ class HipSlabKernels:
         carr = (C.c_double * max(n, 1))(*coefs)
         karr = (C.c_void_p * max(n, 1))(*[k.data_ptr() for k in ks])
         _lib.call("ins_stage_momentum_corr_part_f64", s.handle, 1.0 / s.Re, s.ptr(ustar_prev, True), self._p(p_ext),
-                  s.ptr(k_out, True) if k_out is not None else None, s.ptr(ustart, True), s.ptr(ustar, True), n, carr, karr, float(coef_self),
-                  float(c0m1), float(self_in), int(part), s.stream)
+                  s.ptr(k_out, True) if k_out is not None else None, s.ptr(ustart, True) if ustart is not None else None, s.ptr(ustar, True), n, carr,
+                  karr, float(coef_self), float(c0m1), float(self_in), s.ptr(ustart_out, True) if ustart_out is not None else None, int(part), s.stream)
 
     # stage_momentum_corr(part=...) and xfwd_planes exist: SlabStepper overlaps exchanges with them (INS_SLAB_NO_SPLIT=1: A/B switch)
     splits_stage = not bool(__import__("os").environ.get("INS_SLAB_NO_SPLIT"))
@@ -558,14 +558,36 @@ class SlabStepper:
 
     # -- one RK step -------------------------------------------------------------------------
     def step_(self, u, Δt):
+        """One RK step; `u` valid (x, y, z ghosts filled on return)."""
+        return self._step(u, Δt, False, False)
+
+    def steps_(self, u, Δt, nsteps):
+        """`nsteps` steps of size Δt (the fixed-Δt loop of solve_unsteady, solver.jl:74-83).  `u` is valid before and after.  On the fast
+        slab pipeline the projection's gradient-subtract of every step but the last is applied in registers by the next step's first
+        stage kernel (as csrc/ins_rk.hip does on one GPU): no K4 pass and no full u halo between steps."""
+        chain = (self.vbasis and self.wide and bool(getattr(self.k, "splits_stage", False)) and nsteps > 1
+                 and not os.environ.get("INS_DISABLE_STEP_CHAIN"))
+        if chain and not hasattr(self, "u0"):
+            self.u0 = self.k.vector()  # the corrected start field of a chained step
+        for n in range(nsteps):
+            self._step(u, Δt, chain and n > 0, chain and n < nsteps - 1)
+        return u
+
+    def _step(self, u, Δt, raw_in, raw_out):
+        """raw_in: `u` holds the previous step's uncorrected result (ghost planes already exchanged / in flight) and pX its pressure;
+        raw_out: leave this step's result uncorrected in `u` for the next call."""
         m, K = self.method, self.k
         A = m.A
         ns = len(m.b)
-        K.fill_xy_ghosts(u)
-        self.halo_u(u)
-        u_in = u
-        pending, p_pending = [], []
         split = bool(getattr(K, "splits_stage", False))
+        if raw_in:
+            pending, p_pending = self._carry
+        else:
+            K.fill_xy_ghosts(u)
+            self.halo_u(u)
+            pending, p_pending = [], []
+        ustart = self.u0 if raw_in else u
+        u_in = u
         for i in range(ns):
             coefs, ks, c0m1, self_in = [], [], 0.0, 0.0
             if self.vbasis:
@@ -588,22 +610,23 @@ class SlabStepper:
                         ks.append(self.ku[j])
                 write_k = any(A[i2, i] != 0.0 for i2 in range(i + 1, ns))
             last = i == ns - 1
-            if self.inkernel and i > 0:
-                # previous stage's projection applied in registers from (u*, p) — no K4 pass for that stage.  The z-chunks that read
+            if self.inkernel and (i > 0 or raw_in):
+                # previous stage's (or step's) projection applied in registers from (u*, p) — no K4 pass for it.  The planes that read
                 # no ghost plane run while the ghost planes of p (and the last of u*) are still arriving.
                 kw = self.ku[i] if write_k else None
+                us, uso = (None, self.u0) if i == 0 else (ustart, None)  # chained first stage: the corrected input IS the start field
                 if split:
-                    K.stage_momentum_corr(u_in, self.pX, kw, u, out, coefs, ks, Δt * A[i, i], part=1, c0m1=c0m1, self_in=self_in)
+                    K.stage_momentum_corr(u_in, self.pX, kw, us, out, coefs, ks, Δt * A[i, i], part=1, c0m1=c0m1, self_in=self_in, ustart_out=uso)
                 for req in pending + p_pending:
                     req.wait()
                 pending, p_pending = [], []
                 if split:
-                    K.stage_momentum_corr(u_in, self.pX, kw, u, out, coefs, ks, Δt * A[i, i], part=2, c0m1=c0m1, self_in=self_in)
+                    K.stage_momentum_corr(u_in, self.pX, kw, us, out, coefs, ks, Δt * A[i, i], part=2, c0m1=c0m1, self_in=self_in, ustart_out=uso)
                 else:
-                    K.stage_momentum_corr(u_in, self.pX, kw, u, out, coefs, ks, Δt * A[i, i])
+                    K.stage_momentum_corr(u_in, self.pX, kw, us, out, coefs, ks, Δt * A[i, i])
             else:
-                K.stage_momentum(u_in, self.ku[i] if write_k else None, None if i == 0 else u, out, coefs, ks, Δt * A[i, i])
-            if self.inkernel and not last:
+                K.stage_momentum(u_in, self.ku[i] if write_k else None, None if i == 0 else ustart, out, coefs, ks, Δt * A[i, i])
+            if self.inkernel and (not last or raw_out):
                 # u* is final here (its correction happens inside the next stencil kernel): the w plane the divergence needs
                 # goes first, the other five ghost planes travel while the Poisson solve runs
                 if split and self.zsolve == "tridiag" and self.packed:
@@ -620,6 +643,7 @@ class SlabStepper:
                 self.project_(out)
                 self.halo_u(out)  # z ghost planes for the next stencil (x/y ghosts: K4 images, or periodic addressing in-kernel)
             u_in = out
+        self._carry = (pending, p_pending)
         if ns == 1:
             u.copy_(self.ub[0])
         self.n += 1

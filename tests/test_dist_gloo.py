@@ -36,8 +36,7 @@ def _worker(rank, world, port, n, nsteps, method_name, out_dir, chunks=1, own=Fa
         assert st.zsolve == zsolve
         assert len(st.chunks) == min(chunks, lay.kxn) and st.packed == own and st.inkernel == (own and len(method.b) > 1)
         u = K.from_global(u0)
-        for _ in range(nsteps):
-            st.step_(u, 0.01)
+        st.steps_(u, 0.01, nsteps)
         div = st.max_abs_divergence(u)
         np.save(os.path.join(out_dir, f"u_{rank}.npy"), u.numpy())
         np.save(os.path.join(out_dir, f"div_{rank}.npy"), np.array([div]))
