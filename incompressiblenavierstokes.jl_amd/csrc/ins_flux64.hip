@@ -514,7 +514,8 @@ int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, con
   a.Z = make_dir(G, 2, visc);
   if (epi) a.epi = *epi;
   const int waves_x = cdiv(g.N[0] - 2, 64);
-  const int xw = g_xw ? g_xw : (waves_x >= 4 ? 4 : (waves_x >= 2 ? 2 : 1));
+  // wavefronts side by side: 4 for 256-wide rows (2.85 vs 2.90 ms/step with 2), 2 + 2 stacked for 512-wide ones (23.7 vs 24.3 ms/step)
+  const int xw = g_xw ? g_xw : (waves_x >= 8 ? 2 : (waves_x >= 4 ? 4 : (waves_x >= 2 ? 2 : 1)));
   int rows = corr_mode ? (g_rows_corr ? g_rows_corr : 2) : (g_rows ? g_rows : 4);
   rows = std::min(std::max(rows, 2), corr_mode ? 5 : 6);
 #define INS_F64_CASE(RR, FUSE)                                            \
