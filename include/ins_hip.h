@@ -239,6 +239,10 @@ int ins_slab_fft_xy_inverse_only(ins_slab_fft_t* fft, double* work, double* pI, 
  * chunk width cw (chunk c = kx in [c*cw, min((c+1)*cw, nx/2+1))), so no pack / unpack pass exists; with from_u != 0 the
  * right-hand side Ω·div(u) is formed inside the x pass from the slab's velocity (`src` = u on `grid`, z via ghost planes). */
 int ins_slab_fft_is_own(const ins_slab_fft_t* fft);
+int ins_slab_fft_forward_packed(ins_slab_fft_t* fft, const ins_grid_t* grid, const double* src, int from_u, double* work, double* sendbuf,
+                                int cw, void* stream);
+int ins_slab_fft_inverse_packed(ins_slab_fft_t* fft, double* recvbuf, double* work, double* pI, int cw, void* stream);
+
 /* Transpose-free distributed solve (csrc/ins_ztri.hip): after the local (x, y) transforms the z direction of
  * pressure.jl:326-341 is one periodic tridiagonal system per (kx, ky) line — the circulant matrix the reference's z-FFT
  * diagonalises — solved across ranks by the partition method; ranks exchange two complex numbers per line instead of the
@@ -259,9 +263,6 @@ int ins_slab_ztri_inverse(ins_slab_fft_t* S, double* work, double* pI, void* str
 /* x pass of ins_slab_ztri_forward (from_u = 1) for local planes [kz0, kz0 + nkz) only; follow with ins_slab_ztri_forward(from_u = 2).
  * Planes >= 1 read no ghost plane of u, so they can run while the w plane below the slab is still in flight. */
 int ins_slab_xfwd_planes(ins_slab_fft_t* S, const ins_grid_t* grid, const double* u, double* work, int kz0, int nkz, void* stream);
-int ins_slab_fft_forward_packed(ins_slab_fft_t* fft, const ins_grid_t* grid, const double* src, int from_u, double* work, double* sendbuf,
-                                int cw, void* stream);
-int ins_slab_fft_inverse_packed(ins_slab_fft_t* fft, double* recvbuf, double* work, double* pI, int cw, void* stream);
 
 #ifdef __cplusplus
 }

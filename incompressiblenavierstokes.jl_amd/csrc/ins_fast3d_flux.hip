@@ -487,7 +487,8 @@ int ins_k_momentum_flux3d(const ins_grid* G, double visc, const double* u, doubl
   int rc;
   // plain K1: the 64-wide kernel wins up to ~400^3 (-10% at 256^3); from 448 on this kernel moves less data out of L2
   // (1.30x vs 1.38x read amplification at 512^3, profiles/r01f_k1_traffic.txt) and is 3% faster
-  if (ins_flux64_supported(G) && G->g.N[0] - 2 < 448) {
+  static const bool plain_all = getenv("INS_FLUX64_PLAIN_ALL") != nullptr;  // experiment: no size routing
+  if (ins_flux64_supported(G) && (plain_all || G->g.N[0] - 2 < 448)) {
     if ((rc = ins_k_flux64(G, visc, u, F, nullptr, nullptr, 0, s))) return rc;
   } else {
     if ((rc = ins_flux3d_prepare(G, visc, s))) return rc;

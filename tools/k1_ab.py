@@ -15,16 +15,17 @@ torch.manual_seed(0)
 u = ins.vectorfield(setup); u.copy_(torch.randn(u.shape, dtype=torch.float64, device=u.device)); ins.apply_bc_u_(u, 0.0, setup)
 F = ins.vectorfield(setup)
 # (label, disable, rows, zc, skel, burst, lds)
-variants = [("old62", 1, 0, 0, 0, 0, 0)]
-for r in (2, 3, 4):
-    for zc in (8, 16, 32, 64):
-        variants.append((f"f64 R{r} zc{zc}", 0, r, zc, 0, 0, 0))
-variants += [("skel R4 zc32", 0, 4, 32, 1, 0, 0), ("f64 R4 zc32 lds70k", 0, 4, 32, 0, 0, 70000), ("f64 R2 zc32 lds50k", 0, 2, 32, 0, 0, 50000)]
+variants = [("old62", 1, 0, 0, 0, 0, 0, 0)]
+for xw in (2, 4):
+    for r in (4,):
+        for zc in (16, 32, 64):
+            variants.append((f"f64 R{r} zc{zc} xw{xw}", 0, r, zc, 0, 0, 0, xw))
+variants += [("skel R4 zc32 xw2", 0, 4, 32, 1, 0, 0, 2), ("f64 R4 zc32 xw2 lds70k", 0, 4, 32, 0, 0, 70000, 2)]
 times = {v[0]: [] for v in variants}
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for rep in range(6):
-    for (label, dis, r, zc, sk, bu, lds) in variants:
-        tune(dis, r, -1, zc, -1, sk, bu, lds)
+    for (label, dis, r, zc, sk, bu, lds, xw) in variants:
+        tune(dis, r, -1, zc, xw, sk, bu, lds)
         ins.momentum_(F, u, None, 0.0, setup)
         e0.record()
         for _ in range(5): ins.momentum_(F, u, None, 0.0, setup)
