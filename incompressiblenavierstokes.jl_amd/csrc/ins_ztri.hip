@@ -93,20 +93,23 @@ __global__ __launch_bounds__(256) void k_ztri_fwd(ZtriArgs a, double* __restrict
     // r^(m-k) by a running product re-seeded from exp() every chunk: r >= ~0.1 on these grids, so a seed that underflows
     // cannot become significant within 16 steps, and the product never has to climb out of an underflow
     double pb = exp((a.m - k0) * L.lnr);
-#pragma unroll
-    for (int j = 0; j < CH; ++j) {
+    auto one = [&](int j) {
       const int k = k0 + j;
-      if (k < a.m) {
-        const double g = a.scale * buf[j];
-        const double inv = rc * (1.0 - E) * frcp(1.0 - E * L.r2);
-        gp = inv * (g + a.c * gp);
-        x[k * ps] = gp;
-        SA += pa * g;
-        SB += pb * g;
-        E *= L.r2;
-        pa *= L.r;
-        pb *= rinv;
-      }
+      const double g = a.scale * buf[j];
+      const double inv = rc * (1.0 - E) * frcp(1.0 - E * L.r2);
+      gp = inv * (g + a.c * gp);
+      x[k * ps] = gp;
+      SA += pa * g;
+      SB += pb * g;
+      E *= L.r2;
+      pa *= L.r;
+      pb *= rinv;
+    };
+    if (k0 + CH <= a.m) {  // whole chunk: straight-line code (one scalar test instead of one per plane)
+#pragma unroll
+      for (int j = 0; j < CH; ++j) one(j);
+    } else {
+      for (int j = 0; j < a.m - k0; ++j) one(j);
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) buf[j] = nxt[j];
@@ -198,18 +201,21 @@ __global__ __launch_bounds__(256) void k_ztri_bwd(ZtriArgs a, const double* __re
 #pragma unroll
     for (int j = 0; j < CH; ++j) nxt[j] = x[(long long)max(k0 - CH - j, 0) * ps];
     double pa = exp((k0 + 1.0) * L.lnr);  // r^(k+1), running product re-seeded every chunk
-#pragma unroll
-    for (int j = 0; j < CH; ++j) {
+    auto one = [&](int j) {
       const int k = k0 - j;
-      if (k >= 0) {
-        const double q = frcp(1.0 - pa * pa * L.r2);
-        const double cinv = L.r * (1.0 - pa * pa) * q;  // c / den_k
-        double v = buf[j] + (pa * omr2 * q) * Lp;        // + c L φ_k
-        if (k == a.m - 1) v += cinv * Fn;
-        p = v + cinv * p;
-        x[k * ps] = p;
-        pa *= rinv;
-      }
+      const double q = frcp(1.0 - pa * pa * L.r2);
+      const double cinv = L.r * (1.0 - pa * pa) * q;  // c / den_k
+      double v = buf[j] + (pa * omr2 * q) * Lp;        // + c L φ_k
+      if (k == a.m - 1) v += cinv * Fn;
+      p = v + cinv * p;
+      x[k * ps] = p;
+      pa *= rinv;
+    };
+    if (k0 - CH >= -1) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) one(j);
+    } else {
+      for (int j = 0; j <= k0; ++j) one(j);
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) buf[j] = nxt[j];
