@@ -124,6 +124,13 @@ __global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long
           y[q]->x *= s;
           y[q]->y *= s;
         }
+        // ... and the first inverse stage (L = 4, unit twiddles) works on the same four values: do it now, one LDS round trip
+        // and one barrier fewer (the inverse loop below starts at L = 16)
+        const double2 u0 = cadd(y0, y2), u1 = csub(y0, y2), u2 = cadd(y1, y3), u3 = mul_pi(csub(y1, y3));
+        y0 = cadd(u0, u2);
+        y1 = cadd(u1, u3);
+        y2 = csub(u0, u2);
+        y3 = csub(u1, u3);
       }
       buf[base] = y0;
       buf[base + Q * TK] = y1;
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long
 
   // ---------------- inverse: DIT, mirrored stage order, conjugated twiddles ----------------
 #pragma unroll 1
-  for (L = 4; L <= (ODD ? N / 2 : N); L <<= 2) {
+  for (L = 16; L <= (ODD ? N / 2 : N); L <<= 2) {
     const int Q = L / 4, step = N / L;
     for (int w = t; w < (N / 4) * TK; w += 256) {
       const int c = w % TK, b = w / TK;
