@@ -232,15 +232,22 @@ def test_cg_matches_oracle_cg(ins, oracle, geom):
     assert rell2(got[ip], want[ip]) < 1e-6  # both stop at reltol sqrt(eps); they agree to that level
 
 
+def _pressure_left(o, D=2):  # PressureBC on LEFT sides (two ghost layers there) next to Dirichlet / Symmetric / Pressure
+    x = (o.cosine_grid(0.0, 1.0, 7), np.linspace(0.0, 1.0, 6), o.tanh_grid(0.0, 0.5, 5, 1.2))[:D]
+    bcs = ((o.PressureBC(), o.DirichletBC()), (o.PressureBC(), o.PressureBC()), (o.SymmetricBC(), o.PressureBC()))[:D]
+    return o.make_setup(x, bcs, Re=100.0)
+
+
 def _mixed2d(o):  # Periodic x (Symmetric | Pressure): every ghost rule of apply_bc_p! in two dimensions
     x = (np.linspace(0.0, 2.0, 11), o.tanh_grid(0.0, 1.0, 9, 1.4))
     return o.make_setup(x, ((o.PeriodicBC(), o.PeriodicBC()), (o.SymmetricBC(), o.PressureBC())), Re=200.0)
 
 
-@pytest.mark.parametrize("geom", ["periodic2d", "periodic3d", "dirichlet2d", "dirichlet3d", "mixed2d", "mixed3d", "channel3d"])
+@pytest.mark.parametrize("geom", ["periodic2d", "periodic3d", "dirichlet2d", "dirichlet3d", "mixed2d", "mixed3d", "channel3d", "pleft2d", "pleft3d"])
 def test_project_matches_oracle(ins, oracle, geom):
     o = oracle
-    so = _mixed2d(o) if geom == "mixed2d" else (_channel(o) if geom == "channel3d" else GEOMS[geom](o))
+    special = {"mixed2d": _mixed2d, "channel3d": _channel, "pleft2d": lambda o: _pressure_left(o, 2), "pleft3d": lambda o: _pressure_left(o, 3)}
+    so = special[geom](o) if geom in special else GEOMS[geom](o)
     sp = mirror(ins, so, o)
     g = so.grid
     u_h = o.apply_bc_u(fx.randn_field(g.N + (g.D,), 12), 0.0, so)
@@ -557,3 +564,22 @@ def test_chained_steps_equal_single_steps(ins, oracle, n):
     (u3, _, t3), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 0.05), ustart=ins.from_numpy(sp, u0), psolver=psp, Δt=0.01)
     assert rell2(ins.to_numpy(u3), a) < 1e-13
     del psp, sp
+
+
+@pytest.mark.parametrize("geom", ["mixed3d", "pleft3d", "channel3d", "dirichlet3d"])
+def test_rk44_nonperiodic3d_matches_oracle(ins, oracle, geom):
+    """The fused non-periodic stage (RK epilogue in the masked stencil kernel, direct solver fused into project!) on every
+    boundary-condition mix, against the oracle's reference-ordered stage loop."""
+    o = oracle
+    special = {"channel3d": _channel, "pleft3d": lambda o: _pressure_left(o, 3)}
+    so = special[geom](o) if geom in special else GEOMS[geom](o)
+    sp = mirror(ins, so, o)
+    pso, psp = o.psolver_direct(so), ins.default_psolver(sp)
+    assert psp.kind == "direct"
+    u0 = o.apply_bc_u(0.1 * fx.randn_field(so.grid.N + (3,), 31), 0.0, so)
+    u0 = o.project_(u0.copy(order="F"), so, pso, o.scalarfield(so))
+    u0 = o.apply_bc_u_(u0, 0.0, so)
+    st = o.solve_unsteady(so, (0.0, 0.004), u0, psolver=pso, dt=0.001)
+    (u, _, t), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 0.004), ustart=ins.from_numpy(sp, u0), psolver=psp, Δt=0.001)
+    assert np.isfinite(st["u"]).all()
+    assert rell2(ins.to_numpy(u), st["u"]) < STEP_TOL
