@@ -115,3 +115,50 @@ def test_multi_rank_slab_on_one_gpu_matches_oracle(tmp_path, oracle, world, n, c
         packed, inkernel, nch = np.load(tmp_path / f"flags_{r}.npy")
         pow2 = all(v & (v - 1) == 0 for v in n)
         assert bool(packed) == pow2 and bool(inkernel) == pow2 and nch == chunks  # the fast slab pipeline really ran
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,n", [(8, (32, 8, 64)), (16, (16, 16, 64)), (5, (20, 10, 40)), (1, (32, 16, 16))])
+def test_ztri_many_ranks_in_one_process(oracle, P, n):
+    """The transpose-free z solve for rank counts this box cannot host as processes: P slab handles are driven one after the other in ONE
+    process (each does its local sweeps; the gathered interface buffer is assembled by hand) and the result must be the global spectral solve."""
+    _need_gpu()
+    import ctypes as C
+
+    import ins_amd as ins
+    from ins_amd import _lib
+
+    o = oracle
+    x = tuple(np.linspace(0.0, 1.0, ni + 1) for ni in n)
+    so = o.make_setup(x, Re=100.0)
+    f = np.zeros(so.grid.N, order="F")
+    ip = tuple(slice(lo, hi) for lo, hi in so.grid.Ip)
+    f[ip] = np.random.default_rng(3).standard_normal(n)
+    want = o.poisson(o.psolver_spectral(so), f)[ip]
+    h = [1.0 / ni for ni in n]
+    nzl = n[2] // P
+    dev = torch.device("cuda:0")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    handles, works, edges = [], [], []
+    for r in range(P):
+        S = C.c_void_p()
+        _lib.call("ins_slab_fft_create", (C.c_int32 * 3)(*n), (C.c_double * 3)(*h), r, P, C.byref(S))
+        nr, nc, ne = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.call("ins_slab_fft_sizes", S, C.byref(nr), C.byref(nc))
+        _lib.call("ins_slab_ztri_edge_elems", S, C.byref(ne))
+        pI = torch.from_numpy(np.ascontiguousarray(f[ip][:, :, r * nzl : (r + 1) * nzl].reshape(-1, order="F"))).to(dev)
+        work = torch.zeros(2 * nc.value, dtype=torch.float64, device=dev)
+        edge = torch.zeros(ne.value, dtype=torch.float64, device=dev)
+        _lib.call("ins_slab_ztri_forward", S, None, C.c_void_p(pI.data_ptr()), 0, C.c_void_p(work.data_ptr()), C.c_void_p(edge.data_ptr()), stream)
+        handles.append(S)
+        works.append(work)
+        edges.append(edge)
+    edges_all = torch.cat(edges)
+    got = np.zeros(n, order="F")
+    for r in range(P):
+        out = torch.zeros(n[0] * n[1] * nzl, dtype=torch.float64, device=dev)
+        _lib.call("ins_slab_ztri_finish", handles[r], C.c_void_p(works[r].data_ptr()), C.c_void_p(edges_all.data_ptr()), C.c_void_p(out.data_ptr()), stream)
+        got[:, :, r * nzl : (r + 1) * nzl] = out.cpu().numpy().reshape((n[0], n[1], nzl), order="F")
+    for S in handles:
+        _lib.load().ins_slab_fft_destroy(S)
+    assert rell2(got, want) < 1e-11
