@@ -162,3 +162,99 @@ def test_ztri_many_ranks_in_one_process(oracle, P, n):
     for S in handles:
         _lib.load().ins_slab_fft_destroy(S)
     assert rell2(got, want) < 1e-11
+
+
+class _ThreadWorld:
+    """In-process stand-in for a communicator: `world` Python threads, one per rank, exchanging tensors through FIFO queues.
+    Lets one process on one GPU run rank counts the box cannot host as processes (the exchanges are device-to-device copies on the
+    default stream, whose order is the order of the queue operations)."""
+
+    def __init__(self, world):
+        import queue
+        import threading
+
+        self.world = world
+        self.q = {(s, d): queue.Queue() for s in range(world) for d in range(world)}
+        self.slots = [None] * world
+        self.bar = threading.Barrier(world)
+
+
+class _ThreadComm:
+    backend = "thread"
+
+    def __init__(self, shared, rank):
+        self.s, self.rank, self.world = shared, rank, shared.world
+
+    def exchange(self, sends, recvs):
+        for t, dst in sends:
+            self.s.q[(self.rank, dst)].put(t.clone())
+        for t, src in recvs:
+            t.copy_(self.s.q[(src, self.rank)].get(timeout=120))
+
+    def exchange_async(self, sends, recvs):
+        self.exchange(sends, recvs)
+        return []
+
+    def all_gather(self, out, inp):
+        self.s.slots[self.rank] = inp.clone()
+        self.s.bar.wait(timeout=120)
+        out.copy_(torch.cat(self.s.slots))
+        self.s.bar.wait(timeout=120)
+
+    def all_gather_async(self, out, inp):
+        self.all_gather(out, inp)
+        return []
+
+    def barrier(self):
+        self.s.bar.wait(timeout=120)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,n,zchunks", [(8, (128, 16, 64), 1), (8, (128, 16, 64), 2), (6, (72, 12, 24), 1)])
+def test_slab_stepper_many_ranks_as_threads(oracle, P, n, zchunks, monkeypatch):
+    """The whole slab pipeline (plane-range stage launches, overlapped exchanges, transpose-free solve, stage-velocity basis, chained steps)
+    with 8 ranks — the driver's largest configuration — as 8 threads of one process on one GPU, against the single-domain oracle."""
+    _need_gpu()
+    import threading
+
+    import ins_amd as ins
+
+    if zchunks > 1:
+        monkeypatch.setenv("INS_SLAB_ZCHUNKS", str(zchunks))
+    o = oracle
+    x = tuple(np.linspace(0.0, 1.0, ni + 1) for ni in n)
+    so = o.make_setup(x, Re=500.0)
+    ps = o.psolver_spectral(so)
+    u0 = o.random_field(so, kp=2, seed=7)
+    nsteps = 3
+    want = o.solve_unsteady(so, (0.0, 0.01 * nsteps), u0, psolver=ps, dt=0.01)["u"]
+    shared = _ThreadWorld(P)
+    results, errors, flags = [None] * P, [], [None] * P
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            lay = ins.SlabLayout(n, P, r)
+            K = ins.HipSlabKernels(lay, Re=500.0, device="cuda:0")
+            st = ins.SlabStepper(ins.RKMethods.RK44(), lay, K, _ThreadComm(shared, r), zsolve="tridiag")
+            u = K.from_global(u0)
+            st.steps_(u, 0.01, nsteps)
+            torch.cuda.synchronize()
+            results[r] = ins.to_numpy(u)
+            flags[r] = (st.packed, st.inkernel, st.vbasis, st.zsolve, st.zchunks)
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+            shared.bar.abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    nzl = n[2] // P
+    pow2 = all(v & (v - 1) == 0 for v in n)
+    for r in range(P):
+        ks = [(r * nzl + k - 1) % n[2] + 1 for k in range(nzl + 2)]
+        assert rell2(results[r], want[:, :, ks, :]) < 1e-10, r
+        assert flags[r] == (pow2, pow2, pow2, "tridiag", zchunks)
