@@ -61,18 +61,29 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_doub
 // spikes v_k = (r^(k+1) - r^(m+1) r^(m-k)) / (1 - r^(2m+2)) = c (A_r⁻¹ e_0)_k,  w_k = v_{m-1-k}
 // One work-item per REAL component of a line (re and im obey the same real recurrence): twice the parallelism of one per line,
 // which matters because a slab has only kxn·ny lines and every one is a serial march over the local planes.
+template <bool SKEL>  // SKEL (INS_ZTRI_SKEL=1, measurement only): the same loads and stores without the recurrence
 __global__ __launch_bounds__(256) void k_ztri_fwd(ZtriArgs a, double* __restrict__ edge, double* __restrict__ line0, long long l_lo, long long l_cnt) {
   // flat index over (ky, kx, re/im) of the line range of this launch: a 256-wide workgroup reads 2 KB of consecutive memory per plane
+  const long long ps = 2LL * a.kxs * a.n1;
+  if (l_lo == 0 && blockIdx.x == gridDim.x - 1) {
+    // the extra workgroup of a range that starts at line 0 (kx = ky = 0, the singular line): hand its scaled right-hand side to the
+    // gather with one work-item per plane.  (Left to the line's own two work-items this is a chain of m dependent HBM round trips
+    // that the whole launch then waits for: 100 us instead of 60 at m = 256.)  The solve itself is ztri_line0 (in the k_ztri_bwd launch).
+    const double* x0 = reinterpret_cast<const double*>(a.data);
+    for (int k = threadIdx.x; k < a.m; k += 256) {
+      line0[2 * k] = a.scale * x0[k * ps];
+      line0[2 * k + 1] = a.scale * x0[k * ps + 1];
+    }
+    return;
+  }
   const long long r2 = (long long)blockIdx.x * 256 + threadIdx.x;  // component index inside the range
   if (r2 >= 2 * l_cnt) return;
   const long long lines2 = 2 * l_cnt, l2 = 2 * l_lo + r2;
   const int ky = (int)(l2 / (2 * a.kxn)), t = (int)(l2 - (long long)ky * 2 * a.kxn);
   const int kx = t >> 1;
-  const long long ps = 2LL * a.kxs * a.n1;
   double* x = reinterpret_cast<double*>(a.data) + t + 2LL * a.kxs * ky;
   const double sxy = a.ax[kx] + a.ay[ky];
-  if (sxy == 0.0) {  // the singular line: hand the scaled right-hand side to the gather, leave the rest to k_ztri_line0
-    for (int k = 0; k < a.m; ++k) line0[2 * k + (t & 1)] = a.scale * x[k * ps];
+  if (sxy == 0.0) {  // the singular line (only kx = ky = 0 has a zero eigenvalue: see the extra workgroup above)
     edge[r2] = edge[lines2 + r2] = 0.0;
     return;
   }
@@ -83,7 +94,7 @@ __global__ __launch_bounds__(256) void k_ztri_fwd(ZtriArgs a, double* __restrict
   const double rinv = 1.0 / L.r;
   // 16-plane chunks, double-buffered in registers: the loads of chunk c+1 are issued before the stores of chunk c (the compiler
   // may not move a load above a store to the same array, and a load-compute-store chain per plane costs one HBM round trip each)
-  constexpr int CH = 16;
+  constexpr int CH = 16;  // planes per chunk (32 measured no faster: the sweep is not limited by bytes in flight)
   double buf[CH], nxt[CH];
 #pragma unroll
   for (int j = 0; j < CH; ++j) buf[j] = x[(long long)min(j, a.m - 1) * ps];
@@ -91,11 +102,15 @@ __global__ __launch_bounds__(256) void k_ztri_fwd(ZtriArgs a, double* __restrict
 #pragma unroll
     for (int j = 0; j < CH; ++j) nxt[j] = x[(long long)min(k0 + CH + j, a.m - 1) * ps];
     // r^(m-k) by a running product re-seeded from exp() every chunk: r >= ~0.1 on these grids, so a seed that underflows
-    // cannot become significant within 16 steps, and the product never has to climb out of an underflow
+    // cannot become significant within a chunk (16 steps), and the product never has to climb out of an underflow
     double pb = exp((a.m - k0) * L.lnr);
     auto one = [&](int j) {
       const int k = k0 + j;
       const double g = a.scale * buf[j];
+      if (SKEL) {
+        x[k * ps] = g;
+        return;
+      }
       const double inv = rc * (1.0 - E) * frcp(1.0 - E * L.r2);
       gp = inv * (g + a.c * gp);
       x[k * ps] = gp;
@@ -109,7 +124,9 @@ __global__ __launch_bounds__(256) void k_ztri_fwd(ZtriArgs a, double* __restrict
 #pragma unroll
       for (int j = 0; j < CH; ++j) one(j);
     } else {
-      for (int j = 0; j < a.m - k0; ++j) one(j);
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+        if (j < a.m - k0) one(j);  // predicated, not a rolled loop: buf[] must stay in registers
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) buf[j] = nxt[j];
@@ -122,8 +139,20 @@ __global__ __launch_bounds__(256) void k_ztri_fwd(ZtriArgs a, double* __restrict
 //   F_r - α L_{r-1} - β F_{r+1} = yF_r,   L_r - β L_{r-1} - α F_{r+1} = yL_r,   α = v_0, β = v_{m-1}
 // edges_all: [rank][ per-rank block of `stride` complex: yF[lines], yL[lines], line0[m] ];  out bc: [2][lines] = (L_{r-1}, F_{r+1})
 constexpr int ZTRI_MAX_RANKS = 16;
+// PT: the rank count as a compile-time constant (0 = any count up to ZTRI_MAX_RANKS).  With a run-time count the per-rank values live
+// in scratch memory and every term of the O(P²) sums waits for a scratch load: 61 us instead of ~10 at P = 8, 131 k lines.
+template <int PT>
 __global__ __launch_bounds__(256) void k_ztri_iface(ZtriArgs a, const double2* __restrict__ edges_all, long long stride, double2* __restrict__ bc,
                                                     long long l_lo, long long l_cnt) {
+  // e^{-2πi k/P}, k < P, once per workgroup (evaluated per (j, q) pair the P² sincospi calls were 14x the rest of this kernel at P = 8)
+  __shared__ double2 tw[ZTRI_MAX_RANKS];
+  const int P = PT ? PT : a.nranks;
+  if ((int)threadIdx.x < P) {
+    double sn, cs;
+    sincospi(-2.0 * (double)threadIdx.x / P, &sn, &cs);
+    tw[threadIdx.x] = make_double2(cs, sn);
+  }
+  __syncthreads();
   const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
   if (r >= l_cnt) return;
   const long long lines = l_cnt, l = r;  // edges_all / bc are indexed inside the range
@@ -137,26 +166,28 @@ __global__ __launch_bounds__(256) void k_ztri_iface(ZtriArgs a, const double2* _
   const LineConst L = line_const(sxy / a.c, a.m);
   const double alpha = L.r * (-expm1(2.0 * a.m * L.lnr)) / L.D;
   const double beta = exp(a.m * L.lnr) * (1.0 - L.r2) / L.D;
-  const int P = a.nranks;
-  double2 yF[ZTRI_MAX_RANKS], yL[ZTRI_MAX_RANKS];
+  double2 yF[PT ? PT : ZTRI_MAX_RANKS], yL[PT ? PT : ZTRI_MAX_RANKS];
+#pragma unroll PT ? PT : 1
   for (int q = 0; q < P; ++q) {
     yF[q] = edges_all[q * stride + l];
     yL[q] = edges_all[q * stride + lines + l];
   }
   double2 Lprev = make_double2(0.0, 0.0), Fnext = Lprev;
   const int rp = (a.rank + P - 1) % P, rn = (a.rank + 1) % P;
+  auto conj = [](double2 z) { return make_double2(z.x, -z.y); };
+#pragma unroll PT ? PT : 1
   for (int j = 0; j < P; ++j) {
     double2 hF = make_double2(0.0, 0.0), hL = hF;
-    for (int q = 0; q < P; ++q) {  // forward DFT over ranks: e^{-iθ_j q}
-      double sn, cs;
-      sincospi(-2.0 * (double)((j * q) % P) / P, &sn, &cs);
-      const double2 w = make_double2(cs, sn);
+#pragma unroll PT ? PT : 1
+    for (int q = 0, jq = 0; q < P; ++q) {  // forward DFT over ranks: e^{-iθ_j q}
+      const double2 w = tw[jq];
       hF = hF + cmul(w, yF[q]);
       hL = hL + cmul(w, yL[q]);
+      jq += j;
+      if (jq >= P) jq -= P;
     }
-    double sn, cs;
-    sincospi(2.0 * (double)j / P, &sn, &cs);
-    const double2 ep = make_double2(cs, sn), em = make_double2(cs, -sn);  // e^{+iθ}, e^{-iθ}
+    const double2 em = tw[j], ep = conj(em);  // e^{-iθ}, e^{+iθ}
+    const double cs = em.x;
     // [ 1 - β e^{+iθ}    -α e^{-iθ} ] [F̂]   [ŷF]
     // [   -α e^{+iθ}   1 - β e^{-iθ} ] [L̂] = [ŷL]
     const double2 a11 = make_double2(1.0 - beta * ep.x, -beta * ep.y), a22 = make_double2(1.0 - beta * em.x, -beta * em.y);
@@ -164,20 +195,24 @@ __global__ __launch_bounds__(256) void k_ztri_iface(ZtriArgs a, const double2* _
     const double det = 1.0 - 2.0 * beta * cs + beta * beta - alpha * alpha;  // a11 a22 - a12 a21 (real)
     const double2 Fh = (1.0 / det) * (cmul(a22, hF) + (-1.0) * cmul(a12, hL));
     const double2 Lh = (1.0 / det) * (cmul(a11, hL) + (-1.0) * cmul(a21, hF));
-    double s2, c2;
-    sincospi(2.0 * (double)((j * rp) % P) / P, &s2, &c2);
-    Lprev = Lprev + cmul(make_double2(c2, s2), Lh);
-    sincospi(2.0 * (double)((j * rn) % P) / P, &s2, &c2);
-    Fnext = Fnext + cmul(make_double2(c2, s2), Fh);
+    Lprev = Lprev + cmul(conj(tw[(j * rp) % P]), Lh);  // inverse DFT at ranks r-1 and r+1: e^{+iθ_j r'}
+    Fnext = Fnext + cmul(conj(tw[(j * rn) % P]), Fh);
   }
   bc[l] = (1.0 / P) * Lprev;
   bc[lines + l] = (1.0 / P) * Fnext;
 }
 
+__device__ void ztri_line0(const ZtriArgs& a, const double2* __restrict__ edges_all, long long stride, long long line0_off, int lane);
+
 // ---- pass 2: back substitution with the interface values folded in -------------------------------------------------------
 // g̃ = g + c L_{r-1} e_0 + c F_{r+1} e_{m-1}  =>  gp̃_k = gp_k + c L φ_k (+ c F /den_{m-1} at k = m-1),  φ_k = r^(k+1)(1-r²)/(c(1-E_k r²))
 // p_{m-1} = gp̃_{m-1},  p_k = gp̃_k + (c/den_k) p_{k+1}
-__global__ __launch_bounds__(256) void k_ztri_bwd(ZtriArgs a, const double* __restrict__ bc, long long l_lo, long long l_cnt) {
+__global__ __launch_bounds__(256) void k_ztri_bwd(ZtriArgs a, const double* __restrict__ bc, const double2* __restrict__ edges_all, long long stride,
+                                                  long long l_lo, long long l_cnt) {
+  if (l_lo == 0 && blockIdx.x == gridDim.x - 1) {  // extra workgroup of the range that holds line 0: the singular line's solve
+    if (threadIdx.x < 64) ztri_line0(a, edges_all, stride, 2 * l_cnt, threadIdx.x);
+    return;
+  }
   // flat index over (ky, kx, re/im) of the line range of this launch: a 256-wide workgroup reads 2 KB of consecutive memory per plane
   const long long r2 = (long long)blockIdx.x * 256 + threadIdx.x;  // component index inside the range
   if (r2 >= 2 * l_cnt) return;
@@ -187,13 +222,13 @@ __global__ __launch_bounds__(256) void k_ztri_bwd(ZtriArgs a, const double* __re
   const long long ps = 2LL * a.kxs * a.n1;
   double* x = reinterpret_cast<double*>(a.data) + t + 2LL * a.kxs * ky;
   const double sxy = a.ax[kx] + a.ay[ky];
-  if (sxy == 0.0) return;  // k_ztri_line0
+  if (sxy == 0.0) return;  // ztri_line0
   const LineConst L = line_const(sxy / a.c, a.m);
   const double Lp = bc[r2], Fn = bc[lines2 + r2];  // bc of this range: [L (cnt)][F (cnt)]
   const double omr2 = 1.0 - L.r2;
   double p = 0.0;
   const double rinv = 1.0 / L.r;
-  constexpr int CH = 16;  // double-buffered 16-plane chunks, see k_ztri_fwd
+  constexpr int CH = 16;  // double-buffered chunks, see k_ztri_fwd
   double buf[CH], nxt[CH];
 #pragma unroll
   for (int j = 0; j < CH; ++j) buf[j] = x[(long long)max(a.m - 1 - j, 0) * ps];
@@ -215,7 +250,9 @@ __global__ __launch_bounds__(256) void k_ztri_bwd(ZtriArgs a, const double* __re
 #pragma unroll
       for (int j = 0; j < CH; ++j) one(j);
     } else {
-      for (int j = 0; j <= k0; ++j) one(j);
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+        if (j <= k0) one(j);
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) buf[j] = nxt[j];
@@ -246,8 +283,8 @@ __device__ __forceinline__ double2 wave_excl_scan(double2 v, int lane) {  // exc
   return make_double2(inc.x - v.x, inc.y - v.y);
 }
 
-__global__ __launch_bounds__(64) void k_ztri_line0(ZtriArgs a, const double2* __restrict__ edges_all, long long stride, long long line0_off) {
-  const int lane = threadIdx.x;
+// (one wavefront: run by the extra workgroup of k_ztri_bwd, beside the other lines' back substitution)
+__device__ void ztri_line0(const ZtriArgs& a, const double2* __restrict__ edges_all, long long stride, long long line0_off, int lane) {
   const int P = a.nranks, m = a.m, N = P * m;
   const int C = (N + 63) / 64, s = min(lane * C, N), e = min(s + C, N);
   auto g_at = [&](int k) { return edges_all[(long long)(k / m) * stride + line0_off + (k % m)]; };
@@ -298,7 +335,12 @@ int ins_k_ztri_forward(double* work, int kxn, int kxs, int n1, int m, int nranks
                        double scale, double* edge, long long l_lo, long long l_cnt, hipStream_t s) {
   ZtriArgs a{reinterpret_cast<double2*>(work), kxn, kxs, n1, m, nranks, rank, ax, ay, c, scale};
   if (l_cnt <= 0) return INS_OK;
-  hipLaunchKernelGGL(k_ztri_fwd, dim3(cdiv(2 * l_cnt, 256)), dim3(256), 0, s, a, edge, edge + 4 * l_cnt, l_lo, l_cnt);  // one work-item per real component
+  const int extra = l_lo == 0 ? 1 : 0;  // one more workgroup for the singular line's right-hand side
+  static const bool skel = getenv("INS_ZTRI_SKEL") && atoi(getenv("INS_ZTRI_SKEL"));
+  if (skel)
+    hipLaunchKernelGGL(k_ztri_fwd<true>, dim3(cdiv(2 * l_cnt, 256) + extra), dim3(256), 0, s, a, edge, edge + 4 * l_cnt, l_lo, l_cnt);
+  else
+    hipLaunchKernelGGL(k_ztri_fwd<false>, dim3(cdiv(2 * l_cnt, 256) + extra), dim3(256), 0, s, a, edge, edge + 4 * l_cnt, l_lo, l_cnt);  // one work-item per real component
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -314,9 +356,16 @@ int ins_k_ztri_finish(double* work, int kxn, int kxs, int n1, int m, int nranks,
   ZtriArgs a{reinterpret_cast<double2*>(work), kxn, kxs, n1, m, nranks, rank, ax, ay, c, 0.0};
   const double2* ea = reinterpret_cast<const double2*>(edges_all);
   double2* b = reinterpret_cast<double2*>(bc);
-  hipLaunchKernelGGL(k_ztri_iface, dim3(cdiv(l_cnt, 256)), dim3(256), 0, s, a, ea, stride, b, l_lo, l_cnt);
-  hipLaunchKernelGGL(k_ztri_bwd, dim3(cdiv(2 * l_cnt, 256)), dim3(256), 0, s, a, (const double*)bc, l_lo, l_cnt);
-  if (l_lo == 0) hipLaunchKernelGGL(k_ztri_line0, dim3(1), dim3(64), 0, s, a, ea, stride, 2 * l_cnt);
+#define INS_IFACE(PT) hipLaunchKernelGGL(k_ztri_iface<PT>, dim3(cdiv(l_cnt, 256)), dim3(256), 0, s, a, ea, stride, b, l_lo, l_cnt)
+  switch (nranks) {
+    case 1: INS_IFACE(1); break;
+    case 2: INS_IFACE(2); break;
+    case 4: INS_IFACE(4); break;
+    case 8: INS_IFACE(8); break;
+    default: INS_IFACE(0); break;
+  }
+#undef INS_IFACE
+  hipLaunchKernelGGL(k_ztri_bwd, dim3(cdiv(2 * l_cnt, 256) + (l_lo == 0 ? 1 : 0)), dim3(256), 0, s, a, (const double*)bc, ea, stride, l_lo, l_cnt);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }

@@ -89,7 +89,7 @@ def _worker(rank, world, port, n, nsteps, out_dir, chunks=1, zsolve="fft"):
                                                    (4, (64, 32, 32), 1, "fft"), (2, (64, 16, 32), 4, "fft"), (2, (66, 16, 32), 3, "fft"),
                                                    (2, (128, 16, 32), 4, "fft"), (2, (64, 16, 32), 1, "tridiag"), (4, (64, 32, 32), 1, "tridiag"),
                                                    (2, (66, 16, 24), 1, "tridiag"), (3, (128, 18, 24), 1, "tridiag"), (2, (128, 16, 32), 1, "tridiag"), (2, (64, 16, 32), 1, "tridiag-2ranges")])
-def test_multi_rank_slab_on_one_gpu_matches_oracle(tmp_path, oracle, world, n, chunks, zsolve):
+def test_multi_rank_slab_on_one_gpu_matches_oracle(tmp_path, oracle, world, n, chunks, zsolve, monkeypatch):
     """(66,16,24): rocFFT x/y + rocFFT z; power-of-two boxes: own x/y passes with the digit-reversed ky order split
     across ranks + the fused z kernel."""
     _need_gpu()
@@ -97,9 +97,9 @@ def test_multi_rank_slab_on_one_gpu_matches_oracle(tmp_path, oracle, world, n, c
     nsteps = 2
     if zsolve.endswith("-2ranges"):  # pipelined interface gather over two line ranges
         zsolve = "tridiag"
-        os.environ["INS_SLAB_ZCHUNKS"] = "2"
+        monkeypatch.setenv("INS_SLAB_ZCHUNKS", "2")  # inherited by the spawned ranks, undone after the test
     else:
-        os.environ.pop("INS_SLAB_ZCHUNKS", None)
+        monkeypatch.delenv("INS_SLAB_ZCHUNKS", raising=False)
     mp.spawn(_worker, args=(world, _free_port(), n, nsteps, str(tmp_path), chunks, zsolve), nprocs=world, join=True)
     x = tuple(np.linspace(0.0, 1.0, ni + 1) for ni in n)
     so = o.make_setup(x, Re=500.0)
