@@ -176,6 +176,41 @@ int ins_rk_profile_read(ins_rk_t* rk, double* momentum_ms, int64_t* momentum_lau
 int ins_rk_pressure(const ins_rk_t* rk, double** p);
 int ins_rk_stage_force(const ins_rk_t* rk, int i, double** ku);
 
+/* ---------------------------------------------------------------------------------- step-adjacent field operators
+ * (SURVEY.md §8f rows 2 and 4).  Vector fields: D components of N cells, component slowest; scalar fields: N cells. */
+/* vorticity!(ω, u, setup)                  operators.jl:985-1020  (2-D: scalar ω; 3-D: vector ω; written on 0 .. N-2) */
+int ins_vorticity_f64(const ins_grid_t* grid, const double* u, double* w, void* stream);
+/* interpolate_u_p!(up, u, setup)           operators.jl:1311-1326 (writes Ip) */
+int ins_interpolate_u_p_f64(const ins_grid_t* grid, const double* u, double* up, void* stream);
+/* interpolate_ω_p!(ωp, ω, setup)           operators.jl:1336-1370 (writes Ip) */
+int ins_interpolate_w_p_f64(const ins_grid_t* grid, const double* w, double* wp, void* stream);
+/* Dfield!(d, G, p, setup; ϵ)               operators.jl:1385-1422: pressuregradient!(G, p) then d = |G|/2/lap on Ip; G is scratch/out */
+int ins_dfield_f64(const ins_grid_t* grid, const double* p, double* G, double* d, double eps, void* stream);
+/* Qfield!(Q, u, setup)                     operators.jl:1440-1460 */
+int ins_qfield_f64(const ins_grid_t* grid, const double* u, double* Q, void* stream);
+/* dissipation_from_strain!(ϵ, u, setup)    operators.jl:836-854; visc = 1/Re */
+int ins_dissipation_from_strain_f64(const ins_grid_t* grid, double visc, const double* u, double* eps_out, void* stream);
+/* eig2field!(λ, u, setup)                  operators.jl:1472-1492 (3-D only; middle eigenvalue of S² + R² in closed form) */
+int ins_eig2field_f64(const ins_grid_t* grid, const double* u, double* lam, void* stream);
+/* apply_bc_temp!(temp, t, setup)           boundary_conditions.jl:236-246 (+338-339, 391-405, 466-467, 512-513).
+ * bc[2β+side] = INS_BC_* of setup.temperature.boundary_conditions, val[2β+side] = Dirichlet constant; `planes` (nullable, and nullable
+ * per entry) = DEVICE buffers of Dirichlet values over the full padded plane in memory order, the way closures cross the ABI. */
+int ins_apply_bc_temp_f64(const ins_grid_t* grid, const int32_t* bc, const double* val, const double* const* planes, double* temp, void* stream);
+/* convection_diffusion_temp!(c, u, temp, setup)   operators.jl:712-737 (c += ...); a4 = setup.temperature.α4 */
+int ins_convection_diffusion_temp_f64(const ins_grid_t* grid, double a4, const double* u, const double* temp, double* c, void* stream);
+/* dissipation!(diss, diff, u, setup)       operators.jl:791-814 (diss += ...; diff is scratch); visc = 1/Re, coef = Re·α1/γ */
+int ins_dissipation_f64(const ins_grid_t* grid, double visc, double coef, const double* u, double* diff, double* diss, void* stream);
+/* gravity!(F, temp, setup)                 operators.jl:914-931 (F[:, gdir] += α2 avg(temp)); gdir 0-based */
+int ins_gravity_f64(const ins_grid_t* grid, int gdir, double a2, const double* temp, double* F, void* stream);
+/* smagtensor!(σ, u, θ, setup)              operators.jl:1135-1150.  σ is symmetric: D(D+1)/2 scalar fields [xx, yy, (zz), xy, (xz, yz)]
+ * (the reference stores D×D SMatrix per cell); ghost-fill each with ins_apply_bc_p_f64 as smagorinsky_closure does (:1296). */
+int ins_smagtensor_f64(const ins_grid_t* grid, double theta, const double* u, double* sigma, void* stream);
+/* divoftensor!(s, σ, setup)                operators.jl:1203-1236 (writes Iu[α]) */
+int ins_divoftensor_f64(const ins_grid_t* grid, const double* sigma, double* s, void* stream);
+/* ins_combine_f64 for scalar fields (tempstart + Σ Δt A[i,j] ktemp[j], step_explicit_runge_kutta.jl:39-44) */
+int ins_combine_scalar_f64(const ins_grid_t* grid, const double* base, double* out, int nterms, const double* coefs,
+                           const double* const* ks, void* stream);
+
 /* ---------------------------------------------------------------------------------- multi-GPU z-slabs
  * One process per GPU.  Rank r owns nz/P interior z-planes (+1 ghost plane per side); its
  * `ins_grid_t` is created with bc[2] = {INS_BC_HALO, INS_BC_HALO} and the local slice of the z metrics.

@@ -10,10 +10,38 @@ from ._lib import INSHipError
 from .boundary_conditions import DirichletBC, HaloBC, PeriodicBC, PressureBC, SymmetricBC
 from .distributed import HipSlabKernels, SlabComm, SlabLayout, SlabStepper
 from .grid import Grid, cosine_grid, max_size, stretched_grid, tanh_grid
-from .initializers import random_field, velocityfield
+from .initializers import random_field, temperaturefield, velocityfield
 from .operators import (
+    Dfield,
+    Dfield_,
+    Qfield,
+    Qfield_,
     apply_bc_p,
     apply_bc_p_,
+    apply_bc_temp,
+    apply_bc_temp_,
+    applybodyforce,
+    applybodyforce_,
+    convection_diffusion_temp,
+    convection_diffusion_temp_,
+    dissipation,
+    dissipation_,
+    dissipation_from_strain,
+    dissipation_from_strain_,
+    divoftensor_,
+    eig2field,
+    eig2field_,
+    gravity,
+    gravity_,
+    interpolate_u_p,
+    interpolate_u_p_,
+    interpolate_ω_p,
+    interpolate_ω_p_,
+    smagorinsky_closure,
+    smagtensor_,
+    tensorfield,
+    vorticity,
+    vorticity_,
     apply_bc_u,
     apply_bc_u_,
     applypressure,
@@ -49,7 +77,7 @@ from .pressure import (
     psolver_direct,
     psolver_spectral,
 )
-from .setup import Setup, copyfield, from_numpy, scalarfield, to_numpy, vectorfield
+from .setup import Setup, copyfield, from_numpy, scalarfield, temperature_equation, to_numpy, vectorfield
 from .sciml import create_right_hand_side, right_hand_side_
 from .solver import get_cfl_timestep_, get_state, solve_unsteady
 from .time_steppers import (

@@ -57,6 +57,20 @@ SIGNATURES = {
     "ins_total_kinetic_energy_f64": (C.c_int, [vp, vp, C.c_int, c_double_p, vp]),
     "ins_cfl_timestep_f64": (C.c_int, [vp, C.c_double, vp, c_double_p, vp]),
     "ins_max_abs_divergence_f64": (C.c_int, [vp, vp, c_double_p, vp]),
+    "ins_vorticity_f64": (C.c_int, [vp, vp, vp, vp]),
+    "ins_interpolate_u_p_f64": (C.c_int, [vp, vp, vp, vp]),
+    "ins_interpolate_w_p_f64": (C.c_int, [vp, vp, vp, vp]),
+    "ins_dfield_f64": (C.c_int, [vp, vp, vp, vp, C.c_double, vp]),
+    "ins_qfield_f64": (C.c_int, [vp, vp, vp, vp]),
+    "ins_dissipation_from_strain_f64": (C.c_int, [vp, C.c_double, vp, vp, vp]),
+    "ins_eig2field_f64": (C.c_int, [vp, vp, vp, vp]),
+    "ins_apply_bc_temp_f64": (C.c_int, [vp, C.POINTER(C.c_int32), c_double_p, C.POINTER(vp), vp, vp]),
+    "ins_convection_diffusion_temp_f64": (C.c_int, [vp, C.c_double, vp, vp, vp, vp]),
+    "ins_dissipation_f64": (C.c_int, [vp, C.c_double, C.c_double, vp, vp, vp, vp]),
+    "ins_gravity_f64": (C.c_int, [vp, C.c_int, C.c_double, vp, vp, vp]),
+    "ins_smagtensor_f64": (C.c_int, [vp, C.c_double, vp, vp, vp]),
+    "ins_divoftensor_f64": (C.c_int, [vp, vp, vp, vp]),
+    "ins_combine_scalar_f64": (C.c_int, [vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), vp]),
     "ins_poisson_spectral_create": (C.c_int, [vp, C.POINTER(vp)]),
     "ins_poisson_cg_create": (C.c_int, [vp, C.c_double, C.c_double, C.c_int64, C.POINTER(vp)]),
     "ins_poisson_cg_bordered": (C.c_int, [vp, C.c_int]),

@@ -50,9 +50,21 @@ __global__ __launch_bounds__(256) void k_combine(long long n, const double* usta
 
 }  // namespace
 
+static int combine_n(long long nvec, const double* base, double* out, int nterms, const double* coefs, const double* const* ks, void* stream);
+
 extern "C" int ins_combine_f64(const ins_grid_t* G, const double* base, double* out, int nterms, const double* coefs,
                                const double* const* ks, void* stream) {
   INS_REQUIRE(G && base && out, "null argument");
+  return combine_n(G->ncell * G->g.D, base, out, nterms, coefs, ks, stream);
+}
+
+extern "C" int ins_combine_scalar_f64(const ins_grid_t* G, const double* base, double* out, int nterms, const double* coefs,
+                                      const double* const* ks, void* stream) {
+  INS_REQUIRE(G && base && out, "null argument");
+  return combine_n(G->ncell, base, out, nterms, coefs, ks, stream);
+}
+
+static int combine_n(long long nvec, const double* base, double* out, int nterms, const double* coefs, const double* const* ks, void* stream) {
   INS_REQUIRE(nterms >= 0 && nterms <= INS_MAX_STAGES && (nterms == 0 || (coefs && ks)), "bad stage terms");
   Combine cb;
   cb.n = 0;
@@ -63,7 +75,6 @@ extern "C" int ins_combine_f64(const ins_grid_t* G, const double* base, double* 
     cb.k[cb.n] = ks[q];
     ++cb.n;
   }
-  const long long nvec = G->ncell * G->g.D;
   const unsigned nblk = (unsigned)std::min<long long>((nvec / 2 + 255) / 256, 8192);
   hipLaunchKernelGGL(k_combine, dim3(nblk), dim3(256), 0, as_stream(stream), nvec, base, out, cb);
   INS_LAUNCH_CHECK();

@@ -2,7 +2,7 @@
 import numpy as np
 import torch
 
-from .operators import apply_bc_u_
+from .operators import apply_bc_temp_, apply_bc_u_
 from .pressure import default_psolver, project
 from .setup import from_numpy, vectorfield
 
@@ -30,6 +30,24 @@ def velocityfield(setup, ufunc, t=0.0, *, psolver=None, doproject=True):
         u = project(u, setup, psolver)
         apply_bc_u_(u, t, setup)
     return u
+
+
+def temperaturefield(setup, tempfunc, t=0.0):
+    """Create temperature field from function with boundary conditions at time `t` (initializers.jl:48-57).
+    `tempfunc(x, y[, z])` is called once with broadcastable coordinate arrays of the pressure points."""
+    g = setup.grid
+    D = g.dimension
+    host = np.zeros(g.N, dtype=np.float64, order="F")
+    xs = []
+    for be in range(D):
+        lo, hi = g.Ip[be]
+        shape = [1] * D
+        shape[be] = hi - lo
+        xs.append(np.asarray(g.xp[be][lo:hi]).reshape(shape))
+    sl = tuple(slice(lo, hi) for lo, hi in g.Ip)
+    host[sl] = np.broadcast_to(tempfunc(*xs), tuple(hi - lo for lo, hi in g.Ip))
+    temp = from_numpy(setup, host)
+    return apply_bc_temp_(temp, t, setup)
 
 
 def random_field(setup, t=0.0, *, A=1.0, kp=10, psolver=None, seed=0):

@@ -148,10 +148,12 @@ def convectiondiffusion_(F, u, setup):
 
 
 def momentum_(F, u, temp, t, setup):
-    """operators.jl:967-976 with bodyforce = temp = nothing"""
-    if temp is not None:
-        raise NotImplementedError("temperature is outside the HIP hot path")
+    """operators.jl:967-976: fill!(F, 0) + convectiondiffusion! (one fused write-only pass), then the body force and gravity terms."""
     _lib.call("ins_momentum_f64", setup.handle, 1.0 / setup.Re, setup.ptr(u, True), setup.ptr(F, True), setup.stream)
+    if setup.bodyforce is not None:
+        applybodyforce_(F, u, t, setup)
+    if temp is not None:
+        gravity_(F, temp, setup)
     return F
 
 
@@ -181,3 +183,215 @@ def max_abs_divergence(u, setup):
     out = C.c_double()
     _lib.call("ins_max_abs_divergence_f64", setup.handle, setup.ptr(u, True), C.byref(out), setup.stream)
     return out.value
+
+
+# ------------------------------------------------------------------------------------ body force
+def applybodyforce_(F, u, t, setup):
+    """operators.jl:873-897 (adds to F): the stored field when steady, else `bodyforce.(α, xu[α]..., t)` evaluated on the host."""
+    f = setup.bodyforce if setup.issteadybodyforce else setup.bodyforce_field(t)
+    setup.ptr(F, True), setup.ptr(f, True)
+    F.add_(f)  # same-layout elementwise add (torch: plumbing, as the reference's broadcast)
+    return F
+
+
+def applybodyforce(u, t, setup):
+    """operators.jl:856-866"""
+    return copyfield(setup.bodyforce) if setup.issteadybodyforce else setup.bodyforce_field(t)
+
+
+# ------------------------------------------------------------------------------------ temperature equation
+def _temp_bc_args(setup, t):
+    g = setup.grid
+    D = g.dimension
+    bcs = setup.temperature.boundary_conditions
+    codes = (C.c_int32 * 6)()
+    vals = (C.c_double * 6)()
+    planes = (C.c_void_p * 6)()
+    keep, anyplane = [], False
+    for be in range(D):
+        for side in range(2):
+            bc = bcs[be][side]
+            codes[2 * be + side] = bc.code
+            if not isinstance(bc, DirichletBC) or bc.u is None:
+                continue
+            if callable(bc.u):  # bc.u(x..., t) on the full padded plane (boundary_conditions.jl:391-405)
+                lo, hi = g.Ip[be]
+                i = hi if side else lo - 1
+                xs = []
+                for ga in range(D):
+                    coords = g.xp[ga][i : i + 1] if ga == be else g.xp[ga]
+                    shape = [1] * D
+                    shape[ga] = coords.size
+                    xs.append(np.asarray(coords).reshape(shape))
+                full = np.broadcast_to(bc.u(*xs, t), [1 if b == be else g.N[b] for b in range(D)])
+                plane = np.ascontiguousarray(np.transpose(np.squeeze(full, axis=be)))  # memory order: fastest direction first
+                buf = torch.from_numpy(plane.astype(np.float64)).to(setup.device)
+                keep.append(buf)
+                planes[2 * be + side] = buf.data_ptr()
+                anyplane = True
+            else:
+                vals[2 * be + side] = float(bc.u)
+    return codes, vals, (planes if anyplane else None), keep
+
+
+def apply_bc_temp_(temp, t, setup):
+    """Apply temperature boundary conditions, in place (boundary_conditions.jl:236-246)."""
+    codes, vals, planes, keep = _temp_bc_args(setup, t)
+    _lib.call("ins_apply_bc_temp_f64", setup.handle, codes, vals, planes, setup.ptr(temp, False), setup.stream)
+    if keep:
+        torch.cuda.current_stream(setup.device).synchronize()  # the plane buffers die with this frame
+    return temp
+
+
+def apply_bc_temp(temp, t, setup):
+    return apply_bc_temp_(copyfield(temp), t, setup)
+
+
+def convection_diffusion_temp_(c, u, temp, setup):
+    """operators.jl:712-737 (adds to c)"""
+    _lib.call("ins_convection_diffusion_temp_f64", setup.handle, setup.temperature.α4, setup.ptr(u, True), setup.ptr(temp, False),
+              setup.ptr(c, False), setup.stream)
+    return c
+
+
+def convection_diffusion_temp(u, temp, setup):
+    return convection_diffusion_temp_(scalarfield(setup), u, temp, setup)
+
+
+def dissipation_(diss, diff, u, setup):
+    """operators.jl:791-814 (adds to diss; `diff` is scratch: it receives diffusion(u))"""
+    T = setup.temperature
+    _lib.call("ins_dissipation_f64", setup.handle, 1.0 / setup.Re, setup.Re * T.α1 / T.γ, setup.ptr(u, True), setup.ptr(diff, True),
+              setup.ptr(diss, False), setup.stream)
+    return diss
+
+
+def dissipation(u, setup):
+    return dissipation_(scalarfield(setup), vectorfield(setup), u, setup)
+
+
+def dissipation_from_strain_(ϵ, u, setup):
+    """operators.jl:836-854"""
+    _lib.call("ins_dissipation_from_strain_f64", setup.handle, 1.0 / setup.Re, setup.ptr(u, True), setup.ptr(ϵ, False), setup.stream)
+    return ϵ
+
+
+def dissipation_from_strain(u, setup):
+    return dissipation_from_strain_(scalarfield(setup), u, setup)
+
+
+def gravity_(F, temp, setup):
+    """operators.jl:914-931 (adds to F)"""
+    T = setup.temperature
+    _lib.call("ins_gravity_f64", setup.handle, int(T.gdir), T.α2, setup.ptr(temp, False), setup.ptr(F, True), setup.stream)
+    return F
+
+
+def gravity(temp, setup):
+    return gravity_(vectorfield(setup), temp, setup)
+
+
+# ------------------------------------------------------------------------------------ field diagnostics
+def _vort_field(setup):
+    return scalarfield(setup) if setup.grid.dimension == 2 else vectorfield(setup)
+
+
+def vorticity_(ω, u, setup):
+    """operators.jl:985-1020"""
+    _lib.call("ins_vorticity_f64", setup.handle, setup.ptr(u, True), setup.ptr(ω, setup.grid.dimension == 3), setup.stream)
+    return ω
+
+
+def vorticity(u, setup):
+    return vorticity_(_vort_field(setup), u, setup)
+
+
+def interpolate_u_p_(up, u, setup):
+    """operators.jl:1311-1326"""
+    _lib.call("ins_interpolate_u_p_f64", setup.handle, setup.ptr(u, True), setup.ptr(up, True), setup.stream)
+    return up
+
+
+def interpolate_u_p(u, setup):
+    return interpolate_u_p_(vectorfield(setup), u, setup)
+
+
+def interpolate_ω_p_(ωp, ω, setup):
+    """operators.jl:1336-1370"""
+    vec = setup.grid.dimension == 3
+    _lib.call("ins_interpolate_w_p_f64", setup.handle, setup.ptr(ω, vec), setup.ptr(ωp, vec), setup.stream)
+    return ωp
+
+
+def interpolate_ω_p(ω, setup):
+    return interpolate_ω_p_(_vort_field(setup), ω, setup)
+
+
+def Dfield_(d, G, p, setup, ϵ=np.finfo(np.float64).eps):
+    """operators.jl:1385-1422"""
+    _lib.call("ins_dfield_f64", setup.handle, setup.ptr(p, False), setup.ptr(G, True), setup.ptr(d, False), float(ϵ), setup.stream)
+    return d
+
+
+def Dfield(p, setup, **kw):
+    return Dfield_(scalarfield(setup), vectorfield(setup), p, setup, **kw)
+
+
+def Qfield_(Q, u, setup):
+    """operators.jl:1440-1460"""
+    _lib.call("ins_qfield_f64", setup.handle, setup.ptr(u, True), setup.ptr(Q, False), setup.stream)
+    return Q
+
+
+def Qfield(u, setup):
+    return Qfield_(scalarfield(setup), u, setup)
+
+
+def eig2field_(λ, u, setup):
+    """operators.jl:1472-1492 (3-D only)"""
+    _lib.call("ins_eig2field_f64", setup.handle, setup.ptr(u, True), setup.ptr(λ, False), setup.stream)
+    return λ
+
+
+def eig2field(u, setup):
+    return eig2field_(scalarfield(setup), u, setup)
+
+
+# ------------------------------------------------------------------------------------ Smagorinsky closure
+def tensorfield(setup):
+    """Symmetric tensor field: D(D+1)/2 scalar fields [xx, yy, (zz), xy, (xz, yz)] (the reference stores a D×D SMatrix per cell)."""
+    from .setup import _alloc
+
+    D = setup.grid.dimension
+    return _alloc(setup, setup.grid.N + (D * (D + 1) // 2,))
+
+
+def smagtensor_(σ, u, θ, setup):
+    """operators.jl:1135-1150"""
+    D = setup.grid.dimension
+    _lib.call("ins_smagtensor_f64", setup.handle, float(θ), setup.ptr(u, True), setup.ptr(σ, D * (D + 1) // 2), setup.stream)
+    return σ
+
+
+def divoftensor_(s, σ, setup):
+    """operators.jl:1158-1175, 1203-1236"""
+    D = setup.grid.dimension
+    _lib.call("ins_divoftensor_f64", setup.handle, setup.ptr(σ, D * (D + 1) // 2), setup.ptr(s, True), setup.stream)
+    return s
+
+
+def smagorinsky_closure(setup):
+    """Create Smagorinsky closure model `m(u, θ)` (operators.jl:1284-1300)."""
+    σ = tensorfield(setup)
+    s = vectorfield(setup)
+    D = setup.grid.dimension
+    ncell = int(np.prod(setup.grid.N))
+
+    def closure(u, θ):
+        smagtensor_(σ, u, θ, setup)
+        base = setup.ptr(σ, D * (D + 1) // 2).value
+        for q in range(D * (D + 1) // 2):  # apply_bc_p!(σ, 0, setup): every component is a pressure-point scalar
+            _lib.call("ins_apply_bc_p_f64", setup.handle, C.c_void_p(base + 8 * ncell * q), setup.stream)
+        return divoftensor_(s, σ, setup)
+
+    return closure

@@ -5,6 +5,8 @@ shape `N + (D,)` and Fortran strides, so `u[i, j, k, a]` is Julia's `u[i+1, j+1,
 `u.data_ptr()` can be handed to libinship (or to a Julia `unsafe_wrap`) unchanged.
 """
 import ctypes as C
+import math
+from types import SimpleNamespace
 
 import numpy as np
 import torch
@@ -22,15 +24,35 @@ def _fortran_strides(shape):
     return tuple(st)
 
 
+class Temperature(SimpleNamespace):
+    """The named tuple `temperature_equation` returns (setup.jl:48-87): α1..α4, γ, dodissipation, boundary_conditions, gdir (0-based)."""
+
+
+def temperature_equation(*, Pr, Ra, Ge, boundary_conditions, dodissipation=True, gdir=1, nondim_type=1):
+    """Create temperature equation setup (setup.jl:48-87).  `gdir` is 0-based here (the reference's default 2 is 1)."""
+    if nondim_type == 1:  # free fall velocity
+        a1, a2, a3, a4 = math.sqrt(Pr / Ra), 1.0, Ge * math.sqrt(Pr / Ra), 1 / math.sqrt(Pr * Ra)
+    elif nondim_type == 2:  # heat conduction time scale
+        a1, a2, a3, a4 = Pr, Pr * Ra, Ge / Ra, 1.0
+    elif nondim_type == 3:
+        a1, a2, a3, a4 = math.sqrt(Pr * Ge / Ra), Ge, math.sqrt(Pr * Ge / Ra), math.sqrt(Ge / (Pr * Ra))
+    else:
+        raise ValueError(f"nondim_type = {nondim_type}")
+    bcs = tuple(tuple(side) for side in boundary_conditions)
+    return Temperature(α1=a1, α2=a2, α3=a3, α4=a4, γ=a1 / a3, dodissipation=bool(dodissipation), boundary_conditions=bcs, gdir=int(gdir))
+
+
 class Setup:
     """Problem setup (setup.jl:2-46).  `backend`/`workgroupsize` of the reference are replaced by
-    `device` (a torch CUDA/HIP device); everything else keeps its name.  bodyforce, closure_model and
-    temperature are outside the accelerated path and must stay `None`."""
+    `device` (a torch CUDA/HIP device); everything else keeps its name.
 
-    def __init__(self, *, x, boundary_conditions=None, Re=1000.0, bodyforce=None, closure_model=None,
+    `bodyforce(α, x..., t)` (α 0-based) is evaluated on the host over the padded coordinates `xu[α]` and uploaded: once, at t = 0,
+    when `issteadybodyforce` (setup.jl:25-32), otherwise at every `applybodyforce_` call.  `closure_model(u, θ)` returns a vector
+    field on the device (e.g. `smagorinsky_closure(setup)`).  With any of the three the time steppers drive the operator-level
+    kernels from the host (closure hook caveat); without them a step is one native call."""
+
+    def __init__(self, *, x, boundary_conditions=None, Re=None, bodyforce=None, issteadybodyforce=True, closure_model=None,
                  temperature=None, device=None):
-        if bodyforce is not None or closure_model is not None or temperature is not None:
-            raise NotImplementedError("bodyforce / closure_model / temperature are outside the HIP hot path (SURVEY.md §2)")
         D = len(x)
         if boundary_conditions is None:
             boundary_conditions = tuple((PeriodicBC(), PeriodicBC()) for _ in range(D))
@@ -39,10 +61,19 @@ class Setup:
             if isinstance(a, PeriodicBC) != isinstance(b, PeriodicBC):
                 raise ValueError("PeriodicBC must be periodic on both sides")
         self.grid = Grid(x, self.boundary_conditions)
+        if Re is None:  # setup.jl:12
+            Re = 1000.0 if temperature is None else 1.0 / temperature.α1
         self.Re = float(Re)
         self.bodyforce = None
-        self.closure_model = None
-        self.temperature = None
+        self.issteadybodyforce = False
+        self.closure_model = closure_model
+        self.temperature = temperature
+        if temperature is not None:
+            if len(temperature.boundary_conditions) != D:
+                raise ValueError("temperature boundary conditions: one (left, right) pair per direction")
+            for a, b in temperature.boundary_conditions:
+                if isinstance(a, PeriodicBC) != isinstance(b, PeriodicBC):
+                    raise ValueError("PeriodicBC must be periodic on both sides")
         if device is None:
             if not torch.cuda.is_available():
                 raise _lib.INSHipError("no HIP device visible: the accelerated path has no CPU fallback")
@@ -52,6 +83,27 @@ class Setup:
             raise _lib.INSHipError(f"Setup needs a HIP device, got {self.device}")
         self._handle = None
         self._make_handle()
+        if bodyforce is not None:
+            if not callable(bodyforce):
+                raise TypeError("bodyforce must be callable: bodyforce(α, x..., t)")
+            self.bodyforce = bodyforce
+            if issteadybodyforce:  # setup.jl:25-32
+                self.bodyforce = self.bodyforce_field(0.0)
+                self.issteadybodyforce = True
+
+    def bodyforce_field(self, t):
+        """`bodyforce.(α, xu[α]..., t)` over the whole padded arrays (operators.jl:885-896), as a device vector field."""
+        g = self.grid
+        D = g.dimension
+        F = np.zeros(g.N + (D,))
+        for a in range(D):
+            xs = []
+            for b in range(D):
+                shape = [1] * D
+                shape[b] = g.N[b]
+                xs.append(np.asarray(g.xu[a][b]).reshape(shape))
+            F[..., a] = np.broadcast_to(self.bodyforce(a, *xs, t), g.N)
+        return from_numpy(self, F)
 
     # -------------------------------------------------------------------------------------------
     def _desc(self):
@@ -113,9 +165,11 @@ class Setup:
 
     # -------------------------------------------------------------------------------------------
     def ptr(self, f, vector):
-        """Device pointer of a field after checking dtype / device / shape / reference layout."""
+        """Device pointer of a field after checking dtype / device / shape / reference layout.
+        `vector`: False (scalar field), True (D components) or an int (that many components, e.g. a symmetric tensor)."""
         g = self.grid
-        shape = g.N + ((g.dimension,) if vector else ())
+        ncomp = g.dimension if vector is True else int(vector)
+        shape = g.N + ((ncomp,) if ncomp else ())
         if not isinstance(f, torch.Tensor) or f.dtype != torch.float64:
             raise TypeError("fields must be float64 torch tensors")
         if f.device != self.device:

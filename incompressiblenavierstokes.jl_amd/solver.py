@@ -26,17 +26,16 @@ def solve_unsteady(*, setup, tlims, ustart, tempstart=None, method=None, psolver
 
     `processors` is a dict name -> object with `initialize(state_getter)` / `finalize(init, state_getter)`
     and an optional `on_step(state)`; returns `((u, temp, t), outputs)` like the reference."""
-    if tempstart is not None:
-        raise NotImplementedError("temperature is outside the HIP hot path")
     method = method or RKMethods.RK44()
     psolver = psolver or default_psolver(setup)
     cache = cache or ode_method_cache(method, setup, psolver)
     processors = processors or {}
     if docopy:
         ustart = copyfield(ustart)
+        tempstart = None if tempstart is None else copyfield(tempstart)
     tstart, tend = tlims
     isadaptive = Δt is None
-    stepper = create_stepper(method, setup=setup, psolver=psolver, u=ustart, temp=None, t=tstart)
+    stepper = create_stepper(method, setup=setup, psolver=psolver, u=ustart, temp=tempstart, t=tstart)
     state = {"value": get_state(stepper)}
     initialized = {k: v.initialize(lambda: state["value"]) for k, v in processors.items()}
 
@@ -65,4 +64,4 @@ def solve_unsteady(*, setup, tlims, ustart, tempstart=None, method=None, psolver
                 stepper = timestep_(method, stepper, Δt, θ=θ, cache=cache)
                 fire()
     outputs = {k: processors[k].finalize(initialized[k], lambda: state["value"]) for k in processors}
-    return (stepper.u, None, stepper.t), outputs
+    return (stepper.u, stepper.temp, stepper.t), outputs

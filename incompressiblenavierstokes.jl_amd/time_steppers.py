@@ -7,7 +7,7 @@ from types import SimpleNamespace
 import numpy as np
 
 from . import _lib
-from .operators import apply_bc_u_, momentum_
+from .operators import apply_bc_temp_, apply_bc_u_, convection_diffusion_temp_, dissipation_, momentum_
 from .pressure import project_
 from .setup import copyfield, scalarfield, vectorfield
 
@@ -97,13 +97,28 @@ class LMWray3:
     c = (0.0, 8 / 15, 2 / 3)
 
 
-def combine_(out, base, coefs, ks, setup):
-    """out = base + Σ coefs[q]·ks[q] (K6; `out` may be `base`)."""
+def combine_(out, base, coefs, ks, setup, vector=True):
+    """out = base + Σ coefs[q]·ks[q] (K6; `out` may be `base`); `vector=False`: scalar fields (the temperature)."""
     n = len(coefs)
     carr = (C.c_double * max(n, 1))(*coefs)
-    karr = (C.c_void_p * max(n, 1))(*[setup.ptr(k, True).value for k in ks])
-    _lib.call("ins_combine_f64", setup.handle, setup.ptr(base, True), setup.ptr(out, True), n, carr, karr, setup.stream)
+    karr = (C.c_void_p * max(n, 1))(*[setup.ptr(k, vector).value for k in ks])
+    _lib.call("ins_combine_f64" if vector else "ins_combine_scalar_f64", setup.handle, setup.ptr(base, vector), setup.ptr(out, vector), n, carr, karr,
+              setup.stream)
     return out
+
+
+def _host_driven(setup, temp):
+    """True when the stage loop must run on the host: a user callback or an extra equation sits between the kernels."""
+    return temp is not None or setup.closure_model is not None or (setup.bodyforce is not None and not setup.issteadybodyforce) or setup.needs_bc_planes
+
+
+def _temp_rhs_(ktemp, diff, u, temp, setup):
+    """ktemp = convection_diffusion_temp + dissipation (step_explicit_runge_kutta.jl:23-27)"""
+    ktemp.zero_()
+    convection_diffusion_temp_(ktemp, u, temp, setup)
+    if setup.temperature.dodissipation:
+        dissipation_(ktemp, diff, u, setup)
+    return ktemp
 
 
 class LMWray3Cache:
@@ -112,28 +127,45 @@ class LMWray3Cache:
     def __init__(self, setup, psolver):
         self.setup, self.psolver = setup, psolver
         self.ustart, self.ku, self.p = vectorfield(setup), vectorfield(setup), scalarfield(setup)
+        if setup.temperature is not None:
+            self.tempstart, self.ktemp, self.diff = scalarfield(setup), scalarfield(setup), vectorfield(setup)
 
 
-def _timestep_lmwray3_(method, stepper, Δt, cache):
-    """step_lmwray3.jl:4-107 (closure_model = temp = nothing): operator-level kernels driven from the host."""
-    setup, psolver, u, n = stepper.setup, stepper.psolver, stepper.u, stepper.n
+def _timestep_lmwray3_(method, stepper, Δt, cache, θ=None):
+    """step_lmwray3.jl:4-107: operator-level kernels driven from the host (with the temperature equation and the closure term)."""
+    setup, psolver, u, temp, n = stepper.setup, stepper.psolver, stepper.u, stepper.temp, stepper.n
     ustart, ku, p = cache.ustart, cache.ku, cache.p
+    m = setup.closure_model
     tstart = stepper.t
     combine_(ustart, u, [], [], setup)                       # state_copyto!(xstart, x)
+    if temp is not None:
+        combine_(cache.tempstart, temp, [], [], setup, vector=False)
     nstage = len(method.a)
     t = tstart
     for i in range(nstage):
         t = tstart + method.c[i] * Δt
         apply_bc_u_(u, t, setup)                             # f!
-        momentum_(ku, u, None, t, setup)
+        if temp is not None:
+            apply_bc_temp_(temp, t, setup)
+        momentum_(ku, u, temp, t, setup)
+        if m is not None:
+            ku.add_(m(u, θ))
+        if temp is not None:
+            _temp_rhs_(cache.ktemp, cache.diff, u, temp, setup)
         combine_(u, ustart, [method.a[i] * Δt], [ku], setup) # x = xstart + Δt a[i] dx
+        if temp is not None:
+            combine_(temp, cache.tempstart, [method.a[i] * Δt], [cache.ktemp], setup, vector=False)
         apply_bc_u_(u, t, setup)                             # correct!
         project_(u, setup, psolver, p)
         if i != nstage - 1:
             combine_(ustart, ustart, [method.b[i] * Δt], [ku], setup)
+            if temp is not None:
+                combine_(cache.tempstart, cache.tempstart, [method.b[i] * Δt], [cache.ktemp], setup, vector=False)
     t = tstart + Δt
     apply_bc_u_(u, t, setup)
-    return create_stepper(method, setup=setup, psolver=psolver, u=u, temp=None, t=t, n=n + 1)
+    if temp is not None:
+        apply_bc_temp_(temp, t, setup)
+    return create_stepper(method, setup=setup, psolver=psolver, u=u, temp=temp, t=t, n=n + 1)
 
 
 class ERKCache:
@@ -185,7 +217,7 @@ def timesteps_(method, stepper, Δt, nsteps, *, θ=None, cache):
     The stepper's `u` is valid on entry and on return (intermediate steps are not observable, as inside the reference's loop
     without processors)."""
     setup, psolver = stepper.setup, stepper.psolver
-    if (nsteps >= 1 and not isinstance(method, LMWray3) and not setup.needs_bc_planes and stepper.temp is None and setup.closure_model is None):
+    if nsteps >= 1 and not isinstance(method, LMWray3) and not _host_driven(setup, stepper.temp) and setup.bodyforce is None:
         if cache.psolver is not psolver:
             raise ValueError("cache was created for a different psolver")
         _lib.call("ins_rk_steps_f64", cache.handle, 1.0 / setup.Re, setup.ptr(stepper.u, True), float(stepper.t), float(Δt), int(nsteps), setup.stream)
@@ -201,37 +233,54 @@ def timestep_(method, stepper, Δt, *, θ=None, cache):
     Fully native (`ins_rk_step_f64`) when boundary data is time-independent; with callable Dirichlet data
     the stage loop runs here and calls the operator-level kernels so `bc.u(α, x..., t)` can be evaluated
     between stages (SURVEY.md §8b closure-hook caveat)."""
-    setup, psolver, u, t, n = stepper.setup, stepper.psolver, stepper.u, stepper.t, stepper.n
-    if stepper.temp is not None or setup.closure_model is not None:
-        raise NotImplementedError("temperature / closure models are outside the HIP hot path")
+    setup, psolver, u, temp, t, n = stepper.setup, stepper.psolver, stepper.u, stepper.temp, stepper.t, stepper.n
+    if (temp is None) != (setup.temperature is None):
+        raise ValueError("a temperature field needs setup.temperature (temperature_equation) and vice versa")
     if isinstance(method, LMWray3):
-        return _timestep_lmwray3_(method, stepper, Δt, cache)
+        return _timestep_lmwray3_(method, stepper, Δt, cache, θ)
     if cache.psolver is not psolver:
         raise ValueError("cache was created for a different psolver")
-    if not setup.needs_bc_planes:
+    if not _host_driven(setup, temp) and setup.bodyforce is None:
         _lib.call("ins_rk_step_f64", cache.handle, 1.0 / setup.Re, setup.ptr(u, True), float(t), float(Δt), None, setup.stream)
         return create_stepper(method, setup=setup, psolver=psolver, u=u, temp=None, t=stepper.t + method.c[-1] * Δt, n=n + 1)
-    # host-driven stage loop (time-dependent boundary data)
+    # host-driven stage loop (time-dependent boundary data, body force, closure model, temperature equation)
     A, c = method.A, method.c
     ns = len(method.b)
+    m = setup.closure_model
     if not hasattr(cache, "_host"):
         cache._host = dict(ustart=vectorfield(setup), ku=[vectorfield(setup) for _ in range(ns)], p=scalarfield(setup))
-    ustart, ku, p = cache._host["ustart"], cache._host["ku"], cache._host["p"]
+        if setup.temperature is not None:  # time_stepper_caches.jl:40-47
+            cache._host.update(tempstart=scalarfield(setup), ktemp=[scalarfield(setup) for _ in range(ns)], diff=vectorfield(setup))
+    H = cache._host
+    ustart, ku, p = H["ustart"], H["ku"], H["p"]
     tstart = t
     combine_(ustart, u, [], [], setup)
+    if temp is not None:
+        combine_(H["tempstart"], temp, [], [], setup, vector=False)
     for i in range(ns):
         apply_bc_u_(u, t, setup)
-        momentum_(ku[i], u, None, t, setup)
+        if temp is not None:
+            apply_bc_temp_(temp, t, setup)
+        momentum_(ku[i], u, temp, t, setup)
+        if temp is not None:
+            _temp_rhs_(H["ktemp"][i], H["diff"], u, temp, setup)
+        if m is not None:
+            ku[i].add_(m(u, θ))
         t = tstart + c[i] * Δt
         combine_(u, ustart, [Δt * A[i, j] for j in range(i + 1)], [ku[j] for j in range(i + 1)], setup)
+        if temp is not None:
+            combine_(temp, H["tempstart"], [Δt * A[i, j] for j in range(i + 1)], [H["ktemp"][j] for j in range(i + 1)], setup, vector=False)
         apply_bc_u_(u, t, setup)
         project_(u, setup, psolver, p)
     apply_bc_u_(u, t, setup)
-    return create_stepper(method, setup=setup, psolver=psolver, u=u, temp=None, t=t, n=n + 1)
+    if temp is not None:
+        apply_bc_temp_(temp, t, setup)
+    return create_stepper(method, setup=setup, psolver=psolver, u=u, temp=temp, t=t, n=n + 1)
 
 
 def timestep(method, stepper, Δt, *, θ=None):
     """Out-of-place twin (step_explicit_runge_kutta.jl:61-120): same result on a copy of `u`."""
     cache = ode_method_cache(method, stepper.setup, stepper.psolver)
-    s2 = create_stepper(method, setup=stepper.setup, psolver=stepper.psolver, u=copyfield(stepper.u), t=stepper.t, n=stepper.n)
+    s2 = create_stepper(method, setup=stepper.setup, psolver=stepper.psolver, u=copyfield(stepper.u),
+                        temp=None if stepper.temp is None else copyfield(stepper.temp), t=stepper.t, n=stepper.n)
     return timestep_(method, s2, Δt, θ=θ, cache=cache)

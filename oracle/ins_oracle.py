@@ -210,6 +210,7 @@ class Setup:
     bodyforce: object = None
     closure_model: object = None
     temperature: object = None
+    issteadybodyforce: bool = True
 
 
 def make_setup(x, boundary_conditions=None, Re=1000.0) -> Setup:
@@ -1086,3 +1087,486 @@ def tgv3d_ufunc(a, x, y, z):
 
 
 tau_ = 2 * np.pi
+
+
+# ======================================================================================
+# field diagnostics, temperature equation, body force, Smagorinsky closure.
+# The reference's tests hold no known-answer values for these operators (test/operators.jl checks them through
+# ChainRules only), so beyond the analytic checks in tests/test_oracle_fields.py their parity is "unpinned": the
+# restatement below follows the cited lines term by term.
+# ======================================================================================
+def _full_ranges(N, trim=0):
+    return tuple((0, n - trim) for n in N)
+
+
+def vorticity_(w, u, setup):  # operators.jl:985-1020   (ndrange = N .- 1)
+    g = setup.grid
+    D = g.D
+    R = _full_ranges(g.N, 1)
+
+    def d(comp, axis):  # (u[I+e(axis), comp] - u[I, comp]) / Δu[axis][I[axis]]
+        return (u[_sl(R, _e(D, axis)) + (comp,)] - u[_sl(R) + (comp,)]) / _vec(g.dxu[axis], R[axis], axis, D)
+
+    if D == 2:
+        w[_sl(R)] = d(1, 0) - d(0, 1)
+    else:
+        for a, ap, am in ((0, 1, 2), (1, 2, 0), (2, 0, 1)):
+            w[_sl(R) + (a,)] = d(am, ap) - d(ap, am)
+    return w
+
+
+def vorticity(u, setup):
+    return vorticity_(scalarfield(setup) if setup.grid.D == 2 else vectorfield(setup), u, setup)
+
+
+def interpolate_u_p_(up, u, setup):  # operators.jl:1311-1326
+    g = setup.grid
+    D, R = g.D, g.Ip
+    for a in range(D):
+        up[_sl(R) + (a,)] = (u[_sl(R, _e(D, a, -1)) + (a,)] + u[_sl(R) + (a,)]) / 2
+    return up
+
+
+def interpolate_u_p(u, setup):
+    return interpolate_u_p_(vectorfield(setup), u, setup)
+
+
+def interpolate_w_p_(wp, w, setup):  # operators.jl:1336-1370  (interpolate_ω_p!)
+    g = setup.grid
+    D, R = g.D, g.Ip
+    if D == 2:
+        wp[_sl(R)] = (w[_sl(R, (-1, -1))] + w[_sl(R)]) / 2
+    else:
+        for a in range(3):
+            ap, am = (a + 1) % 3, (a + 2) % 3
+            sh = _add(_e(D, ap, -1), _e(D, am, -1))
+            wp[_sl(R) + (a,)] = (w[_sl(R, sh) + (a,)] + w[_sl(R) + (a,)]) / 2
+    return wp
+
+
+def interpolate_w_p(w, setup):
+    return interpolate_w_p_(scalarfield(setup) if setup.grid.D == 2 else vectorfield(setup), w, setup)
+
+
+def Dfield_(d, G, p, setup, eps=EPS):  # operators.jl:1385-1422
+    g = setup.grid
+    D, R = g.D, g.Ip
+    pressuregradient_(G, p, setup)
+    gg = 0.0
+    lap = 0.0
+    for a in range(D):
+        Gm, Gc = G[_sl(R, _e(D, a, -1)) + (a,)], G[_sl(R) + (a,)]
+        gg = gg + (Gm + Gc) ** 2
+        lap = lap + (Gc - Gm) / _vec(g.dx[a], R[a], a, D)
+    lap = np.where(lap > 0, np.maximum(lap, eps), np.minimum(lap, -eps))
+    d[_sl(R)] = np.sqrt(gg) / 2 / lap
+    return d
+
+
+def Dfield(p, setup, eps=EPS):
+    return Dfield_(scalarfield(setup), vectorfield(setup), p, setup, eps)
+
+
+def Qfield_(Q, u, setup):  # operators.jl:1440-1460
+    g = setup.grid
+    D, R = g.D, g.Ip
+    q = 0.0
+    for a in range(D):
+        for b in range(D):
+            dab = (u[_sl(R) + (a,)] - u[_sl(R, _e(D, b, -1)) + (a,)]) / _vec(g.dx[b], R[b], b, D)
+            dba = (u[_sl(R) + (b,)] - u[_sl(R, _e(D, a, -1)) + (b,)]) / _vec(g.dx[a], R[a], a, D)
+            q = q - dab * dba / 2
+    Q[_sl(R)] = q
+    return Q
+
+
+def Qfield(u, setup):
+    return Qfield_(scalarfield(setup), u, setup)
+
+
+def gradu(u, setup):
+    """∇(u, I, Δ, Δu) at every pressure point (operators.jl:1023-1034, 1069-1085): array Ip-shape + (D, D), [..., a, b] = ∂u^a/∂x^b."""
+    g = setup.grid
+    D, R = g.D, g.Ip
+    out = np.zeros(tuple(hi - lo for lo, hi in R) + (D, D))
+    for a in range(D):
+        for b in range(D):
+            if a == b:
+                v = (u[_sl(R) + (a,)] - u[_sl(R, _e(D, b, -1)) + (a,)]) / _vec(g.dx[b], R[b], b, D)
+            else:
+                ea, eb = _e(D, a, -1), _e(D, b)
+                emb = _e(D, b, -1)
+                hb = _vec(g.dxu[b], R[b], b, D)
+                hbm = _vec(g.dxu[b], R[b], b, D, -1)
+                v = (
+                    (u[_sl(R, eb) + (a,)] - u[_sl(R) + (a,)]) / hb
+                    + (u[_sl(R, _add(ea, eb)) + (a,)] - u[_sl(R, ea) + (a,)]) / hb
+                    + (u[_sl(R) + (a,)] - u[_sl(R, emb) + (a,)]) / hbm
+                    + (u[_sl(R, ea) + (a,)] - u[_sl(R, _add(ea, emb)) + (a,)]) / hbm
+                ) / 4
+            out[..., a, b] = v
+    return out
+
+
+def dissipation_from_strain_(eps_out, u, setup):  # operators.jl:836-854
+    g = setup.grid
+    G = gradu(u, setup)
+    S = (G + np.swapaxes(G, -1, -2)) / 2
+    eps_out[_sl(g.Ip)] = 2 * (1.0 / setup.Re) * np.sum(S * S, axis=(-1, -2))
+    return eps_out
+
+
+def dissipation_from_strain(u, setup):
+    return dissipation_from_strain_(scalarfield(setup), u, setup)
+
+
+def eig2field_(lam, u, setup):  # operators.jl:1472-1492   (3-D only)
+    g = setup.grid
+    assert g.D == 3
+    G = gradu(u, setup)
+    S = (G + np.swapaxes(G, -1, -2)) / 2
+    Rm = (G - np.swapaxes(G, -1, -2)) / 2
+    M = S @ S + Rm @ Rm
+    lam[_sl(g.Ip)] = np.linalg.eigvalsh(M)[..., 1]
+    return lam
+
+
+def eig2field(u, setup):
+    return eig2field_(scalarfield(setup), u, setup)
+
+
+# ---- temperature equation --------------------------------------------------------------------------------------------
+@dataclass
+class Temperature:  # setup.jl:48-87 (gdir 0-based here)
+    a1: float
+    a2: float
+    a3: float
+    a4: float
+    gamma: float
+    dodissipation: bool
+    boundary_conditions: tuple
+    gdir: int
+
+
+def temperature_equation(Pr, Ra, Ge, boundary_conditions, dodissipation=True, gdir=1, nondim_type=1):
+    if nondim_type == 1:
+        a1, a2, a3, a4 = math.sqrt(Pr / Ra), 1.0, Ge * math.sqrt(Pr / Ra), 1 / math.sqrt(Pr * Ra)
+    elif nondim_type == 2:
+        a1, a2, a3, a4 = Pr, Pr * Ra, Ge / Ra, 1.0
+    elif nondim_type == 3:
+        a1, a2, a3, a4 = math.sqrt(Pr * Ge / Ra), Ge, math.sqrt(Pr * Ge / Ra), math.sqrt(Ge / (Pr * Ra))
+    else:
+        raise ValueError(nondim_type)
+    return Temperature(a1, a2, a3, a4, a1 / a3, bool(dodissipation), tuple(boundary_conditions), int(gdir))
+
+
+def apply_bc_temp_(temp, t, setup):  # boundary_conditions.jl:236-246, 338-339, 391-405, 466-467, 512-513
+    g = setup.grid
+    D, N = g.D, g.N
+    bcs = setup.temperature.boundary_conditions
+    for be in range(D):
+        for isright in (False, True):
+            bc = bcs[be][int(isright)]
+            lo, hi = g.Ip[be]
+            i = hi if isright else lo - 1
+            if isinstance(bc, PeriodicBC):
+                if isright:
+                    continue
+                temp[_plane(N, be, lo - 1)] = temp[_plane(N, be, hi - 1)]
+                temp[_plane(N, be, hi)] = temp[_plane(N, be, lo)]
+            elif isinstance(bc, DirichletBC):
+                # `boundary(β, N, Ip, isright)` (boundary_conditions.jl:97-103) spans 1:N in the other directions
+                if bc.u is None:
+                    val = 0.0
+                elif callable(bc.u):
+                    xs = []
+                    for b in range(D):
+                        shape = [1] * D
+                        if b == be:
+                            xs.append(g.xp[b][i : i + 1].reshape(shape))
+                        else:
+                            shape[b] = N[b]
+                            xs.append(g.xp[b].reshape(shape))
+                    val = bc.u(*xs, t)
+                else:
+                    val = float(bc.u)
+                temp[_plane(N, be, i)] = val
+            elif isinstance(bc, (SymmetricBC, PressureBC)):
+                j = i - 1 if isright else i + 1
+                temp[_plane(N, be, i)] = temp[_plane(N, be, j)]
+            else:
+                raise TypeError(bc)
+    return temp
+
+
+def apply_bc_temp(temp, t, setup):
+    return apply_bc_temp_(temp.copy(order="F"), t, setup)
+
+
+def temperaturefield(setup, tempfunc, t=0.0):  # initializers.jl:49-57
+    g = setup.grid
+    D = g.D
+    xs = []
+    for b in range(D):
+        shape = [1] * D
+        shape[b] = g.Ip[b][1] - g.Ip[b][0]
+        xs.append(g.xp[b][g.Ip[b][0] : g.Ip[b][1]].reshape(shape))
+    temp = scalarfield(setup)
+    temp[_sl(g.Ip)] = np.broadcast_to(tempfunc(*xs), tuple(hi - lo for lo, hi in g.Ip))
+    return apply_bc_temp_(temp, t, setup)
+
+
+def _avg(phi, setup, R, a, shift=None):  # operators.jl:59-62 at I + shift, I over R
+    g = setup.grid
+    D = g.D
+    shift = shift or (0,) * D
+    s = shift[a]
+    d0 = _vec(g.dx[a], R[a], a, D, s)
+    d1 = _vec(g.dx[a], R[a], a, D, s + 1)
+    return (d1 * phi[_sl(R, shift)] + d0 * phi[_sl(R, _add(shift, _e(D, a)))]) / (d0 + d1)
+
+
+def convection_diffusion_temp_(c, u, temp, setup):  # operators.jl:712-737   (adds to c)
+    g = setup.grid
+    D, R = g.D, g.Ip
+    a4 = setup.temperature.a4
+    acc = 0.0
+    for b in range(D):
+        em = _e(D, b, -1)
+        dT1 = (temp[_sl(R)] - temp[_sl(R, em)]) / _vec(g.dxu[b], R[b], b, D, -1)
+        dT2 = (temp[_sl(R, _e(D, b))] - temp[_sl(R)]) / _vec(g.dxu[b], R[b], b, D)
+        uT1 = u[_sl(R, em) + (b,)] * _avg(temp, setup, R, b, em)
+        uT2 = u[_sl(R) + (b,)] * _avg(temp, setup, R, b)
+        acc = acc + (-(uT2 - uT1) + a4 * (dT2 - dT1)) / _vec(g.dx[b], R[b], b, D)
+    c[_sl(R)] += acc
+    return c
+
+
+def convection_diffusion_temp(u, temp, setup):
+    return convection_diffusion_temp_(scalarfield(setup), u, temp, setup)
+
+
+def dissipation_(diss, diff, u, setup):  # operators.jl:791-814   (adds to diss; diff is scratch)
+    g = setup.grid
+    D, R = g.D, g.Ip
+    T = setup.temperature
+    diff[...] = 0.0
+    diffusion_(diff, u, setup)
+    acc = 0.0
+    for b in range(D):
+        em = _e(D, b, -1)
+        acc = acc + setup.Re * T.a1 / T.gamma * (u[_sl(R, em) + (b,)] * diff[_sl(R, em) + (b,)] + u[_sl(R) + (b,)] * diff[_sl(R) + (b,)]) / 2
+    diss[_sl(R)] += acc
+    return diss
+
+
+def dissipation(u, setup):
+    return dissipation_(scalarfield(setup), vectorfield(setup), u, setup)
+
+
+def gravity_(F, temp, setup):  # operators.jl:914-931   (adds to F; the whole Iu[gdir] range)
+    g = setup.grid
+    T = setup.temperature
+    R = g.Iu[T.gdir]
+    F[_sl(R) + (T.gdir,)] += T.a2 * _avg(temp, setup, R, T.gdir)
+    return F
+
+
+def gravity(temp, setup):
+    return gravity_(vectorfield(setup), temp, setup)
+
+
+# ---- body force -------------------------------------------------------------------------------------------------------
+def bodyforce_field(setup, f, t):  # operators.jl:878-897: f(α, x..., t) on the FULL padded coordinate vectors xu[α]
+    g = setup.grid
+    D = g.D
+    F = vectorfield(setup)
+    for a in range(D):
+        xs = []
+        for b in range(D):
+            shape = [1] * D
+            shape[b] = g.N[b]
+            xs.append(g.xu[a][b].reshape(shape))
+        F[..., a] = np.broadcast_to(f(a, *xs, t), g.N)
+    return F
+
+
+def applybodyforce_(F, u, t, setup):
+    if setup.issteadybodyforce:
+        F += setup.bodyforce
+    else:
+        F += bodyforce_field(setup, setup.bodyforce, t)
+    return F
+
+
+def make_setup_ext(x, boundary_conditions=None, Re=None, bodyforce=None, issteadybodyforce=True, closure_model=None, temperature=None):
+    """Setup(...) with the optional pieces (setup.jl:2-46): Re defaults to 1/α1 with a temperature equation; a steady body force is
+    evaluated once at t = 0."""
+    if Re is None:
+        Re = 1000.0 if temperature is None else 1.0 / temperature.a1
+    s = make_setup(x, boundary_conditions, Re)
+    s.temperature = temperature
+    s.closure_model = closure_model
+    s.bodyforce = bodyforce
+    s.issteadybodyforce = False
+    if bodyforce is not None and issteadybodyforce:
+        s.bodyforce = bodyforce_field(s, bodyforce, 0.0)
+        s.issteadybodyforce = True
+    return s
+
+
+def momentum_ext_(F, u, temp, t, setup):  # operators.jl:967-976
+    F[...] = 0.0
+    convectiondiffusion_(F, u, setup)
+    if setup.bodyforce is not None:
+        applybodyforce_(F, u, t, setup)
+    if temp is not None:
+        gravity_(F, temp, setup)
+    return F
+
+
+# ---- Smagorinsky closure ----------------------------------------------------------------------------------------------
+def smagtensor_(sig, u, theta, setup):  # operators.jl:1135-1150; sig: N + (D, D)
+    g = setup.grid
+    D, R = g.D, g.Ip
+    G = gradu(u, setup)
+    S = (G + np.swapaxes(G, -1, -2)) / 2
+    d2 = 0.0
+    for a in range(D):
+        d2 = d2 + _vec(g.dx[a], R[a], a, D) ** 2
+    d = np.sqrt(d2)
+    eddy = theta**2 * d**2 * np.sqrt(2 * np.sum(S * S, axis=(-1, -2)))
+    sig[_sl(R)] = 2 * eddy[..., None, None] * S
+    return sig
+
+
+def divoftensor_(s, sig, setup):  # operators.jl:1203-1236
+    g = setup.grid
+    D = g.D
+    for a in range(D):
+        R = g.Iu[a]
+        acc = 0.0
+        for b in range(D):
+            h = _vec(g.dxu[b] if a == b else g.dx[b], R[b], b, D)
+            ea, eb, emb = _e(D, a), _e(D, b), _e(D, b, -1)
+            if a == b:
+                s2 = sig[_sl(R, eb) + (a, b)]
+                s1 = sig[_sl(R) + (a, b)]
+            else:
+                s2 = (sig[_sl(R) + (a, b)] + sig[_sl(R, eb) + (a, b)] + sig[_sl(R, _add(ea, eb)) + (a, b)] + sig[_sl(R, ea) + (a, b)]) / 4
+                s1 = (sig[_sl(R, emb) + (a, b)] + sig[_sl(R) + (a, b)] + sig[_sl(R, _add(ea, emb)) + (a, b)] + sig[_sl(R, ea) + (a, b)]) / 4
+            acc = acc + (s2 - s1) / h
+        s[_sl(R) + (a,)] = acc
+    return s
+
+
+def smagorinsky_closure(setup):  # operators.jl:1289-1300
+    g = setup.grid
+    D = g.D
+    sig = np.zeros(g.N + (D, D), order="F")
+    s = vectorfield(setup)
+
+    def closure(u, theta):
+        smagtensor_(sig, u, theta, setup)
+        for i in range(D):
+            for j in range(D):
+                comp = np.asfortranarray(sig[..., i, j])
+                apply_bc_p_(comp, 0.0, setup)
+                sig[..., i, j] = comp
+        return divoftensor_(s, sig, setup)
+
+    return closure
+
+
+# ---- steppers with temperature / closure / body force -----------------------------------------------------------------
+def ode_method_cache_ext(method, setup):  # time_stepper_caches.jl:34-49
+    ns = len(method.b)
+    c = ode_method_cache(method, setup)
+    if setup.temperature is not None:
+        c.update(tempstart=scalarfield(setup), ktemp=[scalarfield(setup) for _ in range(ns)], diff=vectorfield(setup))
+    return c
+
+
+def timestep_ext_(method, stepper, dt, cache, theta=None):
+    """step_explicit_runge_kutta.jl:4-59 with temperature, closure model and body force."""
+    setup, psolver, u, temp, t, n = (stepper[k] for k in ("setup", "psolver", "u", "temp", "t", "n"))
+    A, b, c = method.A, method.b, method.c
+    ustart, ku, p = cache["ustart"], cache["ku"], cache["p"]
+    m = setup.closure_model
+    T = setup.temperature
+    nstage = len(b)
+    tstart = t
+    ustart[...] = u
+    if temp is not None:
+        cache["tempstart"][...] = temp
+    for i in range(nstage):
+        apply_bc_u_(u, t, setup)
+        if temp is not None:
+            apply_bc_temp_(temp, t, setup)
+        momentum_ext_(ku[i], u, temp, t, setup)
+        if temp is not None:
+            kt = cache["ktemp"][i]
+            kt[...] = 0.0
+            convection_diffusion_temp_(kt, u, temp, setup)
+            if T.dodissipation:
+                dissipation_(kt, cache["diff"], u, setup)
+        if m is not None:
+            ku[i] += m(u, theta)
+        t = tstart + c[i] * dt
+        u[...] = ustart
+        for j in range(i + 1):
+            u += dt * A[i, j] * ku[j]
+        if temp is not None:
+            temp[...] = cache["tempstart"]
+            for j in range(i + 1):
+                temp += dt * A[i, j] * cache["ktemp"][j]
+        apply_bc_u_(u, t, setup)
+        project_(u, setup, psolver, p)
+    apply_bc_u_(u, t, setup)
+    if temp is not None:
+        apply_bc_temp_(temp, t, setup)
+    return dict(setup=setup, psolver=psolver, u=u, temp=temp, t=t, n=n + 1)
+
+
+def timestep_lmwray3_ext_(stepper, dt, cache, theta=None):
+    """step_lmwray3.jl:4-107 with temperature, closure model and body force."""
+    setup, psolver, u, temp, n = (stepper[k] for k in ("setup", "psolver", "u", "temp", "n"))
+    a, b, c = (8 / 15, 5 / 12, 3 / 4), (1 / 4, 0.0), (0.0, 8 / 15, 2 / 3)
+    ustart, ku, p = cache["ustart"], cache["ku"][0], cache["p"]
+    m = setup.closure_model
+    T = setup.temperature
+    tstart = stepper["t"]
+    ustart[...] = u
+    if temp is not None:
+        tempstart, ktemp = cache["tempstart"], cache["ktemp"][0]
+        tempstart[...] = temp
+    t = tstart
+    for i in range(3):
+        t = tstart + c[i] * dt
+        apply_bc_u_(u, t, setup)
+        if temp is not None:
+            apply_bc_temp_(temp, t, setup)
+        momentum_ext_(ku, u, temp, t, setup)
+        if m is not None:
+            ku += m(u, theta)
+        if temp is not None:
+            ktemp[...] = 0.0
+            convection_diffusion_temp_(ktemp, u, temp, setup)
+            if T.dodissipation:
+                dissipation_(ktemp, cache["diff"], u, setup)
+        u[...] = ustart
+        u += a[i] * dt * ku
+        if temp is not None:
+            temp[...] = tempstart
+            temp += a[i] * dt * ktemp
+        apply_bc_u_(u, t, setup)
+        project_(u, setup, psolver, p)
+        if i != 2:
+            ustart += b[i] * dt * ku
+            if temp is not None:
+                tempstart += b[i] * dt * ktemp
+    t = tstart + dt
+    apply_bc_u_(u, t, setup)
+    if temp is not None:
+        apply_bc_temp_(temp, t, setup)
+    return dict(setup=setup, psolver=psolver, u=u, temp=temp, t=t, n=n + 1)

@@ -1,0 +1,204 @@
+"""GPU parity of the step-adjacent operators — field diagnostics, temperature equation, body force,
+Smagorinsky closure and the host-driven steppers that use them — against the CPU oracle on the same seeded inputs.
+Tolerances as in test_gpu_parity.py: single operator <= 1e-12 relative max-norm, multi-step <= 1e-10 relative L2."""
+import numpy as np
+import pytest
+
+from tests import fixtures as fx
+from tests.test_gpu_parity import GEOMS, mirror, rell2, relmax
+
+pytestmark = pytest.mark.gpu
+
+OP_TOL = 1e-12
+STEP_TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def ins():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ins_amd
+
+    return ins_amd
+
+
+def temp_bcs(o, so, kind):
+    """Temperature BCs compatible with the velocity BCs' periodicity."""
+    out = []
+    for be, (a, b) in enumerate(so.boundary_conditions):
+        if isinstance(a, o.PeriodicBC):
+            out.append((o.PeriodicBC(), o.PeriodicBC()))
+        elif kind == "dirichlet":
+            out.append((o.DirichletBC(1.0), o.DirichletBC(0.25)))
+        elif kind == "function":
+            out.append((o.DirichletBC(lambda *xt: 1.0 + 0.1 * xt[(be + 1) % len(so.boundary_conditions)] + 0.5 * xt[-1]), o.SymmetricBC()))
+        else:
+            out.append((o.SymmetricBC(), o.PressureBC()))
+    return tuple(out)
+
+
+def mirror_temp(ins, o, T):
+    cls = {"PeriodicBC": ins.PeriodicBC, "SymmetricBC": ins.SymmetricBC, "PressureBC": ins.PressureBC}
+    bcs = tuple(tuple(ins.DirichletBC(b.u) if isinstance(b, o.DirichletBC) else cls[type(b).__name__]() for b in side) for side in T.boundary_conditions)
+    P = ins.temperature_equation(Pr=0.71, Ra=1e6, Ge=0.1, boundary_conditions=bcs, dodissipation=T.dodissipation, gdir=T.gdir)
+    assert abs(P.α1 - T.a1) < 1e-16 and abs(P.α4 - T.a4) < 1e-16 and abs(P.γ - T.gamma) < 1e-12
+    return P
+
+
+def with_temperature(ins, o, so, kind, **kw):
+    T = o.temperature_equation(Pr=0.71, Ra=1e6, Ge=0.1, boundary_conditions=temp_bcs(o, so, kind), **kw)
+    so.temperature = T
+    sp = mirror(ins, so, o)
+    sp.temperature = mirror_temp(ins, o, T)
+    return sp
+
+
+@pytest.mark.parametrize("geom", list(GEOMS))
+def test_field_diagnostics_match_oracle(ins, oracle, geom):
+    o = oracle
+    so = GEOMS[geom](o)
+    sp = mirror(ins, so, o)
+    g = so.grid
+    D = g.D
+    u_h = o.apply_bc_u(fx.randn_field(g.N + (D,), 1), 0.0, so)
+    p_h = o.apply_bc_p(fx.randn_field(g.N, 2), 0.0, so)
+    u_d, p_d = ins.from_numpy(sp, u_h), ins.from_numpy(sp, p_h)
+    w_h = o.vorticity(u_h, so)
+    assert relmax(ins.to_numpy(ins.vorticity(u_d, sp)), w_h) < OP_TOL
+    assert relmax(ins.to_numpy(ins.interpolate_u_p(u_d, sp)), o.interpolate_u_p(u_h, so)) < OP_TOL
+    assert relmax(ins.to_numpy(ins.interpolate_ω_p(ins.from_numpy(sp, w_h), sp)), o.interpolate_w_p(w_h, so)) < OP_TOL
+    assert relmax(ins.to_numpy(ins.Qfield(u_d, sp)), o.Qfield(u_h, so)) < OP_TOL
+    assert relmax(ins.to_numpy(ins.dissipation_from_strain(u_d, sp)), o.dissipation_from_strain(u_h, so)) < OP_TOL
+    d_h = o.Dfield(p_h, so)
+    d_d = ins.to_numpy(ins.Dfield(p_d, sp))
+    # D = |∇p| / 2 / lap blows up where the discrete Laplacian crosses zero: compare where it is well conditioned
+    ok = np.abs(d_h) < 1e3 * np.median(np.abs(d_h[d_h != 0]))
+    assert np.max(np.abs(d_d - d_h)[ok]) / np.max(np.abs(d_h[ok])) < 1e-10
+    if D == 3:
+        lam_h = o.eig2field(u_h, so)
+        assert relmax(ins.to_numpy(ins.eig2field(u_d, sp)), lam_h) < 1e-11  # closed-form eigenvalues vs LAPACK
+    # in-place versions leave everything outside their write range untouched
+    junk = fx.randn_field(g.N + (D,), 9)
+    out = ins.from_numpy(sp, junk)
+    ins.interpolate_u_p_(out, u_d, sp)
+    ref = o.interpolate_u_p_(junk.copy(order="F"), u_h, so)
+    assert relmax(ins.to_numpy(out), ref) < OP_TOL
+
+
+@pytest.mark.parametrize("geom,kind", [("periodic2d", "any"), ("periodic3d", "any"), ("dirichlet2d", "dirichlet"), ("dirichlet3d", "function"),
+                                       ("mixed3d", "dirichlet"), ("mixed3d", "symmetric"), ("dirichlet2d", "function")])
+def test_temperature_operators_match_oracle(ins, oracle, geom, kind):
+    o = oracle
+    so = GEOMS[geom](o)
+    sp = with_temperature(ins, o, so, kind, gdir=so.grid.D - 1 if geom == "mixed3d" else 1)
+    g = so.grid
+    D = g.D
+    u_h = o.apply_bc_u(fx.randn_field(g.N + (D,), 1), 0.0, so)
+    t_raw = fx.randn_field(g.N, 4)
+    t_h = o.apply_bc_temp(t_raw, 0.3, so)
+    u_d = ins.from_numpy(sp, u_h)
+    t_d = ins.apply_bc_temp(ins.from_numpy(sp, t_raw), 0.3, sp)
+    assert np.array_equal(ins.to_numpy(t_d), t_h)  # ghost fill is copies and constants: bit-exact
+    c0 = fx.randn_field(g.N, 5)
+    c_d = ins.convection_diffusion_temp_(ins.from_numpy(sp, c0), u_d, t_d, sp)
+    assert relmax(ins.to_numpy(c_d), o.convection_diffusion_temp_(c0.copy(order="F"), u_h, t_h, so)) < OP_TOL
+    diff_d = ins.vectorfield(sp)
+    d_d = ins.dissipation_(ins.from_numpy(sp, c0), diff_d, u_d, sp)
+    diff_h = o.vectorfield(so)
+    d_h = o.dissipation_(c0.copy(order="F"), diff_h, u_h, so)
+    # Re α1/γ · u · diffusion(u) on random data is a sum of large terms of both signs: tolerance relative to their size
+    assert relmax(ins.to_numpy(d_d), d_h) < 1e-11
+    assert relmax(ins.to_numpy(diff_d), diff_h) < OP_TOL
+    F0 = fx.randn_field(g.N + (D,), 6)
+    F_d = ins.gravity_(ins.from_numpy(sp, F0), t_d, sp)
+    assert relmax(ins.to_numpy(F_d), o.gravity_(F0.copy(order="F"), t_h, so)) < OP_TOL
+    # momentum! with the gravity term
+    assert relmax(ins.to_numpy(ins.momentum(u_d, t_d, 0.0, sp)), o.momentum_ext_(o.vectorfield(so), u_h, t_h, 0.0, so)) < OP_TOL
+    # temperaturefield
+    f = (lambda x, y: 1 + 0.2 * x - 0.1 * y * y) if D == 2 else (lambda x, y, z: 1 + 0.2 * x - 0.1 * y * y + 0.3 * z)
+    assert np.array_equal(ins.to_numpy(ins.temperaturefield(sp, f, 0.3)), o.temperaturefield(so, f, 0.3))
+
+
+@pytest.mark.parametrize("geom", ["periodic2d", "periodic3d", "dirichlet3d", "mixed3d"])
+def test_smagorinsky_closure_matches_oracle(ins, oracle, geom):
+    o = oracle
+    so = GEOMS[geom](o)
+    sp = mirror(ins, so, o)
+    g = so.grid
+    u_h = o.apply_bc_u(fx.randn_field(g.N + (g.D,), 1), 0.0, so)
+    s_h = o.smagorinsky_closure(so)(u_h, 0.17)
+    s_d = ins.smagorinsky_closure(sp)(ins.from_numpy(sp, u_h), 0.17)
+    assert relmax(ins.to_numpy(s_d), s_h) < 1e-11  # |S| enters through a square root of a sum of squares
+
+
+def _bodyforce(a, x, y, *zt):
+    t = zt[-1]
+    return (a == 0) * np.sin(2 * np.pi * y) * (1 + t) + (a == 1) * 0.3 * np.cos(2 * np.pi * x) + 0 * sum(zt[:-1], 0.0)
+
+
+@pytest.mark.parametrize("geom,steady", [("periodic2d", True), ("periodic3d", False), ("dirichlet3d", True)])
+def test_body_force_matches_oracle(ins, oracle, geom, steady):
+    o = oracle
+    so0 = GEOMS[geom](o)
+    lo = [2 if isinstance(so0.boundary_conditions[a][0], o.PressureBC) else 1 for a in range(so0.grid.D)]
+    xin = [so0.grid.x[a][lo[a]:-1] for a in range(so0.grid.D)]
+    so = o.make_setup_ext(xin, so0.boundary_conditions, Re=so0.Re, bodyforce=_bodyforce, issteadybodyforce=steady)
+    base = mirror(ins, so0, o)
+    sp = ins.Setup(x=xin, boundary_conditions=base.boundary_conditions, Re=so0.Re, bodyforce=_bodyforce, issteadybodyforce=steady)
+    g = so.grid
+    u_h = o.apply_bc_u(fx.randn_field(g.N + (g.D,), 1), 0.0, so)
+    F_h = o.momentum_ext_(o.vectorfield(so), u_h, None, 0.7, so)
+    F_d = ins.momentum(ins.from_numpy(sp, u_h), None, 0.7, sp)
+    assert relmax(ins.to_numpy(F_d), F_h) < OP_TOL
+    assert np.array_equal(ins.to_numpy(ins.applybodyforce(None, 0.7, sp)), so.bodyforce if steady else o.bodyforce_field(so, _bodyforce, 0.7))
+
+
+def _run_steps(ins, o, so, sp, method_name, nsteps, dt, theta=None, temp0=None):
+    ps_h = o.default_psolver(so)
+    ps_d = ins.default_psolver(sp)
+    g = so.grid
+    u0 = o.apply_bc_u(0.1 * fx.randn_field(g.N + (g.D,), 11), 0.0, so)
+    u0 = o.project(u0, so, ps_h)
+    o.apply_bc_u_(u0, 0.0, so)
+    th = None if temp0 is None else o.apply_bc_temp(temp0, 0.0, so)
+    st = dict(setup=so, psolver=ps_h, u=u0.copy(order="F"), temp=None if th is None else th.copy(order="F"), t=0.0, n=0)
+    if method_name == "LMWray3":
+        cache = o.ode_method_cache_ext(o.Wray3(), so)
+        for _ in range(nsteps):
+            st = o.timestep_lmwray3_ext_(st, dt, cache, theta)
+        method = ins.LMWray3()
+    else:
+        cache = o.ode_method_cache_ext(o.RK44(), so)
+        for _ in range(nsteps):
+            st = o.timestep_ext_(o.RK44(), st, dt, cache, theta)
+        method = ins.RKMethods.RK44()
+    (u_d, t_d, t_end), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, nsteps * dt), ustart=ins.from_numpy(sp, u0),
+                                              tempstart=None if th is None else ins.from_numpy(sp, th), method=method, psolver=ps_d, Δt=dt, θ=theta)
+    assert t_end == pytest.approx(nsteps * dt)
+    return st, ins.to_numpy(u_d), None if t_d is None else ins.to_numpy(t_d)
+
+
+@pytest.mark.parametrize("geom,kind,method", [("periodic2d", "any", "RK44"), ("periodic3d", "any", "LMWray3"), ("dirichlet2d", "dirichlet", "RK44"),
+                                              ("mixed3d", "symmetric", "RK44"), ("dirichlet3d", "function", "LMWray3")])
+def test_steppers_with_temperature_match_oracle(ins, oracle, geom, kind, method):
+    """Rayleigh-Bénard-type runs (examples/RayleighBenard*.jl shape): momentum + gravity, temperature convection-diffusion + dissipation."""
+    o = oracle
+    so = GEOMS[geom](o)
+    sp = with_temperature(ins, o, so, kind, gdir=so.grid.D - 1 if geom == "mixed3d" else 1)
+    so.Re = sp.Re = 1.0 / so.temperature.a1  # setup.jl:12
+    temp0 = 0.5 + 0.1 * fx.randn_field(so.grid.N, 4)
+    st, u, temp = _run_steps(ins, o, so, sp, method, 3, 2e-3, temp0=temp0)
+    assert rell2(u, st["u"]) < STEP_TOL and rell2(temp, st["temp"]) < STEP_TOL
+
+
+@pytest.mark.parametrize("geom,method", [("periodic3d", "RK44"), ("dirichlet2d", "LMWray3")])
+def test_steppers_with_closure_model_match_oracle(ins, oracle, geom, method):
+    o = oracle
+    so = GEOMS[geom](o)
+    sp = mirror(ins, so, o)
+    so.closure_model = o.smagorinsky_closure(so)
+    sp.closure_model = ins.smagorinsky_closure(sp)
+    st, u, _ = _run_steps(ins, o, so, sp, method, 3, 2e-3, theta=0.17)
+    assert rell2(u, st["u"]) < STEP_TOL
