@@ -211,6 +211,15 @@ int ins_divoftensor_f64(const ins_grid_t* grid, const double* sigma, double* s, 
 int ins_combine_scalar_f64(const ins_grid_t* grid, const double* base, double* out, int nterms, const double* coefs,
                            const double* const* ks, void* stream);
 
+/* observespectrum(state; setup, npoint, a)   processors.jl:303-332.  The index sets of spectral_stuff (utils.jl:49-108) are built
+ * on the host: bin i sums the modes inds[offsets[i] .. offsets[i+1]), each a 0-based column-major position in the K = Np .÷ 2
+ * array of retained non-negative wavenumbers.  ins_spectrum_f64 writes ehat[0 .. nbin) (DEVICE): per component one ghost strip,
+ * one rocFFT real-to-complex transform and one shell-sum kernel; nothing leaves the device. */
+typedef struct ins_spectrum ins_spectrum_t;
+int ins_spectrum_create(const ins_grid_t* grid, int nbin, const int64_t* offsets, const int64_t* inds, ins_spectrum_t** out);
+int ins_spectrum_destroy(ins_spectrum_t* spectrum);
+int ins_spectrum_f64(ins_spectrum_t* spectrum, const double* u, double* ehat, void* stream);
+
 /* ---------------------------------------------------------------------------------- multi-GPU z-slabs
  * One process per GPU.  Rank r owns nz/P interior z-planes (+1 ghost plane per side); its
  * `ins_grid_t` is created with bc[2] = {INS_BC_HALO, INS_BC_HALO} and the local slice of the z metrics.

@@ -77,6 +77,8 @@ from .pressure import (
     psolver_direct,
     psolver_spectral,
 )
+from .processors import (Observable, fieldsaver, observefield, observespectrum, processor, save_vtk, spectral_stuff, timelogger,
+                         vtk_writer)
 from .setup import Setup, copyfield, from_numpy, scalarfield, temperature_equation, to_numpy, vectorfield
 from .sciml import create_right_hand_side, right_hand_side_
 from .solver import get_cfl_timestep_, get_state, solve_unsteady

@@ -1570,3 +1570,40 @@ def timestep_lmwray3_ext_(stepper, dt, cache, theta=None):
     if temp is not None:
         apply_bc_temp_(temp, t, setup)
     return dict(setup=setup, psolver=psolver, u=u, temp=temp, t=t, n=n + 1)
+
+
+# ---- energy spectrum ---------------------------------------------------------------------------------------------------
+def spectral_stuff(setup, npoint=100, a=(1 + math.sqrt(5)) / 2):  # utils.jl:49-108
+    g = setup.grid
+    D = g.D
+    K = tuple(n // 2 for n in g.Np)
+    ks = np.meshgrid(*[np.arange(k, dtype=np.float64) for k in K], indexing="ij")
+    k = np.sqrt(sum(x**2 for x in ks)).reshape(-1, order="F")
+    kmax = min(K) - 1
+    isort = np.argsort(k, kind="stable")
+    ksort = k[isort]
+    kap = np.exp(np.linspace(0.0, math.log(kmax), npoint))  # logrange(1, kmax, npoint)
+    kap = np.unique(np.rint(kap).astype(np.int64))
+    inds = []
+    for ki in kap:
+        if D == 2:  # dyadic binning
+            lo, hi = ki / a, ki * a
+        else:  # linear binning
+            lo, hi = ki - 0.01, ki + 1 - 0.01
+        jstart = int(np.searchsorted(ksort, lo, side="left"))
+        jstop = int(np.searchsorted(ksort, hi, side="left"))
+        inds.append(isort[jstart:jstop])
+    return inds, kap, K
+
+
+def observespectrum(u, setup, npoint=100, a=(1 + math.sqrt(5)) / 2):  # processors.jl:303-332
+    g = setup.grid
+    D = g.D
+    inds, kap, K = spectral_stuff(setup, npoint, a)
+    e = 0.0
+    for c in range(D):
+        uhat = np.fft.fftn(u[_sl(g.Ip) + (c,)])
+        half = uhat[tuple(slice(0, k) for k in K)]
+        e = e + np.abs(half) ** 2 / (2 * float(np.prod(g.Np)) ** 2)
+    e = e.reshape(-1, order="F")
+    return np.array([e[i].sum() for i in inds]), kap

@@ -202,3 +202,68 @@ def test_steppers_with_closure_model_match_oracle(ins, oracle, geom, method):
     sp.closure_model = ins.smagorinsky_closure(sp)
     st, u, _ = _run_steps(ins, o, so, sp, method, 3, 2e-3, theta=0.17)
     assert rell2(u, st["u"]) < STEP_TOL
+
+
+@pytest.mark.parametrize("geom", ["periodic2d", "periodic3d", "periodic3d_wide"])
+def test_energy_spectrum_matches_oracle(ins, oracle, geom):
+    o = oracle
+    so = GEOMS[geom](o)
+    sp = mirror(ins, so, o)
+    g = so.grid
+    u_h = o.apply_bc_u(fx.randn_field(g.N + (g.D,), 1), 0.0, so)
+    e_h, kap = o.observespectrum(u_h, so)
+    st = ins.spectral_stuff(sp)
+    ih, _, K = o.spectral_stuff(so)
+    assert st["K"] == K and np.array_equal(st["κ"], kap) and all(np.array_equal(a, b) for a, b in zip(st["inds"], ih))
+    obs = ins.observespectrum(dict(u=ins.from_numpy(sp, u_h), temp=None, t=0.0, n=0), setup=sp)
+    assert relmax(obs["ehat"].value, e_h) < 1e-12
+
+
+def test_processors_drive_observers_and_write_vtk(ins, oracle, tmp_path):
+    """solve_unsteady with a timelogger, a fieldsaver, a vtk_writer and an observed field: callbacks fire once per step, the observers
+    see the device state, the VTK files parse back to the observed arrays."""
+    import base64
+    import re
+
+    o = oracle
+    so = fx.setup_periodic(o, (16, 12, 8))
+    sp = mirror(ins, so, o)
+    u0 = o.random_field(so, kp=2, seed=3)
+    lines, seen = [], []
+
+    def watch(state):
+        qf = ins.observefield(state, setup=sp, fieldname="Qfield")
+        vn = ins.observefield(state, setup=sp, fieldname="velocitynorm")
+        state.on(lambda s: seen.append((s["n"], float(np.abs(vn.value).max()), qf.value.shape)))
+        return vn
+
+    procs = dict(log=ins.timelogger(nupdate=2, log=lines.append), save=ins.fieldsaver(setup=sp, nupdate=2),
+                 vtk=ins.vtk_writer(setup=sp, nupdate=2, dir=str(tmp_path), filename="sol", fieldnames=("velocity", "vorticity", "Qfield", 0)),
+                 watch=ins.processor(watch, lambda vn, state: vn.value))
+    (u, temp, t), out = ins.solve_unsteady(setup=sp, tlims=(0.0, 0.04), ustart=ins.from_numpy(sp, u0), Δt=0.01, processors=procs)
+    ref = o.solve_unsteady(so, (0.0, 0.04), u0, dt=0.01)
+    assert rell2(ins.to_numpy(u), ref["u"]) < STEP_TOL
+    assert len(lines) == 2 and "umax" in lines[0] and [n for n, _, _ in seen] == [1, 2, 3, 4]
+    assert [s["n"] for s in out["save"]] == [2, 4] and rell2(out["save"][-1]["u"], ref["u"]) < STEP_TOL
+    up = o.interpolate_u_p(ref["u"], so)
+    sl = tuple(slice(lo, hi) for lo, hi in so.grid.Ip)
+    vn = np.sqrt((up[sl] ** 2).sum(-1))
+    assert relmax(out["watch"], vn) < 1e-9
+    # the collection and the last snapshot
+    pvd = open(out["vtk"]).read()
+    files = re.findall(r'file="([^"]+)"', pvd)
+    assert len(files) == 3  # initial state + steps 2 and 4
+    xml = open(tmp_path / files[-1]).read()
+    arrays = {m.group(1): (int(m.group(2)), m.group(3)) for m in re.finditer(r'Name="([^"]+)" NumberOfComponents="(\d+)" format="binary">([^<]+)<', xml)}
+
+    def decode(name):
+        nc, b64 = arrays[name]
+        raw = base64.b64decode(b64)
+        assert int(np.frombuffer(raw[:8], dtype=np.uint64)[0]) == len(raw) - 8
+        return np.frombuffer(raw[8:], dtype=np.float64).reshape(-1, nc)
+
+    assert decode("TimeValue")[0, 0] == pytest.approx(0.04)
+    vel = decode("velocity")
+    assert vel.shape == (16 * 12 * 8, 3) and relmax(vel[:, 1].reshape((16, 12, 8), order="F"), up[sl][..., 1]) < 1e-9
+    assert relmax(decode("0")[:, 0].reshape((16, 12, 8), order="F"), up[sl][..., 0]) < 1e-9
+    assert decode("x").shape == (16, 1) and decode("vorticity").shape == (16 * 12 * 8, 3)

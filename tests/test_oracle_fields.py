@@ -99,3 +99,20 @@ def test_steppers_with_temperature_keep_mean_temperature(oracle):
         out.append(st)
     assert np.abs(out[0]["u"] - out[1]["u"]).max() < 1e-5 and np.abs(out[0]["temp"] - out[1]["temp"]).max() < 1e-5
     assert np.abs(out[0]["u"] - u0).max() > 1e-3  # buoyancy did act
+
+
+def test_spectrum_of_a_single_mode_lands_in_its_shell(oracle):
+    """One Fourier mode of wavenumber (3, 0, 0) with amplitude A: E = A²/4 per component... all of it in the shell κ = 3 (3-D linear bins)."""
+    o = oracle
+    n = 16
+    s = fx.setup_periodic(o, (n, n, n))
+    u = o.vectorfield(s)
+    X = s.grid.xp[0][:, None, None]
+    u[..., 1] = 0.7 * np.cos(2 * np.pi * 3 * X) + 0 * u[..., 1]
+    ehat, kap = o.observespectrum(u, s)
+    # fft amplitude of A cos at +k: A N³/2 -> |û|²/(2 N⁶) = A²/8 in the retained (non-negative) half
+    i3 = list(kap).index(3)
+    assert ehat[i3] == pytest.approx(0.7**2 / 8, rel=1e-12)
+    assert np.abs(np.delete(ehat, i3)).max() < 1e-28
+    inds, kap2, K = o.spectral_stuff(s)
+    assert K == (8, 8, 8) and kap2[-1] == 7 and all(len(i) > 0 for i in inds)
