@@ -7,31 +7,48 @@
 
 namespace {
 
+// Box of nx*ny*nz work-items as a 1-D grid of 64x4 workgroups with an XCD-aware order: workgroup ids are dealt round-robin to the
+// 8 XCDs, so id & 7 selects one of 8 y-ranges and, inside it, tiles run x fastest, then y, then z.  Every XCD then walks ITS slab of
+// rows plane after plane, and the k-1 / k+1 planes a stencil re-reads are still in that XCD's own 4 MB L2 (3 planes x 1/8 of the
+// rows x 3 components = 0.6 MB at 256^3) instead of coming from HBM three times.
 struct Launch3 {
   dim3 grid, block;
+  int ntx, nty, nty_l;
 };
 inline Launch3 box_launch(int nx, int ny, int nz) {
   Launch3 l;
   l.block = dim3(64, 4, 1);
-  l.grid = dim3(cdiv(nx, 64), cdiv(ny, 4), (unsigned)nz);
+  l.ntx = (int)cdiv(nx, 64);
+  l.nty = (int)cdiv(ny, 4);
+  l.nty_l = (l.nty + 7) / 8;
+  l.grid = dim3(8u * l.ntx * l.nty_l * (unsigned)nz, 1, 1);
   return l;
 }
 
 // work-item -> volume of the box [lo, hi)
-#define INS_BOX_INDEX(lo0, lo1, lo2, hi0, hi1)                   \
-  const int i = (lo0) + blockIdx.x * 64 + threadIdx.x;           \
-  const int j = (lo1) + blockIdx.y * 4 + threadIdx.y;            \
-  const int k = D == 3 ? (lo2) + (int)blockIdx.z : 0;            \
-  if (i >= (hi0) || j >= (hi1)) return;                          \
-  const int I[3] = {i, j, k};                                    \
-  const long long c = i + j * g.sx[1] + k * g.sx[2];             \
+#define INS_BOX_INDEX(lo0, lo1, lo2, hi0, hi1)                              \
+  int seq_ = (int)(blockIdx.x >> 3);                                         \
+  const int tx_ = seq_ % L.ntx;                                              \
+  seq_ /= L.ntx;                                                             \
+  const int ty_ = (int)(blockIdx.x & 7) * L.nty_l + seq_ % L.nty_l;          \
+  if (ty_ >= L.nty) return;                                                  \
+  const int i = (lo0) + tx_ * 64 + threadIdx.x;                              \
+  const int j = (lo1) + ty_ * 4 + threadIdx.y;                               \
+  const int k = D == 3 ? (lo2) + seq_ / L.nty_l : 0;                         \
+  if (i >= (hi0) || j >= (hi1)) return;                                      \
+  const int I[3] = {i, j, k};                                                \
+  const long long c = i + j * g.sx[1] + k * g.sx[2];                         \
   (void)I
+
+struct BoxMap {
+  int ntx, nty, nty_l;
+};
 
 // --------------------------------------------------------------------------------------------
 // vorticity!                                             operators.jl:985-1020 (ndrange = N .- 1)
 // --------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void k_vorticity(GridDev g, const double* __restrict__ u, double* __restrict__ w) {
+__global__ __launch_bounds__(256) void k_vorticity(GridDev g, BoxMap L, const double* __restrict__ u, double* __restrict__ w) {
   INS_BOX_INDEX(0, 0, 0, g.N[0] - 1, g.N[1] - 1);
   if (D == 2) {
     const double* u0 = u;
@@ -50,7 +67,7 @@ __global__ __launch_bounds__(256) void k_vorticity(GridDev g, const double* __re
 
 // interpolate_u_p!                                                     operators.jl:1311-1326
 template <int D>
-__global__ __launch_bounds__(256) void k_interp_u_p(GridDev g, const double* __restrict__ u, double* __restrict__ up) {
+__global__ __launch_bounds__(256) void k_interp_u_p(GridDev g, BoxMap L, const double* __restrict__ u, double* __restrict__ up) {
   INS_BOX_INDEX(g.ip_lo[0], g.ip_lo[1], g.ip_lo[2], g.ip_hi[0], g.ip_hi[1]);
 #pragma unroll
   for (int a = 0; a < D; ++a) {
@@ -61,7 +78,7 @@ __global__ __launch_bounds__(256) void k_interp_u_p(GridDev g, const double* __r
 
 // interpolate_ω_p!                                                     operators.jl:1336-1370
 template <int D>
-__global__ __launch_bounds__(256) void k_interp_w_p(GridDev g, const double* __restrict__ w, double* __restrict__ wp) {
+__global__ __launch_bounds__(256) void k_interp_w_p(GridDev g, BoxMap L, const double* __restrict__ w, double* __restrict__ wp) {
   INS_BOX_INDEX(g.ip_lo[0], g.ip_lo[1], g.ip_lo[2], g.ip_hi[0], g.ip_hi[1]);
   if (D == 2) {
     wp[c] = (w[c - g.sx[0] - g.sx[1]] + w[c]) / 2;
@@ -77,7 +94,7 @@ __global__ __launch_bounds__(256) void k_interp_w_p(GridDev g, const double* __r
 
 // Dfield! (after pressuregradient!)                                    operators.jl:1385-1422
 template <int D>
-__global__ __launch_bounds__(256) void k_Dfield(GridDev g, const double* __restrict__ G, double* __restrict__ d, double eps) {
+__global__ __launch_bounds__(256) void k_Dfield(GridDev g, BoxMap L, const double* __restrict__ G, double* __restrict__ d, double eps) {
   INS_BOX_INDEX(g.ip_lo[0], g.ip_lo[1], g.ip_lo[2], g.ip_hi[0], g.ip_hi[1]);
   double gg = 0.0, lap = 0.0;
 #pragma unroll
@@ -93,7 +110,7 @@ __global__ __launch_bounds__(256) void k_Dfield(GridDev g, const double* __restr
 
 // Qfield!                                                              operators.jl:1440-1460
 template <int D>
-__global__ __launch_bounds__(256) void k_Qfield(GridDev g, const double* __restrict__ u, double* __restrict__ Q) {
+__global__ __launch_bounds__(256) void k_Qfield(GridDev g, BoxMap L, const double* __restrict__ u, double* __restrict__ Q) {
   INS_BOX_INDEX(g.ip_lo[0], g.ip_lo[1], g.ip_lo[2], g.ip_hi[0], g.ip_hi[1]);
   double q = 0.0;
 #pragma unroll
@@ -130,12 +147,9 @@ __device__ __forceinline__ void gradu(const GridDev& g, const double* __restrict
   }
 }
 
-// dissipation_from_strain!                                                operators.jl:836-854
+// ---- per-cell results from the velocity gradient G ------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void k_strain_dissipation(GridDev g, double visc, const double* __restrict__ u, double* __restrict__ e) {
-  INS_BOX_INDEX(g.ip_lo[0], g.ip_lo[1], g.ip_lo[2], g.ip_hi[0], g.ip_hi[1]);
-  double G[D][D];
-  gradu<D>(g, u, c, I, G);
+__device__ __forceinline__ double strain_norm2(const double (&G)[D][D]) {  // Σ S_ab S_ab
   double ss = 0.0;
 #pragma unroll
   for (int a = 0; a < D; ++a)
@@ -144,16 +158,12 @@ __global__ __launch_bounds__(256) void k_strain_dissipation(GridDev g, double vi
       const double s = (G[a][b] + G[b][a]) / 2;
       ss += s * s;
     }
-  e[c] = 2 * visc * ss;
+  return ss;
 }
 
-// eig2field!: middle eigenvalue of S² + R² (3-D)                         operators.jl:1472-1492
-// Closed form for a symmetric 3x3 matrix (trigonometric solution of the characteristic cubic).
-__global__ __launch_bounds__(256) void k_eig2(GridDev g, const double* __restrict__ u, double* __restrict__ lam) {
-  constexpr int D = 3;
-  INS_BOX_INDEX(g.ip_lo[0], g.ip_lo[1], g.ip_lo[2], g.ip_hi[0], g.ip_hi[1]);
-  double G[3][3];
-  gradu<3>(g, u, c, I, G);
+// middle eigenvalue of S² + R² (operators.jl:1484-1488): closed form for a symmetric 3x3 matrix (trigonometric solution of the
+// characteristic cubic) plus one Newton step
+__device__ __forceinline__ double eig2_of(const double (&G)[3][3]) {
   double S[3][3], R[3][3], M[3][3];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
@@ -174,27 +184,125 @@ __global__ __launch_bounds__(256) void k_eig2(GridDev g, const double* __restric
   const double p1 = M[0][1] * M[0][1] + M[0][2] * M[0][2] + M[1][2] * M[1][2];
   const double q = (M[0][0] + M[1][1] + M[2][2]) / 3;
   const double p2 = (M[0][0] - q) * (M[0][0] - q) + (M[1][1] - q) * (M[1][1] - q) + (M[2][2] - q) * (M[2][2] - q) + 2 * p1;
-  double e2;
-  if (p2 <= 0.0) {
-    e2 = q;  // multiple of the identity
+  if (p2 <= 0.0) return q;  // multiple of the identity
+  const double p = sqrt(p2 / 6), ip = 1.0 / p;
+  const double b00 = (M[0][0] - q) * ip, b11 = (M[1][1] - q) * ip, b22 = (M[2][2] - q) * ip;
+  const double b01 = M[0][1] * ip, b02 = M[0][2] * ip, b12 = M[1][2] * ip;
+  double r = (b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02)) / 2;
+  r = fmin(1.0, fmax(-1.0, r));
+  const double phi = acos(r) / 3;
+  const double e1 = q + 2 * p * cos(phi);                             // largest
+  const double e3 = q + 2 * p * cos(phi + 2.0943951023931954923084);  // smallest (phi + 2π/3)
+  double e2 = 3 * q - e1 - e3;
+  // one Newton step on det(M - λ) = 0: the arccosine loses digits when two eigenvalues are close to each other
+  const double a00 = M[0][0] - e2, a11 = M[1][1] - e2, a22 = M[2][2] - e2;
+  const double m0 = a11 * a22 - M[1][2] * M[1][2], m1 = a00 * a22 - M[0][2] * M[0][2], m2 = a00 * a11 - M[0][1] * M[0][1];
+  const double det = a00 * m0 - M[0][1] * (M[0][1] * a22 - M[1][2] * M[0][2]) + M[0][2] * (M[0][1] * M[1][2] - a11 * M[0][2]);
+  const double dd = -(m0 + m1 + m2);  // d det / dλ
+  if (fabs(dd) > 1e-8 * p * p) e2 -= det / dd;
+  return e2;
+}
+
+template <int D>
+__host__ __device__ constexpr int sym_index(int a, int b) {  // [xx, yy, (zz), xy, (xz, yz)]
+  if (a == b) return a;
+  if (D == 2) return 2;
+  const int lo = a < b ? a : b, hi = a < b ? b : a;
+  return lo == 0 ? (hi == 1 ? 3 : 4) : 5;
+}
+
+// OP 0: dissipation_from_strain! (operators.jl:836-854, par = 1/Re)   OP 1: eig2field! (:1472-1492)
+// OP 2: smagtensor! (:1135-1150, par = θ; D(D+1)/2 outputs)
+template <int D, int OP>
+__device__ __forceinline__ void gradient_result(const GridDev& g, const double (&G)[D][D], const int (&I)[3], long long c, double par,
+                                                double* __restrict__ out) {
+  if (OP == 0) {
+    out[c] = 2 * par * strain_norm2<D>(G);
+  } else if (OP == 1) {
+    if constexpr (D == 3) out[c] = eig2_of(G);
   } else {
-    const double p = sqrt(p2 / 6), ip = 1.0 / p;
-    const double b00 = (M[0][0] - q) * ip, b11 = (M[1][1] - q) * ip, b22 = (M[2][2] - q) * ip;
-    const double b01 = M[0][1] * ip, b02 = M[0][2] * ip, b12 = M[1][2] * ip;
-    double r = (b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02)) / 2;
-    r = fmin(1.0, fmax(-1.0, r));
-    const double phi = acos(r) / 3;
-    const double e1 = q + 2 * p * cos(phi);                             // largest
-    const double e3 = q + 2 * p * cos(phi + 2.0943951023931954923084);  // smallest (phi + 2π/3)
-    e2 = 3 * q - e1 - e3;
-    // one Newton step on det(M - λ) = 0: the arccosine loses digits when two eigenvalues are close to each other
-    const double a00 = M[0][0] - e2, a11 = M[1][1] - e2, a22 = M[2][2] - e2;
-    const double m0 = a11 * a22 - M[1][2] * M[1][2], m1 = a00 * a22 - M[0][2] * M[0][2], m2 = a00 * a11 - M[0][1] * M[0][1];
-    const double det = a00 * m0 - M[0][1] * (M[0][1] * a22 - M[1][2] * M[0][2]) + M[0][2] * (M[0][1] * M[1][2] - a11 * M[0][2]);
-    const double dd = -(m0 + m1 + m2);  // d det / dλ
-    if (fabs(dd) > 1e-8 * p * p) e2 -= det / dd;
+    double d2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) d2 += g.dx[a][I[a]] * g.dx[a][I[a]];  // gridsize² = Σ Δα²
+    const double eddy = par * par * d2 * sqrt(2 * strain_norm2<D>(G));
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = a; b < D; ++b) out[sym_index<D>(a, b) * g.sc + c] = 2 * eddy * ((G[a][b] + G[b][a]) / 2);
   }
-  lam[c] = e2;
+}
+
+// one work-item per pressure point, every neighbour from global memory (2-D grids)
+template <int D, int OP>
+__global__ __launch_bounds__(256) void k_gradient_op(GridDev g, BoxMap L, double par, const double* __restrict__ u, double* __restrict__ out) {
+  INS_BOX_INDEX(g.ip_lo[0], g.ip_lo[1], g.ip_lo[2], g.ip_hi[0], g.ip_hi[1]);
+  double G[D][D];
+  gradu<D>(g, u, c, I, G);
+  gradient_result<D, OP>(g, G, I, c, par, out);
+}
+
+// 3-D: a 64x4 tile marches through a z-chunk with a ring of three (tile + 1 halo) planes of u in LDS.  The ~40 neighbour values a
+// cell needs then come from LDS; with one global load per neighbour the kernel was bound by L2 bandwidth (320 B/cell out of L2 for
+// 32 algorithmic bytes: 0.32 ms at 256^3); the ring brings 3 x 6 x 66 / 256 = 4.6 loads per cell and plane.
+constexpr int GT_X = 64, GT_Y = 4;
+template <int OP>
+__global__ __launch_bounds__(256) void k_gradient_march(GridDev g, BoxMap L, int zc, double par, const double* __restrict__ u, double* __restrict__ out) {
+  __shared__ double T[3][3][GT_Y + 2][GT_X + 2];  // [ring slot][component][row][column]
+  int seq = (int)(blockIdx.x >> 3);
+  const int tx = seq % L.ntx;
+  seq /= L.ntx;
+  const int ty = (int)(blockIdx.x & 7) * L.nty_l + seq % L.nty_l;
+  if (ty >= L.nty) return;  // whole workgroup
+  const int chunk = seq / L.nty_l;
+  const int i0 = g.ip_lo[0] + tx * GT_X, j0 = g.ip_lo[1] + ty * GT_Y;
+  const int k0 = g.ip_lo[2] + chunk * zc, k1 = min(k0 + zc, g.ip_hi[2]);
+  const int lx = threadIdx.x, ly = threadIdx.y, tid = ly * 64 + lx;
+  const int i = i0 + lx, j = j0 + ly;
+  const bool active = i < g.ip_hi[0] && j < g.ip_hi[1];
+  auto load_plane = [&](int kk) {
+    const int slot = kk % 3;
+    const long long zoff = (long long)kk * g.sx[2];
+    for (int q = tid; q < 3 * (GT_Y + 2) * (GT_X + 2); q += 256) {
+      const int a = q / ((GT_Y + 2) * (GT_X + 2));
+      const int r = (q / (GT_X + 2)) % (GT_Y + 2), cc = q % (GT_X + 2);
+      const int gi = min(i0 - 1 + cc, g.N[0] - 1), gj = min(j0 - 1 + r, g.N[1] - 1);  // tiles may overhang the box: stay in memory
+      T[slot][a][r][cc] = u[a * g.sc + gi + gj * g.sx[1] + zoff];
+    }
+  };
+  load_plane(k0 - 1);
+  load_plane(k0);
+  for (int k = k0; k < k1; ++k) {
+    load_plane(k + 1);
+    __syncthreads();
+    if (active) {
+      const int sm = (k + 2) % 3, s0 = k % 3, sp = (k + 1) % 3;  // ring slots of planes k-1, k, k+1
+      // value of component a at offset (ox, oy, oz) from this cell
+      auto U = [&](int a, int ox, int oy, int oz) { return T[oz < 0 ? sm : (oz > 0 ? sp : s0)][a][ly + 1 + oy][lx + 1 + ox]; };
+      auto at = [&](int a, int da, int sa_, int db, int sb_) {  // offsets sa_·e_da + sb_·e_db
+        const int ox = (da == 0 ? sa_ : 0) + (db == 0 ? sb_ : 0);
+        const int oy = (da == 1 ? sa_ : 0) + (db == 1 ? sb_ : 0);
+        const int oz = (da == 2 ? sa_ : 0) + (db == 2 ? sb_ : 0);
+        return U(a, ox, oy, oz);
+      };
+      const int I[3] = {i, j, k};
+      double G[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          if (a == b) {
+            G[a][b] = (at(a, a, 0, b, 0) - at(a, a, 0, b, -1)) * g.rdx[b][I[b]];
+          } else {
+            const double r1 = g.rdxu[b][I[b]], r0 = g.rdxu[b][I[b] - 1];
+            G[a][b] = ((at(a, a, 0, b, 1) - at(a, a, 0, b, 0)) * r1 + (at(a, a, -1, b, 1) - at(a, a, -1, b, 0)) * r1 +
+                       (at(a, a, 0, b, 0) - at(a, a, 0, b, -1)) * r0 + (at(a, a, -1, b, 0) - at(a, a, -1, b, -1)) * r0) /
+                      4;
+          }
+        }
+      gradient_result<3, OP>(g, G, I, i + j * g.sx[1] + k * g.sx[2], par, out);
+    }
+    __syncthreads();  // the next iteration overwrites the slot of plane k-1
+  }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -208,7 +316,7 @@ __device__ __forceinline__ double avg_at(const GridDev& g, const double* __restr
 
 // convection_diffusion_temp!  (c += ...)                                       operators.jl:712-737
 template <int D>
-__global__ __launch_bounds__(256) void k_convdiff_temp(GridDev g, double a4, const double* __restrict__ u, const double* __restrict__ temp,
+__global__ __launch_bounds__(256) void k_convdiff_temp(GridDev g, BoxMap L, double a4, const double* __restrict__ u, const double* __restrict__ temp,
                                                        double* __restrict__ out) {
   INS_BOX_INDEX(g.ip_lo[0], g.ip_lo[1], g.ip_lo[2], g.ip_hi[0], g.ip_hi[1]);
   const double tc = temp[c];
@@ -228,7 +336,7 @@ __global__ __launch_bounds__(256) void k_convdiff_temp(GridDev g, double a4, con
 
 // dissipation!: interpolation of u · diffusion(u) to the pressure points  (diss += ...)   operators.jl:800-810
 template <int D>
-__global__ __launch_bounds__(256) void k_dissipation_interp(GridDev g, double coef, const double* __restrict__ u, const double* __restrict__ diff,
+__global__ __launch_bounds__(256) void k_dissipation_interp(GridDev g, BoxMap L, double coef, const double* __restrict__ u, const double* __restrict__ diff,
                                                             double* __restrict__ diss) {
   INS_BOX_INDEX(g.ip_lo[0], g.ip_lo[1], g.ip_lo[2], g.ip_hi[0], g.ip_hi[1]);
   double d = 0.0;
@@ -243,7 +351,7 @@ __global__ __launch_bounds__(256) void k_dissipation_interp(GridDev g, double co
 
 // gravity!  (F[:, gdir] += α2 avg(temp))   over the whole Iu[gdir]                     operators.jl:914-931
 template <int D>
-__global__ __launch_bounds__(256) void k_gravity(GridDev g, int gdir, double a2, const double* __restrict__ temp, double* __restrict__ F) {
+__global__ __launch_bounds__(256) void k_gravity(GridDev g, BoxMap L, int gdir, double a2, const double* __restrict__ temp, double* __restrict__ F) {
   INS_BOX_INDEX(g.iu_lo[gdir][0], g.iu_lo[gdir][1], g.iu_lo[gdir][2], g.iu_hi[gdir][0], g.iu_hi[gdir][1]);
   F[gdir * g.sc + c] += a2 * avg_at(g, temp, c, gdir == 0 ? i : (gdir == 1 ? j : k), gdir);
 }
@@ -284,42 +392,11 @@ __global__ __launch_bounds__(256) void k_bc_temp(GridDev g, double* __restrict__
 
 // --------------------------------------------------------------------------------------------
 // Smagorinsky closure.  The stress tensor is symmetric: stored as D(D+1)/2 scalar fields
-// [xx, yy, (zz), xy, (xz, yz)] instead of the reference's array of D x D SMatrix.
+// [xx, yy, (zz), xy, (xz, yz)] instead of the reference's array of D x D SMatrix (smagtensor!: gradient_result<D, 2>).
 // --------------------------------------------------------------------------------------------
-template <int D>
-__host__ __device__ constexpr int sym_index(int a, int b) {
-  if (a == b) return a;
-  if (D == 2) return 2;
-  const int lo = a < b ? a : b, hi = a < b ? b : a;
-  return lo == 0 ? (hi == 1 ? 3 : 4) : 5;
-}
-
-// smagtensor!                                                                 operators.jl:1135-1150
-template <int D>
-__global__ __launch_bounds__(256) void k_smagtensor(GridDev g, double theta, const double* __restrict__ u, double* __restrict__ sig) {
-  INS_BOX_INDEX(g.ip_lo[0], g.ip_lo[1], g.ip_lo[2], g.ip_hi[0], g.ip_hi[1]);
-  double G[D][D];
-  gradu<D>(g, u, c, I, G);
-  double ss = 0.0, d2 = 0.0;
-#pragma unroll
-  for (int a = 0; a < D; ++a) {
-    d2 += g.dx[a][I[a]] * g.dx[a][I[a]];
-#pragma unroll
-    for (int b = 0; b < D; ++b) {
-      const double s = (G[a][b] + G[b][a]) / 2;
-      ss += s * s;
-    }
-  }
-  const double eddy = theta * theta * d2 * sqrt(2 * ss);  // gridsize² = Σ Δα²
-#pragma unroll
-  for (int a = 0; a < D; ++a)
-#pragma unroll
-    for (int b = a; b < D; ++b) sig[sym_index<D>(a, b) * g.sc + c] = 2 * eddy * ((G[a][b] + G[b][a]) / 2);
-}
-
 // divoftensor!                                                                operators.jl:1203-1236
 template <int D>
-__global__ __launch_bounds__(256) void k_divoftensor(GridDev g, const double* __restrict__ sig, double* __restrict__ s) {
+__global__ __launch_bounds__(256) void k_divoftensor(GridDev g, BoxMap L, const double* __restrict__ sig, double* __restrict__ s) {
   INS_BOX_INDEX(0, 0, 0, g.N[0], g.N[1]);
 #pragma unroll
   for (int a = 0; a < D; ++a) {
@@ -350,14 +427,36 @@ __global__ __launch_bounds__(256) void k_divoftensor(GridDev g, const double* __
 #define INS_LAUNCH_D(KERNEL, L, S, ...)                                                \
   do {                                                                                  \
     if (g.D == 2)                                                                       \
-      hipLaunchKernelGGL((KERNEL<2>), (L).grid, (L).block, 0, S, __VA_ARGS__);          \
+      hipLaunchKernelGGL((KERNEL<2>), (L).grid, (L).block, 0, S, g, BoxMap{(L).ntx, (L).nty, (L).nty_l}, __VA_ARGS__);          \
     else                                                                                \
-      hipLaunchKernelGGL((KERNEL<3>), (L).grid, (L).block, 0, S, __VA_ARGS__);          \
+      hipLaunchKernelGGL((KERNEL<3>), (L).grid, (L).block, 0, S, g, BoxMap{(L).ntx, (L).nty, (L).nty_l}, __VA_ARGS__);          \
     INS_LAUNCH_CHECK();                                                                 \
   } while (0)
 
 inline Launch3 ip_launch(const GridDev& g) {
   return box_launch(g.ip_hi[0] - g.ip_lo[0], g.ip_hi[1] - g.ip_lo[1], g.D == 3 ? g.ip_hi[2] - g.ip_lo[2] : 1);
+}
+
+template <int OP>
+int launch_gradient_op(const ins_grid* G, double par, const double* u, double* out, hipStream_t s) {
+  const GridDev& g = G->g;
+  static const bool march = !(getenv("INS_FIELDS_NO_MARCH") && atoi(getenv("INS_FIELDS_NO_MARCH")));  // A/B switch
+  if (g.D == 2) {
+    if constexpr (OP != 1) {
+      Launch3 l = ip_launch(g);
+      hipLaunchKernelGGL((k_gradient_op<2, OP>), l.grid, l.block, 0, s, g, BoxMap{l.ntx, l.nty, l.nty_l}, par, u, out);
+    }
+  } else if (!march || OP == 1) {  // eig2: its arithmetic dominates; the plain kernel measured faster (0.35 vs 0.43 ms at 256^3)
+    Launch3 l = ip_launch(g);
+    hipLaunchKernelGGL((k_gradient_op<3, OP>), l.grid, l.block, 0, s, g, BoxMap{l.ntx, l.nty, l.nty_l}, par, u, out);
+  } else {
+    const int nz = g.ip_hi[2] - g.ip_lo[2];
+    const int zc = nz >= 64 ? 32 : (nz >= 16 ? 8 : nz);  // planes per z-chunk: (zc + 2) / zc re-read at chunk ends
+    Launch3 l = box_launch(g.ip_hi[0] - g.ip_lo[0], g.ip_hi[1] - g.ip_lo[1], (int)cdiv(nz, zc));
+    hipLaunchKernelGGL((k_gradient_march<OP>), l.grid, l.block, 0, s, g, BoxMap{l.ntx, l.nty, l.nty_l}, zc, par, u, out);
+  }
+  INS_LAUNCH_CHECK();
+  return INS_OK;
 }
 
 }  // namespace
@@ -366,7 +465,7 @@ extern "C" int ins_vorticity_f64(const ins_grid_t* G, const double* u, double* w
   INS_REQUIRE(G && u && w, "null argument");
   const GridDev& g = G->g;
   Launch3 l = box_launch(g.N[0] - 1, g.N[1] - 1, g.D == 3 ? g.N[2] - 1 : 1);
-  INS_LAUNCH_D(k_vorticity, l, as_stream(stream), g, u, w);
+  INS_LAUNCH_D(k_vorticity, l, as_stream(stream), u, w);
   return INS_OK;
 }
 
@@ -374,7 +473,7 @@ extern "C" int ins_interpolate_u_p_f64(const ins_grid_t* G, const double* u, dou
   INS_REQUIRE(G && u && up, "null argument");
   const GridDev& g = G->g;
   Launch3 l = ip_launch(g);
-  INS_LAUNCH_D(k_interp_u_p, l, as_stream(stream), g, u, up);
+  INS_LAUNCH_D(k_interp_u_p, l, as_stream(stream), u, up);
   return INS_OK;
 }
 
@@ -382,7 +481,7 @@ extern "C" int ins_interpolate_w_p_f64(const ins_grid_t* G, const double* w, dou
   INS_REQUIRE(G && w && wp, "null argument");
   const GridDev& g = G->g;
   Launch3 l = ip_launch(g);
-  INS_LAUNCH_D(k_interp_w_p, l, as_stream(stream), g, w, wp);
+  INS_LAUNCH_D(k_interp_w_p, l, as_stream(stream), w, wp);
   return INS_OK;
 }
 
@@ -392,7 +491,7 @@ extern "C" int ins_dfield_f64(const ins_grid_t* G, const double* p, double* Gp, 
   int rc = ins_pressuregradient_f64(G, p, Gp, stream);
   if (rc != INS_OK) return rc;
   Launch3 l = ip_launch(g);
-  INS_LAUNCH_D(k_Dfield, l, as_stream(stream), g, (const double*)Gp, d, eps);
+  INS_LAUNCH_D(k_Dfield, l, as_stream(stream), (const double*)Gp, d, eps);
   return INS_OK;
 }
 
@@ -400,26 +499,19 @@ extern "C" int ins_qfield_f64(const ins_grid_t* G, const double* u, double* Q, v
   INS_REQUIRE(G && u && Q, "null argument");
   const GridDev& g = G->g;
   Launch3 l = ip_launch(g);
-  INS_LAUNCH_D(k_Qfield, l, as_stream(stream), g, u, Q);
+  INS_LAUNCH_D(k_Qfield, l, as_stream(stream), u, Q);
   return INS_OK;
 }
 
 extern "C" int ins_dissipation_from_strain_f64(const ins_grid_t* G, double visc, const double* u, double* e, void* stream) {
   INS_REQUIRE(G && u && e, "null argument");
-  const GridDev& g = G->g;
-  Launch3 l = ip_launch(g);
-  INS_LAUNCH_D(k_strain_dissipation, l, as_stream(stream), g, visc, u, e);
-  return INS_OK;
+  return launch_gradient_op<0>(G, visc, u, e, as_stream(stream));
 }
 
 extern "C" int ins_eig2field_f64(const ins_grid_t* G, const double* u, double* lam, void* stream) {
   INS_REQUIRE(G && u && lam, "null argument");
-  const GridDev& g = G->g;
-  INS_REQUIRE(g.D == 3, "eig2 only implemented in 3D");  // operators.jl:1477
-  Launch3 l = ip_launch(g);
-  hipLaunchKernelGGL(k_eig2, l.grid, l.block, 0, as_stream(stream), g, u, lam);
-  INS_LAUNCH_CHECK();
-  return INS_OK;
+  INS_REQUIRE(G->g.D == 3, "eig2 only implemented in 3D");  // operators.jl:1477
+  return launch_gradient_op<1>(G, 0.0, u, lam, as_stream(stream));
 }
 
 extern "C" int ins_apply_bc_temp_f64(const ins_grid_t* G, const int32_t* bc, const double* val, const double* const* planes, double* temp,
@@ -451,7 +543,7 @@ extern "C" int ins_convection_diffusion_temp_f64(const ins_grid_t* G, double a4,
   INS_REQUIRE(G && u && temp && c, "null argument");
   const GridDev& g = G->g;
   Launch3 l = ip_launch(g);
-  INS_LAUNCH_D(k_convdiff_temp, l, as_stream(stream), g, a4, u, temp, c);
+  INS_LAUNCH_D(k_convdiff_temp, l, as_stream(stream), a4, u, temp, c);
   return INS_OK;
 }
 
@@ -459,11 +551,12 @@ extern "C" int ins_dissipation_f64(const ins_grid_t* G, double visc, double coef
   INS_REQUIRE(G && u && diff && diss, "null argument");
   const GridDev& g = G->g;
   // fill!(diff, 0); diffusion!(diff, u, setup)                                  operators.jl:797-798
-  INS_HIP_TRY(hipMemsetAsync(diff, 0, (size_t)G->ncell * g.D * sizeof(double), as_stream(stream)));
-  int rc = ins_diffusion_f64(G, visc, u, diff, stream);
+  // (one write-only pass: zero outside the DOF ranges, the diffusion term inside)
+  INS_REQUIRE(u != diff, "diffusion! cannot run in place");
+  int rc = ins_k_diffusion_overwrite(G, visc, u, diff, as_stream(stream));
   if (rc != INS_OK) return rc;
   Launch3 l = ip_launch(g);
-  INS_LAUNCH_D(k_dissipation_interp, l, as_stream(stream), g, coef, u, (const double*)diff, diss);
+  INS_LAUNCH_D(k_dissipation_interp, l, as_stream(stream), coef, u, (const double*)diff, diss);
   return INS_OK;
 }
 
@@ -473,22 +566,19 @@ extern "C" int ins_gravity_f64(const ins_grid_t* G, int gdir, double a2, const d
   INS_REQUIRE(gdir >= 0 && gdir < g.D, "gravity direction");
   Launch3 l = box_launch(g.iu_hi[gdir][0] - g.iu_lo[gdir][0], g.iu_hi[gdir][1] - g.iu_lo[gdir][1],
                          g.D == 3 ? g.iu_hi[gdir][2] - g.iu_lo[gdir][2] : 1);
-  INS_LAUNCH_D(k_gravity, l, as_stream(stream), g, gdir, a2, temp, F);
+  INS_LAUNCH_D(k_gravity, l, as_stream(stream), gdir, a2, temp, F);
   return INS_OK;
 }
 
 extern "C" int ins_smagtensor_f64(const ins_grid_t* G, double theta, const double* u, double* sig, void* stream) {
   INS_REQUIRE(G && u && sig, "null argument");
-  const GridDev& g = G->g;
-  Launch3 l = ip_launch(g);
-  INS_LAUNCH_D(k_smagtensor, l, as_stream(stream), g, theta, u, sig);
-  return INS_OK;
+  return launch_gradient_op<2>(G, theta, u, sig, as_stream(stream));
 }
 
 extern "C" int ins_divoftensor_f64(const ins_grid_t* G, const double* sig, double* s, void* stream) {
   INS_REQUIRE(G && sig && s, "null argument");
   const GridDev& g = G->g;
   Launch3 l = box_launch(g.N[0], g.N[1], g.D == 3 ? g.N[2] : 1);
-  INS_LAUNCH_D(k_divoftensor, l, as_stream(stream), g, sig, s);
+  INS_LAUNCH_D(k_divoftensor, l, as_stream(stream), sig, s);
   return INS_OK;
 }

@@ -174,6 +174,7 @@ int ins_k_apply_bc_u(const ins_grid* grid, double* u, int dudt, const double* co
 int ins_k_apply_bc_p(const ins_grid* grid, double* p, hipStream_t s);
 int ins_k_momentum(const ins_grid* grid, double visc, const double* u, double* F, hipStream_t s);
 int ins_k_divergence(const ins_grid* grid, const double* u, double* div, hipStream_t s);
+int ins_k_diffusion_overwrite(const ins_grid* grid, double visc, const double* u, double* F, hipStream_t s);
 int ins_k_scalewithvolume(const ins_grid* grid, double* p, hipStream_t s);
 int ins_k_applypressure(const ins_grid* grid, double* u, const double* p, hipStream_t s);
 int ins_k_laplacian(const ins_grid* grid, const double* p, double* L, hipStream_t s);

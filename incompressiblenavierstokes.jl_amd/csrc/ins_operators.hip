@@ -233,6 +233,10 @@ int ins_k_momentum_generic(const ins_grid* G, double visc, const double* u, doub
   return launch_convdiff<3, true>(G, visc, u, F, s);
 }
 
+int ins_k_diffusion_overwrite(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s) {
+  return launch_convdiff<2, true>(G, visc, u, F, s);  // fill!(F, 0) + diffusion!(F, u) in one write-only pass
+}
+
 int ins_k_divergence(const ins_grid* G, const double* u, double* div, hipStream_t s) {
   const GridDev& g = G->g;
   Launch3 l = box_launch(g.ip_hi[0] - g.ip_lo[0], g.ip_hi[1] - g.ip_lo[1], g.ip_hi[2] - g.ip_lo[2]);
