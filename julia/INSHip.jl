@@ -7,11 +7,14 @@
 module INSHip
 
 using IncompressibleNavierStokes
+using AMDGPU
 using AMDGPU: ROCArray, ROCBackend, HIP
 import IncompressibleNavierStokes:
     apply_bc_u!, apply_bc_p!, divergence!, scalewithvolume!, pressuregradient!, applypressure!, laplacian!,
     convection!, diffusion!, convectiondiffusion!, momentum!, project!, poisson!, psolver_spectral, psolver_cg,
-    timestep!, ode_method_cache, ExplicitRungeKuttaMethod, PeriodicBC, DirichletBC, SymmetricBC, PressureBC
+    timestep!, ode_method_cache, ExplicitRungeKuttaMethod, PeriodicBC, DirichletBC, SymmetricBC, PressureBC,
+    vorticity!, interpolate_u_p!, interpolate_ω_p!, Qfield!, Dfield!, eig2field!, dissipation_from_strain!,
+    convection_diffusion_temp!, dissipation!, gravity!, apply_bc_temp!, smagorinsky_closure
 
 const lib = get(ENV, "INSHIP_LIB", "libinship.so")
 
@@ -126,6 +129,93 @@ function project!(u::ROCArray{Float64}, setup; psolver::HipPSolver, p::ROCArray{
                 handle(setup), psolver.h, pointer(u), pointer(p), stream()))
     u
 end
+
+# ---- step-adjacent operators (SURVEY §8f rows 2 and 4): with these methods the reference's own host-driven `timestep!`
+# (closure model / temperature / body force present) runs entirely on libinship's kernels --------------------------------
+const RA = ROCArray{Float64}
+vorticity!(ω::RA, u::RA, setup) =
+    (check(ccall((:ins_vorticity_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), pointer(u), pointer(ω), stream())); ω)
+interpolate_u_p!(up::RA, u::RA, setup) =
+    (check(ccall((:ins_interpolate_u_p_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), pointer(u), pointer(up), stream())); up)
+interpolate_ω_p!(ωp::RA, ω::RA, setup) =
+    (check(ccall((:ins_interpolate_w_p_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), pointer(ω), pointer(ωp), stream())); ωp)
+Qfield!(Q::RA, u::RA, setup) =
+    (check(ccall((:ins_qfield_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), pointer(u), pointer(Q), stream())); Q)
+Dfield!(d::RA, G::RA, p::RA, setup; ϵ = eps(Float64)) =
+    (check(ccall((:ins_dfield_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Ptr{Cvoid}),
+                 handle(setup), pointer(p), pointer(G), pointer(d), ϵ, stream())); d)
+eig2field!(λ::RA, u::RA, setup) =
+    (check(ccall((:ins_eig2field_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), pointer(u), pointer(λ), stream())); λ)
+dissipation_from_strain!(ϵ::RA, u::RA, setup) =
+    (check(ccall((:ins_dissipation_from_strain_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                 handle(setup), 1 / setup.Re, pointer(u), pointer(ϵ), stream())); ϵ)
+convection_diffusion_temp!(c::RA, u::RA, temp::RA, setup) =
+    (check(ccall((:ins_convection_diffusion_temp_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                 handle(setup), setup.temperature.α4, pointer(u), pointer(temp), pointer(c), stream())); c)
+dissipation!(diss::RA, diff::RA, u::RA, setup) =
+    (check(ccall((:ins_dissipation_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                 handle(setup), 1 / setup.Re, setup.Re * setup.temperature.α1 / setup.temperature.γ, pointer(u), pointer(diff), pointer(diss), stream())); diss)
+gravity!(F::RA, temp::RA, setup) =
+    (check(ccall((:ins_gravity_f64, lib), Cint, (Ptr{Cvoid}, Cint, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                 handle(setup), setup.temperature.gdir - 1, setup.temperature.α2, pointer(temp), pointer(F), stream())); F)
+# apply_bc_temp!: BC codes / Dirichlet constants per (β, side); closures `bc.u(x..., t)` are evaluated here into plane buffers
+function apply_bc_temp!(temp::RA, t, setup; kwargs...)
+    bcs = setup.temperature.boundary_conditions
+    D = length(bcs)
+    codes, vals = zeros(Int32, 6), zeros(Float64, 6)
+    planes, keep = fill(Ptr{Float64}(C_NULL), 6), Any[]
+    for β = 1:D, (side, bc) in enumerate(bcs[β])
+        q = 2(β - 1) + side
+        codes[q] = bccode(bc)
+        bc isa DirichletBC || continue
+        if bc.u isa Number
+            vals[q] = bc.u
+        elseif !isnothing(bc.u)
+            I = IncompressibleNavierStokes.boundary(β, setup.grid.N, setup.grid.Ip, side == 2)
+            xI = ntuple(α -> reshape(Array(setup.grid.xp[α])[I.indices[α]], ntuple(Returns(1), α - 1)..., :), D)
+            buf = ROCArray(vec(bc.u.(xI..., t)))          # memory order of the plane: fastest direction first
+            push!(keep, buf); planes[q] = pointer(buf)
+        end
+    end
+    GC.@preserve keep check(ccall((:ins_apply_bc_temp_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float64}, Ptr{Ptr{Float64}}, Ptr{Float64}, Ptr{Cvoid}),
+                                  handle(setup), codes, vals, planes, pointer(temp), stream()))
+    isempty(keep) || AMDGPU.synchronize()
+    temp
+end
+# momentum!(F, u, temp, t, setup): the fused fill + convection-diffusion pass, then body force and gravity (operators.jl:967-976)
+function momentum!(F::RA, u::RA, temp, t, setup)
+    check(ccall((:ins_momentum_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), 1 / setup.Re, pointer(u), pointer(F), stream()))
+    isnothing(setup.bodyforce) || IncompressibleNavierStokes.applybodyforce!(F, u, t, setup)   # broadcast add of a ROCArray
+    isnothing(temp) || gravity!(F, temp, setup)
+    F
+end
+# smagorinsky_closure(setup): σ as D(D+1)/2 scalar fields [xx, yy, (zz), xy, (xz, yz)]
+function smagorinsky_closure(setup, ::Val{:hip})
+    D = setup.grid.dimension()
+    ns = D * (D + 1) ÷ 2
+    σ = similar(setup.grid.x[1], Float64, (setup.grid.N..., ns)); fill!(σ, 0)
+    s = IncompressibleNavierStokes.vectorfield(setup)
+    ncell = prod(setup.grid.N)
+    function closure(u, θ)
+        check(ccall((:ins_smagtensor_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), θ, pointer(u), pointer(σ), stream()))
+        for q = 0:ns-1   # apply_bc_p!(σ, 0, setup) component by component (operators.jl:1296)
+            check(ccall((:ins_apply_bc_p_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), pointer(σ) + 8 * ncell * q, stream()))
+        end
+        check(ccall((:ins_divoftensor_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), pointer(σ), pointer(s), stream()))
+        s
+    end
+end
+# observespectrum: shells from spectral_stuff (host), everything else on the device
+function spectrum_handle(setup; kwargs...)
+    (; inds) = IncompressibleNavierStokes.spectral_stuff(setup; kwargs...)
+    off = Int64[0; cumsum(length.(inds))]
+    flat = Int64.(reduce(vcat, Array.(inds))) .- 1
+    h = Ref{Ptr{Cvoid}}()
+    check(ccall((:ins_spectrum_create, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Int64}, Ref{Ptr{Cvoid}}), handle(setup), length(inds), off, flat, h))
+    h[]
+end
+spectrum!(ehat::RA, h::Ptr{Cvoid}, u::RA) =
+    (check(ccall((:ins_spectrum_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), h, pointer(u), pointer(ehat), stream())); ehat)
 
 # ---- explicit RK (step_explicit_runge_kutta.jl) -----------------------------------------------------------------
 struct HipRKCache
