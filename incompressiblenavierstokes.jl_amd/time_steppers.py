@@ -2,6 +2,7 @@
 step_explicit_runge_kutta.jl, time_stepper_caches.jl), host side."""
 import ctypes as C
 from dataclasses import dataclass
+from fractions import Fraction
 from types import SimpleNamespace
 
 import numpy as np
@@ -87,6 +88,111 @@ class RKMethods:
     def RK33P2(**kw):  # :506-512
         A = np.array([[0, 0, 0], [1 / 3, 0, 0], [-1, 2, 0]])
         return runge_kutta_method(A, [0, 0.75, 0.25], [0, 1 / 3, 1], **kw)
+
+
+    # ---- the rest of the explicit tableaux of RKMethods.jl (published coefficients; rows of A below the diagonal) ----
+    @staticmethod
+    def _from_rows(rows, b, c=None, r=0.0, **kw):
+        s = len(b)
+        A = np.zeros((s, s))
+        for i, row in enumerate(rows, start=1):
+            A[i, : len(row)] = [float(Fraction(v)) for v in row]
+        b = [float(Fraction(v)) for v in b]
+        c = A.sum(1) if c is None else [float(Fraction(v)) for v in c]
+        return runge_kutta_method(A, b, c, r, **kw)
+
+    @staticmethod
+    def _from_shu_osher(alpha, beta, r, **kw):
+        """Butcher form of a Shu-Osher pair (α, β) with s stages: A = (I − α[:s])⁻¹ β[:s], b = β[s] + Aᵀ α[s]."""
+        s = alpha.shape[1]
+        A = np.linalg.solve(np.eye(s) - alpha[:s], beta[:s])
+        b = beta[s] + A.T @ alpha[s]
+        return runge_kutta_method(np.tril(A, -1), b, A.sum(1), r, **kw)
+
+    @staticmethod
+    def SSP104(**kw):  # RKMethods.jl:91-103
+        s = 10
+        a0 = np.diag(np.ones(s - 1), -1)
+        a0[5, 4], a0[5, 0] = 2 / 5, 3 / 5
+        b0 = np.diag(np.ones(s - 1), -1) / 6
+        b0[5, 4] = 1 / 15
+        A = np.linalg.solve(np.eye(s) - a0, b0)
+        return runge_kutta_method(np.tril(A, -1), [0.1] * s, A.sum(1), 6, **kw)
+
+    @staticmethod
+    def rSSPs2(s=2, **kw):  # :106-117  (optimal low-storage s-stage 2nd order SSP)
+        if s < 2:
+            raise ValueError("Explicit second order SSP family requires s ≥ 2")
+        r = s - 1
+        alpha = np.vstack([np.zeros((1, s)), np.eye(s)])
+        alpha[s, s - 1] = (s - 1) / s
+        beta = alpha / r
+        alpha[s, 0] = 1 / s
+        return RKMethods._from_shu_osher(alpha, beta, r, **kw)
+
+    @staticmethod
+    def rSSPs3(s=4, **kw):  # :120-134  (optimal low-storage s²-stage 3rd order SSP; the reference's `s` IS the square root)
+        if s < 4 or round(s**0.5) ** 2 != s:  # the reference's own check (:121-123), although it then uses s as the root: n = s²
+            raise ValueError("Explicit third order SSP family requires s = n^2, n > 1")
+        n = s * s
+        r = n - s
+        alpha = np.vstack([np.zeros((1, n)), np.eye(n)])
+        alpha[s * (s + 1) // 2, s * (s + 1) // 2 - 1] = (s - 1) / (2 * s - 1)
+        beta = alpha / r
+        alpha[s * (s + 1) // 2, (s - 1) * (s - 2) // 2] = s / (2 * s - 1)
+        return RKMethods._from_shu_osher(alpha, beta, r, **kw)
+
+    @staticmethod
+    def RK56(**kw):  # :149-162
+        rows = [["1/4"], ["1/8", "1/8"], [0, 0, "1/2"], ["3/16", "-3/8", "3/8", "9/16"], ["-3/7", "8/7", "6/7", "-12/7", "8/7"]]
+        return RKMethods._from_rows(rows, ["7/90", 0, "16/45", "2/15", "16/45", "7/90"], [0, "1/4", "1/4", "1/2", "3/4", 1], **kw)
+
+    @staticmethod
+    def DOPRI6(**kw):  # :165-178
+        rows = [["1/5"], ["3/40", "9/40"], ["44/45", "-56/15", "32/9"], ["19372/6561", "-25360/2187", "64448/6561", "-212/729"],
+                ["9017/3168", "-355/33", "46732/5247", "49/176", "-5103/18656"]]
+        return RKMethods._from_rows(rows, ["35/384", 0, "500/1113", "125/192", "-2187/6784", "11/84"], **kw)
+
+    @staticmethod
+    def Mid22(**kw):  # :461-467
+        return RKMethods._from_rows([["1/2"]], [0, 1], [0, "1/2"], 0.5, **kw)
+
+    @staticmethod
+    def MTE22(**kw):  # :470-476
+        return RKMethods._from_rows([["2/3"]], ["1/4", "3/4"], [0, "2/3"], 0.5, **kw)
+
+    @staticmethod
+    def Heun33(**kw):  # :488-494
+        return RKMethods._from_rows([["1/3"], [0, "2/3"]], ["1/4", 0, "3/4"], **kw)
+
+    @staticmethod
+    def RK33C2(**kw):  # :497-503
+        return RKMethods._from_rows([["2/3"], ["1/3", "1/3"]], ["1/4", 0, "3/4"], [0, "2/3", "2/3"], **kw)
+
+    @staticmethod
+    def RK44C23(**kw):  # :533-539
+        return RKMethods._from_rows([["1/2"], ["1/4", "1/4"], [0, -1, 2]], ["1/6", 0, "2/3", "1/6"], [0, "1/2", "1/2", 1], **kw)
+
+    @staticmethod
+    def RK44P2(**kw):  # :542-548
+        return RKMethods._from_rows([[1], ["3/8", "1/8"], ["-1/8", "-3/8", "3/2"]], ["1/6", "-1/18", "2/3", "2/9"], [0, 1, "1/2", 1], **kw)
+
+    @staticmethod
+    def NSSP21(**kw):  # :589-598
+        return RKMethods._from_rows([["3/4"]], [0, 1], [0, "3/4"], **kw)
+
+    @staticmethod
+    def NSSP32(**kw):  # :601-611
+        return RKMethods._from_rows([["1/3"], [0, 1]], ["1/2", 0, "1/2"], [0, "1/3", 1], **kw)
+
+    @staticmethod
+    def NSSP33(**kw):  # :614-624
+        return RKMethods._from_rows([["-4/9"], ["7/6", "-1/2"]], ["1/4", 0, "3/4"], [0, "-4/9", "2/3"], **kw)
+
+    @staticmethod
+    def NSSP53(**kw):  # :627-640
+        rows = [["1/7"], [0, "3/16"], [0, 0, "1/3"], [0, 0, 0, "2/3"]]
+        return RKMethods._from_rows(rows, ["1/4", 0, 0, 0, "3/4"], [0, "1/7", "3/16", "1/3", "2/3"], **kw)
 
 
 class LMWray3:
