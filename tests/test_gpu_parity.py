@@ -583,3 +583,43 @@ def test_rk44_nonperiodic3d_matches_oracle(ins, oracle, geom):
     (u, _, t), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 0.004), ustart=ins.from_numpy(sp, u0), psolver=psp, Δt=0.001)
     assert np.isfinite(st["u"]).all()
     assert rell2(ins.to_numpy(u), st["u"]) < STEP_TOL
+
+
+def test_handles_release_their_device_memory(ins):
+    """Create / use / drop every kind of library handle repeatedly: the device's free memory (hipMemGetInfo) must come back, i.e. the
+    *_destroy entry points free everything the *_create ones and the lazily built caches allocated."""
+    import gc
+
+    import torch
+
+    def cycle(n):
+        x = (np.linspace(0.0, 1.0, n[0] + 1), np.linspace(0.0, 1.0, n[1] + 1), np.linspace(0.0, 1.0, n[2] + 1))
+        sp = ins.Setup(x=x, Re=1000.0)
+        ps = ins.psolver_spectral(sp)
+        m = ins.RKMethods.RK44()
+        cache = ins.ode_method_cache(m, sp, ps)
+        u = ins.random_field(sp, kp=2, psolver=ps, seed=1)
+        st = ins.create_stepper(m, setup=sp, psolver=ps, u=u, t=0.0)
+        st = ins.timesteps_(m, st, 1e-3, 2, cache=cache)
+        ins.observespectrum(dict(u=st.u, temp=None, t=0.0, n=0), setup=sp)
+        bc = ((ins.DirichletBC(), ins.DirichletBC()), (ins.DirichletBC(), ins.PressureBC()), (ins.PeriodicBC(), ins.PeriodicBC()))
+        s2 = ins.Setup(x=(ins.cosine_grid(0.0, 1.0, n[0]), ins.tanh_grid(0.0, 1.0, n[1]), x[2]), boundary_conditions=bc, Re=100.0)
+        for mk in (ins.psolver_direct, ins.psolver_cg):
+            p2 = mk(s2)
+            c2 = ins.ode_method_cache(m, s2, p2)
+            u2 = ins.velocityfield(s2, lambda a, x, y, z: 0 * (x + y + z) + (a == 0), psolver=p2)
+            ins.timestep_(m, ins.create_stepper(m, setup=s2, psolver=p2, u=u2, t=0.0), 1e-3, cache=c2)
+        torch.cuda.synchronize()
+
+    cycle((64, 32, 32))  # first use: code objects, rocFFT / rocBLAS workspaces
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(6):
+        cycle((64, 32, 32))
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 32 * 2**20, f"{(free0 - free1) / 2**20:.1f} MiB not returned after 6 create/destroy cycles"
