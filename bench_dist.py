@@ -73,6 +73,16 @@ def run_distributed(args, ins):
     t1 = time.perf_counter()
     el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    # roofline of the dominant kernel (the correcting stage kernel, K1 + K6 + the previous projection's gradient-subtract): two more
+    # steps with HIP events around its launches on the stream it runs on; outside the timed region
+    K.prof = []
+    st.steps_(u, dt, 2)
+    torch.cuda.synchronize()
+    prof, K.prof = K.prof, None
+    stage_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
+    nstage = sum(1 for _, _, b in prof if b)
+    cells_rank = float(n[0]) * n[1] * lay.nzl
+    stage_bytes = sum(b for _, _, b in prof) * cells_rank
     div = st.max_abs_divergence(u)
     finite = bool(torch.isfinite(u).all())
     if rank == 0:
@@ -95,6 +105,12 @@ def run_distributed(args, ins):
                        "grid": list(n), "decomposition": f"z-slabs x{world} (256^3 cells per GPU), RCCL halo planes + "
                                         + ("one all-gather of interface values per solve (distributed tridiagonal z solve)" if st.zsolve == "tridiag"
                                            else "all-to-all transposes around the z-FFT")},
+            "roofline": {"kernel": "k_flux64 CORR (slab): momentum-RHS stencil + RK stage combination + in-register pressure correction, per rank (rank 0)",
+                         "bound": "hbm", "achieved": stage_bytes / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else None, "peak": 8000.0, "unit": "GB/s",
+                         "frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / 8000.0 if stage_ms > 0 else None, "traffic": None,
+                         "bytes_per_cell": stage_bytes / cells_rank / max(nstage, 1), "avg_launch_ms": stage_ms / max(nstage, 1), "launches": nstage,
+                         "note": "algorithmic bytes of the stages measured (2 chained RK44 steps after the timed region) / HIP-event time of their launches "
+                                 "(interior + boundary plane ranges summed per stage); N = 1 has the PMC traffic figure"},
             "check": {"max_abs_div_times_dx": div * (1.0 / n[0]), "finite": finite, "backend": backend, "zsolve": st.zsolve, "kx_chunks": len(st.chunks)},
         }
         print(json.dumps(out))

@@ -251,9 +251,18 @@ class HipSlabKernels:
         n = len(coefs)
         carr = (C.c_double * max(n, 1))(*coefs)
         karr = (C.c_void_p * max(n, 1))(*[k.data_ptr() for k in ks])
+        prof = getattr(self, "prof", None)
+        if prof is not None:  # measurement hook (bench_dist.py `roofline`): events on the stream the kernel is launched on
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.call("ins_stage_momentum_corr_part_f64", s.handle, 1.0 / s.Re, s.ptr(ustar_prev, True), self._p(p_ext),
                   s.ptr(k_out, True) if k_out is not None else None, s.ptr(ustart, True) if ustart is not None else None, s.ptr(ustar, True), n, carr,
                   karr, float(coef_self), float(c0m1), float(self_in), s.ptr(ustart_out, True) if ustart_out is not None else None, int(part), s.stream)
+        if prof is not None:
+            e1.record()
+            # algorithmic bytes per cell of this stage (counted once, with its first part): R u*, R p, W out, R ustart, R earlier stage fields, ...
+            b = 0 if part == 2 else 24 * (2 + (ustart is not None) + n + (k_out is not None) + (ustart_out is not None)) + 8
+            prof.append((e0, e1, b))
 
     # stage_momentum_corr(part=...) and xfwd_planes exist: SlabStepper overlaps exchanges with them (INS_SLAB_NO_SPLIT=1: A/B switch)
     splits_stage = not bool(__import__("os").environ.get("INS_SLAB_NO_SPLIT"))
