@@ -217,6 +217,9 @@ int ins_combine_scalar_f64(const ins_grid_t* grid, const double* base, double* o
  * one rocFFT real-to-complex transform and one shell-sum kernel; nothing leaves the device. */
 typedef struct ins_spectrum ins_spectrum_t;
 int ins_spectrum_create(const ins_grid_t* grid, int nbin, const int64_t* offsets, const int64_t* inds, ins_spectrum_t** out);
+/* the same with a weight per index: bin i = Σ weights[q] |û[inds[q]]|² / (2 prod(Np)²) — get_scale_numbers' Σ E(k)/k (operators.jl:1591-1612) */
+int ins_spectrum_create_weighted(const ins_grid_t* grid, int nbin, const int64_t* offsets, const int64_t* inds, const double* weights,
+                                 ins_spectrum_t** out);
 int ins_spectrum_destroy(ins_spectrum_t* spectrum);
 int ins_spectrum_f64(ins_spectrum_t* spectrum, const double* u, double* ehat, void* stream);
 

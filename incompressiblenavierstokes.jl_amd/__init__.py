@@ -77,7 +77,7 @@ from .pressure import (
     psolver_direct,
     psolver_spectral,
 )
-from .processors import (Observable, fieldsaver, observefield, observespectrum, processor, save_vtk, spectral_stuff, timelogger,
+from .processors import (Observable, fieldsaver, get_scale_numbers, observefield, observespectrum, processor, save_vtk, spectral_stuff, timelogger,
                          vtk_writer)
 from .setup import Setup, copyfield, from_numpy, scalarfield, temperature_equation, to_numpy, vectorfield
 from .sciml import create_right_hand_side, right_hand_side_

@@ -12,6 +12,7 @@ struct ins_spectrum {
   hipfftDoubleComplex* hat = nullptr;    // (Np0/2+1) Np1 [Np2]
   long long* offsets = nullptr;          // nbin + 1
   long long* inds = nullptr;             // positions inside `hat`
+  double* weights = nullptr;             // optional weight per index (get_scale_numbers: 1/|k|)
   int nbin = 0;
   int np[3] = {1, 1, 1};
   double scale = 0.0;
@@ -31,12 +32,13 @@ __global__ __launch_bounds__(256) void k_strip(GridDev g, const double* __restri
 
 // one wavefront per shell
 __global__ __launch_bounds__(64) void k_shell_sums(const double2* __restrict__ hat, const long long* __restrict__ offsets,
-                                                   const long long* __restrict__ inds, double scale, double* __restrict__ ehat) {
+                                                   const long long* __restrict__ inds, const double* __restrict__ weights, double scale,
+                                                   double* __restrict__ ehat) {
   const int bin = blockIdx.x;
   double acc = 0.0;
   for (long long q = offsets[bin] + threadIdx.x; q < offsets[bin + 1]; q += 64) {
     const double2 v = hat[inds[q]];
-    acc += v.x * v.x + v.y * v.y;
+    acc += (weights ? weights[q] : 1.0) * (v.x * v.x + v.y * v.y);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -52,11 +54,17 @@ extern "C" int ins_spectrum_destroy(ins_spectrum_t* S) {
   (void)hipFree(S->hat);
   (void)hipFree(S->offsets);
   (void)hipFree(S->inds);
+  (void)hipFree(S->weights);
   delete S;
   return INS_OK;
 }
 
 extern "C" int ins_spectrum_create(const ins_grid_t* G, int nbin, const int64_t* offsets, const int64_t* inds, ins_spectrum_t** out) {
+  return ins_spectrum_create_weighted(G, nbin, offsets, inds, nullptr, out);
+}
+
+extern "C" int ins_spectrum_create_weighted(const ins_grid_t* G, int nbin, const int64_t* offsets, const int64_t* inds, const double* weights,
+                                            ins_spectrum_t** out) {
   INS_REQUIRE(G && offsets && inds && out && nbin >= 1, "bad argument");
   const GridDev& g = G->g;
   ins_spectrum* S = new ins_spectrum();
@@ -92,6 +100,8 @@ extern "C" int ins_spectrum_create(const ins_grid_t* G, int nbin, const int64_t*
             hipMalloc(&S->inds, std::max<long long>(nind, 1) * sizeof(long long)) == hipSuccess;
   if (ok) ok = hipMemcpy(S->offsets, off.data(), (nbin + 1) * sizeof(long long), hipMemcpyHostToDevice) == hipSuccess;
   if (ok && nind) ok = hipMemcpy(S->inds, pos.data(), nind * sizeof(long long), hipMemcpyHostToDevice) == hipSuccess;
+  if (ok && weights && nind)
+    ok = hipMalloc(&S->weights, nind * sizeof(double)) == hipSuccess && hipMemcpy(S->weights, weights, nind * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) {
     ins_spectrum_destroy(S);
     ins_set_error("spectrum: device allocation failed");
@@ -123,7 +133,7 @@ extern "C" int ins_spectrum_f64(ins_spectrum_t* S, const double* u, double* ehat
       hipLaunchKernelGGL(k_strip<3>, grid, block, 0, s, g, u + a * g.sc, S->real, S->np[0], S->np[1]);
     INS_LAUNCH_CHECK();
     INS_FFT_TRY(hipfftExecD2Z(S->plan, S->real, S->hat));
-    hipLaunchKernelGGL(k_shell_sums, dim3(S->nbin), dim3(64), 0, s, reinterpret_cast<const double2*>(S->hat), S->offsets, S->inds, S->scale, ehat);
+    hipLaunchKernelGGL(k_shell_sums, dim3(S->nbin), dim3(64), 0, s, reinterpret_cast<const double2*>(S->hat), S->offsets, S->inds, S->weights, S->scale, ehat);
     INS_LAUNCH_CHECK();
   }
   return INS_OK;

@@ -184,14 +184,19 @@ def spectral_stuff(setup, *, npoint=100, a=(1 + math.sqrt(5)) / 2):
 
 
 class _Spectrum:
-    def __init__(self, setup, inds):
+    def __init__(self, setup, inds, weights=None):
         self.setup, self.nbin = setup, len(inds)
         off = np.zeros(self.nbin + 1, dtype=np.int64)
         off[1:] = np.cumsum([len(i) for i in inds])
         flat = np.ascontiguousarray(np.concatenate(inds) if off[-1] else np.zeros(1), dtype=np.int64)
         self._handle = C.c_void_p()
-        _lib.call("ins_spectrum_create", setup.handle, self.nbin, off.ctypes.data_as(C.POINTER(C.c_int64)), flat.ctypes.data_as(C.POINTER(C.c_int64)),
-                  C.byref(self._handle))
+        if weights is None:
+            _lib.call("ins_spectrum_create", setup.handle, self.nbin, off.ctypes.data_as(C.POINTER(C.c_int64)),
+                      flat.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(self._handle))
+        else:
+            w = np.ascontiguousarray(np.concatenate(weights), dtype=np.float64)
+            _lib.call("ins_spectrum_create_weighted", setup.handle, self.nbin, off.ctypes.data_as(C.POINTER(C.c_int64)),
+                      flat.ctypes.data_as(C.POINTER(C.c_int64)), w.ctypes.data_as(_lib.c_double_p), C.byref(self._handle))
         self.ehat = torch.zeros(self.nbin, dtype=torch.float64, device=setup.device)
 
     def __call__(self, u):
@@ -214,6 +219,55 @@ def observespectrum(state, *, setup, npoint=100, a=(1 + math.sqrt(5)) / 2):
     st = spectral_stuff(setup, npoint=npoint, a=a)
     spec = _Spectrum(setup, st["inds"])
     return dict(ehat=state.map(lambda s: spec(s["u"]).cpu().numpy().copy()), κ=st["κ"])
+
+
+def get_scale_numbers(u, setup):
+    """Dimensional scale numbers (operators.jl:1558-1617): uavg, ϵ, η, λ, Reλ, L, τ, Re_int.  Follows the reference's formulas as written —
+    including its `uavg`, which sums ALL components' u² under each component's volume weights (D ⟨u_i u_i⟩ on a uniform grid)."""
+    from .operators import dissipation_from_strain
+
+    g = setup.grid
+    D = g.dimension
+    visc = 1.0 / setup.Re
+    dev = setup.device
+
+    def vec(v, b):
+        shape = [1] * D
+        shape[b] = len(v)
+        return torch.as_tensor(np.asarray(v, dtype=np.float64), device=dev).reshape(shape)
+
+    sl_u = tuple(slice(lo, hi) for lo, hi in g.Iu[0])  # the reference indexes every component with Iu[1]
+    sl_p = tuple(slice(lo, hi) for lo, hi in g.Ip)
+    uavg2 = 0.0
+    for a in range(D):
+        Ωu = 1.0
+        for b in range(D):
+            Ωu = Ωu * vec(g.Δu[b] if a == b else g.Δ[b], b)
+        Ωu = Ωu.expand(g.N)
+        uavg2 += float(((u[sl_u] ** 2) * Ωu[sl_u].unsqueeze(-1)).sum() / Ωu[sl_u].sum())
+    uavg = math.sqrt(uavg2)
+    Ω = 1.0
+    for b in range(D):
+        Ω = Ω * vec(g.Δ[b], b)
+    Ω = Ω.expand(g.N)
+    ϵf = dissipation_from_strain(u, setup)
+    ϵ = float((Ω[sl_p] * ϵf[sl_p]).sum() / Ω[sl_p].sum())
+    η = (visc**3 / ϵ) ** 0.25
+    λ = math.sqrt(5 * visc / ϵ) * uavg
+    Reλ = λ * uavg / math.sqrt(3.0) / visc
+    # L = 3π / (2 uavg²) Σ_{k ≠ 0} E(k) / |k| over the retained non-negative wavenumbers (assert_uniform_periodic in the reference)
+    from .boundary_conditions import PeriodicBC
+
+    if not all(isinstance(bc, PeriodicBC) for side in setup.boundary_conditions for bc in side):
+        raise ValueError("Scale numbers: the integral length scale needs a uniform periodic grid")
+    K = tuple(n // 2 for n in g.Np)
+    ks = np.meshgrid(*[np.arange(k, dtype=np.float64) for k in K], indexing="ij")
+    kk = np.sqrt(sum(x**2 for x in ks)).reshape(-1, order="F")
+    idx = np.arange(1, kk.size, dtype=np.int64)  # without k = (0, ..., 0)
+    spec = _Spectrum(setup, [idx], [1.0 / kk[idx]])
+    L = 3 * math.pi / 2 / uavg**2 * float(spec(u)[0])
+    # (string keys: Python folds the identifier ϵ to ε, the reference's field name is the lunate form)
+    return {"uavg": uavg, "ϵ": ϵ, "η": η, "λ": λ, "Reλ": Reλ, "L": L, "τ": L / uavg, "Re_int": L * uavg / visc}
 
 
 # ------------------------------------------------------------------------------------ VTK output (processors.jl:199-285)

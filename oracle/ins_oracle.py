@@ -1607,3 +1607,43 @@ def observespectrum(u, setup, npoint=100, a=(1 + math.sqrt(5)) / 2):  # processo
         e = e + np.abs(half) ** 2 / (2 * float(np.prod(g.Np)) ** 2)
     e = e.reshape(-1, order="F")
     return np.array([e[i].sum() for i in inds]), kap
+
+
+def get_scale_numbers(u, setup):  # operators.jl:1558-1617, as written (its uavg sums all components under each component's weights)
+    g = setup.grid
+    D = g.D
+    visc = 1.0 / setup.Re
+
+    def outer(vs):
+        w = 1.0
+        for b, v in enumerate(vs):
+            shape = [1] * D
+            shape[b] = len(v)
+            w = w * np.asarray(v).reshape(shape)
+        return np.broadcast_to(w, g.N)
+
+    Om = outer([g.dx[b] for b in range(D)])
+    uavg2 = 0.0
+    for a in range(D):
+        Omu = outer([g.dxu[b] if a == b else g.dx[b] for b in range(D)])
+        field = u**2 * Omu[..., None]
+        uavg2 += field[_sl(g.Iu[0])].sum() / Omu[_sl(g.Iu[0])].sum()
+    uavg = math.sqrt(uavg2)
+    eps = dissipation_from_strain(u, setup)
+    eps = (Om * eps)[_sl(g.Ip)].sum() / Om[_sl(g.Ip)].sum()
+    eta = (visc**3 / eps) ** 0.25
+    lam = math.sqrt(5 * visc / eps) * uavg
+    Relam = lam * uavg / math.sqrt(3.0) / visc
+    assert_uniform_periodic(setup, "Scale numbers")
+    K = tuple(n // 2 for n in g.Np)
+    up = u[_sl(g.Ip)]
+    uhat = np.fft.fftn(up, axes=tuple(range(D)))[tuple(slice(0, k) for k in K)]
+    e = np.abs(uhat) ** 2 / (2 * float(np.prod(g.Np)) ** 2)
+    ks = np.meshgrid(*[np.arange(k, dtype=np.float64) for k in K], indexing="ij")
+    kk = np.sqrt(sum(x**2 for x in ks))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        e = e / kk[..., None]
+    e = e.sum(axis=-1)
+    e[(0,) * D] = 0.0
+    L = 3 * math.pi / 2 / uavg**2 * e.sum()
+    return dict(uavg=uavg, eps=eps, eta=eta, lam=lam, Relam=Relam, L=L, tau=L / uavg, Re_int=L * uavg / visc)

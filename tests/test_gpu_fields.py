@@ -267,3 +267,15 @@ def test_processors_drive_observers_and_write_vtk(ins, oracle, tmp_path):
     assert vel.shape == (16 * 12 * 8, 3) and relmax(vel[:, 1].reshape((16, 12, 8), order="F"), up[sl][..., 1]) < 1e-9
     assert relmax(decode("0")[:, 0].reshape((16, 12, 8), order="F"), up[sl][..., 0]) < 1e-9
     assert decode("x").shape == (16, 1) and decode("vorticity").shape == (16 * 12 * 8, 3)
+
+
+@pytest.mark.parametrize("geom", ["periodic2d", "periodic3d"])
+def test_scale_numbers_match_oracle(ins, oracle, geom):
+    o = oracle
+    so = GEOMS[geom](o)
+    sp = mirror(ins, so, o)
+    u_h = o.random_field(so, kp=3, seed=2)
+    ref = o.get_scale_numbers(u_h, so)
+    got = ins.get_scale_numbers(ins.from_numpy(sp, u_h), sp)
+    for a, b in (("uavg", "uavg"), ("ϵ", "eps"), ("η", "eta"), ("λ", "lam"), ("Reλ", "Relam"), ("L", "L"), ("τ", "tau"), ("Re_int", "Re_int")):
+        assert got[a] == pytest.approx(ref[b], rel=1e-11), a
