@@ -224,8 +224,11 @@ def observespectrum(state, *, setup, npoint=100, a=(1 + math.sqrt(5)) / 2):
 def get_scale_numbers(u, setup):
     """Dimensional scale numbers (operators.jl:1558-1617): uavg, ϵ, η, λ, Reλ, L, τ, Re_int.  Follows the reference's formulas as written —
     including its `uavg`, which sums ALL components' u² under each component's volume weights (D ⟨u_i u_i⟩ on a uniform grid)."""
+    from .boundary_conditions import PeriodicBC
     from .operators import dissipation_from_strain
 
+    if not all(isinstance(bc, PeriodicBC) for side in setup.boundary_conditions for bc in side):
+        raise ValueError("Scale numbers: the integral length scale needs a uniform periodic grid")  # assert_uniform_periodic, utils.jl:1-13
     g = setup.grid
     D = g.dimension
     visc = 1.0 / setup.Re
@@ -256,10 +259,6 @@ def get_scale_numbers(u, setup):
     λ = math.sqrt(5 * visc / ϵ) * uavg
     Reλ = λ * uavg / math.sqrt(3.0) / visc
     # L = 3π / (2 uavg²) Σ_{k ≠ 0} E(k) / |k| over the retained non-negative wavenumbers (assert_uniform_periodic in the reference)
-    from .boundary_conditions import PeriodicBC
-
-    if not all(isinstance(bc, PeriodicBC) for side in setup.boundary_conditions for bc in side):
-        raise ValueError("Scale numbers: the integral length scale needs a uniform periodic grid")
     K = tuple(n // 2 for n in g.Np)
     ks = np.meshgrid(*[np.arange(k, dtype=np.float64) for k in K], indexing="ij")
     kk = np.sqrt(sum(x**2 for x in ks)).reshape(-1, order="F")

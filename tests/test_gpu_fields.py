@@ -279,3 +279,24 @@ def test_scale_numbers_match_oracle(ins, oracle, geom):
     got = ins.get_scale_numbers(ins.from_numpy(sp, u_h), sp)
     for a, b in (("uavg", "uavg"), ("ϵ", "eps"), ("η", "eta"), ("λ", "lam"), ("Reλ", "Relam"), ("L", "L"), ("τ", "tau"), ("Re_int", "Re_int")):
         assert got[a] == pytest.approx(ref[b], rel=1e-11), a
+
+
+def test_error_behaviour_of_the_field_operators(ins, oracle):
+    """Same failure modes as the reference: eig2 is 3-D only (operators.jl:1477 `@assert`), fields must have the setup's shape and layout,
+    a temperature field needs a temperature equation, scale numbers need a periodic box (utils.jl:1-13)."""
+    o = oracle
+    s2 = mirror(ins, GEOMS["periodic2d"](o), o)
+    u2 = ins.vectorfield(s2)
+    with pytest.raises(ins.INSHipError, match="3D"):
+        ins.eig2field(u2, s2)
+    with pytest.raises(ValueError, match="shape"):
+        ins.vorticity_(ins.vectorfield(s2), u2, s2)  # 2-D vorticity is a scalar field
+    with pytest.raises(ValueError):
+        ins.timestep_(ins.RKMethods.RK44(), ins.create_stepper(ins.RKMethods.RK44(), setup=s2, psolver=ins.psolver_spectral(s2), u=u2, temp=ins.scalarfield(s2)), 1e-3,
+                      cache=ins.ode_method_cache(ins.RKMethods.RK44(), s2))
+    sd = mirror(ins, GEOMS["dirichlet2d"](o), o)
+    with pytest.raises(ValueError, match="periodic"):
+        ins.get_scale_numbers(ins.vectorfield(sd) + 1.0, sd)
+    with pytest.raises(ValueError, match="periodic"):
+        ins.temperature_equation(Pr=1.0, Ra=1.0, Ge=1.0, boundary_conditions=((ins.PeriodicBC(), ins.DirichletBC()),) * 2) and ins.Setup(
+            x=(np.linspace(0, 1, 9),) * 2, temperature=ins.temperature_equation(Pr=1.0, Ra=1.0, Ge=1.0, boundary_conditions=((ins.PeriodicBC(), ins.DirichletBC()),) * 2))
