@@ -265,7 +265,7 @@ class HipSlabKernels:
             prof.append((e0, e1, b))
 
     # stage_momentum_corr(part=...) and xfwd_planes exist: SlabStepper overlaps exchanges with them (INS_SLAB_NO_SPLIT=1: A/B switch)
-    splits_stage = not bool(__import__("os").environ.get("INS_SLAB_NO_SPLIT"))
+    splits_stage = not bool(os.environ.get("INS_SLAB_NO_SPLIT"))
 
     def wide_stage_kernel(self):
         """The 64-outputs-per-wavefront stage kernel runs on this slab: the stencil input can then be a term of the combination."""
