@@ -54,3 +54,20 @@ def test_actuator_2d():
     r = load("Actuator2D").main(n=12, tend=1.0, dt=0.05, verbose=False)
     assert r["maxdiv"] < 1e-10 and r["wake"] < r["free"]  # the disk slows the flow behind it
     assert all(np.isfinite(f).all() for f in r["fields"].values())
+
+
+def test_kolmogorov_2d():
+    r = load("Kolmogorov2D").main(n=64, tend=0.1, dt=1e-3, verbose=False)
+    E = [e for _, e in r["energy"]]
+    assert E[-1] > E[0] and r["forced_mode"] > 0.05 and r["maxdiv"] < 1e-11  # the body force feeds the sin(8πy) mode
+
+
+def test_shear_layer_2d():
+    r = load("ShearLayer2D").main(n=64, tend=0.3, dt=0.01, verbose=False)
+    # ½∫|u|² over the (2π)² box with |u| ≈ 1 outside the layers; layers of thickness π/15: |ω| ~ 1/d ≈ 4.8
+    assert r["maxdiv"] < 1e-11 and 0.3 < r["E"] / (4 * np.pi**2) < 0.55 and r["hist"][-1][1] > 2.0
+
+
+def test_planar_mixing_2d():
+    r = load("PlanarMixing2D").main(n=16, tend=2.0, verbose=False)
+    assert r["t"] == pytest.approx(2.0) and r["maxdiv"] < 1e-9 and r["ulo"] < 1.0 < r["uhi"] and np.isfinite(r["vmax"])
