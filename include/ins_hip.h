@@ -173,6 +173,10 @@ int ins_combine_f64(const ins_grid_t* grid, const double* base, double* out, int
  * for the recorded events, returns the accumulated kernel milliseconds and launch count, and resets. */
 int ins_rk_profile_enable(ins_rk_t* rk, int enable);
 int ins_rk_profile_read(ins_rk_t* rk, double* momentum_ms, int64_t* momentum_launches);
+/* Steady body force (setup.bodyforce with issteadybodyforce, setup.jl:25-32; operators.jl:873-880 `F .+= bodyforce`): a DEVICE vector
+ * field the caller keeps alive, added to every stage force inside the stage kernels' combination (one more term: no extra pass).
+ * NULL removes it.  With a force the steps of ins_rk_steps_f64 are not chained. */
+int ins_rk_set_bodyforce(ins_rk_t* rk, const double* force);
 int ins_rk_pressure(const ins_rk_t* rk, double** p);
 int ins_rk_stage_force(const ins_rk_t* rk, int i, double** ku);
 

@@ -90,6 +90,7 @@ SIGNATURES = {
     "ins_combine_f64": (C.c_int, [vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), vp]),
     "ins_rk_profile_enable": (C.c_int, [vp, C.c_int]),
     "ins_rk_profile_read": (C.c_int, [vp, c_double_p, C.POINTER(C.c_int64)]),
+    "ins_rk_set_bodyforce": (C.c_int, [vp, vp]),
     "ins_rk_pressure": (C.c_int, [vp, C.POINTER(vp)]),
     "ins_rk_stage_force": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
     "ins_stage_momentum_f64": (C.c_int, [vp, C.c_double, vp, vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), C.c_double, vp]),

@@ -145,7 +145,8 @@ struct ins_rk {
   std::vector<double*> ku;
   double* p = nullptr;
   double* ub[2] = {nullptr, nullptr};  // ping-pong stage velocities of the fused path
-  std::vector<double*> vb;             // all uncorrected stage velocities V_0..V_{s-2} (stage-velocity basis, ins_rk.hip)
+  std::vector<double*> vb;
+  const double* force = nullptr;  // steady body force field (caller-owned), ins_rk_set_bodyforce             // all uncorrected stage velocities V_0..V_{s-2} (stage-velocity basis, ins_rk.hip)
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;  // (start, stop) pairs around momentum launches
 };

@@ -152,6 +152,12 @@ extern "C" int ins_rk_pressure(const ins_rk_t* rk, double** p) {
   return INS_OK;
 }
 
+extern "C" int ins_rk_set_bodyforce(ins_rk_t* rk, const double* force) {
+  INS_REQUIRE(rk, "null argument");
+  rk->force = force;
+  return INS_OK;
+}
+
 extern "C" int ins_rk_stage_force(const ins_rk_t* rk, int i, double** ku) {
   INS_REQUIRE(rk && ku, "null argument");
   INS_REQUIRE(i >= 0 && i < rk->nstage, "stage index out of range");
@@ -240,6 +246,14 @@ static int rk_step_fused_periodic(ins_rk* rk, double visc, double* u, double dt,
       for (int i2 = i + 1; i2 < ns; ++i2)
         if (rk->A[i2 * ns + i] != 0.0) epi.write_k = 1;
     }
+    if (rk->force) {  // steady body force (operators.jl:873-880): k_j = F_j + f, so f enters with Δt A[i,i] in the stage-velocity basis
+      double cf = dt * rk->A[i * ns + i];  // (the V_m already hold their share) and with Δt Σ_{j<=i} A[i,j] in the k-basis (ku[j] = F_j)
+      if (!vbasis)
+        for (int j = 0; j < i; ++j) cf += dt * rk->A[i * ns + j];
+      epi.coef[epi.n] = cf;
+      epi.k[epi.n] = rk->force;
+      ++epi.n;
+    }
     epi.coef_self = dt * rk->A[i * ns + i];
     epi.ustart = (i == 0) ? nullptr : (raw_in ? rk->ustart : u);  // raw_in: the corrected start field lives in the cache array
     epi.ustar = out;
@@ -276,7 +290,7 @@ extern "C" int ins_rk_steps_f64(ins_rk_t* rk, double visc, double* u, double t, 
   const GridDev& g = G->g;
   static const bool no_fuse = getenv("INS_DISABLE_FUSED_RK") != nullptr, no_corr = getenv("INS_DISABLE_INKERNEL_CORR") != nullptr,
                     no_chain = getenv("INS_DISABLE_STEP_CHAIN") != nullptr;
-  bool ok = !no_fuse && !no_corr && !no_chain && g.D == 3 && G->all_periodic && G->all_dof && rk->ps->kind == POISSON_SPECTRAL && ins_fast3d_supported(G) &&
+  bool ok = !no_fuse && !no_corr && !no_chain && !rk->force && g.D == 3 && G->all_periodic && G->all_dof && rk->ps->kind == POISSON_SPECTRAL && ins_fast3d_supported(G) &&
             ins_flux64_supported(G) && G->uniform_exact && rk->nstage > 1 && g.N[0] >= 8 && g.N[1] >= 8 && g.N[2] >= 8;  // = in-kernel correction runs
   if (!ok || nsteps < 2) {
     for (int n = 0; n < nsteps; ++n) {
@@ -343,6 +357,13 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
         epi.k[epi.n] = rk->ku[j];
         ++epi.n;
       }
+      if (rk->force) {
+        double cf = 0.0;
+        for (int j = 0; j <= i; ++j) cf += dt * rk->A[i * ns + j];
+        epi.coef[epi.n] = cf;
+        epi.k[epi.n] = rk->force;
+        ++epi.n;
+      }
       epi.coef_self = dt * rk->A[i * ns + i];
       epi.ustart = (i == 0) ? nullptr : u;
       epi.ustar = out;
@@ -393,6 +414,13 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
       if (coef == 0.0) continue;
       cb.coef[cb.n] = coef;
       cb.k[cb.n] = rk->ku[j];
+      ++cb.n;
+    }
+    if (rk->force) {
+      double cf = 0.0;
+      for (int j = 0; j <= i; ++j) cf += dt * rk->A[i * ns + j];
+      cb.coef[cb.n] = cf;
+      cb.k[cb.n] = rk->force;
       ++cb.n;
     }
     const unsigned nblk = (unsigned)std::min<long long>((nvec / 2 + 255) / 256, 8192);

@@ -213,6 +213,14 @@ def combine_(out, base, coefs, ks, setup, vector=True):
     return out
 
 
+def _native_force(cache, setup):
+    """Hand a steady body force to the native stage loop (ins_rk_set_bodyforce); the field lives in `setup`."""
+    f = setup.bodyforce if (setup.bodyforce is not None and setup.issteadybodyforce) else None
+    if getattr(cache, "_force", None) is not f:
+        _lib.call("ins_rk_set_bodyforce", cache.handle, setup.ptr(f, True) if f is not None else None)
+        cache._force = f
+
+
 def _host_driven(setup, temp):
     """True when the stage loop must run on the host: a user callback or an extra equation sits between the kernels."""
     return temp is not None or setup.closure_model is not None or (setup.bodyforce is not None and not setup.issteadybodyforce) or setup.needs_bc_planes
@@ -323,9 +331,10 @@ def timesteps_(method, stepper, Δt, nsteps, *, θ=None, cache):
     The stepper's `u` is valid on entry and on return (intermediate steps are not observable, as inside the reference's loop
     without processors)."""
     setup, psolver = stepper.setup, stepper.psolver
-    if nsteps >= 1 and not isinstance(method, LMWray3) and not _host_driven(setup, stepper.temp) and setup.bodyforce is None:
+    if nsteps >= 1 and not isinstance(method, LMWray3) and not _host_driven(setup, stepper.temp):
         if cache.psolver is not psolver:
             raise ValueError("cache was created for a different psolver")
+        _native_force(cache, setup)
         _lib.call("ins_rk_steps_f64", cache.handle, 1.0 / setup.Re, setup.ptr(stepper.u, True), float(stepper.t), float(Δt), int(nsteps), setup.stream)
         return create_stepper(method, setup=setup, psolver=psolver, u=stepper.u, temp=None, t=stepper.t + nsteps * method.c[-1] * Δt, n=stepper.n + nsteps)
     for _ in range(nsteps):
@@ -346,7 +355,8 @@ def timestep_(method, stepper, Δt, *, θ=None, cache):
         return _timestep_lmwray3_(method, stepper, Δt, cache, θ)
     if cache.psolver is not psolver:
         raise ValueError("cache was created for a different psolver")
-    if not _host_driven(setup, temp) and setup.bodyforce is None:
+    if not _host_driven(setup, temp):
+        _native_force(cache, setup)
         _lib.call("ins_rk_step_f64", cache.handle, 1.0 / setup.Re, setup.ptr(u, True), float(t), float(Δt), None, setup.stream)
         return create_stepper(method, setup=setup, psolver=psolver, u=u, temp=None, t=stepper.t + method.c[-1] * Δt, n=n + 1)
     # host-driven stage loop (time-dependent boundary data, body force, closure model, temperature equation)

@@ -233,8 +233,11 @@ function timestep!(method::ExplicitRungeKuttaMethod, stepper, Δt; θ = nothing,
     (; setup, psolver, u, temp, t, n) = stepper
     # The fused native step is valid only without closure model / temperature / unsteady body force (SURVEY.md §8b caveat);
     # otherwise fall back to the operator-level methods above so user callbacks can run between kernels.
-    (isnothing(setup.closure_model) && isnothing(temp) && isnothing(setup.bodyforce)) ||
+    # A steady body force rides inside the native stage kernels (ins_rk_set_bodyforce: one more term of the stage combination).
+    (isnothing(setup.closure_model) && isnothing(temp) && (isnothing(setup.bodyforce) || setup.issteadybodyforce)) ||
         return invoke(timestep!, Tuple{ExplicitRungeKuttaMethod,Any,Any}, method, stepper, Δt; θ, cache)
+    check(ccall((:ins_rk_set_bodyforce, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), cache.h,
+                isnothing(setup.bodyforce) ? Ptr{Float64}(C_NULL) : pointer(setup.bodyforce)))
     check(ccall((:ins_rk_step_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Cdouble, Cdouble, Ptr{Ptr{Float64}}, Ptr{Cvoid}),
                 cache.h, 1 / setup.Re, pointer(u), t, Δt, C_NULL, stream()))
     IncompressibleNavierStokes.create_stepper(method; setup, psolver, u, temp, t = t + method.c[end] * Δt, n = n + 1)

@@ -300,3 +300,47 @@ def test_error_behaviour_of_the_field_operators(ins, oracle):
     with pytest.raises(ValueError, match="periodic"):
         ins.temperature_equation(Pr=1.0, Ra=1.0, Ge=1.0, boundary_conditions=((ins.PeriodicBC(), ins.DirichletBC()),) * 2) and ins.Setup(
             x=(np.linspace(0, 1, 9),) * 2, temperature=ins.temperature_equation(Pr=1.0, Ra=1.0, Ge=1.0, boundary_conditions=((ins.PeriodicBC(), ins.DirichletBC()),) * 2))
+
+
+@pytest.mark.parametrize("geom,method", [("periodic3d_exact", "RK44"), ("periodic3d_exact", "Wray3"), ("periodic3d", "RK44"), ("dirichlet3d", "RK44"),
+                                         ("periodic2d", "RK44"), ("mixed3d", "SSP33")])
+def test_native_stage_loops_with_a_steady_body_force(ins, oracle, geom, method):
+    """A steady body force rides inside the native stage kernels' combination (ins_rk_set_bodyforce): fully fused periodic path with the
+    stage-velocity basis (exact box), the 62-wide / masked fused branches, the generic 2-D loop — against the oracle's stage loop."""
+    o = oracle
+    if geom == "periodic3d_exact":
+        so0 = fx.setup_periodic(o, (128, 16, 8))  # spacings are exact binary fractions: in-kernel correction + stage-velocity basis run
+    else:
+        so0 = GEOMS[geom](o)
+    D = so0.grid.D
+    lo = [2 if isinstance(so0.boundary_conditions[a][0], o.PressureBC) else 1 for a in range(D)]
+    xin = [so0.grid.x[a][lo[a]:-1] for a in range(D)]
+
+    def force(a, x, y, *zt):
+        return (a == 0) * (1.0 + np.sin(2 * np.pi * y)) + (a == 1) * 0.3 * np.cos(2 * np.pi * x) + 0 * sum(zt[:-1], 0.0)
+
+    so = o.make_setup_ext(xin, so0.boundary_conditions, Re=so0.Re, bodyforce=force, issteadybodyforce=True)
+    sp = ins.Setup(x=xin, boundary_conditions=mirror(ins, so0, o).boundary_conditions, Re=so0.Re, bodyforce=force, issteadybodyforce=True)
+    ps_h, ps_d = o.default_psolver(so), ins.default_psolver(sp)
+    u0 = o.project(o.apply_bc_u(0.1 * fx.randn_field(so.grid.N + (D,), 11), 0.0, so), so, ps_h)
+    o.apply_bc_u_(u0, 0.0, so)
+    mo = getattr(o, method)()
+    m = getattr(ins.RKMethods, method)()
+    st = dict(setup=so, psolver=ps_h, u=u0.copy(order="F"), temp=None, t=0.0, n=0)
+    cache = o.ode_method_cache_ext(mo, so)
+    for _ in range(3):
+        st = o.timestep_ext_(mo, st, 2e-3, cache)
+    (u, _, t), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 6e-3), ustart=ins.from_numpy(sp, u0), method=m, psolver=ps_d, Δt=2e-3)
+    # Compare the degrees of freedom and the boundary / ghost values next to them.  Beyond a Dirichlet wall the normal component has one
+    # more storage slot that no operator reads and no boundary condition writes; the reference's broadcasts (`F .+= bodyforce`,
+    # `u .+= Δt A k`) drag the force through it, the fused stage kernels leave it alone.
+    g = so.grid
+    mask = np.zeros(g.N + (D,), dtype=bool)
+    for a in range(D):
+        mask[tuple(slice(max(lo_ - 1, 0), min(hi_ + 1, n_)) for (lo_, hi_), n_ in zip(g.Iu[a], g.N)) + (a,)] = True
+    got = ins.to_numpy(u)
+    assert rell2(got[mask], st["u"][mask]) < STEP_TOL
+    # and the force really acted: the same run without it differs
+    sp0 = ins.Setup(x=xin, boundary_conditions=sp.boundary_conditions, Re=so0.Re)
+    (v, _, _), _ = ins.solve_unsteady(setup=sp0, tlims=(0.0, 6e-3), ustart=ins.from_numpy(sp0, u0), method=m, psolver=ins.default_psolver(sp0), Δt=2e-3)
+    assert rell2(ins.to_numpy(v), st["u"]) > 1e-4
