@@ -211,6 +211,9 @@ int ins_gravity_f64(const ins_grid_t* grid, int gdir, double a2, const double* t
 int ins_smagtensor_f64(const ins_grid_t* grid, double theta, const double* u, double* sigma, void* stream);
 /* divoftensor!(s, σ, setup)                operators.jl:1203-1236 (writes Iu[α]) */
 int ins_divoftensor_f64(const ins_grid_t* grid, const double* sigma, double* s, void* stream);
+/* tensorbasis!(B, V, u, setup)            tensorbasis.jl:16-72 (writes Ip): nb, nv = 3, 2 (2-D) or 11, 5 (3-D).  B is nb·D·D scalar fields,
+ * element (a, b) of basis tensor ib at field index ib·D·D + a + D·b (the SMatrix' column-major order); V is nv scalar fields. */
+int ins_tensorbasis_f64(const ins_grid_t* grid, const double* u, double* B, double* V, void* stream);
 /* ins_combine_f64 for scalar fields (tempstart + Σ Δt A[i,j] ktemp[j], step_explicit_runge_kutta.jl:39-44) */
 int ins_combine_scalar_f64(const ins_grid_t* grid, const double* base, double* out, int nterms, const double* coefs,
                            const double* const* ks, void* stream);

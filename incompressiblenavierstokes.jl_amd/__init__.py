@@ -39,6 +39,9 @@ from .operators import (
     interpolate_ω_p_,
     smagorinsky_closure,
     smagtensor_,
+    tensorbasis,
+    tensorbasis_,
+    tensorbasis_matrices,
     tensorfield,
     vorticity,
     vorticity_,

@@ -241,6 +241,98 @@ __global__ __launch_bounds__(256) void k_gradient_op(GridDev g, BoxMap L, double
   gradient_result<D, OP>(g, G, I, c, par, out);
 }
 
+// tensorbasis!: symmetry tensor basis B[1..nb] and invariants V[1..nv] of Silvis et al. (tensorbasis.jl:16-72), nb, nv = 3, 2 in 2-D and
+// 11, 5 in 3-D.  Stored as scalar fields: B[(ib * D*D + a + D*b) * ncell + c] (the SMatrix' column-major element order), V[iv * ncell + c].
+template <int D>
+struct Mat {
+  double m[D][D];
+};
+template <int D>
+__device__ __forceinline__ Mat<D> mmul(const Mat<D>& x, const Mat<D>& y) {
+  Mat<D> r;
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = 0; b < D; ++b) {
+      double v = 0.0;
+#pragma unroll
+      for (int q = 0; q < D; ++q) v += x.m[a][q] * y.m[q][b];
+      r.m[a][b] = v;
+    }
+  return r;
+}
+template <int D>
+__device__ __forceinline__ Mat<D> madd(const Mat<D>& x, const Mat<D>& y, double sy) {
+  Mat<D> r;
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = 0; b < D; ++b) r.m[a][b] = x.m[a][b] + sy * y.m[a][b];
+  return r;
+}
+template <int D>
+__device__ __forceinline__ double mtrace(const Mat<D>& x) {
+  double t = 0.0;
+#pragma unroll
+  for (int a = 0; a < D; ++a) t += x.m[a][a];
+  return t;
+}
+template <int D>
+__device__ __forceinline__ void put(double* __restrict__ B, const GridDev& g, long long c, int ib, const Mat<D>& x) {
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = 0; b < D; ++b) B[(long long)(ib * D * D + a + D * b) * g.sc + c] = x.m[a][b];
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_tensorbasis(GridDev g, BoxMap L, const double* __restrict__ u, double* __restrict__ B, double* __restrict__ V) {
+  INS_BOX_INDEX(g.ip_lo[0], g.ip_lo[1], g.ip_lo[2], g.ip_hi[0], g.ip_hi[1]);
+  double G[D][D];
+  gradu<D>(g, u, c, I, G);
+  Mat<D> S, R, Id;
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = 0; b < D; ++b) {
+      S.m[a][b] = (G[a][b] + G[b][a]) / 2;
+      R.m[a][b] = (G[a][b] - G[b][a]) / 2;
+      Id.m[a][b] = a == b ? 1.0 : 0.0;
+    }
+  const Mat<D> SR = mmul<D>(S, R), RS = mmul<D>(R, S);
+  put<D>(B, g, c, 0, Id);
+  put<D>(B, g, c, 1, S);
+  put<D>(B, g, c, 2, madd<D>(SR, RS, -1.0));
+  if (D == 2) {
+    double ss = 0.0, rr = 0.0;  // dot(S, S), dot(R, R)                                   tensorbasis.jl:49-50
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = 0; b < D; ++b) {
+        ss += S.m[a][b] * S.m[a][b];
+        rr += R.m[a][b] * R.m[a][b];
+      }
+    V[c] = ss;
+    V[g.sc + c] = rr;
+  } else {
+    const Mat<D> SS = mmul<D>(S, S), RR = mmul<D>(R, R);
+    put<D>(B, g, c, 3, SS);
+    put<D>(B, g, c, 4, RR);
+    put<D>(B, g, c, 5, madd<D>(mmul<D>(SS, R), mmul<D>(R, SS), -1.0));           // S S R - R S S
+    put<D>(B, g, c, 6, madd<D>(mmul<D>(S, RR), mmul<D>(RR, S), 1.0));            // S R R + R R S
+    put<D>(B, g, c, 7, madd<D>(mmul<D>(RS, RR), mmul<D>(RR, SR), -1.0));         // R S R R - R R S R
+    put<D>(B, g, c, 8, madd<D>(mmul<D>(SR, SS), mmul<D>(SS, RS), -1.0));         // S R S S - S S R S
+    const Mat<D> SSRR = mmul<D>(SS, RR);
+    put<D>(B, g, c, 9, madd<D>(SSRR, mmul<D>(RR, SS), 1.0));                     // S S R R + R R S S
+    put<D>(B, g, c, 10, madd<D>(mmul<D>(R, SSRR), mmul<D>(mmul<D>(RR, SS), R), -1.0));  // R S S R R - R R S S R
+    V[c] = mtrace<D>(SS);
+    V[g.sc + c] = mtrace<D>(RR);
+    V[2 * g.sc + c] = mtrace<D>(mmul<D>(SS, S));
+    V[3 * g.sc + c] = mtrace<D>(mmul<D>(S, RR));
+    V[4 * g.sc + c] = mtrace<D>(SSRR);
+  }
+}
+
 // 3-D: a 64x4 tile marches through a z-chunk with a ring of three (tile + 1 halo) planes of u in LDS.  The ~40 neighbour values a
 // cell needs then come from LDS; with one global load per neighbour the kernel was bound by L2 bandwidth (320 B/cell out of L2 for
 // 32 algorithmic bytes: 0.32 ms at 256^3); the ring brings 3 x 6 x 66 / 256 = 4.6 loads per cell and plane.
@@ -580,5 +672,13 @@ extern "C" int ins_divoftensor_f64(const ins_grid_t* G, const double* sig, doubl
   const GridDev& g = G->g;
   Launch3 l = box_launch(g.N[0], g.N[1], g.D == 3 ? g.N[2] : 1);
   INS_LAUNCH_D(k_divoftensor, l, as_stream(stream), sig, s);
+  return INS_OK;
+}
+
+extern "C" int ins_tensorbasis_f64(const ins_grid_t* G, const double* u, double* B, double* V, void* stream) {
+  INS_REQUIRE(G && u && B && V, "null argument");
+  const GridDev& g = G->g;
+  Launch3 l = ip_launch(g);
+  INS_LAUNCH_D(k_tensorbasis, l, as_stream(stream), u, B, V);
   return INS_OK;
 }

@@ -395,3 +395,28 @@ def smagorinsky_closure(setup):
         return divoftensor_(s, σ, setup)
 
     return closure
+
+
+# ------------------------------------------------------------------------------------ tensor basis
+def tensorbasis_(B, V, u, setup):
+    """tensorbasis.jl:16-28.  `B`: N + (nb·D·D,) with element (a, b) of tensor ib at ib·D·D + a + D·b; `V`: N + (nv,)."""
+    D = setup.grid.dimension
+    nb, nv = (3, 2) if D == 2 else (11, 5)
+    _lib.call("ins_tensorbasis_f64", setup.handle, setup.ptr(u, True), setup.ptr(B, nb * D * D), setup.ptr(V, nv), setup.stream)
+    return B, V
+
+
+def tensorbasis(u, setup):
+    """Compute symmetry tensor basis B[1]..B[nb] and invariants V[1]..V[nv] (tensorbasis.jl:1-10): returns `(B, V)` with
+    `B.reshape(N + (nb, D, D))[..., ib, b, a]` = element (a, b) of tensor ib (use `tensorbasis_matrices` for that view)."""
+    from .setup import _alloc
+
+    D = setup.grid.dimension
+    nb, nv = (3, 2) if D == 2 else (11, 5)
+    return tensorbasis_(_alloc(setup, setup.grid.N + (nb * D * D,)), _alloc(setup, setup.grid.N + (nv,)), u, setup)
+
+
+def tensorbasis_matrices(B, setup):
+    """View of `B` as N + (nb, D, D) with [..., ib, a, b] = element (a, b)."""
+    D = setup.grid.dimension
+    return B.reshape(tuple(setup.grid.N) + (-1, D, D)).transpose(-1, -2)

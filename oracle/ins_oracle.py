@@ -1647,3 +1647,27 @@ def get_scale_numbers(u, setup):  # operators.jl:1558-1617, as written (its uavg
     e[(0,) * D] = 0.0
     L = 3 * math.pi / 2 / uavg**2 * e.sum()
     return dict(uavg=uavg, eps=eps, eta=eta, lam=lam, Relam=Relam, L=L, tau=L / uavg, Re_int=L * uavg / visc)
+
+
+def tensorbasis(u, setup):  # tensorbasis.jl:16-72; returns B: N + (nb, D, D), V: N + (nv,)
+    g = setup.grid
+    D = g.D
+    G = gradu(u, setup)
+    S = (G + np.swapaxes(G, -1, -2)) / 2
+    R = (G - np.swapaxes(G, -1, -2)) / 2
+    Id = np.broadcast_to(np.eye(D), S.shape)
+    tr = lambda X: np.trace(X, axis1=-2, axis2=-1)
+    if D == 2:
+        Bs = [Id, S, S @ R - R @ S]
+        Vs = [np.sum(S * S, axis=(-1, -2)), np.sum(R * R, axis=(-1, -2))]
+    else:
+        Bs = [Id, S, S @ R - R @ S, S @ S, R @ R, S @ S @ R - R @ S @ S, S @ R @ R + R @ R @ S, R @ S @ R @ R - R @ R @ S @ R,
+              S @ R @ S @ S - S @ S @ R @ S, S @ S @ R @ R + R @ R @ S @ S, R @ S @ S @ R @ R - R @ R @ S @ S @ R]
+        Vs = [tr(S @ S), tr(R @ R), tr(S @ S @ S), tr(S @ R @ R), tr(S @ S @ R @ R)]
+    B = np.zeros(g.N + (len(Bs), D, D))
+    V = np.zeros(g.N + (len(Vs),))
+    for i, b in enumerate(Bs):
+        B[_sl(g.Ip) + (i,)] = b
+    for i, v in enumerate(Vs):
+        V[_sl(g.Ip) + (i,)] = v
+    return B, V

@@ -344,3 +344,20 @@ def test_native_stage_loops_with_a_steady_body_force(ins, oracle, geom, method):
     sp0 = ins.Setup(x=xin, boundary_conditions=sp.boundary_conditions, Re=so0.Re)
     (v, _, _), _ = ins.solve_unsteady(setup=sp0, tlims=(0.0, 6e-3), ustart=ins.from_numpy(sp0, u0), method=m, psolver=ins.default_psolver(sp0), Δt=2e-3)
     assert rell2(ins.to_numpy(v), st["u"]) > 1e-4
+
+
+@pytest.mark.parametrize("geom", ["periodic2d", "dirichlet2d", "periodic3d", "mixed3d"])
+def test_tensorbasis_matches_oracle(ins, oracle, geom):
+    o = oracle
+    so = GEOMS[geom](o)
+    sp = mirror(ins, so, o)
+    g = so.grid
+    u_h = o.apply_bc_u(fx.randn_field(g.N + (g.D,), 1), 0.0, so)
+    B_h, V_h = o.tensorbasis(u_h, so)
+    B_d, V_d = ins.tensorbasis(ins.from_numpy(sp, u_h), sp)
+    Bm = ins.tensorbasis_matrices(B_d, sp).cpu().numpy()
+    assert Bm.shape == B_h.shape
+    for ib in range(B_h.shape[-3]):  # the higher products grow like |∇u|^5: compare tensor by tensor
+        assert relmax(Bm[..., ib, :, :], B_h[..., ib, :, :]) < 1e-11, ib
+    for iv in range(V_h.shape[-1]):
+        assert relmax(ins.to_numpy(V_d)[..., iv], V_h[..., iv]) < 1e-11, iv
