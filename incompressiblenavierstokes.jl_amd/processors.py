@@ -117,7 +117,7 @@ def fieldsaver(*, setup, nupdate=1):
 def observefield(state, *, setup, fieldname, logtol=np.finfo(np.float64).eps, psolver=None):
     """Observe field `fieldname` at pressure points (processors.jl:78-197): an Observable of a host array over Ip, recomputed on the
     device whenever `state` changes.  fieldname: 0/1/2 (velocity component), "velocity", "velocitynorm", "vorticity", "pressure",
-    "Dfield", "Qfield", "eig2field", "temperature"."""
+    "Dfield", "Qfield", "eig2field", "temperature", "B1".."B11" (tensor-valued), "V1".."V5"."""
     if not isinstance(state, Observable):
         state = Observable(state)
     g = setup.grid
@@ -158,6 +158,13 @@ def observefield(state, *, setup, fieldname, logtol=np.finfo(np.float64).eps, ps
             f = logclip(eig2field_(Q, u, setup), -1.0)
         elif fieldname == "temperature":
             f = temp
+        elif isinstance(fieldname, str) and fieldname[:1] in "BV" and fieldname[1:].isdigit():  # "B1".."B11" / "V1".."V5" (processors.jl:121-127)
+            from .operators import tensorbasis, tensorbasis_matrices
+
+            B, V = tensorbasis(u, setup)
+            idx = int(fieldname[1:]) - 1
+            f = V[..., idx] if fieldname[0] == "V" else tensorbasis_matrices(B, setup)[..., idx, :, :]
+            return f[sl].cpu().numpy()
         else:
             raise ValueError(f"Unknown fieldname {fieldname!r}")
         return to_numpy(f[sl])

@@ -361,3 +361,15 @@ def test_tensorbasis_matches_oracle(ins, oracle, geom):
         assert relmax(Bm[..., ib, :, :], B_h[..., ib, :, :]) < 1e-11, ib
     for iv in range(V_h.shape[-1]):
         assert relmax(ins.to_numpy(V_d)[..., iv], V_h[..., iv]) < 1e-11, iv
+
+
+def test_observefield_of_tensor_basis_fields(ins, oracle):
+    o = oracle
+    so = GEOMS["periodic3d"](o)
+    sp = mirror(ins, so, o)
+    u_h = o.random_field(so, kp=2, seed=4)
+    B_h, V_h = o.tensorbasis(u_h, so)
+    sl = tuple(slice(lo, hi) for lo, hi in so.grid.Ip)
+    state = dict(u=ins.from_numpy(sp, u_h), temp=None, t=0.0, n=0)
+    assert relmax(ins.observefield(state, setup=sp, fieldname="V3").value, V_h[sl + (2,)]) < 1e-11
+    assert relmax(ins.observefield(state, setup=sp, fieldname="B7").value, B_h[sl + (6,)]) < 1e-11
