@@ -87,6 +87,58 @@ __global__ __launch_bounds__(256) void k_convdiff(GridDev g, double visc, const 
   }
 }
 
+// K1 + K6 for every grid the tiled 3-D kernels do not take (2-D, tiny boxes): momentum! (fill + convection-diffusion) with the stage
+// combination of step_explicit_runge_kutta.jl:35-38 as its epilogue, over the WHOLE padded array like the reference's broadcasts:
+//   u*[c] = (ustart ? ustart[c] : u[c]) + Σ_q coef_q k_q[c] + coef_self F[c],   k_i[c] = F[c] when a later stage reads it.
+// One pass instead of three (kernel, k_combine, the ustart snapshot).  `epi.ustar` must not alias `u` (neighbours are read).
+template <int D>
+__global__ __launch_bounds__(256) void k_convdiff_rk(GridDev g, double visc, const double* __restrict__ u, double* __restrict__ F, RkEpi epi) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int j = blockIdx.y * 4 + threadIdx.y;
+  const int k = D == 3 ? (int)blockIdx.z : 0;
+  if (i >= g.N[0] || j >= g.N[1]) return;
+  const int I[3] = {i, j, k};
+  const long long c = i + j * g.sx[1] + k * g.sx[2];
+  bool inside = true;
+#pragma unroll
+  for (int a = 0; a < D; ++a) inside = inside && I[a] >= 1 && I[a] <= g.N[a] - 2;
+#pragma unroll
+  for (int al = 0; al < D; ++al) {
+    const bool dof = inside && in_range<D>(I, g.iu_lo[al], g.iu_hi[al]);
+    const double* ua = u + al * g.sc;
+    const double uc = ua[c];
+    double f = 0.0;
+    if (dof) {
+      const long long sa = g.sx[al];
+#pragma unroll
+      for (int be = 0; be < D; ++be) {
+        const long long sb = g.sx[be];
+        const int ib = I[be];
+        const double um = ua[c - sb], up = ua[c + sb];
+        const double r = (al == be ? g.rdxu[be] : g.rdx[be])[ib];
+        const double ma = al == be ? g.mdx[be][ib] : g.mdxu[be][ib - 1];
+        const double mb = al == be ? g.mdx[be][ib + 1] : g.mdxu[be][ib];
+        double term = visc * ((up - uc) * mb - (uc - um) * ma);
+        const double* ub = u + be * g.sc;
+        const double* A1 = g.A1[be][al];
+        const double* A2 = g.A2[be][al];
+        const int ia = I[al];
+        const double uab1 = (um + uc) * 0.5;
+        const double uab2 = (uc + up) * 0.5;
+        const double uba1 = A2[ia - (al == be)] * ub[c - sb] + A1[ia + (al != be)] * ub[c - sb + sa];
+        const double uba2 = A2[ia] * ub[c] + A1[ia + 1] * ub[c + sa];
+        term -= (uab2 * uba2 - uab1 * uba1);
+        f += term * r;
+      }
+    }
+    const long long ca = al * g.sc + c;
+    double sv = epi.ustart ? epi.ustart[ca] : uc;
+    for (int q = 0; q < epi.n; ++q) sv += epi.coef[q] * epi.k[q][ca];
+    epi.ustar[ca] = sv + epi.coef_self * f;
+    if (epi.write_k) F[ca] = f;
+  }
+}
+
 template <int MODE, bool OVERWRITE>
 int launch_convdiff(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s) {
   const GridDev& g = G->g;
@@ -229,6 +281,17 @@ __global__ __launch_bounds__(256) void k_cfl(GridDev g, const double* __restrict
 // ------------------------------------------------------------------------------------------------
 // internal launchers
 // ------------------------------------------------------------------------------------------------
+int ins_k_momentum_rk_fused_generic(const ins_grid* G, double visc, const double* u, double* k_out, const RkEpi& epi, hipStream_t s) {
+  const GridDev& g = G->g;
+  Launch3 l = box_launch(g.N[0], g.N[1], g.N[2]);
+  if (g.D == 2)
+    hipLaunchKernelGGL(k_convdiff_rk<2>, l.grid, l.block, 0, s, g, visc, u, k_out, epi);
+  else
+    hipLaunchKernelGGL(k_convdiff_rk<3>, l.grid, l.block, 0, s, g, visc, u, k_out, epi);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
 int ins_k_momentum_generic(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s) {
   return launch_convdiff<3, true>(G, visc, u, F, s);
 }

@@ -333,11 +333,12 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
   }
   int rc;
   const int ns = rk->nstage;
-  // 3-D grids with the flux kernel and time-independent boundary data: K6 runs as K1's epilogue (no k_combine pass, no
+  // Time-independent boundary data: K6 runs as K1's epilogue (no k_combine pass, no
   // snapshot copy: the caller's u is ustart for the whole step and the stage velocities ping-pong in two library buffers,
   // as on the periodic path).  Every non-interior volume of a stage buffer is (re)written by apply_bc_u! before it is read.
   static const bool no_fuse_np = getenv("INS_DISABLE_FUSED_RK") != nullptr;
-  if (!no_fuse_np && !planes && ins_fast3d_supported(G)) {
+  const bool tiled = ins_fast3d_supported(G);  // else: the generic kernel with the same epilogue (2-D grids, tiny boxes)
+  if (!no_fuse_np && !planes) {
     const size_t vbytes = (size_t)nvec * sizeof(double);
     for (int b = 0; b < 2; ++b)
       if (!rk->ub[b]) {
@@ -375,7 +376,7 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
         INS_HIP_TRY(hipEventCreate(&e1));
         INS_HIP_TRY(hipEventRecord(e0, s));
       }
-      if ((rc = ins_k_momentum_rk_fused(G, visc, cur, rk->ku[i], epi, s))) return rc;   // :21, :35-38
+      if ((rc = tiled ? ins_k_momentum_rk_fused(G, visc, cur, rk->ku[i], epi, s) : ins_k_momentum_rk_fused_generic(G, visc, cur, rk->ku[i], epi, s))) return rc;   // :21, :35-38
       if (rk->profiling) {
         INS_HIP_TRY(hipEventRecord(e1, s));
         rk->prof_events.push_back(e0);
