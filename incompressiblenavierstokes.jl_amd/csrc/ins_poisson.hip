@@ -390,6 +390,11 @@ extern "C" int ins_poisson_spectral_create(const ins_grid_t* G, ins_poisson_t** 
     return code;
   };
   ps->ownfft = D == 3 && ins_ownfft_supported(ps->np);
+  // 2-D power-of-two boxes: own x passes around the fused solve kernel run along y (FFT · symbol · inverse FFT in one pass):
+  // three kernels instead of rocFFT's eight plus its three staging copies per solve
+  const int np2[3] = {ps->np[0], 16, ps->np[1]};
+  const bool own2d = D == 2 && ins_ownfft_supported(np2);
+  if (own2d) ps->ownfft = true;
   if (ps->ownfft) {  // rows of phat padded to whole 128-B lines: the y / z tiles then never straddle a line (profiles/r01f_pmc_traffic.json)
     ps->kxs = getenv("INS_PHAT_DENSE") ? ps->kmax[0] : ((ps->kmax[0] + 7) & ~7);
     ncplx = (long long)ps->kxs * ps->kmax[1] * ps->kmax[2];
@@ -406,7 +411,7 @@ extern "C" int ins_poisson_spectral_create(const ins_grid_t* G, ins_poisson_t** 
       const double sn = std::sin(M_PI * ((double)k / ps->np[a]));
       ah[k] = 4 * om * sn * sn / (G->h[a] * G->h[a]);
     }
-    if (ps->ownfft && a == 1) {  // the own y pass leaves ky in digit-reversed order (ins_fft.hip)
+    if (ps->ownfft && D == 3 && a == 1) {  // the own y pass leaves ky in digit-reversed order (ins_fft.hip)
       std::vector<double> perm(ah.size());
       ins_ownfft_permute_symbol(ps->np[1], ah.data(), perm.data());
       ah.swap(perm);
@@ -420,7 +425,13 @@ extern "C" int ins_poisson_spectral_create(const ins_grid_t* G, ins_poisson_t** 
   // plan_rfft(pI): all D dims, real -> half-complex along x (pressure.jl:316).  hipFFT takes lengths slowest first.
   // plan_rfft(pI): all D dims, real -> half-complex along x (pressure.jl:316); hipFFT takes lengths slowest first.
   // 3-D with a power-of-two nz: batched 2-D (x,y) plans + ONE fused z kernel (FFT · symbol · inverse FFT) = 5 passes.
-  if (ps->ownfft) {  // no rocFFT plans at all
+  if (own2d) {
+    if ((rc = ins_zsolve_twiddles(ps->np[0], &ps->tw_x))) return fail(rc);
+    if ((rc = ins_zsolve_twiddles(ps->np[1], &ps->tw))) return fail(rc);
+    // the solve kernel adds ay[line / kxs] to the symbol: one "row" of lines here, contributing nothing
+    if (hipMalloc(&ps->ahat[2], sizeof(double)) != hipSuccess || hipMemset(ps->ahat[2], 0, sizeof(double)) != hipSuccess) return fail(INS_ERR_HIP);
+    ps->zfused = true;
+  } else if (ps->ownfft) {  // no rocFFT plans at all
     if ((rc = ins_zsolve_twiddles(ps->np[0], &ps->tw_x))) return fail(rc);
     if ((rc = ins_zsolve_twiddles(ps->np[1], &ps->tw_y))) return fail(rc);
     if ((rc = ins_zsolve_twiddles(ps->np[2], &ps->tw))) return fail(rc);
@@ -443,6 +454,11 @@ static int ownfft_transform(ins_poisson* ps, const double* from_u, hipStream_t s
   const int n0 = ps->np[0], n1 = ps->np[1], n2 = ps->np[2], kxn = ps->kmax[0], kxs = ps->kxs;
   double* ph = reinterpret_cast<double*>(ps->phat);
   int rc;
+  if (ps->grid->g.D == 2) {  // x forward, fused solve along y (lines = kx, "planes" = ky), x inverse
+    if ((rc = ins_k_ownfft_xfwd(ps->grid, ps->pI, false, ph, n0, n1, 1, ps->tw_x, s, kxs))) return rc;
+    if ((rc = ins_k_zsolve(ph, n1, (long long)kxs, ps->ahat[0], kxn, ps->ahat[2], ps->ahat[1], ps->tw, 1.0 / ((double)n0 * n1), true, s, kxs))) return rc;
+    return ins_k_ownfft_xinv(ph, ps->pI, n0, n1, 1, ps->tw_x, s, kxs);
+  }
   if ((rc = ins_k_ownfft_xfwd(ps->grid, from_u ? from_u : ps->pI, from_u != nullptr, ph, n0, n1, n2, ps->tw_x, s, kxs))) return rc;
   if ((rc = ins_k_ownfft_y(ph, kxn, n1, n2, ps->tw_y, false, s, kxs))) return rc;
   const double inv_n = 1.0 / ((double)n0 * n1 * n2);

@@ -623,3 +623,26 @@ def test_handles_release_their_device_memory(ins):
     torch.cuda.empty_cache()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 32 * 2**20, f"{(free0 - free1) / 2**20:.1f} MiB not returned after 6 create/destroy cycles"
+
+
+@pytest.mark.parametrize("n", [(32, 32), (64, 16), (1024, 32), (16, 256)])
+def test_own_fft_2d_poisson_matches_oracle_and_rocfft(ins, oracle, n, monkeypatch):
+    """2-D power-of-two boxes: own x passes + the fused solve kernel along y, against the oracle and against the rocFFT route
+    (INS_DISABLE_OWNFFT, read when the solver is created)."""
+    o = oracle
+    so = fx.setup_periodic(o, n, D=2, L=2 * np.pi)
+    sp = mirror(ins, so, o)
+    f = fx.randn_field(so.grid.N, 7)
+    want = o.psolver_spectral(so)(f.copy(order="F"))
+    got = ins.to_numpy(ins.psolver_spectral(sp)(ins.from_numpy(sp, f)))
+    sl = tuple(slice(lo, hi) for lo, hi in so.grid.Ip)
+    assert rell2(got[sl], want[sl]) < POISSON_TOL
+    monkeypatch.setenv("INS_DISABLE_OWNFFT", "1")
+    ref = ins.to_numpy(ins.psolver_spectral(sp)(ins.from_numpy(sp, f)))
+    assert rell2(got[sl], ref[sl]) < POISSON_TOL
+    monkeypatch.delenv("INS_DISABLE_OWNFFT")
+    # and a few RK44 steps through the native loop
+    u0 = o.random_field(so, kp=3, seed=5)
+    refu = o.solve_unsteady(so, (0.0, 3e-3), u0, dt=1e-3)
+    (u, _, _), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 3e-3), ustart=ins.from_numpy(sp, u0), Δt=1e-3)
+    assert rell2(ins.to_numpy(u), refu["u"]) < STEP_TOL
