@@ -181,6 +181,8 @@ int ins_k_applypressure(const ins_grid* grid, double* u, const double* p, hipStr
 int ins_k_laplacian(const ins_grid* grid, const double* p, double* L, hipStream_t s);
 int ins_k_project(const ins_grid* grid, ins_poisson* ps, double* u, double* p, hipStream_t s);
 int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s);
+bool ins_flux2d_supported(const ins_grid* G);
+int ins_k_flux2d(const ins_grid* G, double visc, const double* u, double* F, const RkEpi* epi, hipStream_t s);
 int ins_k_momentum_rk_fused_generic(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s);
 int ins_k_momentum_rk_fused_corr(const ins_grid* G, double visc, const double* ustar_prev, const double* pI, double* k_out, const RkEpi& epi,
                                  hipStream_t s);

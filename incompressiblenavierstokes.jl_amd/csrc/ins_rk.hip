@@ -376,7 +376,9 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
         INS_HIP_TRY(hipEventCreate(&e1));
         INS_HIP_TRY(hipEventRecord(e0, s));
       }
-      if ((rc = tiled ? ins_k_momentum_rk_fused(G, visc, cur, rk->ku[i], epi, s) : ins_k_momentum_rk_fused_generic(G, visc, cur, rk->ku[i], epi, s))) return rc;   // :21, :35-38
+      rc = tiled ? ins_k_momentum_rk_fused(G, visc, cur, rk->ku[i], epi, s)
+                 : (ins_flux2d_supported(G) ? ins_k_flux2d(G, visc, cur, rk->ku[i], &epi, s) : ins_k_momentum_rk_fused_generic(G, visc, cur, rk->ku[i], epi, s));
+      if (rc) return rc;   // :21, :35-38
       if (rk->profiling) {
         INS_HIP_TRY(hipEventRecord(e1, s));
         rk->prof_events.push_back(e0);
