@@ -188,6 +188,8 @@ int ins_k_momentum_rk_fused_corr(const ins_grid* G, double visc, const double* u
                                  hipStream_t s);
 int ins_k_momentum_rk_fused_corr_slab(const ins_grid* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out,
                                       const RkEpi& epi, hipStream_t s, int part = 0);
+int ins_k_project_periodic_fused_2d(const ins_grid* G, ins_poisson* ps, double* u, double* p, bool keep_p, hipStream_t s);
+bool ins_poisson_own2d(const ins_poisson* ps);
 int ins_k_project_periodic_solve_only(const ins_grid* G, ins_poisson* ps, const double* u, hipStream_t s);
 int ins_k_poisson_solve(ins_poisson* ps, double* p, hipStream_t s);
 // blocking reductions over an index box of a scalar field; op: 0 sum(a*b), 1 max|a|, 2 min(a)

@@ -165,6 +165,46 @@ __global__ __launch_bounds__(256) void k_grad_from_pI(GridDev g, double* __restr
 // (operators.jl:225-233, p read from the unpadded pI with periodic wrap) and ALSO writes the periodic ghost
 // images of the updated velocity (boundary_conditions.jl:276-288) — up to 7 images for a corner volume — so no
 // separate apply_bc_u! pass is needed before the next stage.  KEEP_P: also store the padded, ghost-filled p.
+template <int D, bool KEEP_P>
+__global__ __launch_bounds__(256) void k_grad_ghost(GridDev g, double* __restrict__ u, double* __restrict__ p, const double* __restrict__ pI, int n0,
+                                                    int n1, int n2) {
+  const int ii = blockIdx.x * 64 + threadIdx.x;
+  const int jj = blockIdx.y * 4 + threadIdx.y;
+  const int kk = D == 3 ? (int)blockIdx.z : 0;
+  if (ii >= n0 || jj >= n1) return;
+  const int n[3] = {n0, n1, n2};
+  const int w[3] = {ii, jj, kk};
+  const int I[3] = {ii + 1, jj + 1, D == 3 ? kk + 1 : 0};
+  const long long q = ii + (long long)n0 * (jj + (long long)n1 * kk);
+  const long long qs[3] = {1, n0, (long long)n0 * n1};
+  long long c = I[0] + I[1] * g.sx[1];
+  if (D == 3) c += I[2] * g.sx[2];
+  const double pc = pI[q];
+  double un[D];
+  int img[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    const long long qn = (w[a] + 1 < n[a]) ? q + qs[a] : q - (long long)(n[a] - 1) * qs[a];
+    un[a] = u[a * g.sc + c] - (pI[qn] - pc) * g.rdxu[a][I[a]];
+    img[a] = I[a] == 1 ? g.N[a] - 1 : (I[a] == g.N[a] - 2 ? 0 : -1);
+  }
+#pragma unroll
+  for (int m = 0; m < (1 << D); ++m) {
+    bool ok = true;
+    long long cc = 0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      const bool use = (m >> a) & 1;
+      ok = ok && (!use || img[a] >= 0);
+      cc += (long long)(use ? img[a] : I[a]) * g.sx[a];
+    }
+    if (ok) {
+#pragma unroll
+      for (int a = 0; a < D; ++a) u[cc + a * g.sc] = un[a];
+      if (KEEP_P) p[cc] = pc;
+    }
+  }
+}
 template <bool KEEP_P>
 __global__ __launch_bounds__(256) void k_grad_ghost3(GridDev g, double* __restrict__ u, double* __restrict__ p,
                                                      const double* __restrict__ pI, int n0, int n1, int n2) {
@@ -791,6 +831,27 @@ int ins_k_project_periodic_fused(const ins_grid* G, ins_poisson* ps, double* u, 
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
+
+// The same for 2-D (own x passes + the fused solve kernel along y): x forward with the divergence formed inside, solve, x inverse,
+// gradient-subtract with the periodic ghost images.  Four launches per projection.
+int ins_k_project_periodic_fused_2d(const ins_grid* G, ins_poisson* ps, double* u, double* p, bool keep_p, hipStream_t s) {
+  const GridDev& g = G->g;
+  const int n0 = ps->np[0], n1 = ps->np[1], kxn = ps->kmax[0], kxs = ps->kxs;
+  double* ph = reinterpret_cast<double*>(ps->phat);
+  int rc;
+  if ((rc = ins_k_ownfft_xfwd(G, u, 3, ph, n0, n1, 1, ps->tw_x, s, kxs))) return rc;
+  if ((rc = ins_k_zsolve(ph, n1, (long long)kxs, ps->ahat[0], kxn, ps->ahat[2], ps->ahat[1], ps->tw, 1.0 / ((double)n0 * n1), true, s, kxs))) return rc;
+  if ((rc = ins_k_ownfft_xinv(ph, ps->pI, n0, n1, 1, ps->tw_x, s, kxs))) return rc;
+  dim3 block(64, 4, 1), grid(cdiv(n0, 64), cdiv(n1, 4), 1);
+  if (keep_p)
+    hipLaunchKernelGGL((k_grad_ghost<2, true>), grid, block, 0, s, g, u, p, ps->pI, n0, n1, 1);
+  else
+    hipLaunchKernelGGL((k_grad_ghost<2, false>), grid, block, 0, s, g, u, p, ps->pI, n0, n1, 1);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+bool ins_poisson_own2d(const ins_poisson* ps) { return ps->kind == POISSON_SPECTRAL && ps->ownfft && ps->grid->g.D == 2; }
 
 // First half of the fused periodic projection only: pI <- solution of L p = Ω div(u) (u: interior volumes valid).
 // The gradient-subtract is left to the next stage's stencil kernel (k_momentum_flux<..., CORR>).

@@ -281,6 +281,62 @@ static int rk_step_fused_periodic(ins_rk* rk, double visc, double* u, double dt,
   return INS_OK;
 }
 
+// Fused periodic path in 2-D (uniform periodic power-of-two boxes): per stage the flux-form stage kernel (K1 + K6, ins_flux2d.hip) and the
+// four-launch projection above — five launches per stage instead of ten, which is what a 128² .. 512² grid is bound by.
+static int rk_step_fused_periodic_2d(ins_rk* rk, double visc, double* u, double dt, hipStream_t s) {
+  const ins_grid* G = rk->grid;
+  const int ns = rk->nstage;
+  const size_t vbytes = (size_t)G->ncell * 2 * sizeof(double);
+  for (int b = 0; b < 2; ++b)
+    if (!rk->ub[b]) {
+      INS_HIP_TRY(hipMalloc(&rk->ub[b], vbytes));
+      INS_HIP_TRY(hipMemsetAsync(rk->ub[b], 0, vbytes, s));
+    }
+  int rc;
+  if ((rc = ins_k_apply_bc_u(G, u, 0, nullptr, s))) return rc;  // :19 (first stage; later ghosts come with the gradient-subtract)
+  const double* in = u;
+  for (int i = 0; i < ns; ++i) {
+    double* out = (i == ns - 1 && ns > 1) ? u : rk->ub[i & 1];
+    RkEpi epi;
+    memset(&epi, 0, sizeof(epi));
+    for (int j = 0; j < i; ++j) {
+      const double coef = dt * rk->A[i * ns + j];
+      if (coef == 0.0) continue;
+      epi.coef[epi.n] = coef;
+      epi.k[epi.n] = rk->ku[j];
+      ++epi.n;
+    }
+    if (rk->force) {
+      double cf = 0.0;
+      for (int j = 0; j <= i; ++j) cf += dt * rk->A[i * ns + j];
+      epi.coef[epi.n] = cf;
+      epi.k[epi.n] = rk->force;
+      ++epi.n;
+    }
+    for (int i2 = i + 1; i2 < ns; ++i2)
+      if (rk->A[i2 * ns + i] != 0.0) epi.write_k = 1;
+    epi.coef_self = dt * rk->A[i * ns + i];
+    epi.ustart = (i == 0) ? nullptr : u;
+    epi.ustar = out;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (rk->profiling) {
+      INS_HIP_TRY(hipEventCreate(&e0));
+      INS_HIP_TRY(hipEventCreate(&e1));
+      INS_HIP_TRY(hipEventRecord(e0, s));
+    }
+    if ((rc = ins_k_flux2d(G, visc, in, rk->ku[i], &epi, s))) return rc;
+    if (rk->profiling) {
+      INS_HIP_TRY(hipEventRecord(e1, s));
+      rk->prof_events.push_back(e0);
+      rk->prof_events.push_back(e1);
+    }
+    if ((rc = ins_k_project_periodic_fused_2d(G, rk->ps, out, rk->p, i == ns - 1, s))) return rc;
+    in = out;
+  }
+  if (ns == 1) INS_HIP_TRY(hipMemcpyAsync(u, rk->ub[0], vbytes, hipMemcpyDeviceToDevice, s));
+  return INS_OK;
+}
+
 // nsteps steps of size dt with the final correction of every step but the last folded into the next step's first stage kernel
 // (same arithmetic per cell; the uncorrected intermediate results never become visible).  Falls back to single steps elsewhere.
 extern "C" int ins_rk_steps_f64(ins_rk_t* rk, double visc, double* u, double t, double dt, int nsteps, void* stream) {
@@ -317,6 +373,7 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
     bool ok = !no_fuse && !planes && g.D == 3 && G->all_periodic && G->all_dof && rk->ps->kind == POISSON_SPECTRAL && ins_fast3d_supported(G);
     for (int a = 0; ok && a < 3; ++a) ok = rk->ps->np[a] >= 2;
     if (ok) return rk_step_fused_periodic(rk, visc, u, dt, s);
+    if (!no_fuse && !planes && g.D == 2 && ins_poisson_own2d(rk->ps) && ins_flux2d_supported(G)) return rk_step_fused_periodic_2d(rk, visc, u, dt, s);
   }
   const long long nvec = G->ncell * G->g.D;
   const double** dplanes = nullptr;
