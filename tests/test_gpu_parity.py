@@ -646,3 +646,25 @@ def test_own_fft_2d_poisson_matches_oracle_and_rocfft(ins, oracle, n, monkeypatc
     refu = o.solve_unsteady(so, (0.0, 3e-3), u0, dt=1e-3)
     (u, _, _), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 3e-3), ustart=ins.from_numpy(sp, u0), Δt=1e-3)
     assert rell2(ins.to_numpy(u), refu["u"]) < STEP_TOL
+
+
+@pytest.mark.parametrize("n,L", [((96, 12, 10), 2 * np.pi), ((128, 16, 8), 3.1), ((200, 10, 6), 2 * np.pi)])
+def test_nearly_uniform_boxes_take_the_constant_record_kernels(ins, oracle, n, L):
+    """Boxes whose spacings are uniform only up to the rounding of the coordinates ([0, 2π]³, 1/96 …) run on the constant-record kernels
+    (64-wide stage kernel, in-register correction, stage-velocity basis, chained steps) and still match the table-driven reference arithmetic."""
+    import ins_amd
+
+    o = oracle
+    x = tuple(np.linspace(0.0, L, ni + 1) for ni in n)
+    so = o.make_setup(x, Re=500.0)
+    sp = mirror(ins, so, o)
+    assert not all(np.ptp(np.diff(xi)) == 0.0 for xi in x)  # not bitwise uniform ...
+    assert ins_amd._lib.load().ins_grid_is_uniform_exact(sp.handle) == 1  # ... but classified as constant
+    u_h = o.apply_bc_u(fx.randn_field(so.grid.N + (3,), 3), 0.0, so)
+    assert relmax(ins.to_numpy(ins.momentum(ins.from_numpy(sp, u_h), None, 0.0, sp)), o.momentum(u_h, None, 0.0, so)) < OP_TOL
+    ps_h, ps_d = o.psolver_spectral(so), ins.psolver_spectral(sp)
+    u0 = o.random_field(so, kp=2, seed=9, psolver=ps_h)
+    ref = o.solve_unsteady(so, (0.0, 4e-3), u0, psolver=ps_h, dt=1e-3)
+    (u, _, _), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 4e-3), ustart=ins.from_numpy(sp, u0), psolver=ps_d, Δt=1e-3)  # 4 chained steps
+    assert rell2(ins.to_numpy(u), ref["u"]) < STEP_TOL
+    assert ins.max_abs_divergence(u, sp) * (L / n[0]) < 1e-11
