@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void k_flux2d(Flux2dArgs a) {
 
 bool ins_flux2d_supported(const ins_grid* G) {
   static const bool off = getenv("INS_DISABLE_FLUX2D") != nullptr;  // A/B switch
-  return !off && G->g.D == 2 && G->all_periodic && G->all_dof && G->uniform && G->g.N[0] >= 4 && G->g.N[1] >= 4;
+  // uniform_exact: spacings and interpolation weights constant to the rounding of the coordinates (ins_grid.hip), so one h per direction is exact enough
+  return !off && G->g.D == 2 && G->all_periodic && G->all_dof && G->uniform_exact && G->g.N[0] >= 4 && G->g.N[1] >= 4;
 }
 
 // epi == nullptr: plain momentum! into F (ghost ring of F untouched: the caller's F has a zero ring or does not read it)
