@@ -6,7 +6,7 @@
 
 struct ins_spectrum {
   const ins_grid* grid;
-  hipfftHandle plan = 0;
+  hipfftHandle plan = 0, plan_inv = 0;  // the inverse exists only because the validating factory builds pairs
   bool has_plan = false;
   double* real = nullptr;                // Np
   hipfftDoubleComplex* hat = nullptr;    // (Np0/2+1) Np1 [Np2]
@@ -49,7 +49,11 @@ __global__ __launch_bounds__(64) void k_shell_sums(const double2* __restrict__ h
 
 extern "C" int ins_spectrum_destroy(ins_spectrum_t* S) {
   if (!S) return INS_OK;
-  if (S->has_plan) (void)hipfftDestroy(S->plan);
+  if (S->has_plan) {
+    (void)hipfftDestroy(S->plan);
+    (void)hipfftDestroy(S->plan_inv);
+    ins_fft_solver_released();
+  }
   (void)hipFree(S->real);
   (void)hipFree(S->hat);
   (void)hipFree(S->offsets);
@@ -109,10 +113,12 @@ extern "C" int ins_spectrum_create_weighted(const ins_grid_t* G, int nbin, const
   }
   int dims[3];
   for (int a = 0; a < g.D; ++a) dims[a] = S->np[g.D - 1 - a];  // slowest first
-  if (hipfftPlanMany(&S->plan, g.D, dims, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, 1) != HIPFFT_SUCCESS) {
+  // through the validating factory (csrc/ins_fftcheck.hip): rocFFT can hand out a real-transform plan with a wrong twiddle table when
+  // another live plan has the same nx·ny in a different shape; the factory checks output bins against a direct DFT and retries / fails loudly
+  const int rc = ins_fft_make_real_plans(&S->plan, &S->plan_inv, g.D, dims, 1);
+  if (rc != INS_OK) {
     ins_spectrum_destroy(S);
-    ins_set_error("spectrum: hipfftPlanMany failed");
-    return INS_ERR_FFT;
+    return rc;
   }
   S->has_plan = true;
   *out = S;
