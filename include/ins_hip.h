@@ -66,6 +66,9 @@ typedef struct ins_grid_desc {
 
 /* ---------------------------------------------------------------------------------- library / errors */
 int ins_version(void);
+/* How often the library reset rocFFT's process-wide caches (containment of a rocFFT plan-cache defect).  A reset invalidates
+ * hipFFT plans held OUTSIDE the library (e.g. PyTorch's torch.fft plan cache): compare around solver creation and drop them when it moved. */
+int ins_fft_reset_count(void);
 const char* ins_last_error(void);
 /* Device the calling thread's handles live on (hipSetDevice).  Blocking. */
 int ins_set_device(int device);

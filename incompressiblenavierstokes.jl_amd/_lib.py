@@ -36,6 +36,7 @@ class GridDesc(C.Structure):
 # name -> (restype, argtypes); must list EVERY symbol include/ins_hip.h declares (tests/test_abi.py checks)
 SIGNATURES = {
     "ins_version": (C.c_int, []),
+    "ins_fft_reset_count": (C.c_int, []),
     "ins_last_error": (C.c_char_p, []),
     "ins_set_device": (C.c_int, [C.c_int]),
     "ins_sync": (C.c_int, [vp]),
@@ -159,3 +160,19 @@ def check(rc):
 
 def call(name, *args):
     check(getattr(load(), name)(*args))
+
+
+_fft_resets_seen = 0
+
+
+def sync_fft_plan_caches():
+    """The library resets rocFFT's process-wide state when it catches the plan-cache defect (csrc/ins_fftcheck.hip); plans that PyTorch
+    cached for torch.fft are then stale.  Called after every solver / observer creation."""
+    global _fft_resets_seen
+    n = load().ins_fft_reset_count()
+    if n != _fft_resets_seen:
+        _fft_resets_seen = n
+        import torch
+
+        torch.cuda.synchronize()
+        torch.backends.cuda.cufft_plan_cache.clear()

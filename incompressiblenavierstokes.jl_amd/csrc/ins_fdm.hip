@@ -10,6 +10,7 @@
 // is L p = f - mean(f) e with e'p = 0.  Here: subtract mean(f), drop the (now empty) null mode, shift p to zero mean over Ip.
 #include <rocblas/rocblas.h>
 
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -28,6 +29,14 @@ struct ins_fdm {
   double null_scale = 1.0;                       // V₀ = null_scale · 1  =>  Σ f = q[null] / null_scale
   bool singular = true;
   double lam_tol = 0.0;
+  int null_i[3] = {0, 0, 0};            // null mode of each direction (storage index) ...
+  double null_s[3] = {1.0, 1.0, 1.0};   // ... and the constant its eigenvector equals
+  // periodic uniform z: Fourier modes instead of the dense Vz (ins_fdm_enable_zfft)
+  bool zfft = false;
+  double hz = 0.0;
+  double* lzk = nullptr;    // λz(k), k = 0..n2/2
+  double* ztw = nullptr;    // twiddles
+  double* zpart = nullptr;  // block partials of the fused z kernel
 };
 
 namespace {
@@ -74,6 +83,28 @@ __global__ __launch_bounds__(256) void k_fdm_scale(double* __restrict__ q, const
   }
 }
 
+// mean(f) from the (x, y) null line after the x and y transforms: Σ f = Σ_z r[ix0, iy0, z] / (sx sy)
+__global__ __launch_bounds__(64) void k_fdm_null_z(const double* __restrict__ r, long long idx_xy, long long n01, int n2, double inv,
+                                                   double* __restrict__ sums) {
+  double acc = 0.0;
+  for (int z = threadIdx.x; z < n2; z += 64) acc += r[idx_xy + (long long)z * n01];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (threadIdx.x == 0) sums[4096] = acc * inv;
+}
+
+// mean(p) from the block partials of the fused z kernel
+__global__ __launch_bounds__(256) void k_fdm_mean_z(const double* __restrict__ partial, int nblk, double inv_n, double* __restrict__ sums) {
+  __shared__ double lds[4];
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) acc += partial[b];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[4097] = (lds[0] + lds[1] + lds[2] + lds[3]) * inv_n;
+}
+
 __global__ __launch_bounds__(256) void k_fdm_mean(double* __restrict__ sums, int nblk, double inv_n) {
   __shared__ double lds[4];
   double acc = 0.0;
@@ -107,6 +138,9 @@ int ins_fdm_destroy(ins_fdm* F) {
   if (F->a) (void)hipFree(F->a);
   if (F->b) (void)hipFree(F->b);
   if (F->sums) (void)hipFree(F->sums);
+  if (F->lzk) (void)hipFree(F->lzk);
+  if (F->ztw) (void)hipFree(F->ztw);
+  if (F->zpart) (void)hipFree(F->zpart);
   delete F;
   return INS_OK;
 }
@@ -135,6 +169,8 @@ int ins_fdm_create(int D, const int n[3], const double* const V[3], const double
     }
     F->null_index += (long long)inull * (a == 0 ? 1 : (a == 1 ? n[0] : (long long)n[0] * n[1]));
     F->null_scale *= V[a][(size_t)n[a] * inull];
+    F->null_i[a] = inull;
+    F->null_s[a] = V[a][(size_t)n[a] * inull];
     ok = ok && hipMalloc(&F->ones[a], (size_t)n[a] * 8) == hipSuccess &&
          hipMemcpy(F->ones[a], o.data(), (size_t)n[a] * 8, hipMemcpyHostToDevice) == hipSuccess;
   }
@@ -147,6 +183,37 @@ int ins_fdm_create(int D, const int n[3], const double* const V[3], const double
   }
   F->lam_tol = F->singular ? 1e-10 * lmax * D : 0.0;
   *out = F;
+  return INS_OK;
+}
+
+// Periodic uniform z direction with spacing hz: use Fourier modes for it (one fused pass, ins_fft.hip k_fdm_z) instead of the dense Vz
+// (two GEMMs + the scaling pass).  Taken only when the host's eigenvalues of the z factor are the analytic set -(4/hz²) sin²(πk/n) —
+// i.e. when the factor really is the periodic second difference on a uniform grid; otherwise the GEMM route stays.
+int ins_fdm_enable_zfft(ins_fdm* F, double hz, const double* lam_z_host) {
+  static const bool off = getenv("INS_DISABLE_FDM_ZFFT") != nullptr;  // A/B switch
+  const int n2 = F->n[2];
+  if (off || F->D != 3 || (F->n[0] & 1) || n2 < 32 || n2 > 512 || (n2 & (n2 - 1))) return INS_OK;
+  std::vector<double> want(n2), have(lam_z_host, lam_z_host + n2), lzk(n2 / 2 + 1);
+  for (int k = 0; k < n2; ++k) {
+    const double sn = std::sin(M_PI * (double)k / n2);
+    want[k] = -4.0 * sn * sn / (hz * hz);
+    if (k <= n2 / 2) lzk[k] = want[k];
+  }
+  std::sort(want.begin(), want.end());
+  std::sort(have.begin(), have.end());
+  const double scale = 4.0 / (hz * hz);
+  for (int k = 0; k < n2; ++k)
+    if (std::fabs(want[k] - have[k]) > 1e-9 * scale) return INS_OK;
+  const int nblk = (int)(((long long)(F->n[0] / 2) * F->n[1] + 7) / 8);
+  if (hipMalloc(&F->lzk, lzk.size() * 8) != hipSuccess || hipMemcpy(F->lzk, lzk.data(), lzk.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMalloc(&F->zpart, (size_t)nblk * 8) != hipSuccess || hipMemset(F->zpart, 0, (size_t)nblk * 8) != hipSuccess) {
+    ins_set_error("ins_fdm_enable_zfft: allocation failed");
+    return INS_ERR_HIP;
+  }
+  int rc = ins_zsolve_twiddles(n2, &F->ztw);
+  if (rc) return rc;
+  F->hz = hz;
+  F->zfft = true;
   return INS_OK;
 }
 
@@ -163,6 +230,22 @@ int ins_fdm_solve(ins_fdm* F, hipStream_t s) {
   INS_BLAS_TRY(rocblas_dgemm(F->h, rocblas_operation_transpose, rocblas_operation_none, n0, n1 * n2, n0, &one, F->V[0], n0, x, n0, &zero, y, n0));
   INS_BLAS_TRY(rocblas_dgemm_strided_batched(F->h, rocblas_operation_none, rocblas_operation_none, n0, n1, n1, &one, y, n0, n01, F->V[1], n1, 0,
                                              &zero, x, n0, n01, n2));
+  if (F->zfft) {  // x holds (Vxᵀ ⊗ Vyᵀ) f: the z transform, the scaling and the inverse z transform are one pass
+    const long long idx_xy = F->null_i[0] + (long long)n0 * F->null_i[1];
+    if (F->singular)
+      hipLaunchKernelGGL(k_fdm_null_z, dim3(1), dim3(64), 0, s, x, idx_xy, n01, n2, 1.0 / (F->null_s[0] * F->null_s[1] * (double)total), F->sums);
+    int nb = 0;
+    int rc = ins_k_fdm_z(x, n0, n1, n2, F->lam[0], F->lam[1], F->lzk, F->ones[0], F->ones[1], F->hz, F->lam_tol, F->singular ? 1 : 0, F->sums + 4096,
+                         F->zpart, F->ztw, &nb, s);
+    if (rc) return rc;
+    if (F->singular) hipLaunchKernelGGL(k_fdm_mean_z, dim3(1), dim3(256), 0, s, F->zpart, nb, 1.0 / (double)total, F->sums);
+    INS_LAUNCH_CHECK();
+    INS_BLAS_TRY(rocblas_dgemm_strided_batched(F->h, rocblas_operation_none, rocblas_operation_transpose, n0, n1, n1, &one, x, n0, n01, F->V[1], n1,
+                                               0, &zero, y, n0, n01, n2));
+    INS_BLAS_TRY(rocblas_dgemm(F->h, rocblas_operation_none, rocblas_operation_none, n0, n1 * n2, n0, &one, F->V[0], n0, y, n0, &zero, x, n0));
+    if (x != F->a) INS_HIP_TRY(hipMemcpyAsync(F->a, x, total * 8, hipMemcpyDeviceToDevice, s));
+    return INS_OK;
+  }
   if (F->D == 3) {
     INS_BLAS_TRY(rocblas_dgemm(F->h, rocblas_operation_none, rocblas_operation_none, (int)n01, n2, n2, &one, x, (int)n01, F->V[2], n2, &zero, y,
                                (int)n01));

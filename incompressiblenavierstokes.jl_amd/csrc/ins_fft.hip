@@ -322,6 +322,103 @@ __global__ __launch_bounds__(256) void k_xinv(const double2* __restrict__ in, do
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// psolver_direct with a periodic uniform z direction (ins_fdm.hip): the z eigenvectors are Fourier modes, so the two z GEMMs and the
+// scaling pass become one pass.  The work array is REAL, r[z][y][x]; two adjacent x-columns (a = 2m, b = 2m+1) are taken as the real and
+// imaginary part of one complex z-line: forward FFT in LDS, the two spectra separated through the k <-> N-k pairing inside the line
+// (A = (Z_k + conj Z_{N-k})/2, B = (Z_k - conj Z_{N-k})/(2i)), each divided by its own h (λx + λy + λz(k)) — the columns differ in λx —,
+// recombined, inverse FFT.  Singular systems (ins_fdm.hip): mean(f)·(Vᵀ1) is subtracted at k = 0, the null mode is dropped, and the
+// k = 0 coefficients give the block partials of Σ (Vᵀ1) q' = n·mean(p).
+// ------------------------------------------------------------------------------------------------------------
+struct FdmZArgs {
+  double2* data;          // [N][nl] complex view of the real array: nl = (n0/2) n1 lines
+  long long nl;
+  int n0h;                // n0 / 2
+  const double *lx, *ly;  // generalised eigenvalues of the x and y factors
+  const double* lz;       // λz(k), k = 0..N/2: -(4/h²) sin²(πk/N)
+  const double *ox, *oy;  // Vxᵀ1, Vyᵀ1
+  double h, tol;
+  int singular;
+  const double* meanf;    // device scalar mean(f)
+  double* partial;        // [gridDim.x] block partials of Σ ox oy R'[k=0] / h
+};
+
+template <int LOGN, int TK>
+__global__ __launch_bounds__(256) void k_fdm_z(FdmZArgs a, const double2* __restrict__ tw_g) {
+  constexpr int N = 1 << LOGN;
+  extern __shared__ double2 lds_dyn[];
+  double2* buf = lds_dyn;          // [N][TK]
+  double2* tw = lds_dyn + N * TK;  // [N]
+  __shared__ double red[4];
+  const int t = threadIdx.x;
+  const int col = t % TK;
+  const long long line = (long long)blockIdx.x * TK + col;
+  const bool live = line < a.nl;
+  for (int m = t; m < N; m += 256) tw[m] = tw_g[m];
+  constexpr int RPT = 256 / TK;
+  constexpr int NIT = N / RPT;
+  {
+    double2 v[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) v[q] = live ? a.data[(long long)(t / TK + q * RPT) * a.nl + line] : make_double2(0.0, 0.0);
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) buf[(t / TK + q * RPT) * TK + col] = v[q];
+  }
+  __syncthreads();
+  fft_dif<LOGN, TK, TK, 1, false>(buf, tw, t);
+  __syncthreads();
+  const double mf = a.singular ? *a.meanf : 0.0;
+  const double inv = 1.0 / (a.h * (double)N);
+  double acc = 0.0;
+  for (int idx = t; idx < (N / 2 + 1) * TK; idx += 256) {
+    const int c = idx % TK, k = idx / TK;
+    const long long ln = (long long)blockIdx.x * TK + c;
+    if (ln >= a.nl) continue;
+    const int m = (int)(ln % a.n0h), j = (int)(ln / a.n0h);
+    const int ia = 2 * m, ib = ia + 1;
+    const int pk = pos_of_freq<LOGN>(k), pm = pos_of_freq<LOGN>((N - k) & (N - 1));
+    const double2 zk = buf[pk * TK + c], zm = buf[pm * TK + c];
+    const bool self = k == 0 || k == N / 2;
+    double2 A = self ? make_double2(zk.x, 0.0) : make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+    double2 B = self ? make_double2(zk.y, 0.0) : make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+    const double lyz = a.ly[j] + a.lz[k];
+    const double la = a.lx[ia] + lyz, lb = a.lx[ib] + lyz;
+    if (a.singular) {
+      const double oa = a.ox[ia] * a.oy[j], ob = a.ox[ib] * a.oy[j];
+      if (k == 0) {
+        A.x -= mf * oa * (double)N;
+        B.x -= mf * ob * (double)N;
+      }
+      const double sa = fabs(la) <= a.tol ? 0.0 : 1.0 / la, sb = fabs(lb) <= a.tol ? 0.0 : 1.0 / lb;
+      A.x *= sa;
+      A.y *= sa;
+      B.x *= sb;
+      B.y *= sb;
+      if (k == 0) acc += (oa * A.x + ob * B.x) / a.h;
+    } else {
+      A.x /= la;
+      A.y /= la;
+      B.x /= lb;
+      B.y /= lb;
+    }
+    buf[pk * TK + c] = make_double2(inv * (A.x - B.y), inv * (A.y + B.x));
+    if (!self) buf[pm * TK + c] = make_double2(inv * (A.x + B.y), inv * (B.x - A.y));
+  }
+  __syncthreads();
+  fft_dit<LOGN, TK, TK, 1, false>(buf, tw, t);
+  __syncthreads();
+  if (live)
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) a.data[(long long)(t / TK + q * RPT) * a.nl + line] = buf[(t / TK + q * RPT) * TK + col];
+  if (a.singular) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((t & 63) == 0) red[t >> 6] = acc;
+    __syncthreads();
+    if (t == 0) a.partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
 template <typename K>
 int set_lds(K kernel, size_t lds) {
   if (lds > 64 * 1024) INS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -467,4 +564,38 @@ int ins_k_ownfft_y_packed(double* phat, double* packed, int kxn, int n1, int nzl
 #define CALL(LG) launch_y<LG>(d, kxn, kxn, nzl, w, inverse, &pm, s)
   INS_POW2_SWITCH(n1, CALL)
 #undef CALL
+}
+
+// In-place on the real work array of the direct solver (n0 even, nz a power of two in 32..512); see k_fdm_z.  Returns the block count.
+int ins_k_fdm_z(double* data, int n0, int n1, int nz, const double* lx, const double* ly, const double* lz, const double* ox, const double* oy,
+                double h, double tol, int singular, const double* meanf, double* partial, const double* tw, int* nblk, hipStream_t s) {
+  FdmZArgs a;
+  a.data = reinterpret_cast<double2*>(data);
+  a.n0h = n0 / 2;
+  a.nl = (long long)a.n0h * n1;
+  a.lx = lx; a.ly = ly; a.lz = lz; a.ox = ox; a.oy = oy;
+  a.h = h; a.tol = tol; a.singular = singular; a.meanf = meanf; a.partial = partial;
+  constexpr int TK = 8;
+  const unsigned nb = (unsigned)((a.nl + TK - 1) / TK);
+  if (nblk) *nblk = (int)nb;
+  const double2* w = reinterpret_cast<const double2*>(tw);
+#define INS_FDMZ(LOG)                                                                                          \
+  {                                                                                                             \
+    const size_t lds = ((size_t)(1 << LOG) * TK + (1 << LOG)) * sizeof(double2);                                \
+    int rc = set_lds(&k_fdm_z<LOG, TK>, lds);                                                                   \
+    if (rc) return rc;                                                                                          \
+    hipLaunchKernelGGL((k_fdm_z<LOG, TK>), dim3(nb), dim3(256), lds, s, a, w);                                  \
+    break;                                                                                                      \
+  }
+  switch (nz) {
+    case 32: INS_FDMZ(5)
+    case 64: INS_FDMZ(6)
+    case 128: INS_FDMZ(7)
+    case 256: INS_FDMZ(8)
+    case 512: INS_FDMZ(9)
+    default: ins_set_error("ins_k_fdm_z: unsupported nz = %d", nz); return INS_ERR_UNSUPPORTED;
+  }
+#undef INS_FDMZ
+  INS_LAUNCH_CHECK();
+  return INS_OK;
 }

@@ -111,6 +111,7 @@ int ins_validate_real_plans(hipfftHandle fwd, hipfftHandle inv, int rank, const 
 // plans, so the error is returned instead (message says what to do).
 // ------------------------------------------------------------------------------------------------------------
 static std::atomic<int> g_live_fft_solvers{0};
+static std::atomic<int> g_fft_resets{0};  // how often rocFFT's process-wide state was reset (other hipFFT users must drop their plans)
 
 void ins_fft_solver_released() { g_live_fft_solvers.fetch_sub(1); }
 
@@ -146,6 +147,7 @@ int ins_fft_make_real_plans(hipfftHandle* fwd, hipfftHandle* inv, int rank, int*
     (void)hipDeviceSynchronize();
     rocfft_cleanup();
     rocfft_setup();
+    g_fft_resets.fetch_add(1);
     r = make_pair(fwd, inv, rank, n, batch);
     if (r != HIPFFT_SUCCESS) {
       ins_set_error("hipfftPlan (rank %d, batch %d) failed after rocFFT reset: %d", rank, batch, (int)r);
@@ -161,3 +163,8 @@ int ins_fft_make_real_plans(hipfftHandle* fwd, hipfftHandle* inv, int rank, int*
   g_live_fft_solvers.fetch_add(1);
   return INS_OK;
 }
+
+// Number of rocFFT resets this library has performed in this process.  A reset invalidates every hipFFT / rocFFT plan that lives outside
+// the library (PyTorch keeps a plan cache for torch.fft): a host that uses rocFFT itself compares this counter around solver creation and
+// drops its plans when it moved (ins_amd does: torch.backends.cuda.cufft_plan_cache.clear()).
+extern "C" int ins_fft_reset_count(void) { return g_fft_resets.load(); }

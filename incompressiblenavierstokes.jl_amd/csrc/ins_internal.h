@@ -99,6 +99,7 @@ enum PoissonKind { POISSON_SPECTRAL = 0, POISSON_CG = 1, POISSON_FDM = 2 };
 struct ins_fdm;
 int ins_fdm_create(int D, const int n[3], const double* const V[3], const double* const lam[3], int singular, ins_fdm** out);
 int ins_fdm_destroy(ins_fdm* F);
+int ins_fdm_enable_zfft(ins_fdm* F, double hz, const double* lam_z_host);
 int ins_fdm_solve(ins_fdm* F, hipStream_t s);
 double* ins_fdm_buffer(ins_fdm* F);
 const double* ins_fdm_mean(ins_fdm* F);  // device scalar the consumer subtracts (singular systems), or nullptr
@@ -211,6 +212,8 @@ int ins_k_ownfft_y(double* phat, int kxn, int n1, int n2, const double* tw, bool
 int ins_k_ownfft_y_packed(double* phat, double* packed, int kxn, int n1, int nzl, int nyl, int cw, const double* tw, bool inverse,
                           hipStream_t s);
 int ins_zsolve_twiddles(int nz, double** out);
+int ins_k_fdm_z(double* data, int n0, int n1, int nz, const double* lx, const double* ly, const double* lz, const double* ox, const double* oy,
+                double h, double tol, int singular, const double* meanf, double* partial, const double* tw, int* nblk, hipStream_t s);
 int ins_k_zsolve(double* data, int nz, long long nl, const double* ax, int kxn, const double* ay, const double* az, const double* tw,
                  double inv_n, bool zero_mean, hipStream_t s, int kxs = 0);
 

@@ -741,6 +741,17 @@ extern "C" int ins_poisson_fdm_create(const ins_grid_t* G, const double* const* 
     delete ps;
     return rc;
   }
+  if (g.D == 3 && g.bc[2][0] == INS_BC_PERIODIC && g.bc[2][1] == INS_BC_PERIODIC) {  // periodic z: Fourier modes if the spacing is constant
+    const ins_grid_desc_t& d = G->desc;
+    bool uni = true;
+    const double hz = d.dx[2][1];
+    const double ztol = 4.0 * d.N[2] * 2.220446049250313e-16 * hz;
+    for (int k = 0; k < d.N[2]; ++k) uni = uni && std::fabs(d.dx[2][k] - hz) <= ztol && (k == d.N[2] - 1 || std::fabs(d.dxu[2][k] - hz) <= ztol);  // (the last Δu is Δ/2 by construction, grid.jl:196)
+    if (uni && (rc = ins_fdm_enable_zfft(ps->fdm, hz, lam[2]))) {
+      ins_poisson_destroy(ps);
+      return rc;
+    }
+  }
   *out = ps;
   return INS_OK;
 }

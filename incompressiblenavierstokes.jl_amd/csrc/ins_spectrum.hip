@@ -6,7 +6,7 @@
 
 struct ins_spectrum {
   const ins_grid* grid;
-  hipfftHandle plan = 0, plan_inv = 0;  // the inverse exists only because the validating factory builds pairs
+  hipfftHandle plan = 0;
   bool has_plan = false;
   double* real = nullptr;                // Np
   hipfftDoubleComplex* hat = nullptr;    // (Np0/2+1) Np1 [Np2]
@@ -49,11 +49,7 @@ __global__ __launch_bounds__(64) void k_shell_sums(const double2* __restrict__ h
 
 extern "C" int ins_spectrum_destroy(ins_spectrum_t* S) {
   if (!S) return INS_OK;
-  if (S->has_plan) {
-    (void)hipfftDestroy(S->plan);
-    (void)hipfftDestroy(S->plan_inv);
-    ins_fft_solver_released();
-  }
+  if (S->has_plan) (void)hipfftDestroy(S->plan);
   (void)hipFree(S->real);
   (void)hipFree(S->hat);
   (void)hipFree(S->offsets);
@@ -113,12 +109,13 @@ extern "C" int ins_spectrum_create_weighted(const ins_grid_t* G, int nbin, const
   }
   int dims[3];
   for (int a = 0; a < g.D; ++a) dims[a] = S->np[g.D - 1 - a];  // slowest first
-  // through the validating factory (csrc/ins_fftcheck.hip): rocFFT can hand out a real-transform plan with a wrong twiddle table when
-  // another live plan has the same nx·ny in a different shape; the factory checks output bins against a direct DFT and retries / fails loudly
-  const int rc = ins_fft_make_real_plans(&S->plan, &S->plan_inv, g.D, dims, 1);
-  if (rc != INS_OK) {
+  // A plain hipFFT plan.  (The validating factory of the Poisson solvers, csrc/ins_fftcheck.hip, is not used here: when it suspects the
+  // rocFFT plan-cache defect it resets rocFFT's process-wide state, which a diagnostic must not do to its host — PyTorch's torch.fft plans
+  // die with it — and which leaks ~30 MB of code objects per reset.  The observer's output is checked against the oracle in the tests.)
+  if (hipfftPlanMany(&S->plan, g.D, dims, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, 1) != HIPFFT_SUCCESS) {
     ins_spectrum_destroy(S);
-    return rc;
+    ins_set_error("spectrum: hipfftPlanMany failed");
+    return INS_ERR_FFT;
   }
   S->has_plan = true;
   *out = S;

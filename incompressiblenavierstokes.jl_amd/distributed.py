@@ -176,6 +176,7 @@ class HipSlabKernels:
         h3 = (C.c_double * 3)(*h)
         self._fft = C.c_void_p()
         _lib.call("ins_slab_fft_create", np3, h3, lay.rank, lay.world, C.byref(self._fft))
+        _lib.sync_fft_plan_caches()
         nr, nc = C.c_int64(), C.c_int64()
         _lib.call("ins_slab_fft_sizes", self._fft, C.byref(nr), C.byref(nc))
         self.real_elems, self.complex_elems = nr.value, nc.value

@@ -56,6 +56,7 @@ class psolver_spectral(_PSolver):
     def __init__(self, setup):
         super().__init__(setup)
         _lib.call("ins_poisson_spectral_create", setup.handle, C.byref(self._handle))
+        _lib.sync_fft_plan_caches()
 
 
 class psolver_cg(_PSolver):

@@ -204,6 +204,7 @@ class _Spectrum:
             w = np.ascontiguousarray(np.concatenate(weights), dtype=np.float64)
             _lib.call("ins_spectrum_create_weighted", setup.handle, self.nbin, off.ctypes.data_as(C.POINTER(C.c_int64)),
                       flat.ctypes.data_as(C.POINTER(C.c_int64)), w.ctypes.data_as(_lib.c_double_p), C.byref(self._handle))
+        _lib.sync_fft_plan_caches()
         self.ehat = torch.zeros(self.nbin, dtype=torch.float64, device=setup.device)
 
     def __call__(self, u):

@@ -152,13 +152,25 @@ def _channel(o):
     return o.make_setup(x, bcs, Re=100.0)
 
 
-@pytest.mark.parametrize("geom", ["dirichlet2d", "dirichlet3d", "mixed3d", "periodic2d", "periodic3d", "channel3d"])
+def _zperiodic(o, kind):
+    """Walls / open sides in x and y, a periodic uniform power-of-two z: the direct solver's fused z pass (Fourier modes instead of Vz)."""
+    x = (o.cosine_grid(0.0, 1.0, 12), o.tanh_grid(0.0, 1.0, 10, 1.3), np.linspace(-0.2, 0.2, 33))
+    D, P, S, W = o.DirichletBC, o.PeriodicBC, o.SymmetricBC, o.PressureBC
+    bcs = {"cavity": ((D(), D()), (D(), D((1.0, 0.0, 0.2))), (P(), P())),
+           "open": ((D(), W()), (S(), S()), (P(), P())),
+           "xyper": ((P(), P()), (D(), D()), (P(), P()))}[kind]
+    if kind == "xyper":
+        x = (np.linspace(0.0, 1.0, 17), x[1], np.linspace(0.0, 2 * np.pi, 65))
+    return o.make_setup(x, bcs, Re=100.0)
+
+
+@pytest.mark.parametrize("geom", ["dirichlet2d", "dirichlet3d", "mixed3d", "periodic2d", "periodic3d", "channel3d", "z:cavity", "z:open", "z:xyper"])
 @pytest.mark.parametrize("consistent", [True, False])
 def test_direct_matches_oracle_direct(ins, oracle, geom, consistent):
     """psolver_direct (fast diagonalisation on rocBLAS) against the oracle's sparse-LU factorisation of laplacian_mat,
     including right-hand sides outside the range of a singular L (the bordered system, pressure.jl:133-140)."""
     o = oracle
-    so = _channel(o) if geom == "channel3d" else GEOMS[geom](o)
+    so = _channel(o) if geom == "channel3d" else (_zperiodic(o, geom[2:]) if geom.startswith("z:") else GEOMS[geom](o))
     sp = mirror(ins, so, o)
     g = so.grid
     if consistent:
