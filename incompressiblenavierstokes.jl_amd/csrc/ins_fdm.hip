@@ -37,6 +37,13 @@ struct ins_fdm {
   double* lzk = nullptr;    // λz(k), k = 0..n2/2
   double* ztw = nullptr;    // twiddles
   double* zpart = nullptr;  // block partials of the fused z kernel
+  // periodic uniform x as well (channel flows): real-to-complex x passes (ins_fft.hip) instead of the dense Vx
+  bool xfft = false;
+  int kxs = 0;              // complex row stride of the half spectrum (n0/2+1 rounded up to 8)
+  double hx = 0.0;
+  double* lxd = nullptr;    // λx per REAL slot of a spectrum row (re and im of a mode share it), 2 kxs
+  double* oxd = nullptr;    // Vxᵀ1 in that layout: sqrt(n0/hx) at the real part of kx = 0
+  double* xtw = nullptr;
 };
 
 namespace {
@@ -141,6 +148,9 @@ int ins_fdm_destroy(ins_fdm* F) {
   if (F->lzk) (void)hipFree(F->lzk);
   if (F->ztw) (void)hipFree(F->ztw);
   if (F->zpart) (void)hipFree(F->zpart);
+  if (F->lxd) (void)hipFree(F->lxd);
+  if (F->oxd) (void)hipFree(F->oxd);
+  if (F->xtw) (void)hipFree(F->xtw);
   delete F;
   return INS_OK;
 }
@@ -217,6 +227,53 @@ int ins_fdm_enable_zfft(ins_fdm* F, double hz, const double* lam_z_host) {
   return INS_OK;
 }
 
+// Periodic uniform x on top of a Fourier z (channel flows): the x eigenvectors are Fourier modes too.  The real-to-complex x pass turns a
+// row into n0/2+1 complex modes (padded to kxs); the y GEMMs and the fused z pass are real-linear and act on the interleaved (re, im) slots as
+// on any other real column — both slots of a mode carry the same λx, so the z pass's per-column scaling is simply the complex scaling.
+// The 1/sqrt(hx n0) of the D-orthonormal convention rides on the two y GEMMs (alpha).
+int ins_fdm_enable_xfft(ins_fdm* F, double hx, const double* lam_x_host) {
+  static const bool off = getenv("INS_DISABLE_FDM_XFFT") != nullptr;  // A/B switch
+  const int n0 = F->n[0], n1 = F->n[1], n2 = F->n[2];
+  if (off || !F->zfft || n0 < 16 || n0 > 1024 || (n0 & (n0 - 1)) || (n1 & 1)) return INS_OK;
+  std::vector<double> want(n0), have(lam_x_host, lam_x_host + n0);
+  for (int k = 0; k < n0; ++k) {
+    const double sn = std::sin(M_PI * (double)k / n0);
+    want[k] = -4.0 * sn * sn / (hx * hx);
+  }
+  std::vector<double> ws(want);
+  std::sort(ws.begin(), ws.end());
+  std::sort(have.begin(), have.end());
+  for (int k = 0; k < n0; ++k)
+    if (std::fabs(ws[k] - have[k]) > 1e-9 * 4.0 / (hx * hx)) return INS_OK;
+  const int kxn = n0 / 2 + 1, kxs = (kxn + 7) & ~7;
+  std::vector<double> lxd(2 * kxs, -1e300), oxd(2 * kxs, 0.0);  // padding slots: data is zero, keep the division harmless
+  for (int m = 0; m < kxn; ++m) lxd[2 * m] = lxd[2 * m + 1] = want[m];
+  oxd[0] = std::sqrt((double)n0 / hx);
+  const size_t elems = std::max<size_t>((size_t)n0 * n1 * n2, (size_t)2 * kxs * n1 * n2);
+  const int nblk = (int)(((long long)kxs * n1 + 7) / 8);
+  (void)hipFree(F->a);
+  (void)hipFree(F->b);
+  (void)hipFree(F->zpart);
+  F->a = F->b = F->zpart = nullptr;
+  bool ok = hipMalloc(&F->a, elems * 8) == hipSuccess && hipMalloc(&F->b, elems * 8) == hipSuccess && hipMemset(F->a, 0, elems * 8) == hipSuccess &&
+            hipMemset(F->b, 0, elems * 8) == hipSuccess && hipMalloc(&F->zpart, (size_t)nblk * 8) == hipSuccess &&
+            hipMemset(F->zpart, 0, (size_t)nblk * 8) == hipSuccess && hipMalloc(&F->lxd, lxd.size() * 8) == hipSuccess &&
+            hipMalloc(&F->oxd, oxd.size() * 8) == hipSuccess && hipMemcpy(F->lxd, lxd.data(), lxd.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(F->oxd, oxd.data(), oxd.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    ins_set_error("ins_fdm_enable_xfft: allocation failed");
+    return INS_ERR_HIP;
+  }
+  int rc = ins_zsolve_twiddles(n0, &F->xtw);
+  if (rc) return rc;
+  F->kxs = kxs;
+  F->hx = hx;
+  F->null_i[0] = 0;
+  F->null_s[0] = 1.0 / std::sqrt(hx * (double)n0);
+  F->xfft = true;
+  return INS_OK;
+}
+
 // in: f on the unpadded block (n0,n1,n2) in F->a; out: p in F->a
 int ins_fdm_solve(ins_fdm* F, hipStream_t s) {
   const int n0 = F->n[0], n1 = F->n[1], n2 = F->D == 3 ? F->n[2] : 1;
@@ -225,6 +282,27 @@ int ins_fdm_solve(ins_fdm* F, hipStream_t s) {
   INS_BLAS_TRY(rocblas_set_stream(F->h, s));
   INS_BLAS_TRY(rocblas_set_pointer_mode(F->h, rocblas_pointer_mode_host));
   double *x = F->a, *y = F->b;
+  if (F->xfft) {  // x and z in Fourier modes, y through its eigenvectors: x r2c, y GEMM, fused z pass, y GEMM, x c2r
+    const int m2 = 2 * F->kxs;
+    const long long m2n1 = (long long)m2 * n1;
+    const double alpha = 1.0 / std::sqrt(F->hx * (double)n0);
+    int rc = ins_k_ownfft_xfwd(nullptr, x, 0, y, n0, n1, n2, F->xtw, s, F->kxs, 0);
+    if (rc) return rc;
+    INS_BLAS_TRY(rocblas_dgemm_strided_batched(F->h, rocblas_operation_none, rocblas_operation_none, m2, n1, n1, &alpha, y, m2, m2n1, F->V[1], n1, 0,
+                                               &zero, x, m2, m2n1, n2));
+    if (F->singular)
+      hipLaunchKernelGGL(k_fdm_null_z, dim3(1), dim3(64), 0, s, x, (long long)m2 * F->null_i[1], m2n1, n2,
+                         1.0 / (F->null_s[0] * F->null_s[1] * (double)total), F->sums);
+    int nb = 0;
+    rc = ins_k_fdm_z(x, m2, n1, n2, F->lxd, F->lam[1], F->lzk, F->oxd, F->ones[1], F->hz, F->lam_tol, F->singular ? 1 : 0, F->sums + 4096, F->zpart,
+                     F->ztw, &nb, s);
+    if (rc) return rc;
+    if (F->singular) hipLaunchKernelGGL(k_fdm_mean_z, dim3(1), dim3(256), 0, s, F->zpart, nb, 1.0 / (double)total, F->sums);
+    INS_LAUNCH_CHECK();
+    INS_BLAS_TRY(rocblas_dgemm_strided_batched(F->h, rocblas_operation_none, rocblas_operation_transpose, m2, n1, n1, &alpha, x, m2, m2n1, F->V[1], n1,
+                                               0, &zero, y, m2, m2n1, n2));
+    return ins_k_ownfft_xinv(y, x, n0, n1, n2, F->xtw, s, F->kxs);
+  }
   const int nblk = (int)std::min<long long>((total + 255) / 256, 4096);
   // forward: q = (Vxᵀ ⊗ Vyᵀ ⊗ Vzᵀ) f
   INS_BLAS_TRY(rocblas_dgemm(F->h, rocblas_operation_transpose, rocblas_operation_none, n0, n1 * n2, n0, &one, F->V[0], n0, x, n0, &zero, y, n0));

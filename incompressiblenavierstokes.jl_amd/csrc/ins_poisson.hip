@@ -751,6 +751,16 @@ extern "C" int ins_poisson_fdm_create(const ins_grid_t* G, const double* const* 
       ins_poisson_destroy(ps);
       return rc;
     }
+    if (uni && g.bc[0][0] == INS_BC_PERIODIC && g.bc[0][1] == INS_BC_PERIODIC) {  // periodic x too (channel flows)
+      const double hx = d.dx[0][1];
+      const double xtol = 4.0 * d.N[0] * 2.220446049250313e-16 * hx;
+      bool unix_ = true;
+      for (int k = 0; k < d.N[0]; ++k) unix_ = unix_ && std::fabs(d.dx[0][k] - hx) <= xtol && (k == d.N[0] - 1 || std::fabs(d.dxu[0][k] - hx) <= xtol);
+      if (unix_ && (rc = ins_fdm_enable_xfft(ps->fdm, hx, lam[0]))) {
+        ins_poisson_destroy(ps);
+        return rc;
+      }
+    }
   }
   *out = ps;
   return INS_OK;

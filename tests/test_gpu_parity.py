@@ -158,13 +158,16 @@ def _zperiodic(o, kind):
     D, P, S, W = o.DirichletBC, o.PeriodicBC, o.SymmetricBC, o.PressureBC
     bcs = {"cavity": ((D(), D()), (D(), D((1.0, 0.0, 0.2))), (P(), P())),
            "open": ((D(), W()), (S(), S()), (P(), P())),
-           "xyper": ((P(), P()), (D(), D()), (P(), P()))}[kind]
+           "xyper": ((P(), P()), (D(), D()), (P(), P())),
+           "channel": ((P(), P()), (D(), W()), (P(), P()))}[kind]
     if kind == "xyper":
         x = (np.linspace(0.0, 1.0, 17), x[1], np.linspace(0.0, 2 * np.pi, 65))
+    if kind == "channel":  # open top: a regular (non-singular) system with Fourier x and z
+        x = (np.linspace(0.0, 2 * np.pi, 33), o.tanh_grid(0.0, 2.0, 12, 1.5), np.linspace(0.0, np.pi, 33))
     return o.make_setup(x, bcs, Re=100.0)
 
 
-@pytest.mark.parametrize("geom", ["dirichlet2d", "dirichlet3d", "mixed3d", "periodic2d", "periodic3d", "channel3d", "z:cavity", "z:open", "z:xyper"])
+@pytest.mark.parametrize("geom", ["dirichlet2d", "dirichlet3d", "mixed3d", "periodic2d", "periodic3d", "channel3d", "z:cavity", "z:open", "z:xyper", "z:channel"])
 @pytest.mark.parametrize("consistent", [True, False])
 def test_direct_matches_oracle_direct(ins, oracle, geom, consistent):
     """psolver_direct (fast diagonalisation on rocBLAS) against the oracle's sparse-LU factorisation of laplacian_mat,
