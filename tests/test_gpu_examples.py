@@ -71,3 +71,10 @@ def test_shear_layer_2d():
 def test_planar_mixing_2d():
     r = load("PlanarMixing2D").main(n=16, tend=2.0, verbose=False)
     assert r["t"] == pytest.approx(2.0) and r["maxdiv"] < 1e-9 and r["ulo"] < 1.0 < r["uhi"] and np.isfinite(r["vmax"])
+
+
+def test_turbulent_channel():
+    r = load("TurbulentChannel").main(n=16, tend=0.02, verbose=False)
+    p = r["profile"]
+    assert r["psolver"] == "psolver_direct" and r["maxdiv"] < 1e-10 and r["t"] == pytest.approx(0.02)
+    assert p[len(p) // 2] > 0.8 and p[0] < 0.5 * p[len(p) // 2] and p[-1] < 0.5 * p[len(p) // 2]  # parabola-like: fast core, slow walls
