@@ -44,6 +44,12 @@ struct ins_fdm {
   double* lxd = nullptr;    // λx per REAL slot of a spectrum row (re and im of a mode share it), 2 kxs
   double* oxd = nullptr;    // Vxᵀ1 in that layout: sqrt(n0/hx) at the real part of kx = 0
   double* xtw = nullptr;
+  // periodic uniform x AND y with any z (walls in z: the orientation of TurbulentChannel.jl): x and y through the own FFT passes, z through Vz
+  bool xyfft = false;
+  double hy = 0.0;
+  double* lyp = nullptr;    // λy in the digit-reversed order the own y pass leaves behind
+  double* oyp = nullptr;    // Vyᵀ1 in that layout: sqrt(n1/hy) at position 0
+  double* ytw = nullptr;
 };
 
 namespace {
@@ -151,6 +157,9 @@ int ins_fdm_destroy(ins_fdm* F) {
   if (F->lxd) (void)hipFree(F->lxd);
   if (F->oxd) (void)hipFree(F->oxd);
   if (F->xtw) (void)hipFree(F->xtw);
+  if (F->lyp) (void)hipFree(F->lyp);
+  if (F->oyp) (void)hipFree(F->oyp);
+  if (F->ytw) (void)hipFree(F->ytw);
   delete F;
   return INS_OK;
 }
@@ -274,6 +283,69 @@ int ins_fdm_enable_xfft(ins_fdm* F, double hx, const double* lam_x_host) {
   return INS_OK;
 }
 
+// Periodic uniform x and y, any z (walls in z): real-to-complex x pass, own y pass (digit-reversed ky), z through its dense eigenvectors on the
+// interleaved (re, im) slots, the ordinary scaling pass with the eigenvalue vectors laid out like the data, and back.
+static bool analytic_spectrum(const double* lam_host, int n, double h) {
+  std::vector<double> want(n), have(lam_host, lam_host + n);
+  for (int k = 0; k < n; ++k) {
+    const double sn = std::sin(M_PI * (double)k / n);
+    want[k] = -4.0 * sn * sn / (h * h);
+  }
+  std::sort(want.begin(), want.end());
+  std::sort(have.begin(), have.end());
+  for (int k = 0; k < n; ++k)
+    if (std::fabs(want[k] - have[k]) > 1e-9 * 4.0 / (h * h)) return false;
+  return true;
+}
+
+int ins_fdm_enable_xyfft(ins_fdm* F, double hx, double hy, const double* lam_x_host, const double* lam_y_host) {
+  static const bool off = getenv("INS_DISABLE_FDM_XYFFT") != nullptr;  // A/B switch
+  const int n0 = F->n[0], n1 = F->n[1], n2 = F->D == 3 ? F->n[2] : 1;
+  auto pow2 = [](int n) { return n >= 16 && n <= 1024 && !(n & (n - 1)); };
+  if (off || F->xfft || F->zfft || F->D != 3 || !pow2(n0) || !pow2(n1)) return INS_OK;
+  if (!analytic_spectrum(lam_x_host, n0, hx) || !analytic_spectrum(lam_y_host, n1, hy)) return INS_OK;
+  const int kxn = n0 / 2 + 1, kxs = (kxn + 7) & ~7;
+  std::vector<double> lxd(2 * kxs, -1e300), oxd(2 * kxs, 0.0), ly(n1), lyp(n1), oyp(n1, 0.0);
+  for (int m = 0; m < kxn; ++m) {
+    const double sn = std::sin(M_PI * (double)m / n0);
+    lxd[2 * m] = lxd[2 * m + 1] = -4.0 * sn * sn / (hx * hx);
+  }
+  for (int k = 0; k < n1; ++k) {
+    const double sn = std::sin(M_PI * (double)k / n1);
+    ly[k] = -4.0 * sn * sn / (hy * hy);
+  }
+  ins_ownfft_permute_symbol(n1, ly.data(), lyp.data());
+  oxd[0] = std::sqrt((double)n0 / hx);
+  oyp[0] = std::sqrt((double)n1 / hy);  // frequency 0 sits at position 0
+  const size_t elems = std::max<size_t>((size_t)n0 * n1 * n2, (size_t)2 * kxs * n1 * n2);
+  (void)hipFree(F->a);
+  (void)hipFree(F->b);
+  F->a = F->b = nullptr;
+  bool ok = hipMalloc(&F->a, elems * 8) == hipSuccess && hipMalloc(&F->b, elems * 8) == hipSuccess && hipMemset(F->a, 0, elems * 8) == hipSuccess &&
+            hipMemset(F->b, 0, elems * 8) == hipSuccess && hipMalloc(&F->lxd, lxd.size() * 8) == hipSuccess && hipMalloc(&F->oxd, oxd.size() * 8) == hipSuccess &&
+            hipMalloc(&F->lyp, lyp.size() * 8) == hipSuccess && hipMalloc(&F->oyp, oyp.size() * 8) == hipSuccess &&
+            hipMemcpy(F->lxd, lxd.data(), lxd.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(F->oxd, oxd.data(), oxd.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(F->lyp, lyp.data(), lyp.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(F->oyp, oyp.data(), oyp.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    ins_set_error("ins_fdm_enable_xyfft: allocation failed");
+    return INS_ERR_HIP;
+  }
+  int rc = ins_zsolve_twiddles(n0, &F->xtw);
+  if (rc) return rc;
+  if ((rc = ins_zsolve_twiddles(n1, &F->ytw))) return rc;
+  F->kxs = kxs;
+  F->hx = hx;
+  F->hy = hy;
+  // null mode: kx = 0 (real slot), ky = 0 (position 0), the z null mode as before; V₀ = scale · 1 with the Fourier directions' 1/sqrt(h n)
+  const double sx = 1.0 / std::sqrt(hx * (double)n0), sy = 1.0 / std::sqrt(hy * (double)n1);
+  F->null_index = (long long)F->null_i[2] * (2LL * kxs) * n1;
+  F->null_scale = sx * sy * F->null_s[2];
+  F->xyfft = true;
+  return INS_OK;
+}
+
 // in: f on the unpadded block (n0,n1,n2) in F->a; out: p in F->a
 int ins_fdm_solve(ins_fdm* F, hipStream_t s) {
   const int n0 = F->n[0], n1 = F->n[1], n2 = F->D == 3 ? F->n[2] : 1;
@@ -301,6 +373,25 @@ int ins_fdm_solve(ins_fdm* F, hipStream_t s) {
     INS_LAUNCH_CHECK();
     INS_BLAS_TRY(rocblas_dgemm_strided_batched(F->h, rocblas_operation_none, rocblas_operation_transpose, m2, n1, n1, &alpha, x, m2, m2n1, F->V[1], n1,
                                                0, &zero, y, m2, m2n1, n2));
+    return ins_k_ownfft_xinv(y, x, n0, n1, n2, F->xtw, s, F->kxs);
+  }
+  if (F->xyfft) {  // x r2c, y FFT (own passes), z GEMM on the interleaved slots, scaling, and back
+    const int kxn = n0 / 2 + 1, m2 = 2 * F->kxs;
+    const long long rows = (long long)m2 * n1, tot2 = rows * n2;
+    const double alpha = 1.0 / (std::sqrt(F->hx * (double)n0) * std::sqrt(F->hy * (double)n1));
+    const int nblk2 = (int)std::min<long long>((tot2 + 255) / 256, 4096);
+    int rc = ins_k_ownfft_xfwd(nullptr, x, 0, y, n0, n1, n2, F->xtw, s, F->kxs, 0);
+    if (rc) return rc;
+    if ((rc = ins_k_ownfft_y(y, kxn, n1, n2, F->ytw, false, s, F->kxs))) return rc;
+    INS_BLAS_TRY(rocblas_dgemm(F->h, rocblas_operation_none, rocblas_operation_none, (int)rows, n2, n2, &alpha, y, (int)rows, F->V[2], n2, &zero, x, (int)rows));
+    if (F->singular) hipLaunchKernelGGL(k_fdm_null, dim3(1), dim3(1), 0, s, x, F->null_index, 1.0 / (F->null_scale * (double)total), F->sums);
+    hipLaunchKernelGGL(k_fdm_scale, dim3(nblk2), dim3(256), 0, s, x, F->lxd, F->lyp, F->lam[2], F->oxd, F->oyp, F->ones[2], m2, n1, n2, F->lam_tol,
+                       F->singular ? 1 : 0, F->sums);
+    if (F->singular) hipLaunchKernelGGL(k_fdm_mean, dim3(1), dim3(256), 0, s, F->sums, nblk2, 1.0 / (double)total);
+    INS_LAUNCH_CHECK();
+    INS_BLAS_TRY(rocblas_dgemm(F->h, rocblas_operation_none, rocblas_operation_transpose, (int)rows, n2, n2, &alpha, x, (int)rows, F->V[2], n2, &zero, y,
+                               (int)rows));
+    if ((rc = ins_k_ownfft_y(y, kxn, n1, n2, F->ytw, true, s, F->kxs))) return rc;
     return ins_k_ownfft_xinv(y, x, n0, n1, n2, F->xtw, s, F->kxs);
   }
   const int nblk = (int)std::min<long long>((total + 255) / 256, 4096);

@@ -762,6 +762,21 @@ extern "C" int ins_poisson_fdm_create(const ins_grid_t* G, const double* const* 
       }
     }
   }
+  if (g.D == 3 && g.bc[0][0] == INS_BC_PERIODIC && g.bc[0][1] == INS_BC_PERIODIC && g.bc[1][0] == INS_BC_PERIODIC && g.bc[1][1] == INS_BC_PERIODIC &&
+      !(g.bc[2][0] == INS_BC_PERIODIC && g.bc[2][1] == INS_BC_PERIODIC)) {  // periodic x and y, walls / open sides in z
+    const ins_grid_desc_t& d = G->desc;
+    bool uni = true;
+    double hh[2];
+    for (int a = 0; a < 2; ++a) {
+      hh[a] = d.dx[a][1];
+      const double tol = 4.0 * d.N[a] * 2.220446049250313e-16 * hh[a];
+      for (int k = 0; k < d.N[a]; ++k) uni = uni && std::fabs(d.dx[a][k] - hh[a]) <= tol && (k == d.N[a] - 1 || std::fabs(d.dxu[a][k] - hh[a]) <= tol);
+    }
+    if (uni && (rc = ins_fdm_enable_xyfft(ps->fdm, hh[0], hh[1], lam[0], lam[1]))) {
+      ins_poisson_destroy(ps);
+      return rc;
+    }
+  }
   *out = ps;
   return INS_OK;
 }

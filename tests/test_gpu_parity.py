@@ -156,6 +156,9 @@ def _zperiodic(o, kind):
     """Walls / open sides in x and y, a periodic uniform power-of-two z: the direct solver's fused z pass (Fourier modes instead of Vz)."""
     x = (o.cosine_grid(0.0, 1.0, 12), o.tanh_grid(0.0, 1.0, 10, 1.3), np.linspace(-0.2, 0.2, 33))
     D, P, S, W = o.DirichletBC, o.PeriodicBC, o.SymmetricBC, o.PressureBC
+    if kind in ("zwall", "zopen"):  # periodic x and y, walls (or an open top) in z: the orientation of the reference's TurbulentChannel.jl
+        x = (np.linspace(0.0, 2 * np.pi, 33), np.linspace(0.0, 1.0, 17), o.tanh_grid(0.0, 1.0, 11, 1.4))
+        return o.make_setup(x, ((P(), P()), (P(), P()), (D(), D() if kind == "zwall" else W())), Re=100.0)
     bcs = {"cavity": ((D(), D()), (D(), D((1.0, 0.0, 0.2))), (P(), P())),
            "open": ((D(), W()), (S(), S()), (P(), P())),
            "xyper": ((P(), P()), (D(), D()), (P(), P())),
@@ -167,7 +170,7 @@ def _zperiodic(o, kind):
     return o.make_setup(x, bcs, Re=100.0)
 
 
-@pytest.mark.parametrize("geom", ["dirichlet2d", "dirichlet3d", "mixed3d", "periodic2d", "periodic3d", "channel3d", "z:cavity", "z:open", "z:xyper", "z:channel"])
+@pytest.mark.parametrize("geom", ["dirichlet2d", "dirichlet3d", "mixed3d", "periodic2d", "periodic3d", "channel3d", "z:cavity", "z:open", "z:xyper", "z:channel", "z:zwall", "z:zopen"])
 @pytest.mark.parametrize("consistent", [True, False])
 def test_direct_matches_oracle_direct(ins, oracle, geom, consistent):
     """psolver_direct (fast diagonalisation on rocBLAS) against the oracle's sparse-LU factorisation of laplacian_mat,
