@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Body-force-driven channel flow: periodic in the streamwise and spanwise directions, tanh-stretched no-slip walls (the setting of
-examples/TurbulentChannel.jl).  The walls are put in y here — with periodic uniform x and z the direct Poisson solver runs both of them
-in Fourier modes and only the wall-normal direction through its dense eigenvectors (csrc/ins_fdm.hip).
+examples/TurbulentChannel.jl, which has its walls in z; here they are in y).  In either orientation the direct Poisson solver runs the two
+periodic uniform directions in Fourier modes and only the wall-normal direction through its dense eigenvectors (csrc/ins_fdm.hip).
     python examples/TurbulentChannel.py n=64 tend=1"""
 import numpy as np
 
