@@ -347,7 +347,8 @@ int ins_fdm_enable_xyfft(ins_fdm* F, double hx, double hy, const double* lam_x_h
 }
 
 // in: f on the unpadded block (n0,n1,n2) in F->a; out: p in F->a
-int ins_fdm_solve(ins_fdm* F, hipStream_t s) {
+// G, u given (only meaningful when ins_fdm_takes_u): the right-hand side Ω·div(u) is formed inside the x pass instead of being read from F->a
+int ins_fdm_solve(ins_fdm* F, hipStream_t s, const ins_grid* G, const double* u) {
   const int n0 = F->n[0], n1 = F->n[1], n2 = F->D == 3 ? F->n[2] : 1;
   const long long n01 = (long long)n0 * n1, total = n01 * n2;
   const double one = 1.0, zero = 0.0;
@@ -358,7 +359,7 @@ int ins_fdm_solve(ins_fdm* F, hipStream_t s) {
     const int m2 = 2 * F->kxs;
     const long long m2n1 = (long long)m2 * n1;
     const double alpha = 1.0 / std::sqrt(F->hx * (double)n0);
-    int rc = ins_k_ownfft_xfwd(nullptr, x, 0, y, n0, n1, n2, F->xtw, s, F->kxs, 0);
+    int rc = ins_k_ownfft_xfwd(u ? G : nullptr, u ? u : x, u ? 4 : 0, y, n0, n1, n2, F->xtw, s, F->kxs, 0);
     if (rc) return rc;
     INS_BLAS_TRY(rocblas_dgemm_strided_batched(F->h, rocblas_operation_none, rocblas_operation_none, m2, n1, n1, &alpha, y, m2, m2n1, F->V[1], n1, 0,
                                                &zero, x, m2, m2n1, n2));
@@ -380,7 +381,7 @@ int ins_fdm_solve(ins_fdm* F, hipStream_t s) {
     const long long rows = (long long)m2 * n1, tot2 = rows * n2;
     const double alpha = 1.0 / (std::sqrt(F->hx * (double)n0) * std::sqrt(F->hy * (double)n1));
     const int nblk2 = (int)std::min<long long>((tot2 + 255) / 256, 4096);
-    int rc = ins_k_ownfft_xfwd(nullptr, x, 0, y, n0, n1, n2, F->xtw, s, F->kxs, 0);
+    int rc = ins_k_ownfft_xfwd(u ? G : nullptr, u ? u : x, u ? 4 : 0, y, n0, n1, n2, F->xtw, s, F->kxs, 0);
     if (rc) return rc;
     if ((rc = ins_k_ownfft_y(y, kxn, n1, n2, F->ytw, false, s, F->kxs))) return rc;
     INS_BLAS_TRY(rocblas_dgemm(F->h, rocblas_operation_none, rocblas_operation_none, (int)rows, n2, n2, &alpha, y, (int)rows, F->V[2], n2, &zero, x, (int)rows));
@@ -441,6 +442,9 @@ int ins_fdm_solve(ins_fdm* F, hipStream_t s) {
 }
 
 double* ins_fdm_buffer(ins_fdm* F) { return F->a; }
+
+// the solve starts with an x pass that can form Ω·div(u) itself (ins_fdm_solve(F, s, G, u))
+bool ins_fdm_takes_u(const ins_fdm* F) { return F->xfft || F->xyfft; }
 
 // device scalar mean(p[Ip]) of the last solve: the consumer of the buffer subtracts it (e'p = 0, pressure.jl:133-140); nullptr when L is regular
 const double* ins_fdm_mean(ins_fdm* F) { return F->singular ? F->sums + 4097 : nullptr; }

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kx
 
 // ------------------------------------------------------------------------------------------------------------
 // Pass 1: x forward, NP row pairs per workgroup.  SRC 0: rows come from pI; SRC 1: rows = Ω·div(u) (K2 fused, periodic
-// wrap in all directions); SRC 2: the same on a z-slab (z neighbour from the ghost plane); SRC 3: the 2-D divergence.
+// wrap in all directions); SRC 2: the same on a z-slab (z neighbour from the ghost plane); SRC 3: the 2-D divergence; SRC 4: the divergence on a grid with walls (ghost volumes of u valid).
 // ------------------------------------------------------------------------------------------------------------
 template <int LOGN, int NP, int SRC>
 __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restrict__ src, double2* __restrict__ out, int n1,
@@ -223,6 +223,14 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
       const int j = min(j0 + row, n1 - 1);
       if (SRC == 0) {
         v[q] = src[i + (long long)N * (j + (long long)n1 * kz)];
+      } else if (SRC == 4) {
+        // Ω · div(u) at the pressure point (i, j, kz) of a grid with walls: the ghost volumes of u are valid (k_div_to_pI<3, false>)
+        const int I0 = g.ip_lo[0] + i, I1 = g.ip_lo[1] + j, I2 = g.ip_lo[2] + kz;
+        const long long c = I0 + I1 * g.sx[1] + I2 * g.sx[2];
+        double d = (src[c] - src[c - 1]) * g.rdx[0][I0];
+        d += (src[g.sc + c] - src[g.sc + c - g.sx[1]]) * g.rdx[1][I1];
+        d += (src[2 * g.sc + c] - src[2 * g.sc + c - g.sx[2]]) * g.rdx[2][I2];
+        v[q] = d * (g.dx[0][I0] * g.dx[1][I1] * g.dx[2][I2]);
       } else if (SRC == 3) {
         // 2-D: Ω · div(u*) at interior cell (i, j) with periodic wrap (k_div_to_pI<2, true>)
         const int I0 = i + 1, I1 = j + 1;
@@ -460,7 +468,9 @@ int launch_xfwd(const GridDev& g, const double* src, int from_u, double2* out, i
   constexpr int NP = N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N);
   constexpr size_t lds = ((size_t)NP * N + N) * sizeof(double2);
   dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
-  if (from_u == 3)
+  if (from_u == 4)
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 4>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0);
+  else if (from_u == 3)
     hipLaunchKernelGGL((k_xfwd<LOGN, NP, 3>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0);
   else if (from_u == 2)
     hipLaunchKernelGGL((k_xfwd<LOGN, NP, 2>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0);

@@ -102,7 +102,8 @@ int ins_fdm_destroy(ins_fdm* F);
 int ins_fdm_enable_zfft(ins_fdm* F, double hz, const double* lam_z_host);
 int ins_fdm_enable_xfft(ins_fdm* F, double hx, const double* lam_x_host);
 int ins_fdm_enable_xyfft(ins_fdm* F, double hx, double hy, const double* lam_x_host, const double* lam_y_host);
-int ins_fdm_solve(ins_fdm* F, hipStream_t s);
+int ins_fdm_solve(ins_fdm* F, hipStream_t s, const ins_grid* G = nullptr, const double* u = nullptr);
+bool ins_fdm_takes_u(const ins_fdm* F);
 double* ins_fdm_buffer(ins_fdm* F);
 const double* ins_fdm_mean(ins_fdm* F);  // device scalar the consumer subtracts (singular systems), or nullptr
 

@@ -825,12 +825,16 @@ int ins_k_project(const ins_grid* G, ins_poisson* ps, double* u, double* p, hipS
     // direct solver: Ω·div(u) straight into the solver's buffer, and copy-back - mean + apply_bc_p! + applypressure! in one pass
     double* buf = ins_fdm_buffer(ps->fdm);
     dim3 block(64, 4, 1), grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), g.D == 3 ? ps->np[2] : 1);
-    if (g.D == 2)
-      hipLaunchKernelGGL(k_div_to_pI<2>, grid, block, 0, s, g, u, buf, ps->np[0], ps->np[1]);
-    else
-      hipLaunchKernelGGL(k_div_to_pI<3>, grid, block, 0, s, g, u, buf, ps->np[0], ps->np[1]);
-    INS_LAUNCH_CHECK();
-    if ((rc = ins_fdm_solve(ps->fdm, s))) return rc;
+    if (ins_fdm_takes_u(ps->fdm)) {  // periodic x: the divergence is formed inside the solver's x pass
+      if ((rc = ins_fdm_solve(ps->fdm, s, G, u))) return rc;
+    } else {
+      if (g.D == 2)
+        hipLaunchKernelGGL(k_div_to_pI<2>, grid, block, 0, s, g, u, buf, ps->np[0], ps->np[1]);
+      else
+        hipLaunchKernelGGL(k_div_to_pI<3>, grid, block, 0, s, g, u, buf, ps->np[0], ps->np[1]);
+      INS_LAUNCH_CHECK();
+      if ((rc = ins_fdm_solve(ps->fdm, s))) return rc;
+    }
     dim3 gridp(cdiv(ps->np[0] + 2, 64), cdiv(ps->np[1] + 2, 4), g.D == 3 ? ps->np[2] + 2 : 1);
     if (g.D == 2)
       hipLaunchKernelGGL(k_unpack_grad_bc<2>, gridp, block, 0, s, g, u, p, (const double*)buf, ps->np[0], ps->np[1], ins_fdm_mean(ps->fdm));
