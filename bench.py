@@ -50,13 +50,12 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(budget_s=15.0):
+def cpu_baseline(n=256, budget_s=20.0):
     """Time the CPU restatement (oracle/c: C + OpenMP stencil passes in the reference's unfused pass structure, scipy
-    pocketfft for the FFTs; NOT Julia) on a bounded TGV3D sample on this host's cores."""
+    pocketfft for the FFTs; NOT Julia) on the bench's own grid (TGV3D n^3, same dt), a bounded number of steps, on this host's cores."""
     from oracle import ins_oracle as o
     from oracle.c_port import CPort
 
-    n = 128
     cores = host_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)
     x = (np.linspace(0.0, 1.0, n + 1),) * 3
@@ -66,10 +65,10 @@ def cpu_baseline(budget_s=15.0):
     m = o.RK44()
     cache = o.ode_method_cache(m, so)
     port = CPort(so, workers=cores)
-    port.timestep_(m, u, 1e-3, cache)  # warm-up
+    port.timestep_(m, u, 1e-3, cache)  # warm-up (page faults of the cache arrays, pocketfft plans)
     t0 = time.perf_counter()
     steps = 0
-    while time.perf_counter() - t0 < budget_s and steps < 200:
+    while steps < 2 or (time.perf_counter() - t0 < budget_s and steps < 200):
         port.timestep_(m, u, 1e-3, cache)
         steps += 1
     dt = time.perf_counter() - t0
@@ -78,9 +77,35 @@ def cpu_baseline(budget_s=15.0):
         "unit": "M cell-updates/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"C+OpenMP CPU restatement (not Julia; reference's unfused pass structure, pocketfft), TGV3D {n}^3 fp64, "
-                  f"{steps} RK4 steps in {dt:.1f} s on {cores} threads",
+        "sample": f"C+OpenMP CPU restatement (not Julia; reference's unfused pass structure, pocketfft), TGV3D {n}^3 fp64 (the bench grid), "
+                  f"{steps} RK4 steps in {dt:.1f} s on {cores} threads after 1 warm-up step",
     }
+
+
+def strong_512_single_gpu(ins, dev, steps=10, warmup=2):
+    """The strong-scaling workload of BASELINE configs[3] (TGV3D 512^3, RK44 + spectral Poisson, dt = 2.5e-4) on ONE GPU: the N = 1 point of the
+    1/2/4/8-GPU curve (`bench.py --gpus N` runs the same box on z-slabs of 512/N planes and reports the same object)."""
+    import torch
+
+    n = 512
+    setup = ins.Setup(x=(np.linspace(0.0, 1.0, n + 1),) * 3, Re=1000.0, device=dev)
+    ps = ins.psolver_spectral(setup)
+    u = ins.velocityfield(setup, tgv3d, 0.0, psolver=ps)
+    method = ins.RKMethods.RK44()
+    cache = ins.ode_method_cache(method, setup, ps)
+    st = ins.create_stepper(method, setup=setup, psolver=ps, u=u, t=0.0)
+    dt = 2.5e-4
+    st = ins.timesteps_(method, st, dt, warmup, cache=cache)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st = ins.timesteps_(method, st, dt, steps, cache=cache)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    div = ins.max_abs_divergence(st.u, setup)
+    assert div / n < 1e-10, f"512^3 state is not divergence-free: {div}"
+    return {"workload": "TaylorGreenVortex3D 512^3 periodic fp64, RK44 + spectral Poisson, dt=2.5e-4 (BASELINE configs[3]), total work fixed over N",
+            "scaling": "strong", "n_gpus": 1, "grid": [n, n, n], "steps": steps, "warmup": warmup, "ms_per_step": ms,
+            "value": float(n) ** 3 / (ms * 1e-3) / 1e6, "unit": "M cell-updates/s", "max_abs_div_times_dx": div / n}
 
 
 def main():
@@ -270,8 +295,12 @@ def main():
                            "note": "per cell and step: 4 Poisson solves x (32 + 16 + 16 + 16 + 16) B + the final K4 (64 B, once per call when chained) + the stage kernels"},
         "check": {"max_abs_div_times_dx": div / n, "kinetic_energy": energy},
     }
+    del stepper, cache, u, ps, setup
+    torch.cuda.empty_cache()
+    if not os.environ.get("INS_BENCH_SKIP_STRONG_512"):
+        out["strong_512"] = strong_512_single_gpu(ins, dev)
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(n)
     print(json.dumps(out))
 
 

@@ -1,7 +1,9 @@
 """Multi-GPU leg of bench.py: z-slab decomposition, one rank per GPU over RCCL (torch.distributed "nccl").
 
-Weak scaling: every rank holds 256^3 cells.  The global box is the TGV on [0,1]^3 with
-(nx, ny, nz) = (256, 256, 512) at N=2, (256, 512, 512) at N=4 and 512^3 at N=8 (= BASELINE configs[3])."""
+Headline line (`value`): weak scaling, every rank holds 256^3 cells — the global box is the TGV on [0,1]^3 with
+(nx, ny, nz) = (256, 256, 512) at N=2, (256, 512, 512) at N=4 and 512^3 at N=8 (= BASELINE configs[3]).
+`strong_512`: the strong-scaling leg the north star asks for — the SAME 512^3 box at every N (z-slabs of 512/N planes);
+bench.py's N = 1 line carries the single-GPU point of that curve."""
 import json
 import os
 import time
@@ -11,6 +13,7 @@ import torch
 import torch.distributed as dist
 
 GLOBAL_GRIDS = {1: (256, 256, 256), 2: (256, 256, 512), 4: (256, 512, 512), 8: (512, 512, 512)}
+STRONG_GRID = (512, 512, 512)  # BASELINE configs[3]: the same box at every N
 
 
 def tgv_local(lay, L=(1.0, 1.0, 1.0)):
@@ -32,6 +35,54 @@ def tgv_local(lay, L=(1.0, 1.0, 1.0)):
     return out
 
 
+def run_slab(ins, n, dt, steps, warmup, dev, backend, profile=True):
+    """Warm-up + timed `steps` chained RK44 steps of the TGV on the global box `n`, this rank's z-slab.  Returns (max-over-ranks seconds,
+    diagnostics).  Barrier + device synchronisation on both sides of the timed region."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lay = ins.SlabLayout(n, world, rank)
+    K = ins.HipSlabKernels(lay, Re=1000.0, device=dev)
+    # zsolve (INS_SLAB_ZSOLVE): "tridiag" (default for > 1 rank) needs no transposes; "fft" pipelines them over kx-chunks on a second
+    # communicator so that back-transposes of finished chunks run beside forward ones (full-duplex xGMI links)
+    zs = os.environ.get("INS_SLAB_ZSOLVE") or ("tridiag" if world > 1 else "fft")
+    nchunks = int(os.environ.get("INS_SLAB_CHUNKS", "4"))
+    g2 = dist.new_group(ranks=list(range(world))) if (nchunks > 1 and zs == "fft") else None
+    comm = ins.SlabComm(group2=g2)
+    st = ins.SlabStepper(ins.RKMethods.RK44(), lay, K, comm, chunks=nchunks)
+    u = K.vector()
+    u.copy_(torch.from_numpy(np.ascontiguousarray(tgv_local(lay))).to(dev))
+    st.project_(u)  # velocityfield(...; doproject = true)  (initializers.jl:38-42)
+    st.halo_u(u)
+    # the fixed-Δt loop of solve_unsteady as on one GPU (bench.py): K steps per call, u valid before and after
+    if warmup:
+        st.steps_(u, dt, warmup)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st.steps_(u, dt, steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t1 = time.perf_counter()
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    info = {"zsolve": st.zsolve, "kx_chunks": len(st.chunks), "nzl": lay.nzl}
+    if profile:
+        # roofline of the dominant kernel (the correcting stage kernel, K1 + K6 + the previous projection's gradient-subtract): two more
+        # steps with HIP events around its launches on the stream it runs on; outside the timed region
+        K.prof = []
+        st.steps_(u, dt, 2)
+        torch.cuda.synchronize()
+        prof, K.prof = K.prof, None
+        info["stage_ms"] = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
+        info["nstage"] = sum(1 for _, _, b in prof if b)
+        info["cells_rank"] = float(n[0]) * n[1] * lay.nzl
+        info["stage_bytes"] = sum(b for _, _, b in prof) * info["cells_rank"]
+    info["div"] = st.max_abs_divergence(u)
+    info["finite"] = bool(torch.isfinite(u).all())
+    del st, K, u
+    torch.cuda.empty_cache()
+    return float(el), info
+
+
 def run_distributed(args, ins):
     world = int(os.environ["WORLD_SIZE"])
     rank = int(os.environ["RANK"])
@@ -47,46 +98,21 @@ def run_distributed(args, ins):
     n = GLOBAL_GRIDS.get(world)
     if n is None:
         n = (args.n, args.n, args.n * world)
-    lay = ins.SlabLayout(n, world, rank)
-    K = ins.HipSlabKernels(lay, Re=1000.0, device=dev)
-    # zsolve (INS_SLAB_ZSOLVE): "tridiag" (default for > 1 rank) needs no transposes; "fft" pipelines them over kx-chunks on a second
-    # communicator so that back-transposes of finished chunks run beside forward ones (full-duplex xGMI links)
-    zs = os.environ.get("INS_SLAB_ZSOLVE") or ("tridiag" if world > 1 else "fft")
-    nchunks = int(os.environ.get("INS_SLAB_CHUNKS", "4"))
-    g2 = dist.new_group(ranks=list(range(world))) if (nchunks > 1 and zs == "fft") else None
-    comm = ins.SlabComm(group2=g2)
-    st = ins.SlabStepper(ins.RKMethods.RK44(), lay, K, comm, chunks=nchunks)
-    u = K.vector()
-    u.copy_(torch.from_numpy(np.ascontiguousarray(tgv_local(lay))).to(dev))
-    st.project_(u)  # velocityfield(...; doproject = true)  (initializers.jl:38-42)
-    st.halo_u(u)
-    dt = 1e-3
-    # the fixed-Δt loop of solve_unsteady as on one GPU (bench.py): K steps per call, u valid before and after
-    if args.warmup:
-        st.steps_(u, dt, args.warmup)
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    st.steps_(u, dt, args.steps)
-    torch.cuda.synchronize()
-    dist.barrier()
-    t1 = time.perf_counter()
-    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    # roofline of the dominant kernel (the correcting stage kernel, K1 + K6 + the previous projection's gradient-subtract): two more
-    # steps with HIP events around its launches on the stream it runs on; outside the timed region
-    K.prof = []
-    st.steps_(u, dt, 2)
-    torch.cuda.synchronize()
-    prof, K.prof = K.prof, None
-    stage_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
-    nstage = sum(1 for _, _, b in prof if b)
-    cells_rank = float(n[0]) * n[1] * lay.nzl
-    stage_bytes = sum(b for _, _, b in prof) * cells_rank
-    div = st.max_abs_divergence(u)
-    finite = bool(torch.isfinite(u).all())
+    el, info = run_slab(ins, n, 1e-3, args.steps, args.warmup, dev, backend)
+    stage_ms, nstage, cells_rank, stage_bytes, div, finite = (info[k] for k in ("stage_ms", "nstage", "cells_rank", "stage_bytes", "div", "finite"))
+    # strong-scaling leg (north star / BASELINE configs[3]): the SAME 512^3 box on every N, z-slabs of 512/N planes
+    strong = None
+    n5 = STRONG_GRID if not os.environ.get("INS_BENCH_STRONG_GRID") else tuple(int(v) for v in os.environ["INS_BENCH_STRONG_GRID"].split("x"))
+    if not os.environ.get("INS_BENCH_SKIP_STRONG_512") and n5[2] % world == 0 and n5[1] % world == 0 and n5[2] // world >= 2:
+        ssteps, swarm = max(2, min(args.steps, 10)), min(args.warmup, 2)
+        el5, info5 = run_slab(ins, n5, 2.5e-4, ssteps, swarm, dev, backend, profile=False)
+        ms5 = el5 * 1e3 / ssteps
+        strong = {"workload": f"TaylorGreenVortex3D {n5[0]}x{n5[1]}x{n5[2]} periodic fp64, RK44 + distributed spectral Poisson, dt=2.5e-4 (BASELINE configs[3]), "
+                              "total work fixed over N", "scaling": "strong", "n_gpus": world, "grid": list(n5), "planes_per_rank": info5["nzl"],
+                  "steps": ssteps, "warmup": swarm, "ms_per_step": ms5, "value": float(n5[0]) * n5[1] * n5[2] / (ms5 * 1e-3) / 1e6, "unit": "M cell-updates/s",
+                  "max_abs_div_times_dx": info5["div"] / n5[0], "finite": info5["finite"], "zsolve": info5["zsolve"]}
     if rank == 0:
-        ms = float(el) * 1e3 / args.steps
+        ms = el * 1e3 / args.steps
         cells = float(n[0]) * n[1] * n[2]
         out = {
             "metric": "M lattice-cell updates/sec (RK4 step incl. Poisson), 3D TGV fp64",
@@ -103,7 +129,7 @@ def run_distributed(args, ins):
             "data": "synthetic",
             "config": {"workload": f"TaylorGreenVortex3D {n[0]}x{n[1]}x{n[2]} periodic fp64, RK44 + distributed spectral Poisson, dt=1e-3, Re=1e3",
                        "grid": list(n), "decomposition": f"z-slabs x{world} (256^3 cells per GPU), RCCL halo planes + "
-                                        + ("one all-gather of interface values per solve (distributed tridiagonal z solve)" if st.zsolve == "tridiag"
+                                        + ("one all-gather of interface values per solve (distributed tridiagonal z solve)" if info["zsolve"] == "tridiag"
                                            else "all-to-all transposes around the z-FFT")},
             "roofline": {"kernel": "k_flux64 CORR (slab): momentum-RHS stencil + RK stage combination + in-register pressure correction, per rank (rank 0)",
                          "bound": "hbm", "achieved": stage_bytes / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else None, "peak": 8000.0, "unit": "GB/s",
@@ -111,7 +137,8 @@ def run_distributed(args, ins):
                          "bytes_per_cell": stage_bytes / cells_rank / max(nstage, 1), "avg_launch_ms": stage_ms / max(nstage, 1), "launches": nstage,
                          "note": "algorithmic bytes of the stages measured (2 chained RK44 steps after the timed region) / HIP-event time of their launches "
                                  "(interior + boundary plane ranges summed per stage); N = 1 has the PMC traffic figure"},
-            "check": {"max_abs_div_times_dx": div * (1.0 / n[0]), "finite": finite, "backend": backend, "zsolve": st.zsolve, "kx_chunks": len(st.chunks)},
+            "strong_512": strong,
+            "check": {"max_abs_div_times_dx": div * (1.0 / n[0]), "finite": finite, "backend": backend, "zsolve": info["zsolve"], "kx_chunks": info["kx_chunks"]},
         }
         print(json.dumps(out))
     dist.destroy_process_group()

@@ -70,6 +70,14 @@ int ins_version(void);
  * hipFFT plans held OUTSIDE the library (e.g. PyTorch's torch.fft plan cache): compare around solver creation and drop them when it moved. */
 int ins_fft_reset_count(void);
 const char* ins_last_error(void);
+/* Run-time switches (A/B paths and tile shapes; DESIGN.md §5 lists them).  Every switch starts from the environment variable of the same
+ * name and can be changed afterwards, so that one process can run e.g. the fused and the reference-order stage loop on the same arrays
+ * ("INS_DISABLE_FUSED_RK", "INS_DISABLE_FLUX64", "INS_FLUX64_ZC", ...).  Unknown name: INS_ERR_INVALID.  Switches that shape a handle
+ * (solver plans, uniformity classification) are read when the handle is created. */
+int ins_set_option(const char* name, int64_t value);
+int ins_get_option(const char* name, int64_t* value);
+int ins_option_count(void);
+const char* ins_option_name(int i);
 /* Device the calling thread's handles live on (hipSetDevice).  Blocking. */
 int ins_set_device(int device);
 /* Blocking: wait for all work on `stream`. */

@@ -38,6 +38,10 @@ SIGNATURES = {
     "ins_version": (C.c_int, []),
     "ins_fft_reset_count": (C.c_int, []),
     "ins_last_error": (C.c_char_p, []),
+    "ins_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
+    "ins_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
+    "ins_option_count": (C.c_int, []),
+    "ins_option_name": (C.c_char_p, [C.c_int]),
     "ins_set_device": (C.c_int, [C.c_int]),
     "ins_sync": (C.c_int, [vp]),
     "ins_grid_create": (C.c_int, [C.POINTER(GridDesc), C.POINTER(vp)]),
@@ -160,6 +164,35 @@ def check(rc):
 
 def call(name, *args):
     check(getattr(load(), name)(*args))
+
+
+def set_option(name, value):
+    """`ins_set_option`: flip a run-time switch of the library (same names as the environment variables)."""
+    call("ins_set_option", name.encode(), int(value))
+
+
+def get_option(name):
+    v = C.c_int64()
+    call("ins_get_option", name.encode(), C.byref(v))
+    return int(v.value)
+
+
+class options:
+    """Context manager: `with options(INS_DISABLE_FUSED_RK=1): ...` — set switches, restore the previous values on exit."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: get_option(k) for k in self.kw}
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 _fft_resets_seen = 0

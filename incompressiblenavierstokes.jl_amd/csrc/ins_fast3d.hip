@@ -246,14 +246,14 @@ extern "C" void ins_tune_fast3d(int rows, int zchunk) {
 bool ins_fast3d_supported(const ins_grid* G) {
   const GridDev& g = G->g;
   if (g.D != 3) return false;
-  if (getenv("INS_DISABLE_FAST3D")) return false;
+  if (ins_opt(OPT_INS_DISABLE_FAST3D)) return false;
   return g.N[0] >= 4 && g.N[1] >= 4 && g.N[2] >= 4;
 }
 
 int ins_k_momentum_flux3d(const ins_grid* G, double visc, const double* u, double* F, bool zero_shell, hipStream_t s);
 
 int ins_k_momentum_fast3d_opts(const ins_grid* G, double visc, const double* u, double* F, bool zero_shell, hipStream_t s) {
-  static const bool use_lds = getenv("INS_K1_LDS") != nullptr;  // A/B switch for experiments
+  const bool use_lds = ins_opt(OPT_INS_K1_LDS) != 0;  // A/B switch for experiments
   if (!use_lds) return ins_k_momentum_flux3d(G, visc, u, F, zero_shell, s);
   const GridDev& g = G->g;
   const int nx = g.N[0] - 2, ny = g.N[1] - 2, nz = g.N[2] - 2;

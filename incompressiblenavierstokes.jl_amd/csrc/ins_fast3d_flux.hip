@@ -386,19 +386,16 @@ __global__ __launch_bounds__(256) void k_zero_shell(GridDev g, double* __restric
 }  // namespace
 
 // Defaults (0 = pick per grid, see below); measured on MI355X, profiles/r01_k1_scan.txt.
-static int env_int(const char* name) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : 0;
-}
-static int g_rows = env_int("INS_FLUX_ROWS");
-static int g_zchunk = env_int("INS_FLUX_ZC");
-static int g_xw = env_int("INS_FLUX_XW");
+// run-time options (ins_options.hip; environment variable of the same name, or ins_set_option)
+#define g_rows ((int)ins_opt(OPT_INS_FLUX_ROWS))
+#define g_zchunk ((int)ins_opt(OPT_INS_FLUX_ZC))
+#define g_xw ((int)ins_opt(OPT_INS_FLUX_XW))
 
 // Tuning knobs for experiments (not part of the public ABI).
 extern "C" void ins_tune_flux3d(int rows, int zchunk, int xw) {
-  g_rows = (rows >= 2 && rows <= 4) ? rows : 0;
-  g_zchunk = zchunk >= 1 ? zchunk : 0;
-  g_xw = (xw == 1 || xw == 2 || xw == 4) ? xw : 0;
+  ins_set_option("INS_FLUX_ROWS", (rows >= 2 && rows <= 4) ? rows : 0);
+  ins_set_option("INS_FLUX_ZC", zchunk >= 1 ? zchunk : 0);
+  ins_set_option("INS_FLUX_XW", (xw == 1 || xw == 2 || xw == 4) ? xw : 0);
 }
 
 int ins_flux3d_prepare(const ins_grid* G, double visc, hipStream_t s) {
@@ -487,7 +484,7 @@ int ins_k_momentum_flux3d(const ins_grid* G, double visc, const double* u, doubl
   int rc;
   // plain K1: the 64-wide kernel wins up to ~400^3 (-10% at 256^3); from 448 on this kernel moves less data out of L2
   // (1.30x vs 1.38x read amplification at 512^3, profiles/r01f_k1_traffic.txt) and is 3% faster
-  static const bool plain_all = getenv("INS_FLUX64_PLAIN_ALL") != nullptr;  // experiment: no size routing
+  const bool plain_all = ins_opt(OPT_INS_FLUX64_PLAIN_ALL) != 0;  // experiment: no size routing
   if (ins_flux64_supported(G) && (plain_all || G->g.N[0] - 2 < 448)) {
     if ((rc = ins_k_flux64(G, visc, u, F, nullptr, nullptr, 0, s))) return rc;
   } else {

@@ -175,10 +175,6 @@ int ins_fdm_create(int D, const int n[3], const double* const V[3], const double
   for (int a = 0; ok && a < D; ++a) {
     F->n[a] = n[a];
     total *= n[a];
-    ok = hipMalloc(&F->V[a], (size_t)n[a] * n[a] * 8) == hipSuccess && hipMalloc(&F->lam[a], (size_t)n[a] * 8) == hipSuccess &&
-         hipMemcpy(F->V[a], V[a], (size_t)n[a] * n[a] * 8, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(F->lam[a], lam[a], (size_t)n[a] * 8, hipMemcpyHostToDevice) == hipSuccess;
-    for (int i = 0; i < n[a]; ++i) lmax = std::fmax(lmax, std::fabs(lam[a][i]));
     // Vαᵀ 1 and the null mode of this direction (largest eigenvalue, ~0 when the system is singular)
     std::vector<double> o(n[a], 0.0);
     int inull = 0;
@@ -186,6 +182,16 @@ int ins_fdm_create(int D, const int n[3], const double* const V[3], const double
       for (int i = 0; i < n[a]; ++i) o[j] += V[a][i + (size_t)n[a] * j];
       if (std::fabs(lam[a][j]) < std::fabs(lam[a][inull])) inull = j;
     }
+    // Singular system: every direction's factor has the constant vector in its null space, so the eigenvalue of that mode IS zero; the
+    // eigensolver returns it to ~eps·λmax.  It is stored as an exact 0, so that the scaling kernels recognise the ONE null mode of the
+    // Kronecker sum by λx + λy + λz == 0 and nothing else: a magnitude threshold would have to sit between that noise (eps·λmax, λmax ~
+    // 4/h_min²) and the lowest physical mode (~π²/L²), and on strongly stretched grids (cosine grid, N >= 1024) there is no such gap.
+    std::vector<double> lam_up(lam[a], lam[a] + n[a]);
+    if (F->singular) lam_up[inull] = 0.0;
+    ok = hipMalloc(&F->V[a], (size_t)n[a] * n[a] * 8) == hipSuccess && hipMalloc(&F->lam[a], (size_t)n[a] * 8) == hipSuccess &&
+         hipMemcpy(F->V[a], V[a], (size_t)n[a] * n[a] * 8, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(F->lam[a], lam_up.data(), (size_t)n[a] * 8, hipMemcpyHostToDevice) == hipSuccess;
+    for (int i = 0; i < n[a]; ++i) lmax = std::fmax(lmax, std::fabs(lam[a][i]));
     F->null_index += (long long)inull * (a == 0 ? 1 : (a == 1 ? n[0] : (long long)n[0] * n[1]));
     F->null_scale *= V[a][(size_t)n[a] * inull];
     F->null_i[a] = inull;
@@ -200,7 +206,8 @@ int ins_fdm_create(int D, const int n[3], const double* const V[3], const double
     ins_fdm_destroy(F);
     return INS_ERR_HIP;
   }
-  F->lam_tol = F->singular ? 1e-10 * lmax * D : 0.0;
+  (void)lmax;
+  F->lam_tol = 0.0;  // only the exact null mode (λx = λy = λz = 0 as stored above / in the analytic Fourier tables) is dropped
   *out = F;
   return INS_OK;
 }
@@ -209,7 +216,7 @@ int ins_fdm_create(int D, const int n[3], const double* const V[3], const double
 // (two GEMMs + the scaling pass).  Taken only when the host's eigenvalues of the z factor are the analytic set -(4/hz²) sin²(πk/n) —
 // i.e. when the factor really is the periodic second difference on a uniform grid; otherwise the GEMM route stays.
 int ins_fdm_enable_zfft(ins_fdm* F, double hz, const double* lam_z_host) {
-  static const bool off = getenv("INS_DISABLE_FDM_ZFFT") != nullptr;  // A/B switch
+  const bool off = ins_opt(OPT_INS_DISABLE_FDM_ZFFT) != 0;  // A/B switch
   const int n2 = F->n[2];
   if (off || F->D != 3 || (F->n[0] & 1) || n2 < 32 || n2 > 512 || (n2 & (n2 - 1))) return INS_OK;
   std::vector<double> want(n2), have(lam_z_host, lam_z_host + n2), lzk(n2 / 2 + 1);
@@ -241,7 +248,7 @@ int ins_fdm_enable_zfft(ins_fdm* F, double hz, const double* lam_z_host) {
 // on any other real column — both slots of a mode carry the same λx, so the z pass's per-column scaling is simply the complex scaling.
 // The 1/sqrt(hx n0) of the D-orthonormal convention rides on the two y GEMMs (alpha).
 int ins_fdm_enable_xfft(ins_fdm* F, double hx, const double* lam_x_host) {
-  static const bool off = getenv("INS_DISABLE_FDM_XFFT") != nullptr;  // A/B switch
+  const bool off = ins_opt(OPT_INS_DISABLE_FDM_XFFT) != 0;  // A/B switch
   const int n0 = F->n[0], n1 = F->n[1], n2 = F->n[2];
   if (off || !F->zfft || n0 < 16 || n0 > 1024 || (n0 & (n0 - 1)) || (n1 & 1)) return INS_OK;
   std::vector<double> want(n0), have(lam_x_host, lam_x_host + n0);
@@ -299,7 +306,7 @@ static bool analytic_spectrum(const double* lam_host, int n, double h) {
 }
 
 int ins_fdm_enable_xyfft(ins_fdm* F, double hx, double hy, const double* lam_x_host, const double* lam_y_host) {
-  static const bool off = getenv("INS_DISABLE_FDM_XYFFT") != nullptr;  // A/B switch
+  const bool off = ins_opt(OPT_INS_DISABLE_FDM_XYFFT) != 0;  // A/B switch
   const int n0 = F->n[0], n1 = F->n[1], n2 = F->D == 3 ? F->n[2] : 1;
   auto pow2 = [](int n) { return n >= 16 && n <= 1024 && !(n & (n - 1)); };
   if (off || F->xfft || F->zfft || F->D != 3 || !pow2(n0) || !pow2(n1)) return INS_OK;

@@ -509,7 +509,7 @@ int launch_xinv(const double2* in, double* pI, int n1, int n2, const double2* tw
   return INS_ERR_UNSUPPORTED;
 
 bool ins_ownfft_supported(const int np[3]) {
-  if (getenv("INS_DISABLE_OWNFFT")) return false;
+  if (ins_opt(OPT_INS_DISABLE_OWNFFT)) return false;
   for (int a = 0; a < 3; ++a)
     if (np[a] < 16 || np[a] > 1024 || (np[a] & (np[a] - 1))) return false;
   return ins_zsolve_supported(np[2]);

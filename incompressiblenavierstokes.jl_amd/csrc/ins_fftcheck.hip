@@ -11,6 +11,8 @@
 
 #include <atomic>
 
+#include <mutex>
+
 #include "ins_internal.h"
 
 // fwd: D2Z plan over `rank` dims n[0..rank-1] (slowest first), batch `batch`, contiguous default layout.
@@ -105,11 +107,14 @@ int ins_validate_real_plans(hipfftHandle fwd, hipfftHandle inv, int rank, const 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Plan factory used by every spectral solver: create the D2Z / Z2D pair, validate it, and if validation fails
-// while no other solver of this library holds rocFFT plans, reset rocFFT's process-wide caches
-// (rocfft_cleanup + rocfft_setup) and try once more.  With other solvers alive the reset would invalidate their
-// plans, so the error is returned instead (message says what to do).
+// Plan factory used by every spectral solver that still needs rocFFT (box sizes the own passes of ins_fft.hip do not take): create the
+// D2Z / Z2D pair and validate it.  A pair that fails validation is NEVER handed out: the error is returned (INS_ERR_FFT, message says what to
+// do).  Only when the host has opted in (option / environment INS_FFT_ALLOW_RESET=1) and no other solver of this library holds rocFFT plans,
+// rocFFT's process-wide caches are reset (rocfft_cleanup + rocfft_setup) and the pair is created once more: that reset invalidates every
+// rocFFT / hipFFT plan the HOST owns (AMDGPU.jl's, PyTorch's torch.fft cache), so it is the host's decision, not the library's.
+// Creation, validation and reset are serialised by one mutex (solver creation from several host threads).
 // ------------------------------------------------------------------------------------------------------------
+static std::mutex g_fft_mutex;
 static std::atomic<int> g_live_fft_solvers{0};
 static std::atomic<int> g_fft_resets{0};  // how often rocFFT's process-wide state was reset (other hipFFT users must drop their plans)
 
@@ -135,13 +140,14 @@ static hipfftResult make_pair(hipfftHandle* fwd, hipfftHandle* inv, int rank, in
 }
 
 int ins_fft_make_real_plans(hipfftHandle* fwd, hipfftHandle* inv, int rank, int* n, int batch) {
+  std::lock_guard<std::mutex> lock(g_fft_mutex);
   hipfftResult r = make_pair(fwd, inv, rank, n, batch);
   if (r != HIPFFT_SUCCESS) {
     ins_set_error("hipfftPlan (rank %d, batch %d) failed: %d", rank, batch, (int)r);
     return INS_ERR_FFT;
   }
   int rc = ins_validate_real_plans(*fwd, *inv, rank, n, batch);
-  if (rc == INS_ERR_FFT && g_live_fft_solvers.load() == 0) {
+  if (rc == INS_ERR_FFT && g_live_fft_solvers.load() == 0 && ins_opt(OPT_INS_FFT_ALLOW_RESET)) {
     (void)hipfftDestroy(*fwd);
     (void)hipfftDestroy(*inv);
     (void)hipDeviceSynchronize();
@@ -158,6 +164,13 @@ int ins_fft_make_real_plans(hipfftHandle* fwd, hipfftHandle* inv, int rank, int*
   if (rc) {
     (void)hipfftDestroy(*fwd);
     (void)hipfftDestroy(*inv);
+    if (rc == INS_ERR_FFT && !ins_opt(OPT_INS_FFT_ALLOW_RESET)) {
+      std::string first = ins_last_error();
+      ins_set_error("%s -- rocFFT returned a plan pair that fails validation (plan-cache defect of ROCm 7.2, DESIGN.md §3).  Destroy the other "
+                    "real-transform plans of this process, or allow the library to reset rocFFT's process-wide state with "
+                    "ins_set_option(\"INS_FFT_ALLOW_RESET\", 1) (the host must then re-create its own rocFFT/hipFFT plans; see ins_fft_reset_count)",
+                    first.c_str());
+    }
     return rc;
   }
   g_live_fft_solvers.fetch_add(1);

@@ -532,7 +532,7 @@ inline Launch3 ip_launch(const GridDev& g) {
 template <int OP>
 int launch_gradient_op(const ins_grid* G, double par, const double* u, double* out, hipStream_t s) {
   const GridDev& g = G->g;
-  static const bool march = !(getenv("INS_FIELDS_NO_MARCH") && atoi(getenv("INS_FIELDS_NO_MARCH")));  // A/B switch
+  const bool march = !ins_opt(OPT_INS_FIELDS_NO_MARCH);  // A/B switch
   if (g.D == 2) {
     if constexpr (OP != 1) {
       Launch3 l = ip_launch(g);

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_flux2d(Flux2dArgs a) {
 }  // namespace
 
 bool ins_flux2d_supported(const ins_grid* G) {
-  static const bool off = getenv("INS_DISABLE_FLUX2D") != nullptr;  // A/B switch
+  const bool off = ins_opt(OPT_INS_DISABLE_FLUX2D) != 0;  // A/B switch
   // uniform_exact: spacings and interpolation weights constant to the rounding of the coordinates (ins_grid.hip), so one h per direction is exact enough
   return !off && G->g.D == 2 && G->all_periodic && G->all_dof && G->uniform_exact && G->g.N[0] >= 4 && G->g.N[1] >= 4;
 }

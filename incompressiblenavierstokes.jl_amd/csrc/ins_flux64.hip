@@ -396,18 +396,15 @@ __global__ __launch_bounds__(256, 2) void k_flux64(FluxArgs a) {
   }
 }
 
-int env_int(const char* name) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : 0;
-}
-int g_disable = env_int("INS_DISABLE_FLUX64");
-int g_rows = env_int("INS_FLUX64_ROWS");
-int g_rows_corr = env_int("INS_FLUX64_ROWS_CORR");
-int g_zchunk = env_int("INS_FLUX64_ZC");
-int g_zchunk_corr = env_int("INS_FLUX64_ZC_CORR");
-int g_xw = env_int("INS_FLUX64_XW");
-int g_lds = env_int("INS_FLUX64_LDS");    // experiment: dynamic LDS bytes per workgroup (caps workgroups per CU)
-int g_skel = env_int("INS_FLUX64_SKEL");  // timing experiment only: wrong results by design
+// tile-shape knobs: run-time options (ins_options.hip; environment variable of the same name, or ins_set_option)
+#define g_disable ((int)ins_opt(OPT_INS_DISABLE_FLUX64))
+#define g_rows ((int)ins_opt(OPT_INS_FLUX64_ROWS))
+#define g_rows_corr ((int)ins_opt(OPT_INS_FLUX64_ROWS_CORR))
+#define g_zchunk ((int)ins_opt(OPT_INS_FLUX64_ZC))
+#define g_zchunk_corr ((int)ins_opt(OPT_INS_FLUX64_ZC_CORR))
+#define g_xw ((int)ins_opt(OPT_INS_FLUX64_XW))
+#define g_lds ((int)ins_opt(OPT_INS_FLUX64_LDS))    // experiment: dynamic LDS bytes per workgroup (caps workgroups per CU)
+#define g_skel ((int)ins_opt(OPT_INS_FLUX64_SKEL))  // timing experiment only: wrong results by design
 
 Dir make_dir(const ins_grid* G, int d, double visc) {
   // the constant record ins_fast3d_flux.hip's UNIFORM kernels read (index 1): same fp64 operations, on the host
@@ -473,14 +470,14 @@ int launch(const ins_grid* G, FluxArgs& a, int corr_mode, int part, hipStream_t 
 
 // Tuning knobs for experiments in one process on one allocation (not part of the public ABI); -1 keeps a value.
 extern "C" void ins_tune_flux64(int disable, int rows, int rows_corr, int zchunk, int xw, int skel, int burst_unused, int lds) {
-  if (disable >= 0) g_disable = disable;
-  if (rows >= 0) g_rows = rows;
-  if (rows_corr >= 0) g_rows_corr = rows_corr;
-  if (zchunk >= 0) g_zchunk = zchunk;
-  if (xw >= 0) g_xw = xw;
-  if (skel >= 0) g_skel = skel;
+  if (disable >= 0) ins_set_option("INS_DISABLE_FLUX64", disable);
+  if (rows >= 0) ins_set_option("INS_FLUX64_ROWS", rows);
+  if (rows_corr >= 0) ins_set_option("INS_FLUX64_ROWS_CORR", rows_corr);
+  if (zchunk >= 0) ins_set_option("INS_FLUX64_ZC", zchunk);
+  if (xw >= 0) ins_set_option("INS_FLUX64_XW", xw);
+  if (skel >= 0) ins_set_option("INS_FLUX64_SKEL", skel);
   (void)burst_unused;
-  if (lds >= 0) g_lds = lds;
+  if (lds >= 0) ins_set_option("INS_FLUX64_LDS", lds);
 }
 
 // 3-D, every interior volume a DOF (all-periodic box or periodic slab), bitwise-constant metric records, room for the

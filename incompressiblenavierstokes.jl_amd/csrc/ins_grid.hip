@@ -159,7 +159,7 @@ extern "C" int ins_grid_create(const ins_grid_desc_t* d, ins_grid_t** out) {
   // every coefficient by <= 4 N eps <= 2.5e-13 relative — inside the 1e-12 parity tolerance — while the constant-record kernels
   // (in-register pressure correction, stage-velocity basis, chained steps) make the step 1.5x faster than the table-driven ones
   // (256³ on [0, 2π]³: 4.2 -> 2.8 ms).  Boxes finer than that bound keep the tables; INS_UNIFORM_BITWISE=1 restores the bitwise test.
-  static const bool bitwise = getenv("INS_UNIFORM_BITWISE") != nullptr;
+  const bool bitwise = ins_opt(OPT_INS_UNIFORM_BITWISE) != 0;
   int nmax = 1;
   for (int a = 0; a < D; ++a) nmax = std::max(nmax, (int)d->N[a]);
   const double tol = bitwise ? 0.0 : std::min(2.5e-13, 4.0 * nmax * 2.220446049250313e-16);

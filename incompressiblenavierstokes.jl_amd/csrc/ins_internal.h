@@ -49,6 +49,46 @@ void ins_set_error(const char* fmt, ...);
 #define INS_LAUNCH_CHECK() INS_HIP_TRY(hipGetLastError())
 
 // ------------------------------------------------------------------------------------------------
+// Run-time switches (ins_options.hip): name = environment variable that initialises it = name accepted by ins_set_option.
+// ------------------------------------------------------------------------------------------------
+#define INS_OPT_LIST(X)          \
+  X(INS_DISABLE_FAST3D)          \
+  X(INS_K1_LDS)                  \
+  X(INS_FLUX_ROWS)               \
+  X(INS_FLUX_ZC)                 \
+  X(INS_FLUX_XW)                 \
+  X(INS_FLUX64_PLAIN_ALL)        \
+  X(INS_DISABLE_FDM_ZFFT)        \
+  X(INS_DISABLE_FDM_XFFT)        \
+  X(INS_DISABLE_FDM_XYFFT)       \
+  X(INS_DISABLE_OWNFFT)          \
+  X(INS_FIELDS_NO_MARCH)         \
+  X(INS_DISABLE_FLUX2D)          \
+  X(INS_DISABLE_FLUX64)          \
+  X(INS_FLUX64_ROWS)             \
+  X(INS_FLUX64_ROWS_CORR)        \
+  X(INS_FLUX64_ZC)               \
+  X(INS_FLUX64_ZC_CORR)          \
+  X(INS_FLUX64_XW)               \
+  X(INS_FLUX64_LDS)              \
+  X(INS_FLUX64_SKEL)             \
+  X(INS_UNIFORM_BITWISE)         \
+  X(INS_PHAT_DENSE)              \
+  X(INS_DISABLE_FDM_FUSED)       \
+  X(INS_DISABLE_INKERNEL_CORR)   \
+  X(INS_RK_KEEP_K)               \
+  X(INS_DISABLE_FUSED_RK)        \
+  X(INS_DISABLE_STEP_CHAIN)      \
+  X(INS_ZSOLVE_SKEL)             \
+  X(INS_DISABLE_ZSOLVE)          \
+  X(INS_ZTRI_SKEL)               \
+  X(INS_FFT_ALLOW_RESET)
+#define INS_OPT_ENUM(id) OPT_##id,
+enum InsOptId { INS_OPT_LIST(INS_OPT_ENUM) INS_OPT_COUNT };
+#undef INS_OPT_ENUM
+long long ins_opt(int id);  // current value (0 = off / default)
+
+// ------------------------------------------------------------------------------------------------
 // Device view of the grid, passed to kernels by value (lives in the kernarg segment -> SGPR loads).
 // Metric tables are tiny 1-D device vectors (<= 4 KB each), L1/L2/K$-resident.
 //   rdx  = 1/Δ      rdxu = 1/Δu        (reciprocal tables: the reference's 27 fp64 divisions per cell
@@ -161,8 +201,8 @@ struct ins_rk {
 struct RkEpi {
   int n;                    // previous-stage terms with non-zero coefficient
   int write_k;              // store k_i
-  double coef[INS_MAX_STAGES];
-  const double* k[INS_MAX_STAGES];
+  double coef[INS_MAX_STAGES + 1];  // + 1: the steady body force is one more term (ins_rk_set_bodyforce)
+  const double* k[INS_MAX_STAGES + 1];
   double coef_self;         // Δt A[i,i]
   double self_in;           // coefficient of the stencil input itself (its uncorrected value, taken from registers: ins_flux64.hip)
   double c0m1;              // ustart enters as (1 + c0m1)·ustart; 0 in the k-basis, -Σ coef in the stage-velocity basis (ins_rk.hip)

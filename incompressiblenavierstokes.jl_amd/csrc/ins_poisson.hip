@@ -436,7 +436,7 @@ extern "C" int ins_poisson_spectral_create(const ins_grid_t* G, ins_poisson_t** 
   const bool own2d = D == 2 && ins_ownfft_supported(np2);
   if (own2d) ps->ownfft = true;
   if (ps->ownfft) {  // rows of phat padded to whole 128-B lines: the y / z tiles then never straddle a line (profiles/r01f_pmc_traffic.json)
-    ps->kxs = getenv("INS_PHAT_DENSE") ? ps->kmax[0] : ((ps->kmax[0] + 7) & ~7);
+    ps->kxs = ins_opt(OPT_INS_PHAT_DENSE) ? ps->kmax[0] : ((ps->kmax[0] + 7) & ~7);
     ncplx = (long long)ps->kxs * ps->kmax[1] * ps->kmax[2];
   }
   if (hipMalloc(&ps->pI, nreal * sizeof(double)) != hipSuccess || hipMalloc(&ps->phat, ncplx * sizeof(hipfftDoubleComplex)) != hipSuccess ||
@@ -821,7 +821,7 @@ int ins_k_project(const ins_grid* G, ins_poisson* ps, double* u, double* p, hipS
     INS_LAUNCH_CHECK();
     return INS_OK;
   }
-  if (ps->kind == POISSON_FDM && !getenv("INS_DISABLE_FDM_FUSED")) {
+  if (ps->kind == POISSON_FDM && !ins_opt(OPT_INS_DISABLE_FDM_FUSED)) {
     // direct solver: Ω·div(u) straight into the solver's buffer, and copy-back - mean + apply_bc_p! + applypressure! in one pass
     double* buf = ins_fdm_buffer(ps->fdm);
     dim3 block(64, 4, 1), grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), g.D == 3 ? ps->np[2] : 1);

@@ -23,8 +23,8 @@ namespace {
 
 struct Combine {
   int n;
-  double coef[INS_MAX_STAGES];
-  const double* k[INS_MAX_STAGES];
+  double coef[INS_MAX_STAGES + 1];  // + 1: the steady body force is one more term (ins_rk_set_bodyforce)
+  const double* k[INS_MAX_STAGES + 1];
 };
 
 // K6: u = ustart + Σ_j (Δt A[i,j]) ku[j]  in ONE pass (the reference does 1 copy + i axpy passes and does
@@ -188,7 +188,7 @@ static int rk_step_fused_periodic(ins_rk* rk, double visc, double* u, double dt,
   if (!raw_in && (rc = ins_k_apply_bc_u(G, u, 0, nullptr, s))) return rc;  // :19 (first stage; later ghosts come from K4)
   // On exactly-uniform grids stages >= 2 read the previous stage's UNCORRECTED u* plus its pressure and apply
   // the projection's gradient-subtract in registers (k_momentum_flux<..., CORR>), so K4 runs for the last stage only.
-  static const bool no_corr = getenv("INS_DISABLE_INKERNEL_CORR") != nullptr;
+  const bool no_corr = ins_opt(OPT_INS_DISABLE_INKERNEL_CORR) != 0;
   const bool inkernel = !no_corr && G->uniform_exact && ns > 1 && G->g.N[0] >= 8 && G->g.N[1] >= 8 && G->g.N[2] >= 8;
   // Stage-velocity basis.  With in-kernel correction the UNCORRECTED stage velocities V_m = ustart + Δt Σ_{j<=m} A[m,j] k_j stay in
   // memory anyway (they are the next stencil's input), and when every A[m,m] != 0 they span the same space as {ustart, k_j}:
@@ -196,7 +196,7 @@ static int rk_step_fused_periodic(ins_rk* rk, double visc, double* u, double dt,
   // So no k_j is ever written or read: RK44 moves 336 instead of 432 B per cell and step through the stage kernels (β_3 = (1/3, 2/3, 1/3),
   // all other β = 0).  Algebraically the reference's combination (step_explicit_runge_kutta.jl:35-38); rounding differs at the 1e-16 level.
   // INS_RK_KEEP_K=1 restores the k-basis (and fills the ku cache arrays, which this basis leaves untouched).
-  static const bool keep_k = getenv("INS_RK_KEEP_K") != nullptr;
+  const bool keep_k = ins_opt(OPT_INS_RK_KEEP_K) != 0;
   bool vbasis = inkernel && !keep_k;
   for (int i = 0; vbasis && i < ns; ++i) vbasis = rk->A[i * ns + i] != 0.0;
   if (vbasis && (int)rk->vb.size() < ns - 1) {
@@ -344,8 +344,8 @@ extern "C" int ins_rk_steps_f64(ins_rk_t* rk, double visc, double* u, double t, 
   const ins_grid* G = rk->grid;
   hipStream_t s = as_stream(stream);
   const GridDev& g = G->g;
-  static const bool no_fuse = getenv("INS_DISABLE_FUSED_RK") != nullptr, no_corr = getenv("INS_DISABLE_INKERNEL_CORR") != nullptr,
-                    no_chain = getenv("INS_DISABLE_STEP_CHAIN") != nullptr;
+  const bool no_fuse = ins_opt(OPT_INS_DISABLE_FUSED_RK) != 0, no_corr = ins_opt(OPT_INS_DISABLE_INKERNEL_CORR) != 0,
+             no_chain = ins_opt(OPT_INS_DISABLE_STEP_CHAIN) != 0;
   bool ok = !no_fuse && !no_corr && !no_chain && !rk->force && g.D == 3 && G->all_periodic && G->all_dof && rk->ps->kind == POISSON_SPECTRAL && ins_fast3d_supported(G) &&
             ins_flux64_supported(G) && G->uniform_exact && rk->nstage > 1 && g.N[0] >= 8 && g.N[1] >= 8 && g.N[2] >= 8;  // = in-kernel correction runs
   if (!ok || nsteps < 2) {
@@ -368,7 +368,7 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
   const ins_grid* G = rk->grid;
   hipStream_t s = as_stream(stream);
   {
-    static const bool no_fuse = getenv("INS_DISABLE_FUSED_RK") != nullptr;
+    const bool no_fuse = ins_opt(OPT_INS_DISABLE_FUSED_RK) != 0;
     const GridDev& g = G->g;
     bool ok = !no_fuse && !planes && g.D == 3 && G->all_periodic && G->all_dof && rk->ps->kind == POISSON_SPECTRAL && ins_fast3d_supported(G);
     for (int a = 0; ok && a < 3; ++a) ok = rk->ps->np[a] >= 2;
@@ -393,7 +393,7 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
   // Time-independent boundary data: K6 runs as K1's epilogue (no k_combine pass, no
   // snapshot copy: the caller's u is ustart for the whole step and the stage velocities ping-pong in two library buffers,
   // as on the periodic path).  Every non-interior volume of a stage buffer is (re)written by apply_bc_u! before it is read.
-  static const bool no_fuse_np = getenv("INS_DISABLE_FUSED_RK") != nullptr;
+  const bool no_fuse_np = ins_opt(OPT_INS_DISABLE_FUSED_RK) != 0;
   const bool tiled = ins_fast3d_supported(G);  // else: the generic kernel with the same epilogue (2-D grids, tiny boxes)
   if (!no_fuse_np && !planes) {
     const size_t vbytes = (size_t)nvec * sizeof(double);

@@ -188,7 +188,7 @@ int launch_zsolve(double2* data, long long nl, const double* ax, int kxn, const 
     INS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_zsolve<LOGN, TK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_zsolve<LOGN, TK>), dim3(nb), dim3(256), lds, s, data, nl, ax, kxn, ay, az, tw, inv_n, zero_mean ? 1 : 0, kxs, getenv("INS_ZSOLVE_SKEL") ? 1 : 0);
+  hipLaunchKernelGGL((k_zsolve<LOGN, TK>), dim3(nb), dim3(256), lds, s, data, nl, ax, kxn, ay, az, tw, inv_n, zero_mean ? 1 : 0, kxs, ins_opt(OPT_INS_ZSOLVE_SKEL) ? 1 : 0);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -196,7 +196,7 @@ int launch_zsolve(double2* data, long long nl, const double* ax, int kxn, const 
 }  // namespace
 
 bool ins_zsolve_supported(int nz) {
-  if (getenv("INS_DISABLE_ZSOLVE")) return false;
+  if (ins_opt(OPT_INS_DISABLE_ZSOLVE)) return false;
   return nz >= 16 && nz <= 1024 && (nz & (nz - 1)) == 0;
 }
 

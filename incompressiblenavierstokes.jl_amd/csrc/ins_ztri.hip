@@ -336,7 +336,7 @@ int ins_k_ztri_forward(double* work, int kxn, int kxs, int n1, int m, int nranks
   ZtriArgs a{reinterpret_cast<double2*>(work), kxn, kxs, n1, m, nranks, rank, ax, ay, c, scale};
   if (l_cnt <= 0) return INS_OK;
   const int extra = l_lo == 0 ? 1 : 0;  // one more workgroup for the singular line's right-hand side
-  static const bool skel = getenv("INS_ZTRI_SKEL") && atoi(getenv("INS_ZTRI_SKEL"));
+  const bool skel = ins_opt(OPT_INS_ZTRI_SKEL) != 0;
   if (skel)
     hipLaunchKernelGGL(k_ztri_fwd<true>, dim3(cdiv(2 * l_cnt, 256) + extra), dim3(256), 0, s, a, edge, edge + 4 * l_cnt, l_lo, l_cnt);
   else

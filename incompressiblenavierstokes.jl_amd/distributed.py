@@ -57,7 +57,11 @@ class SlabComm:
     """Point-to-point plane exchange and the transpose all-to-all over a torch.distributed group.
     With the gloo backend and device tensors the payload is staged through the host (rehearsal mode)."""
 
-    def __init__(self, group=None, group2=None):
+    def __init__(self, group=None, group2=None, loopback=False):
+        """loopback: with ONE rank, still run every exchange through the process group (sends to self) instead of the local copy — the
+        one-GPU rehearsal of the RCCL calls, their matching order when both neighbours are the same peer, and their stream ordering
+        (tests/test_gpu_nccl.py)."""
+        self.loopback = bool(loopback)
         self.group = group
         self.group2 = group2 if group2 is not None else group  # second communicator: back-transposes run beside forward ones
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -69,7 +73,7 @@ class SlabComm:
 
     def exchange(self, sends, recvs):
         """sends: [(tensor, dst)], recvs: [(tensor, src)] — all contiguous, matched pairwise across ranks."""
-        if self.world == 1:
+        if self.world == 1 and not self.loopback:
             for (s, _), (r, _) in zip(sends, recvs):
                 r.copy_(s)
             return
@@ -89,14 +93,14 @@ class SlabComm:
     def exchange_async(self, sends, recvs):
         """Like exchange(), but returns the outstanding requests (RCCL: the transfer runs beside later kernels of the current
         stream; `wait()` orders the stream after it).  Staged / single-rank modes complete immediately."""
-        if self.world == 1 or any(self._stage(t) for t, _ in sends):
+        if (self.world == 1 and not self.loopback) or any(self._stage(t) for t, _ in sends):
             self.exchange(sends, recvs)
             return []
         ops = [dist.P2POp(dist.isend, t, d, self.group) for t, d in sends] + [dist.P2POp(dist.irecv, t, s, self.group) for t, s in recvs]
         return dist.batch_isend_irecv(ops)
 
     def all_to_all(self, recv, send):
-        if self.world == 1:
+        if self.world == 1 and not self.loopback:
             recv.copy_(send)
             return
         if self._stage(send):
@@ -112,7 +116,7 @@ class SlabComm:
 
     def all_to_all_async(self, recv, send, which=0):
         """Start a transpose; returns a handle whose wait() orders the current stream after it (no host block on RCCL)."""
-        if self.world == 1 or self._stage(send):
+        if (self.world == 1 and not self.loopback) or self._stage(send):
             self.all_to_all(recv, send)
             return SlabComm._Done()
         return dist.all_to_all_single(recv, send, group=self.group2 if which else self.group, async_op=True)
@@ -122,7 +126,7 @@ class SlabComm:
         On RCCL the gather is done as direct sends to every peer in one group call: xGMI is a full mesh of point-to-point links,
         so each ~1 MB block crosses exactly one link and all links work at once, instead of the P-1 dependent hops of a ring
         (INS_SLAB_GATHER=collective selects all_gather_into_tensor)."""
-        if self.world == 1:
+        if self.world == 1 and not self.loopback:
             out.copy_(inp)
             return
         n = inp.numel()
@@ -135,8 +139,9 @@ class SlabComm:
             peers = [(self.rank + d) % self.world for d in range(1, self.world)]
             ops = [dist.P2POp(dist.isend, inp, q, self.group) for q in peers]
             ops += [dist.P2POp(dist.irecv, out[q * n : (q + 1) * n], q, self.group) for q in reversed(peers)]
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
         else:
             dist.all_gather_into_tensor(out, inp, group=self.group)
 
@@ -144,7 +149,7 @@ class SlabComm:
         """all_gather whose transfer runs beside later kernels of the current stream; returns requests to wait() on ([] when it
         completed synchronously: one rank, staged rehearsal or the collective route)."""
         mode = os.environ.get("INS_SLAB_GATHER") or ("p2p" if self.backend == "nccl" else "collective")
-        if self.world == 1 or self._stage(inp) or mode != "p2p":
+        if (self.world == 1 and not self.loopback) or self._stage(inp) or mode != "p2p":
             self.all_gather(out, inp)
             return []
         n = inp.numel()
@@ -152,7 +157,7 @@ class SlabComm:
         peers = [(self.rank + d) % self.world for d in range(1, self.world)]
         ops = [dist.P2POp(dist.isend, inp, q, self.group) for q in peers]
         ops += [dist.P2POp(dist.irecv, out[q * n : (q + 1) * n], q, self.group) for q in reversed(peers)]
-        return dist.batch_isend_irecv(ops)
+        return dist.batch_isend_irecv(ops) if ops else []
 
     def barrier(self):
         if self.world > 1:

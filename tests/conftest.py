@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# The test process creates dozens of spectral solvers of different shapes one after another — exactly what trips the rocFFT plan-cache defect
+# (csrc/ins_fftcheck.hip).  The library no longer resets rocFFT's process-wide state on its own; the test host opts in (a product host decides
+# for itself).
+os.environ.setdefault("INS_FFT_ALLOW_RESET", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

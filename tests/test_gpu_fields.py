@@ -373,3 +373,41 @@ def test_observefield_of_tensor_basis_fields(ins, oracle):
     state = dict(u=ins.from_numpy(sp, u_h), temp=None, t=0.0, n=0)
     assert relmax(ins.observefield(state, setup=sp, fieldname="V3").value, V_h[sl + (2,)]) < 1e-11
     assert relmax(ins.observefield(state, setup=sp, fieldname="B7").value, B_h[sl + (6,)]) < 1e-11
+
+
+@pytest.mark.parametrize("geom", ["periodic3d", "dirichlet3d"])
+def test_sixteen_stages_plus_body_force_reference_order_loop(ins, oracle, geom):
+    """rSSPs3(s=4) has INS_MAX_STAGES = 16 stages; with a steady body force the reference-order stage loop
+    (INS_DISABLE_FUSED_RK) combines 16 stage terms + the force = 17 terms.  The term arrays hold INS_MAX_STAGES + 1 entries; this
+    runs that case against the oracle's stage loop and against the fused loop."""
+    from types import SimpleNamespace
+
+    from ins_amd import _lib
+
+    o = oracle
+    so0 = GEOMS[geom](o)
+    D = so0.grid.D
+    xin = [so0.grid.x[a][1:-1] for a in range(D)]
+
+    def force(a, x, y, *zt):
+        return (a == 0) * (1.0 + np.sin(2 * np.pi * y)) + (a == 1) * 0.3 * np.cos(2 * np.pi * x) + 0 * sum(zt[:-1], 0.0)
+
+    so = o.make_setup_ext(xin, so0.boundary_conditions, Re=so0.Re, bodyforce=force, issteadybodyforce=True)
+    sp = ins.Setup(x=xin, boundary_conditions=mirror(ins, so0, o).boundary_conditions, Re=so0.Re, bodyforce=force, issteadybodyforce=True)
+    ps_h, ps_d = o.default_psolver(so), ins.default_psolver(sp)
+    u0 = o.project(o.apply_bc_u(0.1 * fx.randn_field(so.grid.N + (D,), 12), 0.0, so), so, ps_h)
+    o.apply_bc_u_(u0, 0.0, so)
+    m = ins.RKMethods.rSSPs3(4)
+    assert len(m.b) == 16
+    mo = SimpleNamespace(A=m.A, b=m.b, c=m.c, r=m.r, p_add_solve=True)
+    st = dict(setup=so, psolver=ps_h, u=u0.copy(order="F"), temp=None, t=0.0, n=0)
+    cache = o.ode_method_cache_ext(mo, so)
+    st = o.timestep_ext_(mo, st, 2e-3, cache)
+    g = so.grid
+    mask = np.zeros(g.N + (D,), dtype=bool)
+    for a in range(D):
+        mask[tuple(slice(max(lo_ - 1, 0), min(hi_ + 1, n_)) for (lo_, hi_), n_ in zip(g.Iu[a], g.N)) + (a,)] = True
+    for opts in ({"INS_DISABLE_FUSED_RK": 1}, {}):
+        with _lib.options(**opts):
+            (u, _, _), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 2e-3), ustart=ins.from_numpy(sp, u0), method=m, psolver=ps_d, Δt=2e-3)
+        assert rell2(ins.to_numpy(u)[mask], st["u"][mask]) < STEP_TOL, opts
