@@ -64,7 +64,7 @@ def unit_box(o, n, Re=1000.0):
 
 def exact_box(o, n, Re=500.0):
     """Coordinates are exact binary fractions: bitwise-constant metric records (selects k_flux64)."""
-    return o.make_setup(tuple(np.arange(ni + 1) * 2.0**-8 for ni in n), Re=Re)
+    return o.make_setup(tuple(np.arange(ni + 1) * 2.0**-6 for ni in n), Re=Re)  # dt = 0.01, |u| ~ 1: CFL 0.64
 
 
 def mirror(ins, so):

@@ -735,7 +735,7 @@ def test_direct_solver_keeps_physical_modes_on_strongly_stretched_grid(ins, orac
     w, q = want[ip] - want[ip].mean(), got[ip] - got[ip].mean()
     assert rell2(q, w) < 1e-6
     # and the projection really removes the divergence of the large scales
-    assert _flux_imbalance_ratio(ins, sp, solver, u_h, ip) < 1e-7
+    assert _flux_imbalance_ratio(ins, sp, solver, u_h, ip) < 1e-4  # cond(L) ~ 7e11 (observed 1.2e-6); dropped low modes: O(1)
 
 
 def _flux_imbalance_ratio(ins, sp, solver, u_h, ip):
@@ -766,6 +766,6 @@ def test_direct_solver_cosine_grid_1024_projection(ins, oracle):
     solver = ins.psolver_direct(sp)
     p = ins.to_numpy(ins.poisson(solver, ins.from_numpy(sp, f)))
     res = o.laplacian(o.apply_bc_p(p, 0.0, so), so)[ip] - (f[ip] - f[ip].mean())
-    assert np.abs(res).sum() < 1e-8 * np.abs(f[ip]).sum()
-    assert _flux_imbalance_ratio(ins, sp, solver, u_h, ip) < 1e-8
+    assert np.abs(res).sum() < 1e-5 * np.abs(f[ip]).sum()  # cond(L) ~ 1e10..1e11 (observed 1.3e-7); dropped low modes: O(1)
+    assert _flux_imbalance_ratio(ins, sp, solver, u_h, ip) < 1e-5
     assert np.abs(p[ip]).max() > 1e-2  # the pressure of this smooth field lives in the first cosine modes (0.29 at N = 256)
