@@ -482,10 +482,10 @@ int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, con
 
 int ins_k_momentum_flux3d(const ins_grid* G, double visc, const double* u, double* F, bool zero_shell, hipStream_t s) {
   int rc;
-  // plain K1: the 64-wide kernel wins up to ~400^3 (-10% at 256^3); from 448 on this kernel moves less data out of L2
-  // (1.30x vs 1.38x read amplification at 512^3, profiles/r01f_k1_traffic.txt) and is 3% faster
-  const bool plain_all = ins_opt(OPT_INS_FLUX64_PLAIN_ALL) != 0;  // experiment: no size routing
-  if (ins_flux64_supported(G) && (plain_all || G->g.N[0] - 2 < 448)) {
+  // plain K1: the 64-wide kernel (workgroup barrier per plane, 8 wavefronts per workgroup on large boxes) runs at the flat-copy rate;
+  // INS_FLUX64_62_FROM=n routes boxes from n cells per row on to the 62-wide kernel (round-1 routing: 448) for A/B
+  const long long from62 = ins_opt(OPT_INS_FLUX64_62_FROM);
+  if (ins_flux64_supported(G) && (from62 <= 0 || G->g.N[0] - 2 < from62)) {
     if ((rc = ins_k_flux64(G, visc, u, F, nullptr, nullptr, 0, s))) return rc;
   } else {
     if ((rc = ins_flux3d_prepare(G, visc, s))) return rc;

@@ -43,6 +43,7 @@ struct FluxArgs {
   // plane range of this launch: chunk t covers [k_lo + t zc, min(.. + zc, k_hi)); kB > 0: two chunks, [k_lo, k_lo + zc) and [kB, kB + zc)
   // (the host runs the planes that read no ghost plane beside the halo exchange, then the two thin boundary ranges)
   int k_lo, k_hi, kB;
+  int bar;  // one workgroup barrier per plane: the y-stacked wavefronts of a workgroup stay on the same plane (their shared halo rows are then cache hits)
   Dir X, Y, Z;
   RkEpi epi;
 };
@@ -94,11 +95,11 @@ struct Plane {
   double raw[3][R];  // CORR: the output rows before the pressure correction (a term of the stage-velocity basis, ins_rk.hip)
 };
 
-// XW wavefronts side by side in x, 4/XW stacked in y.  CORR as in ins_fast3d_flux.hip: 0 = `u` has valid ghost volumes;
+// NW wavefronts per workgroup: XW side by side in x, NW/XW stacked in y.  CORR as in ins_fast3d_flux.hip: 0 = `u` has valid ghost volumes;
 // 1 = `u` is the previous stage's uncorrected u* (interior only), pI its unpadded pressure, every neighbour through the
 // periodic image; 2 = z-slab: x, y periodic images, z through exchanged ghost planes, pI = [1 | nzl | 2] extended buffer.
-template <int R, int XW, bool FUSE, int CORR, bool SKEL = false>
-__global__ __launch_bounds__(256, 2) void k_flux64(FluxArgs a) {
+template <int R, int XW, bool FUSE, int CORR, bool SKEL = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a) {
   static_assert(R + 2 + (CORR ? 1 : 0) <= 8, "packed halo rows live in 8-lane groups");
   int txi, tyi, tzi;
   {
@@ -117,11 +118,14 @@ __global__ __launch_bounds__(256, 2) void k_flux64(FluxArgs a) {
   const int N0 = a.N0, N1 = a.N1, N2 = a.N2;
   const int n0 = N0 - 2, n1 = N1 - 2, n2 = N2 - 2;
   const int x0 = (txi * XW + wx) * 64;  // interior (0-based) column of lane 0
-  if (x0 >= n0) return;                 // no barriers in this kernel: safe
-  const int jb0 = (tyi * (4 / XW) + wy) * R;  // interior row of the first output row
-  if (jb0 >= n1) return;
+  const int jb0 = (tyi * (NW / XW) + wy) * R;  // interior row of the first output row
   const int k0 = a.kB ? (tzi ? a.kB : a.k_lo) : a.k_lo + tzi * a.zc;  // padded plane index of the first output plane
   const int k1 = a.kB ? k0 + a.zc : min(k0 + a.zc, a.k_hi);
+  if (x0 >= n0 || jb0 >= n1) {  // wavefront outside the box: it only keeps the workgroup's barrier count (one per plane)
+    if (a.bar)
+      for (int k = k0; k < k1; ++k) __builtin_amdgcn_s_barrier();
+    return;
+  }
   const long long sz = (long long)N0 * N1;
   const int ci = x0 + lane;
   const bool xout = ci < n0;
@@ -364,8 +368,10 @@ __global__ __launch_bounds__(256, 2) void k_flux64(FluxArgs a) {
     load_plane(P0, min(k0 + 1, k1));
     int k = k0;
     while (true) {
+      if (a.bar) __builtin_amdgcn_s_barrier();
       body(P1, P0, k, min(k + 2, k1));
       if (++k >= k1) break;
+      if (a.bar) __builtin_amdgcn_s_barrier();
       body(P0, P1, k, min(k + 2, k1));
       if (++k >= k1) break;
     }
@@ -384,10 +390,12 @@ __global__ __launch_bounds__(256, 2) void k_flux64(FluxArgs a) {
     load_p(Pb, Hb, min(k0 + 2, k1 + 1));
     int k = k0;
     while (true) {
+      if (a.bar) __builtin_amdgcn_s_barrier();
       correct(P0, Pa, Ha, Pb, Hb);  // plane k+1 with p(k+1), p(k+2)
       load_p(Pa, Ha, min(k + 3, k1 + 1));
       body(P1, P0, k, min(k + 2, k1));
       if (++k >= k1) break;
+      if (a.bar) __builtin_amdgcn_s_barrier();
       correct(P1, Pb, Hb, Pa, Ha);
       load_p(Pb, Hb, min(k + 3, k1 + 1));
       body(P0, P1, k, min(k + 2, k1));
@@ -418,20 +426,25 @@ Dir make_dir(const ins_grid* G, int d, double visc) {
   return r;
 }
 
-template <int R, int XW, bool FUSE>
+template <int R, int XW, bool FUSE, int NW>
 int launch_range(const ins_grid* G, FluxArgs& a, int corr_mode, hipStream_t s) {
   const unsigned nb = (unsigned)(8LL * a.ntx * ((a.nty + 7) / 8) * a.ntz);
   if (nb == 0) return INS_OK;
-  const dim3 block(64, 4, 1);
-  if (g_skel && corr_mode == 0)
-    hipLaunchKernelGGL((k_flux64<R, XW, FUSE, 0, true>), dim3(nb), block, (size_t)g_lds, s, a);
-  else if (corr_mode == 0)
-    hipLaunchKernelGGL((k_flux64<R, XW, FUSE, 0>), dim3(nb), block, (size_t)g_lds, s, a);
+  const dim3 block(64, NW, 1);
+  if constexpr (NW <= 8 && R == 4) {
+    if (g_skel && corr_mode == 0) {
+      hipLaunchKernelGGL((k_flux64<R, XW, FUSE, 0, true, NW>), dim3(nb), block, (size_t)g_lds, s, a);
+      INS_LAUNCH_CHECK();
+      return INS_OK;
+    }
+  }
+  if (corr_mode == 0)
+    hipLaunchKernelGGL((k_flux64<R, XW, FUSE, 0, false, NW>), dim3(nb), block, (size_t)g_lds, s, a);
   else if constexpr (FUSE && R <= 5) {
     if (corr_mode == 1)
-      hipLaunchKernelGGL((k_flux64<R, XW, true, 1>), dim3(nb), block, (size_t)g_lds, s, a);
+      hipLaunchKernelGGL((k_flux64<R, XW, true, 1, false, NW>), dim3(nb), block, (size_t)g_lds, s, a);
     else
-      hipLaunchKernelGGL((k_flux64<R, XW, true, 2>), dim3(nb), block, (size_t)g_lds, s, a);
+      hipLaunchKernelGGL((k_flux64<R, XW, true, 2, false, NW>), dim3(nb), block, (size_t)g_lds, s, a);
   } else {
     ins_set_error("in-kernel pressure correction needs the fused epilogue and <= 5 rows per thread");
     return INS_ERR_UNSUPPORTED;
@@ -442,11 +455,11 @@ int launch_range(const ins_grid* G, FluxArgs& a, int corr_mode, hipStream_t s) {
 
 // part 0: every plane; 1: the planes that read no ghost plane, [1 + ZB, nzl + 1 - ZB); 2: the two boundary ranges of ZB planes
 constexpr int ZB = 4;
-template <int R, int XW, bool FUSE>
+template <int R, int XW, bool FUSE, int NW = 4>
 int launch(const ins_grid* G, FluxArgs& a, int corr_mode, int part, hipStream_t s) {
   const GridDev& g = G->g;
   a.ntx = cdiv(g.N[0] - 2, 64 * XW);
-  a.nty = cdiv(g.N[1] - 2, (4 / XW) * R);
+  a.nty = cdiv(g.N[1] - 2, (NW / XW) * R);
   const int nzl = g.N[2] - 2;
   a.k_lo = 1;
   a.k_hi = nzl + 1;
@@ -463,7 +476,7 @@ int launch(const ins_grid* G, FluxArgs& a, int corr_mode, int part, hipStream_t 
     a.kB = nzl + 1 - ZB;
   }
   a.ntz = part == 2 ? 2 : cdiv(a.k_hi - a.k_lo, a.zc);
-  return launch_range<R, XW, FUSE>(G, a, corr_mode, s);
+  return launch_range<R, XW, FUSE, NW>(G, a, corr_mode, s);
 }
 
 }  // namespace
@@ -500,26 +513,67 @@ int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, con
   a.N0 = g.N[0];
   a.N1 = g.N[1];
   a.N2 = g.N[2];
-  // z-chunk: every chunk re-reads two planes from HBM ((zc+2)/zc read amplification, measured with FETCH_SIZE), so chunks are
-  // as long as the tile count allows (profiles/r01f_k1_traffic.txt; 64 planes at 256^3: 2.93 -> 2.89 ms per step, one workgroup per CU
-  // for the 4-row kernels and still the fastest)
   const int n2 = g.N[2] - 2;
-  const bool small_plane = (long long)(g.N[0] - 2) * (g.N[1] - 2) <= 256LL * 256;  // 512^2 planes: 32 planes measured faster than 64 (24.0 vs 24.8 ms/step)
-  a.zc = (corr_mode && g_zchunk_corr) ? g_zchunk_corr : (g_zchunk ? g_zchunk : (n2 >= 256 && small_plane ? 64 : (n2 >= 128 ? 32 : (n2 >= 64 ? 16 : (n2 >= 32 ? 8 : 4)))));
   a.X = make_dir(G, 0, visc);
   a.Y = make_dir(G, 1, visc);
   a.Z = make_dir(G, 2, visc);
   if (epi) a.epi = *epi;
   const int waves_x = cdiv(g.N[0] - 2, 64);
-  // wavefronts side by side: 4 for 256-wide rows (2.85 vs 2.90 ms/step with 2), 2 + 2 stacked for 512-wide ones (23.7 vs 24.3 ms/step)
-  const int xw = g_xw ? g_xw : (waves_x >= 8 ? 2 : (waves_x >= 4 ? 4 : (waves_x >= 2 ? 2 : 1)));
+  // wavefronts side by side: 4 for 256-wide rows (2.85 vs 2.90 ms/step with 2), 2 for 512-wide ones (23.7 vs 24.3 ms/step)
+  const int xwo = (corr_mode && ins_opt(OPT_INS_FLUX64_XW_CORR)) ? (int)ins_opt(OPT_INS_FLUX64_XW_CORR) : g_xw;
+  const int xw = xwo ? xwo : (waves_x >= 8 ? 2 : (waves_x >= 4 ? 4 : (waves_x >= 2 ? 2 : 1)));
   int rows = corr_mode ? (g_rows_corr ? g_rows_corr : 2) : (g_rows ? g_rows : 4);
   rows = std::min(std::max(rows, 2), corr_mode ? 5 : 6);
-#define INS_F64_CASE(RR, FUSE)                                            \
-  if (rows == RR) {                                                       \
-    if (xw == 4) return launch<RR, 4, FUSE>(G, a, corr_mode, part, s);    \
-    if (xw == 2) return launch<RR, 2, FUSE>(G, a, corr_mode, part, s);    \
-    return launch<RR, 1, FUSE>(G, a, corr_mode, part, s);                 \
+  // Workgroup shape and z-chunk.  The wavefronts of a workgroup share halo rows / columns; a workgroup barrier per plane keeps them on
+  // the same plane, so those shared lines are cache hits instead of HBM re-reads (512^3 plain K1, same box: 1.45 -> 1.37 ms with 4
+  // wavefronts, 1.28 ms with 8 wavefronts = 128 x 16 cells per plane and workgroup: the flat-copy rate of that box, profiles/r02_k1_lab.txt;
+  // without the barrier 8 wavefronts are SLOWER than 4: 1.53 ms).  Every z-chunk re-reads two planes ((zc+2)/zc), so chunks are as long as
+  // the tile count allows: 8 wavefronts and 64- or 32-plane chunks when that still gives every CU a workgroup, else 4 wavefronts and
+  // shorter chunks (256^3: 8 wavefronts x 32 planes, 2.67 -> 2.61 ms per step; 64 planes would leave half the CUs idle: 0.30 vs 0.21 ms).
+  const int nwo = (int)ins_opt(OPT_INS_FLUX64_NW);
+  const int zco = (corr_mode && g_zchunk_corr) ? g_zchunk_corr : g_zchunk;
+  auto tiles = [&](int nw_, int zc_) {
+    return (long long)cdiv(g.N[0] - 2, 64 * xw) * cdiv(g.N[1] - 2, (nw_ / xw) * rows) * cdiv(n2, zc_);
+  };
+  int nw = nwo == 16 ? 16 : (nwo == 8 ? 8 : (nwo == 4 ? 4 : 0));
+  int zc = zco;
+  if (!nw) {
+    nw = 4;
+    if (xw <= 8 && !g_lds) {
+      for (int z : {64, 32}) {
+        const int zt = zco ? zco : z;
+        if (n2 >= zt && tiles(8, zt) >= 256) {
+          nw = 8;
+          zc = zt;
+          break;
+        }
+      }
+    }
+  }
+  if (!zc) {
+    const bool small_plane = (long long)(g.N[0] - 2) * (g.N[1] - 2) <= 256LL * 256;
+    zc = n2 >= 256 && small_plane ? 64 : (n2 >= 128 ? 32 : (n2 >= 64 ? 16 : (n2 >= 32 ? 8 : 4)));
+  }
+  if (rows != 2 && nw == 16) nw = 8;
+  a.zc = zc;
+  a.bar = ins_opt(OPT_INS_FLUX64_NOBAR) ? 0 : 1;
+#define INS_F64_CASE(RR, FUSE)                                                     \
+  if (rows == RR) {                                                                \
+    if constexpr (RR == 2) {                                                       \
+      if (nw == 16) {                                                              \
+        if (xw == 4) return launch<RR, 4, FUSE, 16>(G, a, corr_mode, part, s);     \
+        if (xw == 2) return launch<RR, 2, FUSE, 16>(G, a, corr_mode, part, s);     \
+        return launch<RR, 1, FUSE, 16>(G, a, corr_mode, part, s);                  \
+      }                                                                            \
+    }                                                                              \
+    if (nw >= 8) {                                                                 \
+      if (xw == 4) return launch<RR, 4, FUSE, 8>(G, a, corr_mode, part, s);        \
+      if (xw == 2) return launch<RR, 2, FUSE, 8>(G, a, corr_mode, part, s);        \
+      return launch<RR, 1, FUSE, 8>(G, a, corr_mode, part, s);                     \
+    }                                                                              \
+    if (xw == 4) return launch<RR, 4, FUSE>(G, a, corr_mode, part, s);             \
+    if (xw == 2) return launch<RR, 2, FUSE>(G, a, corr_mode, part, s);             \
+    return launch<RR, 1, FUSE>(G, a, corr_mode, part, s);                          \
   }
   if (epi) {
     INS_F64_CASE(2, true)

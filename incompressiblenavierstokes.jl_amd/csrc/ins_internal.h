@@ -57,7 +57,7 @@ void ins_set_error(const char* fmt, ...);
   X(INS_FLUX_ROWS)               \
   X(INS_FLUX_ZC)                 \
   X(INS_FLUX_XW)                 \
-  X(INS_FLUX64_PLAIN_ALL)        \
+  X(INS_FLUX64_62_FROM)          \
   X(INS_DISABLE_FDM_ZFFT)        \
   X(INS_DISABLE_FDM_XFFT)        \
   X(INS_DISABLE_FDM_XYFFT)       \
@@ -72,6 +72,9 @@ void ins_set_error(const char* fmt, ...);
   X(INS_FLUX64_XW)               \
   X(INS_FLUX64_LDS)              \
   X(INS_FLUX64_SKEL)             \
+  X(INS_FLUX64_NW)               \
+  X(INS_FLUX64_NOBAR)            \
+  X(INS_FLUX64_XW_CORR)          \
   X(INS_UNIFORM_BITWISE)         \
   X(INS_PHAT_DENSE)              \
   X(INS_DISABLE_FDM_FUSED)       \

@@ -89,11 +89,11 @@ def smooth_field(so, o, seed, amp=1.0):
 
 
 # ------------------------------------------------------------------------------------------------ full size vs oracle/c
-@pytest.mark.parametrize("n,variants", [(256, ("default", "flux62")), (512, ("default", "flux64"))])
+@pytest.mark.parametrize("n,variants", [(256, ("default", "flux62", "nw4", "nobar")), (512, ("default", "flux62", "nw4"))])
 def test_full_size_momentum_vs_c_oracle(ins, oracle, cport, n, variants):
-    """Plain K1 (`momentum!`, operators.jl:967-976 + 647-690) at the bench sizes, every cell, against the C restatement.  At 256^3 the
-    default route is k_flux64 (XW = 4, 64-plane chunks, nty_local = 8); at 512^3 it is k_momentum_flux (62 outputs per wavefront);
-    the other kernel of each size runs through the option switch."""
+    """Plain K1 (`momentum!`, operators.jl:967-976 + 647-690) at the bench sizes, every cell, against the C restatement.  The default route
+    is k_flux64 with 8 wavefronts per workgroup and a barrier per plane (256^3: XW = 4, 32-plane chunks; 512^3: XW = 2, 64-plane chunks);
+    the 62-outputs-per-wavefront kernel, the 4-wavefront workgroups and the barrier-free variant run through the option switches."""
     from ins_amd import _lib
 
     o = oracle
@@ -105,7 +105,7 @@ def test_full_size_momentum_vs_c_oracle(ins, oracle, cport, n, variants):
     port.momentum(want, u_h)
     u = ins.from_numpy(sp, u_h)
     for v in variants:
-        opts = {"default": {}, "flux62": {"INS_DISABLE_FLUX64": 1}, "flux64": {"INS_FLUX64_PLAIN_ALL": 1}}[v]
+        opts = {"default": {}, "flux62": {"INS_DISABLE_FLUX64": 1}, "nw4": {"INS_FLUX64_NW": 4}, "nobar": {"INS_FLUX64_NOBAR": 1}}[v]
         with _lib.options(**opts):
             F = ins.from_numpy(sp, np.full(u_h.shape, 7.0))  # garbage in F: momentum! overwrites
             got = ins.to_numpy(ins.momentum_(F, u, None, 0.0, sp))
@@ -161,8 +161,10 @@ MID_BOXES = [
 ]
 
 
+@pytest.mark.parametrize("nw", [4, 8])
 @pytest.mark.parametrize("n,zc", MID_BOXES)
-def test_mid_size_momentum_matches_oracle(ins, oracle, n, zc):
+def test_mid_size_momentum_matches_oracle(ins, oracle, n, zc, nw):
+    """nw: wavefronts per workgroup (8 = the shape the full-size boxes run by default: XW side by side x 8/XW stacked, barrier per plane)."""
     from ins_amd import _lib
 
     o = oracle
@@ -171,14 +173,14 @@ def test_mid_size_momentum_matches_oracle(ins, oracle, n, zc):
     assert _lib.load().ins_grid_is_uniform_exact(sp.handle)
     u_h = o.apply_bc_u(fx.randn_field(so.grid.N + (3,), 41), 0.0, so)
     want = o.momentum(u_h, None, 0.0, so)
-    with _lib.options(INS_FLUX64_ZC=zc):
+    with _lib.options(INS_FLUX64_ZC=zc, INS_FLUX64_NW=nw):
         got = ins.to_numpy(ins.momentum_(ins.from_numpy(sp, fx.randn_field(so.grid.N + (3,), 42)), ins.from_numpy(sp, u_h), None, 0.0, sp))
     assert relmax(got, want) < OP_TOL
 
 
 @pytest.mark.parametrize("n,zc", [b for b in MID_BOXES if b[0][2] % 2 == 0])
-@pytest.mark.parametrize("method", ["RK44", "Wray3"])
-def test_mid_size_rk_steps_match_oracle(ins, oracle, n, zc, method):
+@pytest.mark.parametrize("method,nw", [("RK44", 8), ("RK44", 4), ("Wray3", 8)])
+def test_mid_size_rk_steps_match_oracle(ins, oracle, n, zc, method, nw):
     """Two steps through the fused stage loop (stage 1: K1 + RK epilogue; later stages: correcting kernel) and the same through
     chained `timesteps_`, on boxes with several y tiles per XCD slot and long z-chunks."""
     from ins_amd import _lib
@@ -190,7 +192,7 @@ def test_mid_size_rk_steps_match_oracle(ins, oracle, n, zc, method):
     u0 = o.random_field(so, kp=2, seed=11, psolver=pso)
     mo, mp_ = getattr(o, method)(), getattr(ins.RKMethods, method)()
     want = o.solve_unsteady(so, (0.0, 0.02), u0, method=mo, psolver=pso, dt=0.01)["u"]
-    with _lib.options(INS_FLUX64_ZC=zc, INS_FLUX64_ZC_CORR=zc):
+    with _lib.options(INS_FLUX64_ZC=zc, INS_FLUX64_ZC_CORR=zc, INS_FLUX64_NW=nw):
         cache = ins.ode_method_cache(mp_, sp, psp)
         st = ins.create_stepper(mp_, setup=sp, psolver=psp, u=ins.from_numpy(sp, u0), t=0.0)
         for _ in range(2):
@@ -240,6 +242,6 @@ def test_fused_vs_reference_order_loop_full_size(ins, oracle, n):
         Fg = ins.momentum(u0, None, 0.0, sp)
     s = float(Fg.abs().max())
     assert float((F64 - Fg).abs().max()) < OP_TOL * s and float((F62 - Fg).abs().max()) < OP_TOL * s
-    with _lib.options(INS_FLUX64_PLAIN_ALL=1):
+    with _lib.options(INS_FLUX64_NW=4):
         F64b = ins.momentum(u0, None, 0.0, sp)
     assert float((F64b - Fg).abs().max()) < OP_TOL * s
