@@ -233,7 +233,7 @@ def main():
         ev1.record()
         torch.cuda.synchronize()
         ms5 = ev0.elapsed_time(ev1) / 10
-        k1_512 = {"kernel": "k_momentum_flux (K1 alone) at 512^3, random data", "bound": "hbm", "achieved": K1_BYTES_PER_CELL * 512.0**3 / (ms5 * 1e-3) / 1e9,
+        k1_512 = {"kernel": "k_flux64 (K1 alone: ins_momentum_f64) at 512^3, random data", "bound": "hbm", "achieved": K1_BYTES_PER_CELL * 512.0**3 / (ms5 * 1e-3) / 1e9,
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_cell": K1_BYTES_PER_CELL, "avg_launch_ms": ms5}
         k1_512["frac"] = k1_512["achieved"] / HBM_PEAK_GBS
         del u5, F5, s5

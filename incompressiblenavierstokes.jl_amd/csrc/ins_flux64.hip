@@ -528,21 +528,23 @@ int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, con
   // the same plane, so those shared lines are cache hits instead of HBM re-reads (512^3 plain K1, same box: 1.45 -> 1.37 ms with 4
   // wavefronts, 1.28 ms with 8 wavefronts = 128 x 16 cells per plane and workgroup: the flat-copy rate of that box, profiles/r02_k1_lab.txt;
   // without the barrier 8 wavefronts are SLOWER than 4: 1.53 ms).  Every z-chunk re-reads two planes ((zc+2)/zc), so chunks are as long as
-  // the tile count allows: 8 wavefronts and 64- or 32-plane chunks when that still gives every CU a workgroup, else 4 wavefronts and
-  // shorter chunks (256^3: 8 wavefronts x 32 planes, 2.67 -> 2.61 ms per step; 64 planes would leave half the CUs idle: 0.30 vs 0.21 ms).
+  // the tile count allows: 8 wavefronts and 64-plane chunks when that still gives every CU a workgroup (256^3: the correcting kernel, 2 rows
+  // per thread; 512^3: every kernel), else 4 wavefronts (256^3 plain K1: 8 wavefronts x 64 planes would leave half the CUs idle, 0.30 vs
+  // 0.205 ms; x 32 planes 0.213 ms).  Same-box steps: 256^3 2.69 (4 wavefronts) -> 2.64 ms, 512^3 23.7 -> 22.35 ms (profiles/r02a_step_lab.txt).
   const int nwo = (int)ins_opt(OPT_INS_FLUX64_NW);
   const int zco = (corr_mode && g_zchunk_corr) ? g_zchunk_corr : g_zchunk;
   auto tiles = [&](int nw_, int zc_) {
     return (long long)cdiv(g.N[0] - 2, 64 * xw) * cdiv(g.N[1] - 2, (nw_ / xw) * rows) * cdiv(n2, zc_);
   };
+  const long long mintiles = ins_opt(OPT_INS_FLUX64_MINTILES) > 0 ? ins_opt(OPT_INS_FLUX64_MINTILES) : 256;  // one workgroup per CU
   int nw = nwo == 16 ? 16 : (nwo == 8 ? 8 : (nwo == 4 ? 4 : 0));
   int zc = zco;
   if (!nw) {
     nw = 4;
     if (xw <= 8 && !g_lds) {
-      for (int z : {64, 32}) {
+      for (int z : {64}) {
         const int zt = zco ? zco : z;
-        if (n2 >= zt && tiles(8, zt) >= 256) {
+        if (n2 >= zt && tiles(8, zt) >= mintiles) {
           nw = 8;
           zc = zt;
           break;

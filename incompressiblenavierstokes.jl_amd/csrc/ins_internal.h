@@ -74,6 +74,7 @@ void ins_set_error(const char* fmt, ...);
   X(INS_FLUX64_SKEL)             \
   X(INS_FLUX64_NW)               \
   X(INS_FLUX64_NOBAR)            \
+  X(INS_FLUX64_MINTILES)         \
   X(INS_FLUX64_XW_CORR)          \
   X(INS_UNIFORM_BITWISE)         \
   X(INS_PHAT_DENSE)              \
