@@ -84,6 +84,10 @@ void ins_set_error(const char* fmt, ...);
   X(INS_DISABLE_FUSED_RK)        \
   X(INS_DISABLE_STEP_CHAIN)      \
   X(INS_ZSOLVE_SKEL)             \
+  X(INS_ZSOLVE_TK)               \
+  X(INS_ZSOLVE_RADIX4)           \
+  X(INS_ZSOLVE_NT)               \
+  X(INS_ZSOLVE_WGS)              \
   X(INS_DISABLE_ZSOLVE)          \
   X(INS_ZTRI_SKEL)               \
   X(INS_FFT_ALLOW_RESET)

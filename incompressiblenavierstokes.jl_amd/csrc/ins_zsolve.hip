@@ -50,43 +50,54 @@ __device__ __forceinline__ int freq_of_pos(int p) {
   return k;
 }
 
-template <int LOGN, int TK>
-__global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long long nl, const double* __restrict__ ax, int kxn,
-                                                const double* __restrict__ ay, const double* __restrict__ az,
-                                                const double2* __restrict__ tw_g, double inv_n, int zero_mean, int kxs, int skel) {
+// NT threads per workgroup.  The workgroup is PERSISTENT: it walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and loads the next tile
+// into registers while the transform of the current one runs in LDS, so HBM stays busy during the LDS stages (the one-tile-per-workgroup
+// form left HBM idle while a CU's workgroups computed: 0.83 ms at 512^3 against 0.64 ms for its loads and stores alone).
+template <int LOGN, int TK, int NT>
+__global__ __launch_bounds__(NT) void k_zsolve(double2* __restrict__ data, long long nl, const double* __restrict__ ax, int kxn,
+                                               const double* __restrict__ ay, const double* __restrict__ az,
+                                               const double2* __restrict__ tw_g, double inv_n, int zero_mean, int kxs, int skel, int ntiles) {
   constexpr int N = 1 << LOGN;
   constexpr bool ODD = LOGN & 1;
   extern __shared__ double2 lds_dyn[];  // dynamic: tiles above 64 KB need the opt-in limit
   double2* buf = lds_dyn;               // [N][TK]
   double2* tw = lds_dyn + N * TK;       // [N]
   const int t = threadIdx.x;
-  const long long l0 = (long long)blockIdx.x * TK;
   const int col = t % TK;
-  const long long line = l0 + col;
-  // lines are (ky, kx) pairs stored with row stride kxs >= kxn; the padding columns hold nothing
-  const int lkx = (int)(line % kxs);
-  const bool live = line < nl && lkx < kxn;
-  for (int m = t; m < N; m += 256) tw[m] = tw_g[m];
-  constexpr int RPT = 256 / TK;  // z-rows covered by one sweep of the workgroup
+  for (int m = t; m < N; m += NT) tw[m] = tw_g[m];
+  constexpr int RPT = NT / TK;  // z-rows covered by one sweep of the workgroup
   constexpr int NIT = N / RPT;  // all loads of a work-item in flight before the first LDS write
-  {
-    double2 v[NIT];
+  static_assert(N % RPT == 0 && NT % TK == 0, "tile shape");
+  double2 v[NIT];
+  auto tile_line = [&](int tile) { return (long long)tile * TK + col; };
+  // lines are (ky, kx) pairs stored with row stride kxs >= kxn; the padding columns hold nothing
+  auto is_live = [&](long long line) { return line < nl && (int)(line % kxs) < kxn; };
+  auto prefetch = [&](int tile) {
+    const long long line = tile_line(tile);
+    const bool live = is_live(line);
 #pragma unroll
     for (int q = 0; q < NIT; ++q) v[q] = live ? data[(long long)(t / TK + q * RPT) * nl + line] : make_double2(0.0, 0.0);
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) prefetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+  const long long line = tile_line(tile);
+  const int lkx = (int)(line % kxs);
+  const bool live = is_live(line);
 #pragma unroll
-    for (int q = 0; q < NIT; ++q) buf[(t / TK + q * RPT) * TK + col] = v[q];
-  }
+  for (int q = 0; q < NIT; ++q) buf[(t / TK + q * RPT) * TK + col] = v[q];
   // 1/((âx + ây) + âz): the (x,y) part of the symbol is fixed per line
   double axy = 1.0;
   if (live) axy = ax[lkx] + ay[(int)(line / kxs)];
   const bool mean_line = zero_mean && line == 0;
   __syncthreads();
+  if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);  // in flight during the LDS stages below
 
   // ---------------- forward: DIF ----------------
   int L = N;
   if (!skel) {  // skel: timing experiment (INS_ZSOLVE_SKEL): loads and stores only
   if (ODD) {
-    for (int w = t; w < (N / 2) * TK; w += 256) {
+    for (int w = t; w < (N / 2) * TK; w += NT) {
       const int c = w % TK, j = w / TK;  // one group of length N
       double2 a0 = buf[j * TK + c], a1 = buf[(j + N / 2) * TK + c];
       buf[j * TK + c] = cadd(a0, a1);
@@ -99,7 +110,7 @@ __global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long
   for (; L >= 4; L >>= 2) {
     const int Q = L / 4, step = N / L;
     const bool last = L == 4;
-    for (int w = t; w < (N / 4) * TK; w += 256) {
+    for (int w = t; w < (N / 4) * TK; w += NT) {
       const int c = w % TK, b = w / TK;
       const int g = b / Q, j = b - g * Q;
       const int base = (g * L + j) * TK + c;
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long
 #pragma unroll 1
   for (L = 16; L <= (ODD ? N / 2 : N); L <<= 2) {
     const int Q = L / 4, step = N / L;
-    for (int w = t; w < (N / 4) * TK; w += 256) {
+    for (int w = t; w < (N / 4) * TK; w += NT) {
       const int c = w % TK, b = w / TK;
       const int g = b / Q, j = b - g * Q;
       const int base = (g * L + j) * TK + c;
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long
     __syncthreads();
   }
   if (ODD) {
-    for (int w = t; w < (N / 2) * TK; w += 256) {
+    for (int w = t; w < (N / 2) * TK; w += NT) {
       const int c = w % TK, j = w / TK;
       const double2 x0 = buf[j * TK + c], x1 = cmulc(buf[(j + N / 2) * TK + c], tw[j]);
       buf[j * TK + c] = cadd(x0, x1);
@@ -176,19 +187,240 @@ __global__ __launch_bounds__(256) void k_zsolve(double2* __restrict__ data, long
   if (live)
 #pragma unroll
     for (int q = 0; q < NIT; ++q) data[(long long)(t / TK + q * RPT) * nl + line] = buf[(t / TK + q * RPT) * TK + col];
+  __syncthreads();  // the tile in LDS is overwritten by the next one
+  }
 }
 
-template <int LOGN, int TK>
-int launch_zsolve(double2* data, long long nl, const double* ax, int kxn, const double* ay, const double* az, const double2* tw,
-                  double inv_n, bool zero_mean, hipStream_t s, int kxs) {
-  const unsigned nb = (unsigned)((nl + TK - 1) / TK);
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Three-pass form for nz = 256 (4 x 8 x 8) and 512 (8 x 8 x 8): every pass is one radix-R1 / radix-8 transform held in REGISTERS.
+//   forward (DIF):  pass 1 straight from global memory (a work-item loads the R1 planes j + q nz/R1 of its line — no LDS fill),
+//                   pass 2 and pass 3 through LDS;  the symbol and the first inverse pass act on the registers of pass 3;
+//   inverse (DIT, mirrored order, conjugated twiddles):  pass 2 through LDS, pass 3 reads LDS and stores straight to global memory.
+// Four LDS round trips of the tile instead of the eleven of the radix-4 kernel above (its LDS traffic and twiddle arithmetic cost as
+// much as its HBM traffic: 0.83 ms at 512^3 with 0.58 ms for loads and stores alone), and the tile never sits in LDS without work.
+// LDS image: position n of line c at ((n ^ ((n >> 3) & 1)) * TK + c): the XOR keeps every access of the three passes conflict-free
+// for ds_read/write_b128 (pass 3 reads positions 8 g + q: without it the sixteen lanes of a b128 group would share eight slots).
+// ------------------------------------------------------------------------------------------------------------------------------
+template <bool INV>
+__device__ __forceinline__ double2 rot90(double2 a) {  // a * (-i) forward, a * (+i) inverse
+  return INV ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
+}
+template <bool INV>
+__device__ __forceinline__ void dft4(double2& x0, double2& x1, double2& x2, double2& x3) {
+  const double2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = rot90<INV>(csub(x1, x3));
+  x0 = cadd(t0, t2);
+  x1 = cadd(t1, t3);
+  x2 = csub(t0, t2);
+  x3 = csub(t1, t3);
+}
+// y[k] = sum_n x[n] w^(nk), w = exp(-+2 pi i / R), in place, natural order in and out
+template <int R, bool INV>
+__device__ __forceinline__ void dft(double2 (&x)[R]) {
+  if constexpr (R == 4) {
+    dft4<INV>(x[0], x[1], x[2], x[3]);
+  } else {
+    static_assert(R == 8, "radix");
+    // even / odd halves (radix 4 each), then the radix-2 combination with W8^k
+    dft4<INV>(x[0], x[2], x[4], x[6]);
+    dft4<INV>(x[1], x[3], x[5], x[7]);
+    constexpr double h = 0.70710678118654752440;
+    const double2 o1 = x[3], o2 = x[5], o3 = x[7];
+    // W8^1 = (1 -+ i)/sqrt2, W8^2 = -+i, W8^3 = (-1 -+ i)/sqrt2
+    const double2 w1 = INV ? make_double2((o1.x - o1.y) * h, (o1.x + o1.y) * h) : make_double2((o1.x + o1.y) * h, (o1.y - o1.x) * h);
+    const double2 w2 = rot90<INV>(o2);
+    const double2 w3 = INV ? make_double2((-o3.x - o3.y) * h, (o3.x - o3.y) * h) : make_double2((o3.y - o3.x) * h, (-o3.x - o3.y) * h);
+    const double2 e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6], w0 = x[1];
+    x[0] = cadd(e0, w0);
+    x[4] = csub(e0, w0);
+    x[1] = cadd(e1, w1);
+    x[5] = csub(e1, w1);
+    x[2] = cadd(e2, w2);
+    x[6] = csub(e2, w2);
+    x[3] = cadd(e3, w3);
+    x[7] = csub(e3, w3);
+  }
+}
+// x[q] *= w^q (q = 1..R-1), powers by multiplication (one table read per transform); CONJ: conjugated twiddle
+template <int R, bool CONJ>
+__device__ __forceinline__ void twiddle(double2 (&x)[R], double2 w1) {
+  if (CONJ) w1.y = -w1.y;
+  const double2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+  x[1] = cmul(x[1], w1);
+  x[2] = cmul(x[2], w2);
+  x[3] = cmul(x[3], w3);
+  if constexpr (R == 8) {
+    const double2 w4 = cmul(w2, w2), w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
+    x[4] = cmul(x[4], w4);
+    x[5] = cmul(x[5], w5);
+    x[6] = cmul(x[6], w6);
+    x[7] = cmul(x[7], w7);
+  }
+}
+
+template <int LOGN, int TK, int NT>
+__global__ __launch_bounds__(NT) void k_zsolve3(double2* __restrict__ data, long long nl, const double* __restrict__ ax, int kxn,
+                                                const double* __restrict__ ay, const double* __restrict__ az,
+                                                const double2* __restrict__ tw_g, double inv_n, int zero_mean, int kxs, int skel, int ntiles) {
+  constexpr int N = 1 << LOGN;
+  constexpr int R1 = N / 64, R2 = 8, R3 = 8;  // 256 = 4 x 8 x 8, 512 = 8 x 8 x 8
+  static_assert(R1 == 4 || R1 == 8, "nz = 256 or 512");
+  constexpr int L2 = N / R1;                  // block length of pass 2 (64)
+  extern __shared__ double2 lds_dyn[];
+  double2* buf = lds_dyn;          // [N][TK], swizzled
+  double2* tw = lds_dyn + N * TK;  // [N]
+  const int t = threadIdx.x;
+  auto at = [&](int n, int c) -> double2& { return buf[(n ^ ((n >> 3) & 1)) * TK + c]; };
+  for (int m = t; m < N; m += NT) tw[m] = tw_g[m];
+  constexpr int B1 = (N / R1) * TK / NT, B2 = (N / R2) * TK / NT, B3 = (N / R3) * TK / NT;  // transforms per work-item and pass
+  static_assert(B1 >= 1 && B2 >= 1 && B3 >= 1 && NT % TK == 0, "tile shape");
+  const int c = t % TK;  // NT is a multiple of TK: a work-item keeps its line column in every pass
+  auto is_live = [&](long long line) { return line < nl && (int)(line % kxs) < kxn; };  // padding columns of a row (kx >= kxn) hold nothing
+  // The workgroup is persistent: tiles blockIdx.x, blockIdx.x + gridDim.x, ...; the pass-1 loads of the next tile are issued as soon as the
+  // registers are free (right after pass 1 of the current tile), so they fly during the LDS passes and the stores of the current tile.
+  double2 x1[B1][R1];
+  auto prefetch = [&](int tile) {
+    const long long line = (long long)tile * TK + c;
+    const bool live = is_live(line);
+#pragma unroll
+    for (int i = 0; i < B1; ++i) {
+      const int j = t / TK + i * (NT / TK);
+#pragma unroll
+      for (int q = 0; q < R1; ++q) x1[i][q] = live ? data[(long long)(j + q * (N / R1)) * nl + line] : make_double2(0.0, 0.0);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) prefetch(tile);
+  __syncthreads();  // twiddle table
+  for (; tile < ntiles; tile += gridDim.x) {
+    const long long line = (long long)tile * TK + c;
+    const int lkx = (int)(line % kxs);
+    const bool live = is_live(line);
+    double axy = 1.0;
+    if (live) axy = ax[lkx] + ay[(int)(line / kxs)];
+    const bool mean_line = zero_mean && line == 0;
+
+    // ---- forward pass 1: (global ->) registers -> LDS
+#pragma unroll
+    for (int i = 0; i < B1; ++i) {
+      const int j = t / TK + i * (NT / TK);
+      if (!skel) {
+        dft<R1, false>(x1[i]);
+        twiddle<R1, false>(x1[i], tw[j]);
+      }
+#pragma unroll
+      for (int q = 0; q < R1; ++q) at(j + q * (N / R1), c) = x1[i][q];
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+    if (!skel) {
+      // ---- forward pass 2 (blocks of L2 = 64)
+#pragma unroll
+      for (int i = 0; i < B2; ++i) {
+        const int b = t / TK + i * (NT / TK), g1 = b / (L2 / R2), j = b % (L2 / R2);
+        double2 x[R2];
+#pragma unroll
+        for (int q = 0; q < R2; ++q) x[q] = at(g1 * L2 + j + q * (L2 / R2), c);
+        dft<R2, false>(x);
+        twiddle<R2, false>(x, tw[j * R1]);  // W_64^j = W_N^(R1 j)
+#pragma unroll
+        for (int q = 0; q < R2; ++q) at(g1 * L2 + j + q * (L2 / R2), c) = x[q];
+      }
+      __syncthreads();
+      // ---- forward pass 3 (blocks of 8, unit twiddles) + symbol + inverse pass 1
+#pragma unroll
+      for (int i = 0; i < B3; ++i) {
+        const int g = t / TK + i * (NT / TK);
+        double2 x[R3];
+#pragma unroll
+        for (int q = 0; q < R3; ++q) x[q] = at(g * R3 + q, c);
+        dft<R3, false>(x);
+        // position p = q1 N/R1 + q2 N/(R1 R2) + q3 holds frequency k = q1 + R1 q2 + R1 R2 q3; here g = q1 R2 + q2, q3 = q
+        const int kbase = g / R2 + R1 * (g % R2);
+#pragma unroll
+        for (int q = 0; q < R3; ++q) {
+          const int k = kbase + R1 * R2 * q;
+          const double sc = (mean_line && k == 0) ? 0.0 : -inv_n / (axy + az[k]);
+          x[q].x *= sc;
+          x[q].y *= sc;
+        }
+        dft<R3, true>(x);
+#pragma unroll
+        for (int q = 0; q < R3; ++q) at(g * R3 + q, c) = x[q];
+      }
+      __syncthreads();
+      // ---- inverse pass 2
+#pragma unroll
+      for (int i = 0; i < B2; ++i) {
+        const int b = t / TK + i * (NT / TK), g1 = b / (L2 / R2), j = b % (L2 / R2);
+        double2 x[R2];
+#pragma unroll
+        for (int q = 0; q < R2; ++q) x[q] = at(g1 * L2 + j + q * (L2 / R2), c);
+        twiddle<R2, true>(x, tw[j * R1]);
+        dft<R2, true>(x);
+#pragma unroll
+        for (int q = 0; q < R2; ++q) at(g1 * L2 + j + q * (L2 / R2), c) = x[q];
+      }
+      __syncthreads();
+    }
+    // ---- inverse pass 3: LDS -> registers -> global
+#pragma unroll
+    for (int i = 0; i < B1; ++i) {
+      const int j = t / TK + i * (NT / TK);
+      double2 x[R1];
+#pragma unroll
+      for (int q = 0; q < R1; ++q) x[q] = at(j + q * (N / R1), c);
+      if (!skel) {
+        twiddle<R1, true>(x, tw[j]);
+        dft<R1, true>(x);
+      }
+      if (live)
+#pragma unroll
+        for (int q = 0; q < R1; ++q) data[(long long)(j + q * (N / R1)) * nl + line] = x[q];
+    }
+    __syncthreads();  // the LDS tile is rewritten by the next tile's pass 1
+  }
+}
+
+template <int LOGN, int TK, int NT>
+int launch_zsolve3(double2* data, long long nl, const double* ax, int kxn, const double* ay, const double* az, const double2* tw,
+                   double inv_n, bool zero_mean, hipStream_t s, int kxs) {
+  const int ntiles = (int)((nl + TK - 1) / TK);
   constexpr size_t lds = ((size_t)(1 << LOGN) * TK + (1 << LOGN)) * sizeof(double2);
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    INS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_zsolve<LOGN, TK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    INS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_zsolve3<LOGN, TK, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_zsolve<LOGN, TK>), dim3(nb), dim3(256), lds, s, data, nl, ax, kxn, ay, az, tw, inv_n, zero_mean ? 1 : 0, kxs, ins_opt(OPT_INS_ZSOLVE_SKEL) ? 1 : 0);
+  // 16-line tiles (136 KB of LDS: one workgroup per CU) run persistent, one workgroup per CU walking its share of the tiles with the next
+  // tile's loads in flight (512^3: 0.587 -> 0.538 ms); 8-line tiles fit several workgroups per CU and run one tile per workgroup (persistent
+  // they are slower: 0.599 vs 0.573 ms).  INS_ZSOLVE_WGS = workgroups per CU overrides.
+  const int fit = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / NT));
+  const long long per_cu = ins_opt(OPT_INS_ZSOLVE_WGS) > 0 ? ins_opt(OPT_INS_ZSOLVE_WGS) : (TK >= 16 ? fit : (1LL << 20));
+  const unsigned nb = (unsigned)std::min<long long>(ntiles, 256LL * per_cu);
+  hipLaunchKernelGGL((k_zsolve3<LOGN, TK, NT>), dim3(nb), dim3(NT), lds, s, data, nl, ax, kxn, ay, az, tw, inv_n, zero_mean ? 1 : 0, kxs,
+                     ins_opt(OPT_INS_ZSOLVE_SKEL) ? 1 : 0, ntiles);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+template <int LOGN, int TK, int NT = 256>
+int launch_zsolve(double2* data, long long nl, const double* ax, int kxn, const double* ay, const double* az, const double2* tw,
+                  double inv_n, bool zero_mean, hipStream_t s, int kxs) {
+  const int ntiles = (int)((nl + TK - 1) / TK);
+  constexpr size_t lds = ((size_t)(1 << LOGN) * TK + (1 << LOGN)) * sizeof(double2);
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    INS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_zsolve<LOGN, TK, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  // persistent workgroups: as many as are resident at once (LDS per workgroup decides), each walks its share of the tiles.
+  // INS_ZSOLVE_WGS: workgroups per CU (0 = what fits; a large value = one tile per workgroup, the non-persistent form)
+  const int fit = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / NT));
+  const long long per_cu = ins_opt(OPT_INS_ZSOLVE_WGS) > 0 ? ins_opt(OPT_INS_ZSOLVE_WGS) : fit;
+  const unsigned nb = (unsigned)std::min<long long>(ntiles, 256LL * per_cu);
+  hipLaunchKernelGGL((k_zsolve<LOGN, TK, NT>), dim3(nb), dim3(NT), lds, s, data, nl, ax, kxn, ay, az, tw, inv_n, zero_mean ? 1 : 0, kxs,
+                     ins_opt(OPT_INS_ZSOLVE_SKEL) ? 1 : 0, ntiles);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -240,10 +472,65 @@ int ins_k_zsolve(double* data, int nz, long long nl, const double* ax, int kxn, 
     case 32: return launch_zsolve<5, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
     case 64: return launch_zsolve<6, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
     case 128: return launch_zsolve<7, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
-    case 256: return launch_zsolve<8, 8>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
-    case 512: return launch_zsolve<9, 8>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);    // 72 KB tile
+    case 256:
+      if (!ins_opt(OPT_INS_ZSOLVE_RADIX4)) {
+        return launch_zsolve3<8, 8, 256>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+      }
+      return launch_zsolve<8, 8>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+    case 512: {
+      const int tk = (int)ins_opt(OPT_INS_ZSOLVE_TK), nt = (int)ins_opt(OPT_INS_ZSOLVE_NT);
+      if (!ins_opt(OPT_INS_ZSOLVE_RADIX4)) {
+        if (tk == 16 && nt == 1024) return launch_zsolve3<9, 16, 1024>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+        if (tk == 8 && nt == 512) return launch_zsolve3<9, 8, 512>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+        if (tk == 8) return launch_zsolve3<9, 8, 256>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+        return launch_zsolve3<9, 16, 512>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);  // 512 B per plane and tile: 4.1 TB/s (8 lines: 3.8)
+      }
+      if (tk == 16 && nt == 1024) return launch_zsolve<9, 16, 1024>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+      if (tk == 16 && nt == 512) return launch_zsolve<9, 16, 512>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+      if (tk == 16) return launch_zsolve<9, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+      if (tk == 4) return launch_zsolve<9, 4>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+      if (nt == 512) return launch_zsolve<9, 8, 512>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+      if (nt == 1024) return launch_zsolve<9, 8, 1024>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+      return launch_zsolve<9, 8>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);    // 72 KB tile
+    }
     case 1024: return launch_zsolve<10, 4>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);  // 80 KB tile
   }
   ins_set_error("ins_k_zsolve: unsupported nz = %d", nz);
   return INS_ERR_UNSUPPORTED;
+}
+
+// Experiment hook (not part of the public ABI, like ins_tune_*): time `reps` launches of the fused z pass on `data` = nbox independent
+// [nz][nl] blocks (nl = nky * kxs lines, kxn live columns), average ms per sweep over all boxes.  tools/zpass_lab.py varies the plane
+// stride (nl * 16 B) at a fixed byte count with it.
+extern "C" int ins_dbg_zsolve(double* data, int nz, long long nl, int kxn, int kxs, int nbox, int reps, float* ms) {
+  double *ax = nullptr, *ay = nullptr, *az = nullptr, *tw = nullptr;
+  const int nky = (int)(nl / kxs);
+  std::vector<double> h(std::max(std::max(kxs, nky), nz), 1.0);
+  INS_HIP_TRY(hipMalloc(&ax, kxs * 8));
+  INS_HIP_TRY(hipMalloc(&ay, nky * 8));
+  INS_HIP_TRY(hipMalloc(&az, nz * 8));
+  INS_HIP_TRY(hipMemcpy(ax, h.data(), kxs * 8, hipMemcpyHostToDevice));
+  INS_HIP_TRY(hipMemcpy(ay, h.data(), nky * 8, hipMemcpyHostToDevice));
+  INS_HIP_TRY(hipMemcpy(az, h.data(), nz * 8, hipMemcpyHostToDevice));
+  int rc = ins_zsolve_twiddles(nz, &tw);
+  if (rc) return rc;
+  hipEvent_t e0, e1;
+  INS_HIP_TRY(hipEventCreate(&e0));
+  INS_HIP_TRY(hipEventCreate(&e1));
+  for (int r = -1; r < reps; ++r) {
+    if (r == 0) INS_HIP_TRY(hipEventRecord(e0, nullptr));
+    for (int b = 0; b < nbox; ++b)
+      if ((rc = ins_k_zsolve(data + 2LL * b * nz * nl, nz, nl, ax, kxn, ay, az, tw, 1.0 / nz, false, nullptr, kxs))) return rc;
+  }
+  INS_HIP_TRY(hipEventRecord(e1, nullptr));
+  INS_HIP_TRY(hipEventSynchronize(e1));
+  INS_HIP_TRY(hipEventElapsedTime(ms, e0, e1));
+  *ms /= (float)std::max(reps, 1);
+  (void)hipFree(ax);
+  (void)hipFree(ay);
+  (void)hipFree(az);
+  (void)hipFree(tw);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return INS_OK;
 }
