@@ -34,6 +34,7 @@ extern "C" {
 #define INS_ERR_FFT (-3)         /* a hipFFT/rocFFT call failed */
 #define INS_ERR_UNSUPPORTED (-4) /* valid request that this build does not implement */
 #define INS_ERR_NOCONV (-5)      /* iterative solver hit maxiter */
+#define INS_ERR_COMM (-6)        /* an RCCL call failed */
 
 /* Boundary-condition codes, boundary_conditions.jl:2-36.  INS_BC_HALO marks a side whose ghost plane is
  * filled by the caller (the z-faces of a slab in the multi-GPU decomposition). */
@@ -46,6 +47,7 @@ extern "C" {
 typedef struct ins_grid ins_grid_t;       /* device copy of `setup.grid` metrics   (grid.jl:100-276)   */
 typedef struct ins_poisson ins_poisson_t; /* a `psolver` closure                   (pressure.jl:85-351) */
 typedef struct ins_rk ins_rk_t;           /* `ode_method_cache` + stepper state    (time_stepper_caches.jl:34-49) */
+typedef struct ins_comm ins_comm_t;       /* one rank of an RCCL communicator (multi-GPU z-slabs; no reference counterpart) */
 
 /* Host-side description of `setup.grid` + `setup.boundary_conditions`; all pointers are HOST pointers
  * to the reference's 1-D metric vectors, copied (and turned into reciprocal tables) by ins_grid_create. */
@@ -328,6 +330,36 @@ int ins_slab_ztri_inverse(ins_slab_fft_t* S, double* work, double* pI, void* str
 /* x pass of ins_slab_ztri_forward (from_u = 1) for local planes [kz0, kz0 + nkz) only; follow with ins_slab_ztri_forward(from_u = 2).
  * Planes >= 1 read no ghost plane of u, so they can run while the w plane below the slab is still in flight. */
 int ins_slab_xfwd_planes(ins_slab_fft_t* S, const ins_grid_t* grid, const double* u, double* work, int kz0, int nkz, void* stream);
+
+/* ---------------------------------------------------------------------------------- multi-GPU communication (RCCL over xGMI)
+ * The reference is single-device; these entry points are the communication half of this library's z-slab decomposition
+ * of its stage loop, so that a non-Python host can drive several GPUs through the boundary.  All exchanges are enqueued on
+ * `stream` (stream-ordered with the kernels that produce / consume the planes), grouped (ncclGroupStart/End), fp64, non-blocking for the host.
+ * librccl is loaded when the first communicator is created. */
+#define INS_COMM_ID_BYTES 128
+/* One process per GPU: rank 0 obtains an id, the host ships the bytes to every rank, each rank creates its communicator with its device current. */
+int ins_comm_unique_id(void* id128);
+int ins_comm_create(int nranks, int rank, const void* id128, ins_comm_t** out);
+/* One process driving ngpu devices (devices == NULL: 0..ngpu-1): out[i] is the communicator of devices[i] (ncclCommInitAll). */
+int ins_comm_create_local(int ngpu, const int* devices, ins_comm_t** out);
+int ins_comm_destroy(ins_comm_t* comm);
+int ins_comm_rank(const ins_comm_t* comm, int* rank, int* nranks);
+/* Generic grouped exchange; messages between one pair of ranks match in posting order. */
+int ins_comm_sendrecv_f64(ins_comm_t* comm, int nsend, const double* const* sendbufs, const int64_t* sendcounts, const int32_t* dsts, int nrecv,
+                          double* const* recvbufs, const int64_t* recvcounts, const int32_t* srcs, void* stream);
+/* z ghost planes of a padded local vector field on a slab grid (z sides INS_BC_HALO): the periodic z part of apply_bc_u!
+ * (boundary_conditions.jl:276-288) across ranks.  comp_mask bit c selects component c; down_only: only plane nzl -> next rank's plane 0
+ * (all `divergence!` needs, operators.jl:122). */
+int ins_halo_exchange_f64(ins_comm_t* comm, const ins_grid_t* slab_grid, double* u, int comp_mask, int down_only, void* stream);
+/* Ghost planes of the extended pressure buffer [1 below | nzl local | 2 above] read by the correcting stage kernel (ins_stage_momentum_corr_f64). */
+int ins_halo_exchange_p_f64(ins_comm_t* comm, double* p_ext, int64_t plane_elems, int nzl, void* stream);
+/* Interface values of the distributed tridiagonal z solve (ins_slab_ztri_forward -> this -> ins_slab_ztri_finish): direct != 0 sends to every
+ * peer over its own xGMI link in one group, 0 uses ncclAllGather. */
+int ins_ztri_allgather_f64(ins_comm_t* comm, const double* edge, double* edges_all, int64_t count, int direct, void* stream);
+/* In-place reductions of device scalars across ranks (CFL minimum: solver.jl:101-125, energies, norms): op 0 sum, 1 max, 2 min. */
+int ins_comm_allreduce_f64(ins_comm_t* comm, double* buf, int64_t count, int op, void* stream);
+/* Transposes around the z-FFT (the alternative Poisson route, ins_slab_fft_*): block r of `send` -> block `rank` of rank r's `recv`. */
+int ins_comm_alltoall_f64(ins_comm_t* comm, const double* send, double* recv, int64_t count, void* stream);
 
 #ifdef __cplusplus
 }

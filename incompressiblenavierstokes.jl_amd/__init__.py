@@ -8,7 +8,7 @@ creating a `Setup` without a HIP device, raises.
 from . import _lib
 from ._lib import INSHipError
 from .boundary_conditions import DirichletBC, HaloBC, PeriodicBC, PressureBC, SymmetricBC
-from .distributed import HipSlabKernels, SlabComm, SlabLayout, SlabStepper
+from .distributed import AbiSlabComm, HipSlabKernels, SlabComm, SlabLayout, SlabStepper
 from .grid import Grid, cosine_grid, max_size, stretched_grid, tanh_grid
 from .initializers import random_field, temperaturefield, velocityfield
 from .operators import (

@@ -128,6 +128,18 @@ SIGNATURES = {
     "ins_slab_ztri_inverse": (C.c_int, [vp, vp, vp, vp]),
     "ins_slab_fft_forward_packed": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp]),
     "ins_slab_fft_inverse_packed": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
+    "ins_comm_unique_id": (C.c_int, [vp]),
+    "ins_comm_create": (C.c_int, [C.c_int, C.c_int, vp, C.POINTER(vp)]),
+    "ins_comm_create_local": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]),
+    "ins_comm_destroy": (C.c_int, [vp]),
+    "ins_comm_rank": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ins_comm_sendrecv_f64": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int, C.POINTER(vp),
+                                        C.POINTER(C.c_int64), C.POINTER(C.c_int32), vp]),
+    "ins_halo_exchange_f64": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
+    "ins_halo_exchange_p_f64": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
+    "ins_ztri_allgather_f64": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, vp]),
+    "ins_comm_allreduce_f64": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
+    "ins_comm_alltoall_f64": (C.c_int, [vp, vp, vp, C.c_int64, vp]),
 }
 
 _lib = None

@@ -164,6 +164,132 @@ class SlabComm:
             dist.barrier(self.group)
 
 
+class AbiSlabComm:
+    """The SlabComm interface on the library's OWN RCCL entry points (`ins_comm_*`, csrc/ins_comm.hip; include/ins_hip.h) instead of
+    torch.distributed — the route a Julia host takes.  One communicator per process / GPU:
+
+        id = AbiSlabComm.unique_id()            # rank 0; ship the 128 bytes to the other ranks (MPI, a file, torch.distributed ...)
+        comm = AbiSlabComm(world, rank, id)     # every rank, its device current
+
+    Exchanges are enqueued on the current stream; the asynchronous variants run on a side stream ordered by events (the RCCL kernels then
+    overlap the compute kernels) and return handles whose wait() orders the current stream after them."""
+
+    backend = "rccl-abi"
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        _lib.call("ins_comm_unique_id", buf)
+        return bytes(buf)
+
+    def __init__(self, world, rank, id_bytes, device=None, loopback=False, overlap=True):
+        self.world, self.rank, self.loopback = int(world), int(rank), bool(loopback)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.call("ins_comm_create", self.world, self.rank, C.create_string_buffer(bytes(id_bytes), 128), C.byref(self._h))
+        self.side = torch.cuda.Stream(self.device) if overlap else None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.load().ins_comm_destroy(h)
+            except Exception:
+                pass
+
+    class _After:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    def _local(self):
+        return self.world == 1 and not self.loopback
+
+    def _stream_ptr(self, stream=None):
+        return C.c_void_p((stream or torch.cuda.current_stream(self.device)).cuda_stream)
+
+    def _sendrecv(self, sends, recvs, stream=None):
+        ns, nr = len(sends), len(recvs)
+        sp = (C.c_void_p * max(ns, 1))(*[t.data_ptr() for t, _ in sends])
+        sc = (C.c_int64 * max(ns, 1))(*[t.numel() for t, _ in sends])
+        sd = (C.c_int32 * max(ns, 1))(*[d for _, d in sends])
+        rp = (C.c_void_p * max(nr, 1))(*[t.data_ptr() for t, _ in recvs])
+        rc = (C.c_int64 * max(nr, 1))(*[t.numel() for t, _ in recvs])
+        rs = (C.c_int32 * max(nr, 1))(*[q for _, q in recvs])
+        _lib.call("ins_comm_sendrecv_f64", self._h, ns, sp, sc, sd, nr, rp, rc, rs, self._stream_ptr(stream))
+
+    def _on_side(self, fn):
+        """Run fn(stream) on the side stream behind everything enqueued so far; returns a handle to wait() on."""
+        if self.side is None:
+            fn(None)
+            return []
+        cur = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(cur)
+        fn(self.side)
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        return [AbiSlabComm._After(ev)]
+
+    def exchange(self, sends, recvs):
+        if self._local():
+            for (s, _), (r, _) in zip(sends, recvs):
+                r.copy_(s)
+            return
+        self._sendrecv(sends, recvs)
+
+    def exchange_async(self, sends, recvs):
+        if self._local():
+            self.exchange(sends, recvs)
+            return []
+        return self._on_side(lambda st: self._sendrecv(sends, recvs, st))
+
+    def all_to_all(self, recv, send, stream=None):
+        if self._local():
+            recv.copy_(send)
+            return
+        _lib.call("ins_comm_alltoall_f64", self._h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), send.numel() // self.world, self._stream_ptr(stream))
+
+    def all_to_all_async(self, recv, send, which=0):
+        if self._local():
+            self.all_to_all(recv, send)
+            return SlabComm._Done()
+        h = self._on_side(lambda st: self.all_to_all(recv, send, st))
+        return h[0] if h else SlabComm._Done()
+
+    def all_gather(self, out, inp, stream=None):
+        if self._local():
+            out.copy_(inp)
+            return
+        direct = 0 if os.environ.get("INS_SLAB_GATHER") == "collective" else 1
+        _lib.call("ins_ztri_allgather_f64", self._h, C.c_void_p(inp.data_ptr()), C.c_void_p(out.data_ptr()), inp.numel(), direct, self._stream_ptr(stream))
+
+    def all_gather_async(self, out, inp):
+        if self._local():
+            self.all_gather(out, inp)
+            return []
+        return self._on_side(lambda st: self.all_gather(out, inp, st))
+
+    def allreduce_(self, t, op="max"):
+        """In-place reduction of a device fp64 tensor across ranks (op: sum / max / min)."""
+        if not self._local():
+            _lib.call("ins_comm_allreduce_f64", self._h, C.c_void_p(t.data_ptr()), t.numel(), {"sum": 0, "max": 1, "min": 2}[op], self._stream_ptr())
+        return t
+
+    def halo_u(self, setup, u, comps=(0, 1, 2), down_only=False):
+        """`ins_halo_exchange_f64`: the z ghost planes of a padded local vector field in one call (what SlabStepper.halo_u assembles plane by plane)."""
+        mask = sum(1 << c for c in comps)
+        _lib.call("ins_halo_exchange_f64", self._h, setup.handle, setup.ptr(u, True), mask, 1 if down_only else 0, self._stream_ptr())
+
+    def barrier(self):
+        if not self._local():
+            t = torch.zeros(1, dtype=torch.float64, device=self.device)
+            self.allreduce_(t, "sum")
+            torch.cuda.synchronize(self.device)
+
+
 class HipSlabKernels:
     """Rank-local numerics of the slab path: HIP kernels + rocFFT through the C ABI (include/ins_hip.h)."""
 
@@ -669,7 +795,9 @@ class SlabStepper:
         self.halo_u(u, comps=(2,), down_only=True)
         self.k.divergence(u, self.pI)
         v = (self.pI.abs().max() / self.k.cell_volume).reshape(1).to(torch.float64)
-        if self.comm.world > 1:
+        if hasattr(self.comm, "allreduce_"):
+            self.comm.allreduce_(v, "max")
+        elif self.comm.world > 1:
             vv = v.cpu() if self.comm.backend == "gloo" else v
             dist.all_reduce(vv, op=dist.ReduceOp.MAX, group=self.comm.group)
             v = vv
