@@ -46,7 +46,14 @@ def run_slab(ins, n, dt, steps, warmup, dev, backend, profile=True):
     zs = os.environ.get("INS_SLAB_ZSOLVE") or ("tridiag" if world > 1 else "fft")
     nchunks = int(os.environ.get("INS_SLAB_CHUNKS", "4"))
     g2 = dist.new_group(ranks=list(range(world))) if (nchunks > 1 and zs == "fft") else None
-    comm = ins.SlabComm(group2=g2)
+    if os.environ.get("INS_BENCH_COMM") == "abi":
+        # every exchange through the library's own RCCL entry points (ins_comm_*, csrc/ins_comm.hip) — the route a Julia host takes;
+        # torch.distributed only ships the 128-byte communicator id and times the run
+        ids = [ins.AbiSlabComm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = ins.AbiSlabComm(world, rank, ids[0], device=dev)
+    else:
+        comm = ins.SlabComm(group2=g2)
     st = ins.SlabStepper(ins.RKMethods.RK44(), lay, K, comm, chunks=nchunks)
     u = K.vector()
     u.copy_(torch.from_numpy(np.ascontiguousarray(tgv_local(lay))).to(dev))

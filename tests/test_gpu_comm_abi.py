@@ -123,11 +123,10 @@ def test_slab_stepper_through_the_comm_abi(ins, n):
     gc.collect()
     lay = ins.SlabLayout(n, 1, 0)
     K = ins.HipSlabKernels(lay, Re=800.0)
-    uid = ins.AbiSlabComm.unique_id()
     for zsolve, chunks in (("tridiag", 1), ("fft", 3)):
         outs = []
         for loop in (True, False):
-            comm = ins.AbiSlabComm(1, 0, uid if loop else ins.AbiSlabComm.unique_id(), loopback=loop)
+            comm = ins.AbiSlabComm(1, 0, ins.AbiSlabComm.unique_id(), loopback=loop)  # an id serves ONE communicator
             st = ins.SlabStepper(ins.RKMethods.RK44(), lay, K, comm, chunks=chunks, zsolve=zsolve)
             assert st.zsolve == zsolve
             u = K.from_global(u0_h)
