@@ -98,7 +98,7 @@ template <int R, bool UNIFORM, bool MASKED, int XW, bool FUSE, int CORR>
 __global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __restrict__ rx, const Rec* __restrict__ ry,
                                                        const Rec* __restrict__ rz, const double* __restrict__ u,
                                                        double* __restrict__ F, int zc, int ntx, int nty, int ntz, RkEpi epi,
-                                                       const double* __restrict__ pI) {
+                                                       const double* __restrict__ pI, int bar) {
   constexpr int XO = CORR ? XOUT - 1 : XOUT;
   // XCD-aware order: consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous run of
   // tiles (y fastest) so halo rows/columns shared by neighbouring tiles are hits in that XCD's L2.
@@ -120,12 +120,15 @@ __global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __r
   const int wx = wave % XW, wy = wave / XW;
   const int N0 = g.N[0], N1 = g.N[1], N2 = g.N[2];
   const int i = (txi * XW + wx) * XO + lane;  // lane 0 = left halo column
-  if (i - lane > N0 - 2) return;                // whole wavefront right of the domain (no barriers: safe)
   const int ic = min(i, N0 - 1);
   const int jb = 1 + (tyi * (4 / XW) + wy) * R; // first output row of this wavefront
-  if (jb > N1 - 2) return;
   const int k0 = 1 + tzi * zc;
   const int k1 = min(k0 + zc, N2 - 1);          // planes [k0, k1)
+  if (i - lane > N0 - 2 || jb > N1 - 2) {       // whole wavefront outside the domain: it only keeps the barrier count (one per plane)
+    if (bar)
+      for (int k = k0; k < k1; ++k) __builtin_amdgcn_s_barrier();
+    return;
+  }
   const long long sz = g.sx[2];
   const bool xout = lane >= 1 && lane <= XO && i <= N0 - 2;
   const int n0 = N0 - 2, n1 = N1 - 2, n2 = N2 - 2;
@@ -293,12 +296,15 @@ __global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __r
     // while the load of plane k+2 into the third buffer is in flight.
     while (true) {
       load_plane(A, min(k + 2, N2 - 1));
+      if (bar) __builtin_amdgcn_s_barrier();  // the wavefronts of a workgroup stay on one plane: shared halo lines are cache hits
       body(B, Cc, k);
       if (++k >= k1) break;
       load_plane(B, min(k + 2, N2 - 1));
+      if (bar) __builtin_amdgcn_s_barrier();  // the wavefronts of a workgroup stay on one plane: shared halo lines are cache hits
       body(Cc, A, k);
       if (++k >= k1) break;
       load_plane(Cc, min(k + 2, N2 - 1));
+      if (bar) __builtin_amdgcn_s_barrier();  // the wavefronts of a workgroup stay on one plane: shared halo lines are cache hits
       body(A, B, k);
       if (++k >= k1) break;
     }
@@ -321,32 +327,38 @@ __global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __r
       correct(Cc, Pa, Pb, k + 1);      // plane k+1 with p(k+1), p(k+2)
       load_plane(A, k + 2);
       load_p(Pa, k + 3);
+      if (bar) __builtin_amdgcn_s_barrier();  // the wavefronts of a workgroup stay on one plane: shared halo lines are cache hits
       body(B, Cc, k);
       if (++k >= k1) break;
       correct(A, Pb, Pa, k + 1);
       load_plane(B, k + 2);
       load_p(Pb, k + 3);
+      if (bar) __builtin_amdgcn_s_barrier();  // the wavefronts of a workgroup stay on one plane: shared halo lines are cache hits
       body(Cc, A, k);
       if (++k >= k1) break;
       correct(B, Pa, Pb, k + 1);
       load_plane(Cc, k + 2);
       load_p(Pa, k + 3);
+      if (bar) __builtin_amdgcn_s_barrier();  // the wavefronts of a workgroup stay on one plane: shared halo lines are cache hits
       body(A, B, k);
       if (++k >= k1) break;
       // second half of the period-6 rotation (the two p buffers have swapped roles)
       correct(Cc, Pb, Pa, k + 1);
       load_plane(A, k + 2);
       load_p(Pb, k + 3);
+      if (bar) __builtin_amdgcn_s_barrier();  // the wavefronts of a workgroup stay on one plane: shared halo lines are cache hits
       body(B, Cc, k);
       if (++k >= k1) break;
       correct(A, Pa, Pb, k + 1);
       load_plane(B, k + 2);
       load_p(Pa, k + 3);
+      if (bar) __builtin_amdgcn_s_barrier();  // the wavefronts of a workgroup stay on one plane: shared halo lines are cache hits
       body(Cc, A, k);
       if (++k >= k1) break;
       correct(B, Pb, Pa, k + 1);
       load_plane(Cc, k + 2);
       load_p(Pb, k + 3);
+      if (bar) __builtin_amdgcn_s_barrier();  // the wavefronts of a workgroup stay on one plane: shared halo lines are cache hits
       body(A, B, k);
       if (++k >= k1) break;
     }
@@ -425,6 +437,7 @@ static int launch_flux(const ins_grid* G, const double* u, double* F, const RkEp
   const Rec* r1 = r0 + g.N[0];
   const Rec* r2 = r1 + g.N[1];
   const int zc = g_zchunk ? g_zchunk : (g.N[2] >= 384 ? 8 : 4);
+  const int bar = ins_opt(OPT_INS_FLUX_BAR) ? 1 : 0;  // measured neutral on the masked cavity kernel (6.31 vs 6.37 ms/step): off by default
   const bool corr = pI != nullptr;
   const bool masked = !G->all_dof;
   constexpr int RC = R > 3 ? 3 : R;              // register-heavy variants cap the rows per thread: masked 3,
@@ -442,16 +455,16 @@ static int launch_flux(const ins_grid* G, const double* u, double* F, const RkEp
     if constexpr (FUSE)
       {
         if (corr_mode == 2)
-          hipLaunchKernelGGL((k_momentum_flux<RK, true, false, XW, true, 2>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
+          hipLaunchKernelGGL((k_momentum_flux<RK, true, false, XW, true, 2>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI, bar);
         else
-          hipLaunchKernelGGL((k_momentum_flux<RK, true, false, XW, true, 1>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
+          hipLaunchKernelGGL((k_momentum_flux<RK, true, false, XW, true, 1>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI, bar);
       }
   } else if (G->uniform_exact && !masked)
-    hipLaunchKernelGGL((k_momentum_flux<R, true, false, XW, FUSE, 0>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
+    hipLaunchKernelGGL((k_momentum_flux<R, true, false, XW, FUSE, 0>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI, bar);
   else if (!masked)
-    hipLaunchKernelGGL((k_momentum_flux<R, false, false, XW, FUSE, 0>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
+    hipLaunchKernelGGL((k_momentum_flux<R, false, false, XW, FUSE, 0>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI, bar);
   else  // masked: the epilogue leaves u* = ustart (+ 0) on volumes that are no DOF, apply_bc_u! sets them afterwards as always
-    hipLaunchKernelGGL((k_momentum_flux<RC, false, true, XW, FUSE, 0>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI);
+    hipLaunchKernelGGL((k_momentum_flux<RC, false, true, XW, FUSE, 0>), dim3(nb), block, 0, s, g, r0, r1, r2, u, F, zc, ntx, nty, ntz, epi, pI, bar);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }

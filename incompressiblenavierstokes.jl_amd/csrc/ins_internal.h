@@ -57,6 +57,7 @@ void ins_set_error(const char* fmt, ...);
   X(INS_FLUX_ROWS)               \
   X(INS_FLUX_ZC)                 \
   X(INS_FLUX_XW)                 \
+  X(INS_FLUX_BAR)                \
   X(INS_FLUX64_62_FROM)          \
   X(INS_DISABLE_FDM_ZFFT)        \
   X(INS_DISABLE_FDM_XFFT)        \
