@@ -1,22 +1,40 @@
 # INSHip.jl — glue that makes libinship.so a backend of IncompressibleNavierStokes.jl.
 #
-# UNTESTED: Julia is not installed in the build container (SURVEY.md §8b/§8c), so this file has never been
-# executed.  It shows the binding a maintainer would add (a weak-dependency package extension in the style of
-# ext/IncompressibleNavierStokesCUDSSExt.jl): AMDGPU.jl is used for device memory ONLY (ROCArray allocation and
-# raw pointers); every kernel lives behind the C ABI of include/ins_hip.h.  No KernelAbstractions kernels run.
+# NOT EXECUTED HERE: Julia is not installed in the build container (SURVEY.md §8b/§8c).  What can be checked without Julia is checked
+# mechanically: tests/test_julia_glue.py parses every `ccall` of this file and compares symbol, arity and argument types with the
+# prototypes of include/ins_hip.h, and checks that every reference function the glue claims to cover has a method here.
+#
+# Shape: a weak-dependency package extension in the style of ext/IncompressibleNavierStokesCUDSSExt.jl.  The user writes what they
+# would write for any AMDGPU run of the reference,
+#
+#     using IncompressibleNavierStokes, AMDGPU, INSHip
+#     setup = Setup(; x, boundary_conditions, Re, backend = ROCBackend())
+#     state, outputs = solve_unsteady(; setup, ustart, tlims, Δt)          # default_psolver(setup) reaches the library too
+#
+# and dispatch does the rest: every `op!` method below is specialised on `ROCArray{Float64}` arguments, the setup-only constructors
+# (`psolver_spectral`, `psolver_cg`, `ode_method_cache`) on a setup whose `backend` field is a `ROCBackend`, `psolver_direct` on the array
+# type exactly like the CUDSS extension (pressure.jl:101-117).  AMDGPU.jl is used for device memory ONLY (ROCArray allocation and raw
+# pointers); every kernel lives behind the C ABI of include/ins_hip.h.  No KernelAbstractions kernel of the reference runs.
 module INSHip
 
 using IncompressibleNavierStokes
+using LinearAlgebra
 using AMDGPU
 using AMDGPU: ROCArray, ROCBackend, HIP
 import IncompressibleNavierStokes:
-    apply_bc_u!, apply_bc_p!, divergence!, scalewithvolume!, pressuregradient!, applypressure!, laplacian!,
-    convection!, diffusion!, convectiondiffusion!, momentum!, project!, poisson!, psolver_spectral, psolver_cg,
-    timestep!, ode_method_cache, ExplicitRungeKuttaMethod, PeriodicBC, DirichletBC, SymmetricBC, PressureBC,
+    apply_bc_u!, apply_bc_p!, apply_bc_temp!, divergence!, scalewithvolume!, pressuregradient!, applypressure!, laplacian!,
+    convection!, diffusion!, convectiondiffusion!, momentum!, project!, poisson!, psolver_spectral, psolver_cg, psolver_direct,
+    timestep!, ode_method_cache, get_cfl_timestep!, kinetic_energy!, total_kinetic_energy,
+    ExplicitRungeKuttaMethod, PeriodicBC, DirichletBC, SymmetricBC, PressureBC,
     vorticity!, interpolate_u_p!, interpolate_ω_p!, Qfield!, Dfield!, eig2field!, dissipation_from_strain!,
-    convection_diffusion_temp!, dissipation!, gravity!, apply_bc_temp!, smagorinsky_closure
+    convection_diffusion_temp!, dissipation!, gravity!, smagorinsky_closure
 
 const lib = get(ENV, "INSHIP_LIB", "libinship.so")
+const RA = ROCArray{Float64}
+
+# A setup whose `backend` is a ROCBackend.  Field order of the NamedTuple: setup.jl:14-24
+# (grid, boundary_conditions, Re, bodyforce, issteadybodyforce, closure_model, backend, workgroupsize, temperature[, dbodyforce]).
+const ROCSetup = NamedTuple{N,<:Tuple{Any,Any,Any,Any,Any,Any,ROCBackend,Vararg{Any}}} where {N}
 
 # ins_grid_desc_t (include/ins_hip.h) — field order and types must match the C struct exactly.
 struct GridDesc
@@ -36,11 +54,21 @@ end
 
 check(rc) = rc == 0 || error("libinship: ", unsafe_string(ccall((:ins_last_error, lib), Cstring, ())))
 stream() = Ptr{Cvoid}(HIP.stream().stream)   # the task-local HIP stream AMDGPU.jl is using
-bccode(::PeriodicBC) = Int32(0); bccode(::DirichletBC) = Int32(1); bccode(::SymmetricBC) = Int32(2); bccode(::PressureBC) = Int32(3)
+bccode(::PeriodicBC) = Int32(0)
+bccode(::DirichletBC) = Int32(1)
+bccode(::SymmetricBC) = Int32(2)
+bccode(::PressureBC) = Int32(3)
+
+"Constant Dirichlet data `bc.u::Tuple` of side (β, s) for component α (boundary_conditions.jl:347-350); 0 for no-slip / closures / other BCs."
+bcconst(bc, α) = 0.0
+bcconst(bc::DirichletBC, α) = bc.u isa Tuple ? Float64(bc.u[α]) : 0.0
+"Does this side carry a closure `bc.u(α, x..., t)` (boundary_conditions.jl:351-357)?  Its values travel as plane buffers."
+isclosure(bc) = bc isa DirichletBC && !(isnothing(bc.u) || bc.u isa Tuple)
 
 "Device handle for `setup.grid`, built once per setup from the HOST copies of the 1-D metric vectors (grid.jl:177-248)."
 function grid_handle(setup)
     g = setup.grid
+    bcs = setup.boundary_conditions
     D = g.dimension()
     host(v) = Array(v)                                   # metrics are tiny; the library keeps its own device copy
     Δ, Δu = host.(g.Δ), host.(g.Δu)
@@ -54,8 +82,9 @@ function grid_handle(setup)
         idx9((α, β) -> Int32(first(g.Iu[α].indices[β]) - 1), Int32),    # Julia a:b -> [a-1, b)
         idx9((α, β) -> Int32(last(g.Iu[α].indices[β])), Int32),
         pad3(i -> Int32(first(g.Ip.indices[i]) - 1), Int32), pad3(i -> Int32(last(g.Ip.indices[i])), Int32),
-        ntuple(k -> (β = (k - 1) ÷ 2 + 1; s = (k - 1) % 2 + 1; β <= D ? bccode(setup.boundary_conditions[β][s]) : Int32(0)), 6),
-        ntuple(_ -> 0.0, 18),   # constant Dirichlet data: fill from bc.u::Tuple as [β][side][α]
+        ntuple(k -> (β = (k - 1) ÷ 2 + 1; s = (k - 1) % 2 + 1; β <= D ? bccode(bcs[β][s]) : Int32(0)), 6),
+        # constant Dirichlet data as [β][side][α] (a lid (1, 0.2, 0) on the upper y side sits at β = 2, side = 2)
+        ntuple(k -> (β = (k - 1) ÷ 6 + 1; s = ((k - 1) ÷ 3) % 2 + 1; α = (k - 1) % 3 + 1; β <= D && α <= D ? bcconst(bcs[β][s], α) : 0.0), 18),
     )
     h = Ref{Ptr{Cvoid}}()
     GC.@preserve Δ Δu A check(ccall((:ins_grid_create, lib), Cint, (Ref{GridDesc}, Ref{Ptr{Cvoid}}), desc, h))
@@ -65,66 +94,206 @@ end
 # One cached handle per setup (setup is an immutable NamedTuple: key on objectid of its grid).
 const HANDLES = Dict{UInt,Ptr{Cvoid}}()
 handle(setup) = get!(() -> grid_handle(setup), HANDLES, objectid(setup.grid))
-iship(setup) = setup.backend isa ROCBackend && setup.grid.x[1] isa ROCArray{Float64}
+
+# ---- boundary conditions (boundary_conditions.jl) -----------------------------------------------------------
+"Plane buffers for closure Dirichlet data: slot 3(2(β-1)+side-1)+α holds `bc.u(α, x..., t)` (or its time derivative) on `boundary(β, N, Iu[α], isright)`."
+function bc_planes(u::RA, t, setup, dudt)
+    g, bcs = setup.grid, setup.boundary_conditions
+    D = g.dimension()
+    any(isclosure, Iterators.flatten(bcs)) || return nothing, nothing
+    planes, keep = fill(Ptr{Float64}(C_NULL), 18), Any[]
+    for β = 1:D, (side, bc) in enumerate(bcs[β])
+        isclosure(bc) || continue
+        for α = 1:D
+            I = IncompressibleNavierStokes.boundary(β, g.N, g.Iu[α], side == 2)
+            xI = ntuple(γ -> reshape(Array(g.xu[α][γ])[I.indices[γ]], ntuple(Returns(1), γ - 1)..., :), D)
+            vals = if dudt                                  # central difference in time, boundary_conditions.jl:351-357
+                h = sqrt(eps(Float64)) * max(abs(t), one(t))
+                (bc.u.(α, xI..., t + h) .- bc.u.(α, xI..., t - h)) ./ 2h
+            else
+                bc.u.(α, xI..., t)
+            end
+            buf = ROCArray(vec(Float64.(vals)))             # memory order of the plane: fastest direction first
+            push!(keep, buf)
+            planes[3 * (2 * (β - 1) + side - 1) + α] = pointer(buf)
+        end
+    end
+    planes, keep
+end
+function apply_bc_u!(u::RA, t, setup; dudt = false, kwargs...)
+    planes, keep = bc_planes(u, t, setup, dudt)
+    GC.@preserve keep check(ccall((:ins_apply_bc_u_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint, Ptr{Ptr{Float64}}, Ptr{Cvoid}),
+                                  handle(setup), pointer(u), dudt, isnothing(planes) ? C_NULL : planes, stream()))
+    isnothing(keep) || AMDGPU.synchronize()                  # the plane buffers may be collected after this call
+    u
+end
+function apply_bc_p!(p::RA, t, setup; kwargs...)
+    check(ccall((:ins_apply_bc_p_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), pointer(p), stream()))
+    p
+end
 
 # ---- operators (operators.jl) -------------------------------------------------------------------------------
-function divergence!(div::ROCArray{Float64}, u::ROCArray{Float64}, setup)
+function divergence!(div::RA, u::RA, setup)
     check(ccall((:ins_divergence_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
                 handle(setup), pointer(u), pointer(div), stream()))
     div
 end
-function momentum!(F::ROCArray{Float64}, u::ROCArray{Float64}, temp::Nothing, t, setup)
-    isnothing(setup.bodyforce) || error("bodyforce is outside the HIP hot path")
-    check(ccall((:ins_momentum_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
-                handle(setup), 1 / setup.Re, pointer(u), pointer(F), stream()))
-    F
+function scalewithvolume!(p::RA, setup)
+    check(ccall((:ins_scalewithvolume_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), pointer(p), stream()))
+    p
 end
-function applypressure!(u::ROCArray{Float64}, p::ROCArray{Float64}, setup)
+function pressuregradient!(G::RA, p::RA, setup)
+    check(ccall((:ins_pressuregradient_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                handle(setup), pointer(p), pointer(G), stream()))
+    G
+end
+function applypressure!(u::RA, p::RA, setup)
     check(ccall((:ins_applypressure_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
                 handle(setup), pointer(u), pointer(p), stream()))
     u
 end
-function apply_bc_u!(u::ROCArray{Float64}, t, setup; dudt = false, kwargs...)
-    # closures bc.u(α, x..., t) are evaluated into plane buffers on the host side (see INTEGRATION.md); constants go through the descriptor
-    check(ccall((:ins_apply_bc_u_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint, Ptr{Ptr{Float64}}, Ptr{Cvoid}),
-                handle(setup), pointer(u), dudt, C_NULL, stream()))
-    u
+function laplacian!(L::RA, p::RA, setup)
+    check(ccall((:ins_laplacian_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                handle(setup), pointer(p), pointer(L), stream()))
+    L
 end
-# scalewithvolume!, pressuregradient!, laplacian!, convection!, diffusion!, convectiondiffusion!, apply_bc_p!
-# follow the same three-line pattern with ins_<name>_f64.
+function convection!(F::RA, u::RA, setup)                    # accumulates into F (operators.jl:378-415)
+    check(ccall((:ins_convection_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                handle(setup), pointer(u), pointer(F), stream()))
+    F
+end
+function diffusion!(F::RA, u::RA, setup; use_viscosity = true)   # accumulates into F (operators.jl:537-573)
+    check(ccall((:ins_diffusion_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                handle(setup), use_viscosity ? 1 / setup.Re : 1.0, pointer(u), pointer(F), stream()))
+    F
+end
+function convectiondiffusion!(F::RA, u::RA, setup)           # accumulates into F (operators.jl:634-690)
+    check(ccall((:ins_convectiondiffusion_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                handle(setup), 1 / setup.Re, pointer(u), pointer(F), stream()))
+    F
+end
+# momentum!(F, u, temp, t, setup): the fused fill + convection-diffusion pass, then body force and gravity (operators.jl:967-976)
+function momentum!(F::RA, u::RA, temp, t, setup)
+    check(ccall((:ins_momentum_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                handle(setup), 1 / setup.Re, pointer(u), pointer(F), stream()))
+    isnothing(setup.bodyforce) || IncompressibleNavierStokes.applybodyforce!(F, u, t, setup)   # broadcast add of a ROCArray
+    isnothing(temp) || gravity!(F, temp, setup)
+    F
+end
+function kinetic_energy!(ke::RA, u::RA, setup; interpolate_first = false)
+    check(ccall((:ins_kinetic_energy_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Cvoid}),
+                handle(setup), pointer(u), pointer(ke), interpolate_first, stream()))
+    ke
+end
+function total_kinetic_energy(u::RA, setup; interpolate_first = false)   # blocking: a scalar is read (operators.jl:1541-1556)
+    e = Ref{Float64}()
+    check(ccall((:ins_total_kinetic_energy_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint, Ref{Float64}, Ptr{Cvoid}),
+                handle(setup), pointer(u), interpolate_first, e, stream()))
+    e[]
+end
+function get_cfl_timestep!(buf, u::RA, setup)                # blocking: a scalar is read (solver.jl:101-125); `buf` is not needed
+    dt = Ref{Float64}()
+    check(ccall((:ins_cfl_timestep_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Ref{Float64}, Ptr{Cvoid}),
+                handle(setup), setup.Re, pointer(u), dt, stream()))
+    dt[]
+end
 
 # ---- pressure solvers (pressure.jl) --------------------------------------------------------------------------
-struct HipPSolver
+mutable struct HipPSolver
     h::Ptr{Cvoid}
     setup::Any
+    function HipPSolver(h, setup)
+        s = new(h, setup)
+        finalizer(x -> ccall((:ins_poisson_destroy, lib), Cint, (Ptr{Cvoid},), x.h), s)
+    end
 end
-function psolver_spectral(setup, ::Val{:hip})
+"Create spectral Poisson solver from setup (pressure.jl:289-351); `default_psolver(setup)` (pressure.jl:85-98) lands here for periodic uniform boxes."
+function psolver_spectral(setup::ROCSetup)
+    IncompressibleNavierStokes.assert_uniform_periodic(setup, "Spectral psolver")
     h = Ref{Ptr{Cvoid}}()
     check(ccall((:ins_poisson_spectral_create, lib), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), handle(setup), h))
     HipPSolver(h[], setup)
 end
-# psolver_direct (pressure.jl:101-154): fast diagonalisation of the separable Laplacian — the generalised eigenpairs of the 1-D factors
-# (T_α v = λ D_α v; T_α = the 1-D factor of laplacian! with its boundary branches, operators.jl:328-350, D_α = Diagonal(Δ[α][Ip[α]]))
-# are computed here once with LinearAlgebra.eigen and handed to the library, which solves with six fp64 GEMMs (rocBLAS).
-# `laplacian_1d(setup, α)` is the 20-line assembly of T_α; see incompressiblenavierstokes.jl_amd/pressure.py:_laplacian_1d.
-function psolver_direct(setup, ::Val{:hip})
+"Conjugate gradients iterative Poisson solver (pressure.jl:209-286), Jacobi preconditioner (`create_laplace_diag`, pressure.jl:188-206)."
+function psolver_cg(setup::ROCSetup; abstol = 0.0, reltol = sqrt(eps(Float64)), maxiter = prod(setup.grid.Np), preconditioner = nothing)
+    isnothing(preconditioner) || error("INSHip.psolver_cg: only the built-in Jacobi preconditioner runs on the device")
+    h = Ref{Ptr{Cvoid}}()
+    check(ccall((:ins_poisson_cg_create, lib), Cint, (Ptr{Cvoid}, Cdouble, Cdouble, Int64, Ref{Ptr{Cvoid}}),
+                handle(setup), abstol, reltol, maxiter, h))
+    HipPSolver(h[], setup)
+end
+
+"""
+The 1-D factor `Tα` of `laplacian!` (operators.jl:328-350) on `Ip[α]`: `(p₊ - p)/Δu[I] - (p - p₋)/Δu[I-1]` with the reference's branch
+order for the first / last volume; ghost pressures of the `else` branch follow `apply_bc_p!` (boundary_conditions.jl:186-215: periodic
+wrap, Neumann copy for Dirichlet / Symmetric, zero for Pressure).  `laplacian_mat(setup)` (matrices.jl:484-492) is
+`Σα Tα ⊗ (⊗β≠α Dβ)` with `Dβ = Diagonal(Δ[β][Ip[β]])`.
+"""
+function laplacian_1d(setup, α)
+    g = setup.grid
+    r = g.Ip.indices[α]
+    n = length(r)
+    Δu = Array(g.Δu[α])
+    bl, br = setup.boundary_conditions[α]
+    T = zeros(n, n)
+    for i = 1:n
+        I = r[i]
+        cr, cl = 1 / Δu[I], 1 / Δu[I-1]
+        isfirst, islast = i == 1, i == n
+        right = left = true          # which one-sided differences survive
+        ghost_r = ghost_l = 0        # column the ghost value aliases; 0 = the ghost pressure is zero (PressureBC)
+        if isfirst && bl isa PressureBC
+        elseif islast && br isa PressureBC
+        elseif isfirst && bl isa DirichletBC
+            left = false
+        elseif islast && br isa DirichletBC
+            right = false
+        else
+            isfirst && (ghost_l = bl isa PeriodicBC ? n : i)
+            islast && (ghost_r = br isa PeriodicBC ? 1 : i)
+        end
+        if right
+            T[i, i] -= cr
+            j = islast ? ghost_r : i + 1
+            j > 0 && (T[i, j] += cr)
+        end
+        if left
+            T[i, i] -= cl
+            j = isfirst ? ghost_l : i - 1
+            j > 0 && (T[i, j] += cl)
+        end
+    end
+    T
+end
+
+"""
+`psolver_direct` for `ROCArray`s (pressure.jl:101-154; same dispatch hook as ext/IncompressibleNavierStokesCUDSSExt.jl:18): fast
+diagonalisation of the separable Laplacian.  The generalised eigenpairs `Tα v = λ Dα v` of the 1-D factors are computed here once and
+handed to the library, which solves with six fp64 GEMMs on rocBLAS (Fourier passes in periodic uniform directions); singular systems
+are solved in the reference's bordered form (pressure.jl:133-140).
+"""
+function psolver_direct(::ROCArray, setup)
     D = setup.grid.dimension()
     V, λ = Matrix{Float64}[], Vector{Float64}[]
     for α = 1:D
-        d = setup.grid.Δ[α][setup.grid.Ip.indices[α]] |> Array
+        d = Array(setup.grid.Δ[α])[setup.grid.Ip.indices[α]]
         T = laplacian_1d(setup, α)
-        E = eigen(Symmetric(Diagonal(d .^ -0.5) * T * Diagonal(d .^ -0.5)))
-        push!(V, Diagonal(d .^ -0.5) * E.vectors)   # column-major, V'DV = I
+        S = Diagonal(d .^ -0.5)
+        E = eigen(Symmetric(S * T * S))
+        push!(V, S * E.vectors)      # column-major, V'DV = I
         push!(λ, E.values)
     end
+    Vp = [pointer(V[min(α, D)]) for α = 1:3]
+    λp = [pointer(λ[min(α, D)]) for α = 1:3]
     h = Ref{Ptr{Cvoid}}()
     GC.@preserve V λ check(ccall((:ins_poisson_fdm_create, lib), Cint, (Ptr{Cvoid}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ref{Ptr{Cvoid}}),
-                                 handle(setup), pointer.(V), pointer.(λ), h))
+                                 handle(setup), Vp, λp, h))
     HipPSolver(h[], setup)
 end
-(s::HipPSolver)(p::ROCArray{Float64}) =
+(s::HipPSolver)(p::RA) =
     (check(ccall((:ins_poisson_solve_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Cvoid}), s.h, pointer(p), stream())); p)
-function project!(u::ROCArray{Float64}, setup; psolver::HipPSolver, p::ROCArray{Float64})
+poisson!(psolver::HipPSolver, p::RA) = psolver(p)
+function project!(u::RA, setup; psolver::HipPSolver, p::RA)
     check(ccall((:ins_project_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
                 handle(setup), psolver.h, pointer(u), pointer(p), stream()))
     u
@@ -132,7 +301,6 @@ end
 
 # ---- step-adjacent operators (SURVEY §8f rows 2 and 4): with these methods the reference's own host-driven `timestep!`
 # (closure model / temperature / body force present) runs entirely on libinship's kernels --------------------------------
-const RA = ROCArray{Float64}
 vorticity!(ω::RA, u::RA, setup) =
     (check(ccall((:ins_vorticity_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), pointer(u), pointer(ω), stream())); ω)
 interpolate_u_p!(up::RA, u::RA, setup) =
@@ -182,15 +350,8 @@ function apply_bc_temp!(temp::RA, t, setup; kwargs...)
     isempty(keep) || AMDGPU.synchronize()
     temp
 end
-# momentum!(F, u, temp, t, setup): the fused fill + convection-diffusion pass, then body force and gravity (operators.jl:967-976)
-function momentum!(F::RA, u::RA, temp, t, setup)
-    check(ccall((:ins_momentum_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), 1 / setup.Re, pointer(u), pointer(F), stream()))
-    isnothing(setup.bodyforce) || IncompressibleNavierStokes.applybodyforce!(F, u, t, setup)   # broadcast add of a ROCArray
-    isnothing(temp) || gravity!(F, temp, setup)
-    F
-end
 # smagorinsky_closure(setup): σ as D(D+1)/2 scalar fields [xx, yy, (zz), xy, (xz, yz)]
-function smagorinsky_closure(setup, ::Val{:hip})
+function smagorinsky_closure(setup::ROCSetup)
     D = setup.grid.dimension()
     ns = D * (D + 1) ÷ 2
     σ = similar(setup.grid.x[1], Float64, (setup.grid.N..., ns)); fill!(σ, 0)
@@ -218,38 +379,76 @@ spectrum!(ehat::RA, h::Ptr{Cvoid}, u::RA) =
     (check(ccall((:ins_spectrum_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), h, pointer(u), pointer(ehat), stream())); ehat)
 
 # ---- explicit RK (step_explicit_runge_kutta.jl) -----------------------------------------------------------------
-struct HipRKCache
+# `solve_unsteady` builds its cache with `ode_method_cache(method, setup)` (solver.jl:33) before it knows the pressure solver, so the native
+# cache is created at the first `timestep!` from the stepper's psolver; `ref` is the reference's own cache (time_stepper_caches.jl:34-49)
+# for the host-driven stage loop (closure model / temperature / unsteady body force), also created on demand.
+mutable struct HipRKCache
     h::Ptr{Cvoid}
+    psolver::Any
+    ref::Any
 end
-function ode_method_cache(method::ExplicitRungeKuttaMethod, setup, psolver::HipPSolver)
+ode_method_cache(method::ExplicitRungeKuttaMethod, setup::ROCSetup) = HipRKCache(C_NULL, nothing, nothing)
+function native!(cache::HipRKCache, method, setup, psolver)
+    cache.h != C_NULL && cache.psolver === psolver && return cache.h
+    cache.h == C_NULL || ccall((:ins_rk_destroy, lib), Cint, (Ptr{Cvoid},), cache.h)
     ns = length(method.b)
-    A = collect(transpose(method.A))        # row-major for C; method.A is already the SHIFTED tableau (methods.jl:231-236)
+    A = collect(transpose(Float64.(method.A)))   # row-major for C; method.A is already the SHIFTED tableau (methods.jl:231-236)
+    c = Float64.(method.c)
     h = Ref{Ptr{Cvoid}}()
     check(ccall((:ins_rk_create, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Ref{Ptr{Cvoid}}),
-                handle(setup), psolver.h, ns, A, method.c, h))
-    HipRKCache(h[])
+                handle(setup), psolver.h, ns, A, c, h))
+    cache.psolver = psolver
+    cache.h = h[]
 end
-function timestep!(method::ExplicitRungeKuttaMethod, stepper, Δt; θ = nothing, cache::HipRKCache)
+# A stepper (create_stepper: (; setup, psolver, u, temp, t, n), step_explicit_runge_kutta.jl:1-2) whose pressure solver is the library's
+const HipStepper = NamedTuple{N,<:Tuple{Any,HipPSolver,Vararg{Any}}} where {N}
+function timestep!(method::ExplicitRungeKuttaMethod, stepper::HipStepper, Δt; θ = nothing, cache::HipRKCache)
     (; setup, psolver, u, temp, t, n) = stepper
-    # The fused native step is valid only without closure model / temperature / unsteady body force (SURVEY.md §8b caveat);
-    # otherwise fall back to the operator-level methods above so user callbacks can run between kernels.
-    # A steady body force rides inside the native stage kernels (ins_rk_set_bodyforce: one more term of the stage combination).
-    (isnothing(setup.closure_model) && isnothing(temp) && (isnothing(setup.bodyforce) || setup.issteadybodyforce)) ||
-        return invoke(timestep!, Tuple{ExplicitRungeKuttaMethod,Any,Any}, method, stepper, Δt; θ, cache)
-    check(ccall((:ins_rk_set_bodyforce, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), cache.h,
+    # The fused native step is valid only without closure model / temperature / unsteady body force and with time-independent boundary
+    # data (SURVEY.md §8b caveat); otherwise the reference's own stage loop runs, on the operator-level methods above, so user callbacks
+    # can run between kernels.  A steady body force rides inside the native stage kernels (ins_rk_set_bodyforce).
+    native = isnothing(setup.closure_model) && isnothing(temp) && (isnothing(setup.bodyforce) || setup.issteadybodyforce) &&
+             !any(isclosure, Iterators.flatten(setup.boundary_conditions))
+    if !native
+        isnothing(cache.ref) && (cache.ref = invoke(ode_method_cache, Tuple{ExplicitRungeKuttaMethod,Any}, method, setup))
+        return invoke(timestep!, Tuple{ExplicitRungeKuttaMethod,Any,Any}, method, stepper, Δt; θ, cache = cache.ref)
+    end
+    h = native!(cache, method, setup, psolver)
+    check(ccall((:ins_rk_set_bodyforce, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), h,
                 isnothing(setup.bodyforce) ? Ptr{Float64}(C_NULL) : pointer(setup.bodyforce)))
     check(ccall((:ins_rk_step_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Cdouble, Cdouble, Ptr{Ptr{Float64}}, Ptr{Cvoid}),
-                cache.h, 1 / setup.Re, pointer(u), t, Δt, C_NULL, stream()))
+                h, 1 / setup.Re, pointer(u), t, Δt, C_NULL, stream()))
     IncompressibleNavierStokes.create_stepper(method; setup, psolver, u, temp, t = t + method.c[end] * Δt, n = n + 1)
 end
 
 # The fixed-Δt loop of solve_unsteady (solver.jl:74-83) when no processor looks at intermediate states: one native call; on the fused
 # periodic path every step but the last leaves its final correction to the next step's first stage kernel.
-function timesteps!(method::ExplicitRungeKuttaMethod, stepper, Δt, nstep; cache::HipRKCache)
+function timesteps!(method::ExplicitRungeKuttaMethod, stepper::HipStepper, Δt, nstep; cache::HipRKCache)
     (; setup, psolver, u, temp, t, n) = stepper
+    h = native!(cache, method, setup, psolver)
     check(ccall((:ins_rk_steps_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Cdouble, Cdouble, Cint, Ptr{Cvoid}),
-                cache.h, 1 / setup.Re, pointer(u), t, Δt, nstep, stream()))
+                h, 1 / setup.Re, pointer(u), t, Δt, nstep, stream()))
     IncompressibleNavierStokes.create_stepper(method; setup, psolver, u, temp, t = t + nstep * method.c[end] * Δt, n = n + nstep)
 end
+
+# ---- run-time switches and multi-GPU communicators (include/ins_hip.h) -------------------------------------------------
+set_option(name::AbstractString, value::Integer) = check(ccall((:ins_set_option, lib), Cint, (Cstring, Int64), name, value))
+"One RCCL communicator per Julia process / GPU: rank 0 calls `comm_unique_id()`, ships the 128 bytes (MPI.jl, Distributed.jl, a file), every rank calls `comm_create`."
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:ins_comm_unique_id, lib), Cint, (Ptr{Cvoid},), id))
+    id
+end
+function comm_create(nranks, rank, id::Vector{UInt8})
+    h = Ref{Ptr{Cvoid}}()
+    check(ccall((:ins_comm_create, lib), Cint, (Cint, Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), nranks, rank, id, h))
+    h[]
+end
+"z ghost planes of the local slab field `u` (slab setup: z sides HaloBC) exchanged with the neighbouring ranks, on the current stream."
+halo_exchange!(comm::Ptr{Cvoid}, u::RA, slab_setup; comps = 0b111, down_only = false) =
+    (check(ccall((:ins_halo_exchange_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Cint, Cint, Ptr{Cvoid}),
+                 comm, handle(slab_setup), pointer(u), comps, down_only, stream())); u)
+allreduce!(comm::Ptr{Cvoid}, buf::RA, op::Integer) =
+    (check(ccall((:ins_comm_allreduce_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Cint, Ptr{Cvoid}), comm, pointer(buf), length(buf), op, stream())); buf)
 
 end # module
