@@ -143,6 +143,11 @@ int ins_poisson_cg_create(const ins_grid_t* grid, double abstol, double reltol, 
  * This is what makes a non-solvable right-hand side (e.g. the lid of examples/LidDrivenCavity3D.jl:29, whose
  * normal component is non-zero) behave as it does under the reference's default (direct) solver. */
 int ins_poisson_cg_bordered(ins_poisson_t* ps, int enable);
+/* z-slab CG: with a communicator set, the solver (created on the rank's slab grid, z sides INS_BC_HALO) sums its two dots and its norm over
+ * the ranks (one scalar all-reduce each, on the stream) and exchanges the ghost planes of the search direction before every laplacian!.
+ * NULL restores the single-domain solver.  The scalars of the iteration (pressure.jl:244-280) live on the device either way: the host reads the
+ * stopping flag once per batch of iterations (option INS_CG_BATCH, default 32) instead of three scalars per iteration. */
+int ins_poisson_cg_set_comm(ins_poisson_t* ps, ins_comm_t* comm);
 /* psolver_direct(setup)                    pressure.jl:101-154 (replaces the SuiteSparse / cuDSS factorisation of
  * `laplacian_mat`, matrices.jl:484-492).  Fast diagonalisation of the separable operator L = Σα Tα ⊗ (⊗β≠α Dβ):
  * V[α] is the Np[α] x Np[α] column-major matrix of Dα-orthonormal generalised eigenvectors (Tα Vα = Dα Vα Λα),
@@ -351,6 +356,8 @@ int ins_comm_sendrecv_f64(ins_comm_t* comm, int nsend, const double* const* send
  * (boundary_conditions.jl:276-288) across ranks.  comp_mask bit c selects component c; down_only: only plane nzl -> next rank's plane 0
  * (all `divergence!` needs, operators.jl:122). */
 int ins_halo_exchange_f64(ins_comm_t* comm, const ins_grid_t* slab_grid, double* u, int comp_mask, int down_only, void* stream);
+/* The same for a padded local SCALAR field (periodic z part of apply_bc_p!, boundary_conditions.jl:306-318). */
+int ins_halo_exchange_scalar_f64(ins_comm_t* comm, const ins_grid_t* slab_grid, double* p, void* stream);
 /* Ghost planes of the extended pressure buffer [1 below | nzl local | 2 above] read by the correcting stage kernel (ins_stage_momentum_corr_f64). */
 int ins_halo_exchange_p_f64(ins_comm_t* comm, double* p_ext, int64_t plane_elems, int nzl, void* stream);
 /* Interface values of the distributed tridiagonal z solve (ins_slab_ztri_forward -> this -> ins_slab_ztri_finish): direct != 0 sends to every

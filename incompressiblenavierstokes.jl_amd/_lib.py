@@ -84,6 +84,7 @@ SIGNATURES = {
     "ins_poisson_spectral_create": (C.c_int, [vp, C.POINTER(vp)]),
     "ins_poisson_cg_create": (C.c_int, [vp, C.c_double, C.c_double, C.c_int64, C.POINTER(vp)]),
     "ins_poisson_cg_bordered": (C.c_int, [vp, C.c_int]),
+    "ins_poisson_cg_set_comm": (C.c_int, [vp, vp]),
     "ins_poisson_fdm_create": (C.c_int, [vp, C.POINTER(c_double_p), C.POINTER(c_double_p), C.POINTER(vp)]),
     "ins_poisson_destroy": (C.c_int, [vp]),
     "ins_poisson_solve_f64": (C.c_int, [vp, vp, vp]),
@@ -136,6 +137,7 @@ SIGNATURES = {
     "ins_comm_sendrecv_f64": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int, C.POINTER(vp),
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int32), vp]),
     "ins_halo_exchange_f64": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
+    "ins_halo_exchange_scalar_f64": (C.c_int, [vp, vp, vp, vp]),
     "ins_halo_exchange_p_f64": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),
     "ins_ztri_allgather_f64": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int, vp]),
     "ins_comm_allreduce_f64": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp]),

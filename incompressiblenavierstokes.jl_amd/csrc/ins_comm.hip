@@ -237,6 +237,30 @@ extern "C" int ins_comm_allreduce_f64(ins_comm_t* c, double* buf, int64_t count,
   return INS_OK;
 }
 
+int ins_comm_allreduce_internal(ins_comm* c, double* buf, long long count, int op, hipStream_t s) {
+  return ins_comm_allreduce_f64(c, buf, count, op, s);
+}
+
+// z ghost planes of a padded local SCALAR field (pressure-like: the search direction of the slab CG): plane nzl -> next rank's plane 0,
+// plane 1 -> previous rank's plane nzl + 1 — the periodic z part of apply_bc_p! (boundary_conditions.jl:306-318) across ranks.
+extern "C" int ins_halo_exchange_scalar_f64(ins_comm_t* c, const ins_grid_t* G, double* p, void* stream) {
+  INS_REQUIRE(c && G && p, "null argument");
+  const GridDev& g = G->g;
+  INS_REQUIRE(g.D == 3 && g.bc[2][0] == INS_BC_HALO && g.bc[2][1] == INS_BC_HALO, "halo exchange needs a slab grid (INS_BC_HALO in z)");
+  const size_t plane = (size_t)g.N[0] * g.N[1];
+  const int nzl = g.N[2] - 2;
+  const int prev = (c->rank + c->nranks - 1) % c->nranks, next = (c->rank + 1) % c->nranks;
+  hipStream_t s = as_stream(stream);
+  INS_NCCL_TRY(g_rccl.GroupStart());
+  INS_NCCL_TRY(g_rccl.Send(p + plane * nzl, plane, ncclDouble, next, c->comm, s));
+  INS_NCCL_TRY(g_rccl.Send(p + plane, plane, ncclDouble, prev, c->comm, s));
+  INS_NCCL_TRY(g_rccl.Recv(p, plane, ncclDouble, prev, c->comm, s));
+  INS_NCCL_TRY(g_rccl.Recv(p + plane * (nzl + 1), plane, ncclDouble, next, c->comm, s));
+  INS_NCCL_TRY(g_rccl.GroupEnd());
+  return INS_OK;
+}
+int ins_comm_halo_scalar_internal(ins_comm* c, const ins_grid* G, double* p, hipStream_t s) { return ins_halo_exchange_scalar_f64(c, G, p, s); }
+
 // Transpose exchange of the z-FFT route: block r of `send` (count elements) -> rank r, whose block `rank` of `recv` receives it.
 extern "C" int ins_comm_alltoall_f64(ins_comm_t* c, const double* send, double* recv, int64_t count, void* stream) {
   INS_REQUIRE(c && send && recv && count >= 0, "bad argument");

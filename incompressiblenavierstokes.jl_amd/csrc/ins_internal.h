@@ -91,6 +91,8 @@ void ins_set_error(const char* fmt, ...);
   X(INS_ZSOLVE_WGS)              \
   X(INS_DISABLE_ZSOLVE)          \
   X(INS_ZTRI_SKEL)               \
+  X(INS_CG_HOSTSYNC)             \
+  X(INS_CG_BATCH)                \
   X(INS_FFT_ALLOW_RESET)
 #define INS_OPT_ENUM(id) OPT_##id,
 enum InsOptId { INS_OPT_LIST(INS_OPT_ENUM) INS_OPT_COUNT };
@@ -185,6 +187,9 @@ struct ins_poisson {
   long long ndof = 0;
   long long last_iter = 0;
   double last_res = 0;
+  double* cg_scal = nullptr;  // device scalars + block partials of the device-resident iteration
+  double* cg_host = nullptr;  // pinned mirror of the scalars
+  struct ins_comm* comm = nullptr;  // z-slab CG: scalar all-reduces + ghost planes of q (ins_poisson_cg_set_comm)
   // fdm (psolver_direct)
   ins_fdm* fdm = nullptr;
 };
@@ -268,6 +273,10 @@ int ins_k_fdm_z(double* data, int n0, int n1, int nz, const double* lx, const do
                 double h, double tol, int singular, const double* meanf, double* partial, const double* tw, int* nblk, hipStream_t s);
 int ins_k_zsolve(double* data, int nz, long long nl, const double* ax, int kxn, const double* ay, const double* az, const double* tw,
                  double inv_n, bool zero_mean, hipStream_t s, int kxs = 0);
+
+// communication used inside the library (ins_comm.hip): op 0 sum, 1 max, 2 min; scalar-field z ghost planes on a slab grid
+int ins_comm_allreduce_internal(struct ins_comm* c, double* buf, long long count, int op, hipStream_t s);
+int ins_comm_halo_scalar_internal(struct ins_comm* c, const ins_grid* G, double* p, hipStream_t s);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }

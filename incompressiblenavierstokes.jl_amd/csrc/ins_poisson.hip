@@ -386,6 +386,140 @@ __global__ __launch_bounds__(256) void k_cg_update(GridDev g, double alpha, doub
   store_partial(s, partial);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same iteration with every scalar on the device (pressure.jl:244-280 reads three scalars per iteration on the host: two dots
+// and a norm).  Flat grid-stride kernels leave NPART block partials; a one-block kernel folds them and derives α / β / the residual /
+// the stopping flag in device memory (slot layout below); the vector kernels read what they need from there and do nothing once
+// the flag is set.  The host looks at the flag once per batch of iterations, so a solve costs iterations/batch synchronisations
+// instead of 3 x iterations, and the stopping rule (and hence the iterate) is exactly the reference's.  With a communicator
+// (z-slabs) the folded sums are all-reduced across ranks between the two steps and q's ghost planes travel before laplacian!.
+// ------------------------------------------------------------------------------------------------
+enum { CG_RHO = 0, CG_RHO_PREV, CG_QL, CG_SS, CG_TOL, CG_DONE, CG_ITERS, CG_ALPHA, CG_BETA, CG_RES, CG_SUM, CG_NSCAL = 16 };
+constexpr int CG_NPART = 1024;
+
+__device__ __forceinline__ bool flat_cell(const GridDev& g, long long t, bool& inp) {
+  const int i0 = (int)(t % g.N[0]);
+  const long long r = t / g.N[0];
+  const int i1 = (int)(r % g.N[1]), i2 = (int)(r / g.N[1]);
+  inp = i0 >= g.ip_lo[0] && i0 < g.ip_hi[0] && i1 >= g.ip_lo[1] && i1 < g.ip_hi[1] && (g.D == 2 || (i2 >= g.ip_lo[2] && i2 < g.ip_hi[2]));
+  return true;
+}
+__device__ __forceinline__ void flat_partial(double v, double* partial) {
+  __shared__ double lds[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+// sc[CG_SUM] = Σ partial (one block)
+__global__ __launch_bounds__(1024) void k_cgd_fold(const double* __restrict__ partial, int n, double* __restrict__ sc) {
+  __shared__ double lds[16];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) v += partial[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += lds[w];
+    sc[CG_SUM] = t;
+  }
+}
+// stage 0: after init (Σ r²); 1: after the preconditioner (ρ, β); 2: after q·L (α); 3: after the update (Σ r², iteration count, stopping flag)
+__global__ void k_cgd_scalars(double* __restrict__ sc, int stage, double reltol, double abstol, double maxiter) {
+  const double v = sc[CG_SUM];
+  if (stage == 0) {
+    const double res = sqrt(v);
+    sc[CG_SS] = v;
+    sc[CG_RES] = res;
+    sc[CG_TOL] = fmax(reltol * res, abstol);
+    sc[CG_RHO_PREV] = 1.0;
+    sc[CG_ITERS] = 0.0;
+    sc[CG_DONE] = (0.0 < maxiter && res > sc[CG_TOL]) ? 0.0 : 1.0;
+    return;
+  }
+  if (sc[CG_DONE] != 0.0) return;
+  if (stage == 1) {
+    sc[CG_RHO] = v;
+    sc[CG_BETA] = v / sc[CG_RHO_PREV];
+  } else if (stage == 2) {
+    sc[CG_QL] = v;
+    sc[CG_ALPHA] = sc[CG_RHO] / v;
+  } else {
+    const double res = sqrt(v);
+    sc[CG_SS] = v;
+    sc[CG_RES] = res;
+    sc[CG_RHO_PREV] = sc[CG_RHO];
+    const double it = sc[CG_ITERS] + 1.0;
+    sc[CG_ITERS] = it;
+    sc[CG_DONE] = (it < maxiter && res > sc[CG_TOL]) ? 0.0 : 1.0;
+  }
+}
+__global__ __launch_bounds__(256) void k_cgd_init(GridDev g, long long n, double* __restrict__ p, double* __restrict__ r, double* __restrict__ q,
+                                                  double* __restrict__ L, double* __restrict__ partial) {
+  double s = 0.0;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+    bool inp;
+    flat_cell(g, t, inp);
+    const double v = p[t];
+    r[t] = v;
+    p[t] = 0.0;
+    q[t] = 0.0;
+    L[t] = 0.0;
+    if (inp) s += v * v;
+  }
+  flat_partial(s, partial);
+}
+__global__ __launch_bounds__(256) void k_cgd_precond(GridDev g, long long n, const double* __restrict__ sc, const double* __restrict__ r,
+                                                     const double* __restrict__ dinv, double* __restrict__ L, double* __restrict__ partial) {
+  if (sc[CG_DONE] != 0.0) return;
+  double s = 0.0;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+    bool inp;
+    flat_cell(g, t, inp);
+    if (inp) {
+      const double rv = r[t], z = -rv * dinv[t];
+      L[t] = z;
+      s += z * rv;
+    }
+  }
+  flat_partial(s, partial);
+}
+__global__ __launch_bounds__(256) void k_cgd_dir(long long n, const double* __restrict__ sc, const double* __restrict__ L, double* __restrict__ q) {
+  if (sc[CG_DONE] != 0.0) return;
+  const double beta = sc[CG_BETA];
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) q[t] = L[t] + beta * q[t];
+}
+__global__ __launch_bounds__(256) void k_cgd_dot(GridDev g, long long n, const double* __restrict__ sc, const double* __restrict__ a,
+                                                 const double* __restrict__ b, double* __restrict__ partial) {
+  if (sc[CG_DONE] != 0.0) return;
+  double s = 0.0;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+    bool inp;
+    flat_cell(g, t, inp);
+    if (inp) s += a[t] * b[t];
+  }
+  flat_partial(s, partial);
+}
+__global__ __launch_bounds__(256) void k_cgd_update(GridDev g, long long n, const double* __restrict__ sc, double* __restrict__ p, double* __restrict__ r,
+                                                    const double* __restrict__ q, const double* __restrict__ L, double* __restrict__ partial) {
+  if (sc[CG_DONE] != 0.0) return;
+  const double alpha = sc[CG_ALPHA];
+  double s = 0.0;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+    bool inp;
+    flat_cell(g, t, inp);
+    p[t] += alpha * q[t];
+    const double rv = r[t] - alpha * L[t];
+    r[t] = rv;
+    if (inp) s += rv * rv;
+  }
+  flat_partial(s, partial);
+}
+
 struct BoxLaunch {
   dim3 grid, block;
   int nblk;
@@ -558,8 +692,8 @@ static int spectral_solve(ins_poisson* ps, double* p, hipStream_t s) {
 extern "C" int ins_poisson_cg_create(const ins_grid_t* G, double abstol, double reltol, int64_t maxiter, ins_poisson_t** out) {
   INS_REQUIRE(G && out, "null argument");
   const GridDev& g = G->g;
-  for (int a = 0; a < g.D; ++a)
-    INS_REQUIRE(g.bc[a][0] != INS_BC_HALO && g.bc[a][1] != INS_BC_HALO, "psolver_cg on a slab grid is not implemented");
+  for (int a = 0; a < 2 && a < g.D; ++a)
+    INS_REQUIRE(g.bc[a][0] != INS_BC_HALO && g.bc[a][1] != INS_BC_HALO, "slabs are cut along z only");
   ins_poisson* ps = new ins_poisson();
   ps->kind = POISSON_CG;
   ps->grid = G;
@@ -603,7 +737,79 @@ static int finish_sum(const ins_grid* G, double* partial_dev, int nblk, hipStrea
   return INS_OK;
 }
 
+
+// Device-resident scalars (default); INS_CG_HOSTSYNC=1 keeps the reference's three host reads per iteration (cg_solve_hostsync below).
+static int cg_solve_device(ins_poisson* ps, double* p, hipStream_t s) {
+  const ins_grid* G = ps->grid;
+  const GridDev& g = G->g;
+  const long long n = G->ncell;
+  if (!ps->cg_scal) {
+    INS_HIP_TRY(hipMalloc(&ps->cg_scal, (CG_NSCAL + CG_NPART) * sizeof(double)));
+    INS_HIP_TRY(hipHostMalloc(&ps->cg_host, CG_NSCAL * sizeof(double)));
+  }
+  double* sc = ps->cg_scal;
+  double* partial = sc + CG_NSCAL;
+  const unsigned nb = (unsigned)std::min<long long>((n + 255) / 256, CG_NPART);
+  int rc;
+  const double maxit = (double)ps->maxiter;
+  auto fold = [&](int stage) -> int {
+    hipLaunchKernelGGL(k_cgd_fold, dim3(1), dim3(1024), 0, s, partial, (int)nb, sc);
+    if (ps->comm) {
+      int r2 = ins_comm_allreduce_internal(ps->comm, sc + CG_SUM, 1, 0, s);
+      if (r2) return r2;
+    }
+    hipLaunchKernelGGL(k_cgd_scalars, dim3(1), dim3(1), 0, s, sc, stage, ps->reltol, ps->abstol, maxit);
+    INS_LAUNCH_CHECK();
+    return INS_OK;
+  };
+  const bool bordered = ps->bordered && ps->singular;
+  if (bordered) {
+    INS_REQUIRE(!ps->comm, "bordered CG on slabs is not implemented");
+    double sum;
+    if ((rc = ins_k_reduce(G, 3, p, nullptr, g.ip_lo, g.ip_hi, &sum, s))) return rc;
+    if (g.D == 2)
+      hipLaunchKernelGGL(k_shift<2>, full_box(g).grid, full_box(g).block, 0, s, g, p, sum / (double)ps->ndof);
+    else
+      hipLaunchKernelGGL(k_shift<3>, full_box(g).grid, full_box(g).block, 0, s, g, p, sum / (double)ps->ndof);
+  }
+  hipLaunchKernelGGL(k_cgd_init, dim3(nb), dim3(256), 0, s, g, n, p, ps->r, ps->q, ps->L, partial);
+  if ((rc = fold(0))) return rc;
+  const long long batch = ins_opt(OPT_INS_CG_BATCH) > 0 ? ins_opt(OPT_INS_CG_BATCH) : 32;
+  long long issued = 0;
+  while (true) {
+    INS_HIP_TRY(hipMemcpyAsync(ps->cg_host, sc, CG_NSCAL * sizeof(double), hipMemcpyDeviceToHost, s));
+    INS_HIP_TRY(hipStreamSynchronize(s));
+    if (ps->cg_host[CG_DONE] != 0.0 || issued >= ps->maxiter) break;
+    for (long long b = 0; b < batch && issued < ps->maxiter; ++b, ++issued) {
+      hipLaunchKernelGGL(k_cgd_precond, dim3(nb), dim3(256), 0, s, g, n, sc, ps->r, ps->dinv, ps->L, partial);
+      if ((rc = fold(1))) return rc;
+      hipLaunchKernelGGL(k_cgd_dir, dim3(nb), dim3(256), 0, s, n, sc, ps->L, ps->q);
+      if ((rc = ins_k_apply_bc_p(G, ps->q, s))) return rc;
+      if (ps->comm && (rc = ins_comm_halo_scalar_internal(ps->comm, G, ps->q, s))) return rc;
+      if ((rc = ins_k_laplacian(G, ps->q, ps->L, s))) return rc;
+      hipLaunchKernelGGL(k_cgd_dot, dim3(nb), dim3(256), 0, s, g, n, sc, ps->q, ps->L, partial);
+      if ((rc = fold(2))) return rc;
+      hipLaunchKernelGGL(k_cgd_update, dim3(nb), dim3(256), 0, s, g, n, sc, p, ps->r, ps->q, ps->L, partial);
+      if ((rc = fold(3))) return rc;
+    }
+  }
+  if (bordered) {
+    double sum;
+    if ((rc = ins_k_reduce(G, 3, p, nullptr, g.ip_lo, g.ip_hi, &sum, s))) return rc;
+    if (g.D == 2)
+      hipLaunchKernelGGL(k_shift<2>, full_box(g).grid, full_box(g).block, 0, s, g, p, sum / (double)ps->ndof);
+    else
+      hipLaunchKernelGGL(k_shift<3>, full_box(g).grid, full_box(g).block, 0, s, g, p, sum / (double)ps->ndof);
+    INS_LAUNCH_CHECK();
+  }
+  ps->last_iter = (long long)ps->cg_host[CG_ITERS];
+  ps->last_res = ps->cg_host[CG_RES];
+  return INS_OK;
+}
+
 static int cg_solve(ins_poisson* ps, double* p, hipStream_t s) {
+  if (!ins_opt(OPT_INS_CG_HOSTSYNC)) return cg_solve_device(ps, p, s);
+  INS_REQUIRE(!ps->comm, "the host-synchronising CG has no slab form");
   const ins_grid* G = ps->grid;
   const GridDev& g = G->g;
   BoxLaunch l = full_box(g);
@@ -666,6 +872,16 @@ static int cg_solve(ins_poisson* ps, double* p, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// z-slab decomposition: the solver's dots and norm are summed over the ranks of `comm` (one scalar all-reduce each) and the ghost planes of the
+// search direction travel before every laplacian! ("Config 5 (CG): halo + 3 scalar all-reduces per iteration").
+// maxiter and the Jacobi preconditioner are local; the convergence test uses the global residual, so all ranks stop together.
+extern "C" int ins_poisson_cg_set_comm(ins_poisson_t* ps, ins_comm_t* comm) {
+  INS_REQUIRE(ps, "null argument");
+  INS_REQUIRE(ps->kind == POISSON_CG, "ins_poisson_cg_set_comm applies to the CG solver only");
+  ps->comm = comm;
+  return INS_OK;
+}
+
 extern "C" int ins_poisson_cg_bordered(ins_poisson_t* ps, int enable) {
   INS_REQUIRE(ps, "null argument");
   INS_REQUIRE(ps->kind == POISSON_CG, "bordered mode applies to the CG solver only");
@@ -688,6 +904,8 @@ extern "C" int ins_poisson_destroy(ins_poisson_t* ps) {
   for (int a = 0; a < 3; ++a)
     if (ps->ahat[a]) (void)hipFree(ps->ahat[a]);
   if (ps->r) (void)hipFree(ps->r);
+  if (ps->cg_scal) (void)hipFree(ps->cg_scal);
+  if (ps->cg_host) (void)hipHostFree(ps->cg_host);
   if (ps->L) (void)hipFree(ps->L);
   if (ps->q) (void)hipFree(ps->q);
   if (ps->dinv) (void)hipFree(ps->dinv);

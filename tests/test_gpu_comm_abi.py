@@ -138,3 +138,38 @@ def test_slab_stepper_through_the_comm_abi(ins, n):
         assert np.array_equal(outs[0], outs[1]), f"{zsolve}: RCCL through the C ABI differs from local copies"
         err = float(np.sqrt(np.sum((outs[0] - uref) ** 2)) / np.sqrt(np.sum(uref**2)))
         assert err < 1e-11, (zsolve, err)
+
+
+def test_slab_cg_one_rank_equals_single_domain_cg(ins, oracle):
+    """psolver_cg on a slab grid (z sides HaloBC) with a communicator: the dots / norm go through ins_comm all-reduces and the ghost planes
+    of the search direction through ins_halo_exchange_scalar_f64 (RCCL, one rank = the whole periodic z range).  Same iteration count and
+    the same solution as the single-domain CG on the periodic box; and against the oracle's CG."""
+    from ins_amd import _lib
+    from tests import fixtures as fx
+
+    o = oracle
+    n = (16, 12, 10)
+    x = tuple(np.linspace(0.0, 1.0, ni + 1) for ni in n)
+    so = o.make_setup(x, Re=100.0)
+    sp = ins.Setup(x=x, Re=100.0)
+    g = so.grid
+    u_h = o.apply_bc_u(fx.randn_field(g.N + (3,), 8), 0.0, so)
+    f = o.scalewithvolume(o.divergence(u_h, so), so)
+    ip = tuple(slice(lo, hi) for lo, hi in g.Ip)
+    single = ins.psolver_cg(sp)
+    want = ins.to_numpy(ins.poisson(single, ins.from_numpy(sp, f)))
+    it0, _ = single.last_info()
+    lay = ins.SlabLayout(n, 1, 0)
+    K = ins.HipSlabKernels(lay, Re=100.0)
+    comm = ins.AbiSlabComm(1, 0, ins.AbiSlabComm.unique_id(), loopback=True)
+    slab = ins.psolver_cg(K.setup)
+    _lib.call("ins_poisson_cg_set_comm", slab.handle, comm._h)
+    got = ins.to_numpy(ins.poisson(slab, ins.from_numpy(K.setup, f)))
+    it1, _ = slab.last_info()
+    assert it1 == it0
+    err = float(np.sqrt(np.sum((got[ip] - want[ip]) ** 2)) / np.sqrt(np.sum(want[ip] ** 2)))
+    assert err < 1e-12
+    info = {}
+    ref = o.poisson(o.psolver_cg(so, info=info), f)
+    assert abs(it1 - info["iterations"]) <= 2
+    assert float(np.sqrt(np.sum((got[ip] - ref[ip]) ** 2)) / np.sqrt(np.sum(ref[ip] ** 2))) < 1e-6

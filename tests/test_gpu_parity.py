@@ -248,6 +248,20 @@ def test_cg_matches_oracle_cg(ins, oracle, geom):
     it, res = solver.last_info()
     assert abs(it - info["iterations"]) <= 2
     assert rell2(got[ip], want[ip]) < 1e-6  # both stop at reltol sqrt(eps); they agree to that level
+    # device-resident scalars (default; the host reads the stopping flag once per batch) against the reference's three host reads per
+    # iteration (INS_CG_HOSTSYNC), and batch sizes that do / do not divide the iteration count: same iteration count, same iterate
+    from ins_amd import _lib
+
+    for opts in ({"INS_CG_HOSTSYNC": 1}, {"INS_CG_BATCH": 1}, {"INS_CG_BATCH": 7}):
+        with _lib.options(**opts):
+            s2 = ins.psolver_cg(sp)
+            got2 = ins.to_numpy(ins.poisson(s2, ins.from_numpy(sp, f)))
+            it2, res2 = s2.last_info()
+        assert it2 == it, opts
+        if "INS_CG_HOSTSYNC" in opts:  # other summation order of the dots (3-D block partials): rounding, amplified by cond(L) on stretched grids
+            assert rell2(got2[ip], got[ip]) < 1e-8, opts
+        else:  # same kernels, only the host's look at the flag moves: bitwise the same iterate
+            assert np.array_equal(got2, got), opts
 
 
 def _pressure_left(o, D=2):  # PressureBC on LEFT sides (two ghost layers there) next to Dirichlet / Symmetric / Pressure
