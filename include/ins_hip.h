@@ -47,6 +47,8 @@ extern "C" {
 typedef struct ins_grid ins_grid_t;       /* device copy of `setup.grid` metrics   (grid.jl:100-276)   */
 typedef struct ins_poisson ins_poisson_t; /* a `psolver` closure                   (pressure.jl:85-351) */
 typedef struct ins_rk ins_rk_t;           /* `ode_method_cache` + stepper state    (time_stepper_caches.jl:34-49) */
+typedef struct ins_poisson32 ins_poisson32_t; /* `psolver_spectral` closure for T = Float32 */
+typedef struct ins_rk32 ins_rk32_t;           /* `ode_method_cache` for T = Float32 */
 typedef struct ins_comm ins_comm_t;       /* one rank of an RCCL communicator (multi-GPU z-slabs; no reference counterpart) */
 
 /* Host-side description of `setup.grid` + `setup.boundary_conditions`; all pointers are HOST pointers
@@ -367,6 +369,25 @@ int ins_ztri_allgather_f64(ins_comm_t* comm, const double* edge, double* edges_a
 int ins_comm_allreduce_f64(ins_comm_t* comm, double* buf, int64_t count, int op, void* stream);
 /* Transposes around the z-FFT (the alternative Poisson route, ins_slab_fft_*): block r of `send` -> block `rank` of rank r's `recv`. */
 int ins_comm_alltoall_f64(ins_comm_t* comm, const double* send, double* recv, int64_t count, void* stream);
+
+/* ---------------------------------------------------------------------------------- the `_f32` family (T = Float32)
+ * The reference is generic in the element type and recommends single precision on GPUs (docs/src/manual/precision.md:3-16;
+ * examples/DecayingTurbulence3D.jl:16 runs T = Float32).  This family covers what that example runs: all-periodic uniform boxes (2-D / 3-D),
+ * the spectral pressure solver, explicit Runge-Kutta.  Fields are the reference layout with Float32 elements; the grid handle is the
+ * fp64 one (`ins_grid_create`).  Other grids return INS_ERR_UNSUPPORTED — there is no silent fp64 fallback.  K1 on wide 3-D boxes is the
+ * 64-outputs-per-wavefront stage kernel instantiated for float (csrc/ins_flux64.hip); the FFTs are hipFFT R2C / C2R plans. */
+int ins_apply_bc_u_f32(const ins_grid_t* grid, float* u, void* stream);                                  /* boundary_conditions.jl:276-288 */
+int ins_apply_bc_p_f32(const ins_grid_t* grid, float* p, void* stream);                                  /* boundary_conditions.jl:306-318 */
+int ins_momentum_f32(const ins_grid_t* grid, float visc, const float* u, float* F, void* stream);        /* operators.jl:967-976 */
+int ins_poisson_spectral_create_f32(const ins_grid_t* grid, ins_poisson32_t** out);                      /* pressure.jl:289-351 */
+int ins_poisson_destroy_f32(ins_poisson32_t* ps);
+int ins_poisson_solve_f32(ins_poisson32_t* ps, float* p, void* stream);                                  /* pressure.jl:318-350 */
+int ins_project_f32(const ins_grid_t* grid, ins_poisson32_t* ps, float* u, float* p, void* stream);      /* pressure.jl:69-82 */
+int ins_rk_create_f32(const ins_grid_t* grid, ins_poisson32_t* ps, int nstage, const double* A, const double* c, ins_rk32_t** out);
+int ins_rk_destroy_f32(ins_rk32_t* rk);
+int ins_rk_step_f32(ins_rk32_t* rk, float visc, float* u, float dt, void* stream);                       /* step_explicit_runge_kutta.jl:4-59 */
+/* maximum(abs, divergence(u)) over Ip; blocking.  operators.jl:106-125 */
+int ins_max_abs_divergence_f32(const ins_grid_t* grid, ins_poisson32_t* ps, const float* u, float* out, void* stream);
 
 #ifdef __cplusplus
 }

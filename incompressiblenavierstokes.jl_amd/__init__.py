@@ -6,6 +6,7 @@ include/ins_hip.h).  There is no CPU fallback: importing this package without th
 creating a `Setup` without a HIP device, raises.
 """
 from . import _lib
+from . import f32  # noqa: F401  (the `_f32` entry-point family, T = Float32)
 from ._lib import INSHipError
 from .boundary_conditions import DirichletBC, HaloBC, PeriodicBC, PressureBC, SymmetricBC
 from .distributed import AbiSlabComm, HipSlabKernels, SlabComm, SlabLayout, SlabStepper

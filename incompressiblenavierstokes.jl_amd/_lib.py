@@ -129,6 +129,17 @@ SIGNATURES = {
     "ins_slab_ztri_inverse": (C.c_int, [vp, vp, vp, vp]),
     "ins_slab_fft_forward_packed": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp]),
     "ins_slab_fft_inverse_packed": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
+    "ins_apply_bc_u_f32": (C.c_int, [vp, vp, vp]),
+    "ins_apply_bc_p_f32": (C.c_int, [vp, vp, vp]),
+    "ins_momentum_f32": (C.c_int, [vp, C.c_float, vp, vp, vp]),
+    "ins_poisson_spectral_create_f32": (C.c_int, [vp, C.POINTER(vp)]),
+    "ins_poisson_destroy_f32": (C.c_int, [vp]),
+    "ins_poisson_solve_f32": (C.c_int, [vp, vp, vp]),
+    "ins_project_f32": (C.c_int, [vp, vp, vp, vp, vp]),
+    "ins_rk_create_f32": (C.c_int, [vp, vp, C.c_int, c_double_p, c_double_p, C.POINTER(vp)]),
+    "ins_rk_destroy_f32": (C.c_int, [vp]),
+    "ins_rk_step_f32": (C.c_int, [vp, C.c_float, vp, C.c_float, vp]),
+    "ins_max_abs_divergence_f32": (C.c_int, [vp, vp, vp, C.POINTER(C.c_float), vp]),
     "ins_comm_unique_id": (C.c_int, [vp]),
     "ins_comm_create": (C.c_int, [C.c_int, C.c_int, vp, C.POINTER(vp)]),
     "ins_comm_create_local": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]),

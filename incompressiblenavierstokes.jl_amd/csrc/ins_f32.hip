@@ -1,0 +1,472 @@
+// The `_f32` entry-point family ("leaves `_f32` as a suffix-parallel family"; the reference is generic in the element
+// type and recommends single precision on GPUs, docs/src/manual/precision.md:3-16; examples/DecayingTurbulence3D.jl:16 runs T = Float32).
+//
+// Scope: all-periodic uniform boxes, 2-D and 3-D — the configuration the reference's own Float32 example runs (spectral pressure solver).
+//   K1 (momentum!)          : the 64-outputs-per-wavefront stage kernel of ins_flux64.hip instantiated for float (wide 3-D boxes: half
+//                             the bytes of the fp64 kernel at the same memory rate), a plain one-cell-per-work-item kernel elsewhere;
+//   spectral projection     : Ω·div(u) with the periodic image of u (no ghost fill needed) -> hipFFT R2C -> symbol -> C2R -> padded p with
+//                             periodic ghosts -> u -= ∇p -> periodic ghosts of u;
+//   explicit RK             : the stage loop of step_explicit_runge_kutta.jl:4-59 on those kernels, the stage combination as K1's epilogue
+//                             on wide 3-D boxes.
+// Arrays are the reference layout with Float32 elements.  The grid handle is the fp64 one (metrics are computed in double and rounded
+// once per launch).  Non-periodic or stretched grids return INS_ERR_UNSUPPORTED: no silent fp64 fallback.
+#include <cmath>
+#include <cstdlib>
+
+#include "ins_internal.h"
+
+bool ins_flux64_supported(const ins_grid* G);
+int ins_k_flux64_f32(const ins_grid* G, double visc, const float* u, float* F, const RkEpi* epi, const float* pI, int corr_mode, hipStream_t s,
+                     int part = 0);
+
+struct ins_poisson32 {
+  const ins_grid* grid = nullptr;
+  hipfftHandle fwd = 0, inv = 0;
+  bool plans = false;
+  float* pI = nullptr;
+  hipfftComplex* phat = nullptr;
+  float* ahat[3] = {nullptr, nullptr, nullptr};
+  int np[3] = {1, 1, 1}, kmax[3] = {1, 1, 1};
+};
+
+struct ins_rk32 {
+  const ins_grid* grid = nullptr;
+  ins_poisson32* ps = nullptr;
+  int nstage = 0;
+  std::vector<double> A, c;
+  std::vector<float*> ku;
+  float* ub[2] = {nullptr, nullptr};
+  float* p = nullptr;
+};
+
+namespace {
+
+struct Box32 {
+  int D, N[3], n[3];
+  long long sx[3], sc;
+  float rh[3];  // 1/h
+  float om;     // cell volume
+};
+
+Box32 box_of(const ins_grid* G) {
+  Box32 b;
+  const GridDev& g = G->g;
+  b.D = g.D;
+  double om = 1.0;
+  for (int a = 0; a < 3; ++a) {
+    b.N[a] = a < g.D ? g.N[a] : 1;
+    b.n[a] = a < g.D ? g.N[a] - 2 : 1;
+    b.sx[a] = g.sx[a];
+    b.rh[a] = a < g.D ? (float)(1.0 / G->h[a]) : 0.f;
+    if (a < g.D) om *= G->h[a];
+  }
+  b.sc = g.sc;
+  b.om = (float)om;
+  return b;
+}
+
+int require_periodic_uniform(const ins_grid* G, const char* what) {
+  if (!(G->all_periodic && G->uniform)) {
+    ins_set_error("%s: the fp32 family covers all-periodic uniform boxes only (use the _f64 entry points elsewhere)", what);
+    return INS_ERR_UNSUPPORTED;
+  }
+  return INS_OK;
+}
+
+// ghost volumes of `ncomp` components: cell 0 <- cell N-2, cell N-1 <- cell 1, direction after direction (corners consistent),
+// boundary_conditions.jl:276-288 / 306-318
+__global__ __launch_bounds__(256) void k32_bc_periodic(Box32 b, float* __restrict__ f, int ncomp, int dir) {
+  const int d1 = (dir + 1) % 3, d2 = (dir + 2) % 3;
+  const long long plane = (long long)b.N[d1] * b.N[d2];
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < plane * ncomp; t += (long long)gridDim.x * 256) {
+    const int c = (int)(t / plane);
+    const long long r = t % plane;
+    const int i1 = (int)(r % b.N[d1]), i2 = (int)(r / b.N[d1]);
+    float* base = f + c * b.sc + i1 * b.sx[d1] + i2 * b.sx[d2];
+    base[0] = base[(long long)(b.N[dir] - 2) * b.sx[dir]];
+    base[(long long)(b.N[dir] - 1) * b.sx[dir]] = base[b.sx[dir]];
+  }
+}
+
+int bc_periodic(const ins_grid* G, float* f, int ncomp, hipStream_t s) {
+  const Box32 b = box_of(G);
+  for (int dir = 0; dir < b.D; ++dir) {
+    const long long work = (long long)b.N[(dir + 1) % 3] * b.N[(dir + 2) % 3] * ncomp;
+    hipLaunchKernelGGL(k32_bc_periodic, dim3((unsigned)std::min<long long>((work + 255) / 256, 4096)), dim3(256), 0, s, b, f, ncomp, dir);
+  }
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+// momentum! on a uniform periodic box, one cell per work-item (operators.jl:647-690 with every weight 1/2 and constant spacings);
+// u needs valid ghosts.  FUSE-free: the wide 3-D boxes take ins_flux64.hip's kernel instead.
+template <int D>
+__global__ __launch_bounds__(256) void k32_momentum(Box32 b, float visc, const float* __restrict__ u, float* __restrict__ F) {
+  const int i = 1 + blockIdx.x * 64 + threadIdx.x, j = 1 + blockIdx.y * 4 + threadIdx.y, k = D == 3 ? 1 + (int)blockIdx.z : 0;
+  if (i > b.n[0] || j > b.n[1]) return;
+  const long long c = i + j * b.sx[1] + k * b.sx[2];
+#pragma unroll
+  for (int al = 0; al < D; ++al) {
+    const float* ua = u + al * b.sc;
+    float f = 0.f;
+#pragma unroll
+    for (int be = 0; be < D; ++be) {
+      const float* ub = u + be * b.sc;
+      const long long sb = b.sx[be], sa = b.sx[al];
+      const float uc = ua[c], um = ua[c - sb], up = ua[c + sb];
+      const float uab1 = 0.5f * (um + uc), uab2 = 0.5f * (uc + up);
+      const float uba1 = 0.5f * (ub[c - sb] + ub[c - sb + sa]), uba2 = 0.5f * (ub[c] + ub[c + sa]);
+      const float d1 = (uc - um) * b.rh[be], d2 = (up - uc) * b.rh[be];
+      f += (visc * (d2 - d1) - (uab2 * uba2 - uab1 * uba1)) * b.rh[be];
+    }
+    F[al * b.sc + c] = f;
+  }
+}
+
+// pI = Ω div(u) with the periodic image of u[I - e_a] (no ghost fill of u needed)        operators.jl:117-125, 81-95, pressure.jl:320
+template <int D>
+__global__ __launch_bounds__(256) void k32_div(Box32 b, const float* __restrict__ u, float* __restrict__ pI) {
+  const int ii = blockIdx.x * 64 + threadIdx.x, jj = blockIdx.y * 4 + threadIdx.y, kk = D == 3 ? (int)blockIdx.z : 0;
+  if (ii >= b.n[0] || jj >= b.n[1]) return;
+  const int I[3] = {ii + 1, jj + 1, D == 3 ? kk + 1 : 0};
+  const long long c = I[0] + I[1] * b.sx[1] + I[2] * b.sx[2];
+  float d = 0.f;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    const float* ua = u + a * b.sc;
+    const long long cm = I[a] == 1 ? c + (long long)(b.N[a] - 3) * b.sx[a] : c - b.sx[a];
+    d += (ua[c] - ua[cm]) * b.rh[a];
+  }
+  pI[ii + (long long)b.n[0] * (jj + (long long)b.n[1] * kk)] = d * b.om;
+}
+
+// phat = -phat / (ax + ay + az) / prod(Np), phat[0] = 0                                  pressure.jl:326-341
+template <int D>
+__global__ __launch_bounds__(256) void k32_symbol(hipfftComplex* __restrict__ phat, const float* __restrict__ ax, const float* __restrict__ ay,
+                                                  const float* __restrict__ az, int k0, int k1, float inv_n) {
+  const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = D == 3 ? (int)blockIdx.z : 0;
+  if (i >= k0 || j >= k1) return;
+  const long long q = i + (long long)k0 * (j + (long long)k1 * k);
+  float den = ax[i] + ay[j];
+  if (D == 3) den += az[k];
+  const float sc = (i == 0 && j == 0 && k == 0) ? 0.f : -inv_n / den;
+  hipfftComplex v = phat[q];
+  v.x *= sc;
+  v.y *= sc;
+  phat[q] = v;
+}
+
+// p (padded, with periodic ghosts) <- pI; one work-item per padded volume                pressure.jl:347, boundary_conditions.jl:306-318
+template <int D>
+__global__ __launch_bounds__(256) void k32_pad(Box32 b, const float* __restrict__ pI, float* __restrict__ p) {
+  const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = D == 3 ? (int)blockIdx.z : 0;
+  if (i >= b.N[0] || j >= b.N[1]) return;
+  auto w = [](int I, int n) { return I == 0 ? n - 1 : (I == n + 1 ? 0 : I - 1); };
+  const long long q = w(i, b.n[0]) + (long long)b.n[0] * (w(j, b.n[1]) + (long long)b.n[1] * (D == 3 ? w(k, b.n[2]) : 0));
+  p[i + j * b.sx[1] + k * b.sx[2]] = pI[q];
+}
+
+// u[I, a] -= (p[I + e_a] - p[I]) / h_a on the interior                                    operators.jl:225-233
+template <int D>
+__global__ __launch_bounds__(256) void k32_applypressure(Box32 b, float* __restrict__ u, const float* __restrict__ p) {
+  const int i = 1 + blockIdx.x * 64 + threadIdx.x, j = 1 + blockIdx.y * 4 + threadIdx.y, k = D == 3 ? 1 + (int)blockIdx.z : 0;
+  if (i > b.n[0] || j > b.n[1]) return;
+  const long long c = i + j * b.sx[1] + k * b.sx[2];
+  const float pc = p[c];
+#pragma unroll
+  for (int a = 0; a < D; ++a) u[a * b.sc + c] -= (p[c + b.sx[a]] - pc) * b.rh[a];
+}
+
+// out = base + Σ coef_q k_q                                                             step_explicit_runge_kutta.jl:35-38
+struct Comb32 {
+  int n;
+  float coef[INS_MAX_STAGES + 1];
+  const float* k[INS_MAX_STAGES + 1];
+};
+__global__ __launch_bounds__(256) void k32_combine(long long n, const float* __restrict__ base, float* __restrict__ out, Comb32 cb) {
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+    float v = base[t];
+    for (int q = 0; q < cb.n; ++q) v += cb.coef[q] * cb.k[q][t];
+    out[t] = v;
+  }
+}
+
+dim3 grid_over(const Box32& b, bool padded) {
+  const int e0 = padded ? b.N[0] : b.n[0], e1 = padded ? b.N[1] : b.n[1], e2 = b.D == 3 ? (padded ? b.N[2] : b.n[2]) : 1;
+  return dim3(cdiv(e0, 64), cdiv(e1, 4), e2);
+}
+
+}  // namespace
+
+extern "C" int ins_apply_bc_u_f32(const ins_grid_t* G, float* u, void* stream) {
+  INS_REQUIRE(G && u, "null argument");
+  int rc = require_periodic_uniform(G, "ins_apply_bc_u_f32");
+  if (rc) return rc;
+  return bc_periodic(G, u, G->g.D, as_stream(stream));
+}
+
+extern "C" int ins_apply_bc_p_f32(const ins_grid_t* G, float* p, void* stream) {
+  INS_REQUIRE(G && p, "null argument");
+  int rc = require_periodic_uniform(G, "ins_apply_bc_p_f32");
+  if (rc) return rc;
+  return bc_periodic(G, p, 1, as_stream(stream));
+}
+
+extern "C" int ins_momentum_f32(const ins_grid_t* G, float visc, const float* u, float* F, void* stream) {
+  INS_REQUIRE(G && u && F, "null argument");
+  int rc = require_periodic_uniform(G, "ins_momentum_f32");
+  if (rc) return rc;
+  hipStream_t s = as_stream(stream);
+  if (ins_flux64_supported(G)) return ins_k_flux64_f32(G, (double)visc, u, F, nullptr, nullptr, 0, s);
+  const Box32 b = box_of(G);
+  if (b.D == 2)
+    hipLaunchKernelGGL(k32_momentum<2>, grid_over(b, false), dim3(64, 4), 0, s, b, visc, u, F);
+  else
+    hipLaunchKernelGGL(k32_momentum<3>, grid_over(b, false), dim3(64, 4), 0, s, b, visc, u, F);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+extern "C" int ins_poisson_destroy_f32(ins_poisson32_t* ps) {
+  if (!ps) return INS_OK;
+  if (ps->plans) {
+    (void)hipfftDestroy(ps->fwd);
+    (void)hipfftDestroy(ps->inv);
+  }
+  if (ps->pI) (void)hipFree(ps->pI);
+  if (ps->phat) (void)hipFree(ps->phat);
+  for (float* a : ps->ahat)
+    if (a) (void)hipFree(a);
+  delete ps;
+  return INS_OK;
+}
+
+// psolver_spectral(setup) with T = Float32                                               pressure.jl:289-351
+extern "C" int ins_poisson_spectral_create_f32(const ins_grid_t* G, ins_poisson32_t** out) {
+  INS_REQUIRE(G && out, "null argument");
+  int rc = require_periodic_uniform(G, "ins_poisson_spectral_create_f32");
+  if (rc) return rc;
+  const GridDev& g = G->g;
+  ins_poisson32* ps = new ins_poisson32();
+  ps->grid = G;
+  long long nreal = 1, ncplx = 1;
+  double om = 1.0;
+  for (int a = 0; a < g.D; ++a) {
+    ps->np[a] = g.N[a] - 2;
+    if (ps->np[a] % 2) {
+      ins_set_error("spectral psolver: the number of volumes must be even in every direction (utils.jl:1-13)");
+      delete ps;
+      return INS_ERR_INVALID;
+    }
+    ps->kmax[a] = a == 0 ? ps->np[a] / 2 + 1 : ps->np[a];
+    nreal *= ps->np[a];
+    ncplx *= ps->kmax[a];
+    om *= G->h[a];
+  }
+  bool ok = hipMalloc(&ps->pI, nreal * sizeof(float)) == hipSuccess && hipMalloc(&ps->phat, ncplx * sizeof(hipfftComplex)) == hipSuccess;
+  for (int a = 0; ok && a < g.D; ++a) {  // âα(k) = 4 Ω sin²(π k / Npα) / Δxα², evaluated in double, stored in float
+    std::vector<float> h(ps->kmax[a]);
+    for (int k = 0; k < ps->kmax[a]; ++k) {
+      const double sn = std::sin(M_PI * (double)k / ps->np[a]);
+      h[k] = (float)(4.0 * om * sn * sn / (G->h[a] * G->h[a]));
+    }
+    ok = hipMalloc(&ps->ahat[a], h.size() * sizeof(float)) == hipSuccess &&
+         hipMemcpy(ps->ahat[a], h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+  }
+  if (ok) {
+    hipfftResult r1, r2;
+    if (g.D == 2) {
+      r1 = hipfftPlan2d(&ps->fwd, ps->np[1], ps->np[0], HIPFFT_R2C);
+      r2 = r1 == HIPFFT_SUCCESS ? hipfftPlan2d(&ps->inv, ps->np[1], ps->np[0], HIPFFT_C2R) : r1;
+    } else {
+      r1 = hipfftPlan3d(&ps->fwd, ps->np[2], ps->np[1], ps->np[0], HIPFFT_R2C);
+      r2 = r1 == HIPFFT_SUCCESS ? hipfftPlan3d(&ps->inv, ps->np[2], ps->np[1], ps->np[0], HIPFFT_C2R) : r1;
+    }
+    if (r1 == HIPFFT_SUCCESS && r2 != HIPFFT_SUCCESS) (void)hipfftDestroy(ps->fwd);
+    ps->plans = r1 == HIPFFT_SUCCESS && r2 == HIPFFT_SUCCESS;
+    ok = ps->plans;
+  }
+  if (!ok) {
+    ins_set_error("ins_poisson_spectral_create_f32: allocation or hipFFT plan creation failed");
+    ins_poisson_destroy_f32(ps);
+    return INS_ERR_FFT;
+  }
+  *out = ps;
+  return INS_OK;
+}
+
+static int solve32(ins_poisson32* ps, hipStream_t s) {  // pI -> pI
+  const GridDev& g = ps->grid->g;
+  INS_FFT_TRY(hipfftSetStream(ps->fwd, s));
+  INS_FFT_TRY(hipfftSetStream(ps->inv, s));
+  INS_FFT_TRY(hipfftExecR2C(ps->fwd, ps->pI, ps->phat));
+  const float inv_n = 1.0f / ((float)ps->np[0] * (float)ps->np[1] * (float)ps->np[2]);
+  const dim3 grid(cdiv(ps->kmax[0], 64), cdiv(ps->kmax[1], 4), g.D == 3 ? ps->kmax[2] : 1);
+  if (g.D == 2)
+    hipLaunchKernelGGL(k32_symbol<2>, grid, dim3(64, 4), 0, s, ps->phat, ps->ahat[0], ps->ahat[1], nullptr, ps->kmax[0], ps->kmax[1], inv_n);
+  else
+    hipLaunchKernelGGL(k32_symbol<3>, grid, dim3(64, 4), 0, s, ps->phat, ps->ahat[0], ps->ahat[1], ps->ahat[2], ps->kmax[0], ps->kmax[1], inv_n);
+  INS_LAUNCH_CHECK();
+  INS_FFT_TRY(hipfftExecC2R(ps->inv, ps->phat, ps->pI));
+  return INS_OK;
+}
+
+// project!(u, setup; psolver, p) with T = Float32                                        pressure.jl:69-82
+// u needs no valid ghosts on entry (periodic images are read); on return u and p carry their periodic ghosts.
+extern "C" int ins_project_f32(const ins_grid_t* G, ins_poisson32_t* ps, float* u, float* p, void* stream) {
+  INS_REQUIRE(G && ps && u && p, "null argument");
+  INS_REQUIRE(ps->grid == G, "psolver was created for a different grid");
+  hipStream_t s = as_stream(stream);
+  const Box32 b = box_of(G);
+  int rc;
+  if (b.D == 2) {
+    hipLaunchKernelGGL(k32_div<2>, grid_over(b, false), dim3(64, 4), 0, s, b, u, ps->pI);
+  } else {
+    hipLaunchKernelGGL(k32_div<3>, grid_over(b, false), dim3(64, 4), 0, s, b, u, ps->pI);
+  }
+  INS_LAUNCH_CHECK();
+  if ((rc = solve32(ps, s))) return rc;
+  if (b.D == 2) {
+    hipLaunchKernelGGL(k32_pad<2>, grid_over(b, true), dim3(64, 4), 0, s, b, ps->pI, p);
+    hipLaunchKernelGGL(k32_applypressure<2>, grid_over(b, false), dim3(64, 4), 0, s, b, u, p);
+  } else {
+    hipLaunchKernelGGL(k32_pad<3>, grid_over(b, true), dim3(64, 4), 0, s, b, ps->pI, p);
+    hipLaunchKernelGGL(k32_applypressure<3>, grid_over(b, false), dim3(64, 4), 0, s, b, u, p);
+  }
+  INS_LAUNCH_CHECK();
+  return bc_periodic(G, u, b.D, s);
+}
+
+// psolver(p): solve L p = f on view(p, Ip) in place (pressure.jl:318-350); ghosts of p are refreshed
+extern "C" int ins_poisson_solve_f32(ins_poisson32_t* ps, float* p, void* stream) {
+  INS_REQUIRE(ps && p, "null argument");
+  hipStream_t s = as_stream(stream);
+  const ins_grid* G = ps->grid;
+  const GridDev& g = G->g;
+  // strip the ghosts (2-D copies), solve, pad
+  const size_t w = (size_t)ps->np[0] * sizeof(float);
+  hipMemcpy3DParms c = {};
+  c.srcPtr = make_hipPitchedPtr(p, (size_t)g.N[0] * sizeof(float), g.N[0], g.N[1]);
+  c.srcPos = make_hipPos(sizeof(float), 1, g.D == 3 ? 1 : 0);
+  c.dstPtr = make_hipPitchedPtr(ps->pI, w, ps->np[0], ps->np[1]);
+  c.extent = make_hipExtent(w, ps->np[1], g.D == 3 ? ps->np[2] : 1);
+  c.kind = hipMemcpyDeviceToDevice;
+  INS_HIP_TRY(hipMemcpy3DAsync(&c, s));
+  int rc = solve32(ps, s);
+  if (rc) return rc;
+  const Box32 b = box_of(G);
+  if (b.D == 2)
+    hipLaunchKernelGGL(k32_pad<2>, grid_over(b, true), dim3(64, 4), 0, s, b, ps->pI, p);
+  else
+    hipLaunchKernelGGL(k32_pad<3>, grid_over(b, true), dim3(64, 4), 0, s, b, ps->pI, p);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- explicit Runge-Kutta, T = Float32
+extern "C" int ins_rk_destroy_f32(ins_rk32_t* rk) {
+  if (!rk) return INS_OK;
+  for (float* k : rk->ku)
+    if (k) (void)hipFree(k);
+  for (float* b : rk->ub)
+    if (b) (void)hipFree(b);
+  if (rk->p) (void)hipFree(rk->p);
+  delete rk;
+  return INS_OK;
+}
+
+extern "C" int ins_rk_create_f32(const ins_grid_t* G, ins_poisson32_t* ps, int nstage, const double* A, const double* c, ins_rk32_t** out) {
+  INS_REQUIRE(G && ps && A && c && out, "null argument");
+  INS_REQUIRE(ps->grid == G, "psolver was created for a different grid");
+  INS_REQUIRE(nstage >= 1 && nstage <= INS_MAX_STAGES, "unsupported number of stages");
+  ins_rk32* rk = new ins_rk32();
+  rk->grid = G;
+  rk->ps = ps;
+  rk->nstage = nstage;
+  rk->A.assign(A, A + nstage * nstage);
+  rk->c.assign(c, c + nstage);
+  const size_t vbytes = (size_t)G->ncell * G->g.D * sizeof(float);
+  rk->ku.assign(nstage, nullptr);
+  bool ok = hipMalloc(&rk->p, G->ncell * sizeof(float)) == hipSuccess && hipMemset(rk->p, 0, G->ncell * sizeof(float)) == hipSuccess;
+  for (int i = 0; ok && i < nstage; ++i) ok = hipMalloc(&rk->ku[i], vbytes) == hipSuccess && hipMemset(rk->ku[i], 0, vbytes) == hipSuccess;
+  for (int b = 0; ok && b < 2; ++b) ok = hipMalloc(&rk->ub[b], vbytes) == hipSuccess && hipMemset(rk->ub[b], 0, vbytes) == hipSuccess;
+  if (!ok) {
+    ins_set_error("ins_rk_create_f32: device allocation failed");
+    ins_rk_destroy_f32(rk);
+    return INS_ERR_HIP;
+  }
+  *out = rk;
+  return INS_OK;
+}
+
+// timestep!(method, stepper, Δt; cache) for closure_model = temp = bodyforce = nothing, T = Float32       step_explicit_runge_kutta.jl:4-59
+// The caller's u is ustart for the whole step; stage velocities ping-pong in two library buffers; on wide 3-D boxes the stage combination
+// is the stencil kernel's epilogue.
+extern "C" int ins_rk_step_f32(ins_rk32_t* rk, float visc, float* u, float dt, void* stream) {
+  INS_REQUIRE(rk && u, "null argument");
+  const ins_grid* G = rk->grid;
+  hipStream_t s = as_stream(stream);
+  const int ns = rk->nstage, D = G->g.D;
+  const long long nvec = G->ncell * D;
+  const bool wide = ins_flux64_supported(G);
+  int rc;
+  if ((rc = bc_periodic(G, u, D, s))) return rc;                                // :19
+  float* cur = u;
+  for (int i = 0; i < ns; ++i) {
+    float* outp = (i == ns - 1 && ns > 1) ? u : rk->ub[i & 1];
+    if (wide) {
+      RkEpi epi;
+      memset(&epi, 0, sizeof(epi));
+      for (int j = 0; j < i; ++j) {
+        const double coef = (double)dt * rk->A[i * ns + j];
+        if (coef == 0.0) continue;
+        epi.coef[epi.n] = coef;
+        epi.k[epi.n] = reinterpret_cast<const double*>(rk->ku[j]);  // float arrays behind RkEpi's untyped pointers (ins_flux64.hip casts back)
+        ++epi.n;
+      }
+      for (int i2 = i + 1; i2 < ns; ++i2)
+        if (rk->A[i2 * ns + i] != 0.0) epi.write_k = 1;
+      epi.coef_self = (double)dt * rk->A[i * ns + i];
+      epi.ustart = i == 0 ? nullptr : reinterpret_cast<const double*>(u);
+      epi.ustar = reinterpret_cast<double*>(outp);
+      if ((rc = ins_k_flux64_f32(G, (double)visc, cur, rk->ku[i], &epi, nullptr, 0, s))) return rc;   // :21, :35-38
+    } else {
+      if ((rc = ins_momentum_f32(G, visc, cur, rk->ku[i], s))) return rc;       // :21
+      Comb32 cb;
+      cb.n = 0;
+      for (int j = 0; j <= i; ++j) {
+        const float coef = dt * (float)rk->A[i * ns + j];
+        if (coef == 0.f) continue;
+        cb.coef[cb.n] = coef;
+        cb.k[cb.n] = rk->ku[j];
+        ++cb.n;
+      }
+      hipLaunchKernelGGL(k32_combine, dim3((unsigned)std::min<long long>((nvec + 255) / 256, 8192)), dim3(256), 0, s, nvec, u, outp, cb);  // :35-38
+      INS_LAUNCH_CHECK();
+    }
+    if ((rc = ins_project_f32(G, rk->ps, outp, rk->p, s))) return rc;           // :48-49 (periodic images: no ghost fill before)
+    cur = outp;
+  }
+  if (ns == 1) INS_HIP_TRY(hipMemcpyAsync(u, rk->ub[0], nvec * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return INS_OK;
+}
+
+// maximum(abs, divergence(u)) over Ip (diagnostic; blocking)                              operators.jl:106-125
+extern "C" int ins_max_abs_divergence_f32(const ins_grid_t* G, ins_poisson32_t* ps, const float* u, float* out, void* stream) {
+  INS_REQUIRE(G && ps && u && out, "null argument");
+  hipStream_t s = as_stream(stream);
+  const Box32 b = box_of(G);
+  if (b.D == 2)
+    hipLaunchKernelGGL(k32_div<2>, grid_over(b, false), dim3(64, 4), 0, s, b, u, ps->pI);
+  else
+    hipLaunchKernelGGL(k32_div<3>, grid_over(b, false), dim3(64, 4), 0, s, b, u, ps->pI);
+  INS_LAUNCH_CHECK();
+  const long long n = (long long)ps->np[0] * ps->np[1] * ps->np[2];
+  std::vector<float> h(n);
+  INS_HIP_TRY(hipMemcpyAsync(h.data(), ps->pI, n * sizeof(float), hipMemcpyDeviceToHost, s));
+  INS_HIP_TRY(hipStreamSynchronize(s));
+  float m = 0.f;
+  for (float v : h) m = std::fmax(m, std::fabs(v));
+  *out = m / b.om;
+  return INS_OK;
+}

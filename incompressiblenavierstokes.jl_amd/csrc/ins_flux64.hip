@@ -32,11 +32,18 @@ struct Dir {
   double rs, ro;  // ¼/Δu, ¼/Δ
   double gs;      // 1/Δu (pressure gradient, CORR)
 };
+// the same record in the arithmetic type T of the kernel (double, or float for the `_f32` entry points: the host computes the
+// constants in double and rounds once)
+template <typename T>
+struct DirT {
+  T vs, vo, rs, ro, gs;
+  __device__ DirT(const Dir& d) : vs((T)d.vs), vo((T)d.vo), rs((T)d.rs), ro((T)d.ro), gs((T)d.gs) {}
+};
 
-struct FluxArgs {
-  const double* u;
-  const double* pI;
-  double* F;
+struct FluxArgs {  // field pointers are T* of the kernel instantiation (RkEpi's pointers likewise)
+  const void* u;
+  const void* pI;
+  void* F;
   long long sc;  // component stride (elements)
   int N0, N1, N2;
   int zc, ntx, nty, ntz;
@@ -52,25 +59,40 @@ __device__ __forceinline__ double rdlane(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 template <int CTRL>
 __device__ __forceinline__ double dpp_old(double old, double v) {  // lanes without a source lane keep `old`
   const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, 0xf, false);
   const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double next_h(double v, double h) { return dpp_old<0x130>(h, v); }  // lane l <- l+1, lane 63 <- h
-__device__ __forceinline__ double prev_h(double v, double h) { return dpp_old<0x138>(h, v); }  // lane l <- l-1, lane 0  <- h
+template <int CTRL>
+__device__ __forceinline__ float dpp_old(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <typename T>
+__device__ __forceinline__ T next_h(T v, T h) { return dpp_old<0x130>(h, v); }  // lane l <- l+1, lane 63 <- h
+template <typename T>
+__device__ __forceinline__ T prev_h(T v, T h) { return dpp_old<0x138>(h, v); }  // lane l <- l-1, lane 0  <- h
 
 // Buffer addressing: descriptor (4 SGPRs) = one plane of one array, soffset (SGPR) = row start, voffset (VGPR) = column.
 // All plane / row arithmetic runs on the scalar unit; a lane holds one 32-bit offset for every load and store it issues.
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 using rsrc_t = __amdgpu_buffer_rsrc_t;
-__device__ __forceinline__ rsrc_t plane_rsrc(const double* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, bytes, 0x00020000);
+template <typename T>
+__device__ __forceinline__ rsrc_t plane_rsrc(const T* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, bytes, 0x00020000);
 }
-__device__ __forceinline__ double ldb(rsrc_t r, unsigned voff, unsigned soff) {
+template <typename T>
+__device__ __forceinline__ T ldb(rsrc_t r, unsigned voff, unsigned soff);
+template <>
+__device__ __forceinline__ double ldb<double>(rsrc_t r, unsigned voff, unsigned soff) {
   const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
   return __hiloint2double((int)v.y, (int)v.x);
+}
+template <>
+__device__ __forceinline__ float ldb<float>(rsrc_t r, unsigned voff, unsigned soff) {
+  return __int_as_float((int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 __device__ __forceinline__ void stb(rsrc_t r, unsigned voff, unsigned soff, double x) {
   v2u v;
@@ -78,9 +100,13 @@ __device__ __forceinline__ void stb(rsrc_t r, unsigned voff, unsigned soff, doub
   v.y = (unsigned)__double2hiint(x);
   __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
+__device__ __forceinline__ void stb(rsrc_t r, unsigned voff, unsigned soff, float x) {
+  __builtin_amdgcn_raw_buffer_store_b32((unsigned)__float_as_int(x), r, voff, soff, 0);
+}
 
 // 4 × face flux:  4ν(up - uc)/Δb - (uc + up)(ub0 + ub1)        [ν(up - uc)/Δb - ½(uc + up)·½(ub0 + ub1), times 4]
-__device__ __forceinline__ double flux(double uc, double up, double ub0, double ub1, double vd4) {
+template <typename T>
+__device__ __forceinline__ T flux(T uc, T up, T ub0, T ub1, T vd4) {
   return (up - uc) * vd4 - (uc + up) * (ub0 + ub1);
 }
 
@@ -88,18 +114,22 @@ __device__ __forceinline__ int wrapi(int q, int n) {  // q in [-n, 2n) -> [0, n)
   return q < 0 ? q + n : (q >= n ? q - n : q);
 }
 
-template <int R>
+template <typename T, int R>
 struct Plane {
-  double v[3][R + 2];
-  double h[3];  // packed halo columns: lane r = row r of column x0-1, lane 16+r = row r of column x0+64
-  double raw[3][R];  // CORR: the output rows before the pressure correction (a term of the stage-velocity basis, ins_rk.hip)
+  T v[3][R + 2];
+  T h[3];  // packed halo columns: lane r = row r of column x0-1, lane 16+r = row r of column x0+64
+  T raw[3][R];  // CORR: the output rows before the pressure correction (a term of the stage-velocity basis, ins_rk.hip)
 };
 
 // NW wavefronts per workgroup: XW side by side in x, NW/XW stacked in y.  CORR as in ins_fast3d_flux.hip: 0 = `u` has valid ghost volumes;
 // 1 = `u` is the previous stage's uncorrected u* (interior only), pI its unpadded pressure, every neighbour through the
 // periodic image; 2 = z-slab: x, y periodic images, z through exchanged ghost planes, pI = [1 | nzl | 2] extended buffer.
-template <int R, int XW, bool FUSE, int CORR, bool SKEL = false, int NW = 4>
+template <typename T, int R, int XW, bool FUSE, int CORR, bool SKEL = false, int NW = 4>
 __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a) {
+  constexpr unsigned EB = (unsigned)sizeof(T);  // element bytes
+  const T* const a_u = static_cast<const T*>(a.u);
+  const T* const a_pI = static_cast<const T*>(a.pI);
+  T* const a_F = static_cast<T*>(a.F);
   static_assert(R + 2 + (CORR ? 1 : 0) <= 8, "packed halo rows live in 8-lane groups");
   int txi, tyi, tzi;
   {
@@ -129,7 +159,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
   const long long sz = (long long)N0 * N1;
   const int ci = x0 + lane;
   const bool xout = ci < n0;
-  const Dir X = a.X, Y = a.Y, Z = a.Z;
+  const DirT<T> X(a.X), Y(a.Y), Z(a.Z);
 
   // padded row / column of a (possibly out-of-range) interior index
   auto prow_of = [&](int jr) { return CORR ? wrapi(jr, n1) + 1 : min(jr + 1, N1 - 1); };
@@ -139,48 +169,48 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
   unsigned urow[R + 2];  // u: byte offset of the padded row inside a plane
   unsigned qrow[R + 3];  // p: byte offset of the interior row inside an unpadded plane (CORR)
 #pragma unroll
-  for (int rr = 0; rr < R + 2; ++rr) urow[rr] = (unsigned)(prow_of(jb0 - 1 + rr) * N0) * 8u;
+  for (int rr = 0; rr < R + 2; ++rr) urow[rr] = (unsigned)(prow_of(jb0 - 1 + rr) * N0) * EB;
   if (CORR) {
 #pragma unroll
-    for (int rr = 0; rr < R + 3; ++rr) qrow[rr] = (unsigned)((prow_of(jb0 - 1 + rr) - 1) * n0) * 8u;
+    for (int rr = 0; rr < R + 3; ++rr) qrow[rr] = (unsigned)((prow_of(jb0 - 1 + rr) - 1) * n0) * EB;
   }
-  const unsigned ubytes = (unsigned)sz * 8u, qbytes = (unsigned)(n0 * n1) * 8u;
-  const unsigned ucol = (unsigned)pcol_of(ci) * 8u;            // main lanes: own column
-  const unsigned qcol = CORR ? (unsigned)(pcol_of(ci) - 1) * 8u : 0u;
+  const unsigned ubytes = (unsigned)sz * EB, qbytes = (unsigned)(n0 * n1) * EB;
+  const unsigned ucol = (unsigned)pcol_of(ci) * EB;            // main lanes: own column
+  const unsigned qcol = CORR ? (unsigned)(pcol_of(ci) - 1) * EB : 0u;
   unsigned uhoff, qhoff = 0;  // packed halo loads: in-plane byte offset of this lane's (row, column)
   {
     const int r = lane & 7, grp = (lane >> 3) & 3;
     const int ru = r <= R + 1 ? r : 0;
     const int colu = (grp == 2) ? pcol_of(x0 + 64) : pcol_of(x0 - 1);
-    uhoff = (unsigned)(prow_of(jb0 - 1 + ru) * N0 + colu) * 8u;
+    uhoff = (unsigned)(prow_of(jb0 - 1 + ru) * N0 + colu) * EB;
     if (CORR) {
       const int rq = r <= R + 2 ? r : 0;
       const int cq = grp == 0 ? x0 - 1 : (grp == 1 ? x0 : (grp == 2 ? x0 + 64 : x0 + 65));
-      qhoff = (unsigned)((prow_of(jb0 - 1 + rq) - 1) * n0 + (pcol_of(cq) - 1)) * 8u;
+      qhoff = (unsigned)((prow_of(jb0 - 1 + rq) - 1) * n0 + (pcol_of(cq) - 1)) * EB;
     }
   }
 
   auto uplane = [&](int kk) {  // padded plane index -> plane actually read
     return CORR == 1 ? wrapi(kk - 1, n2) + 1 : (CORR == 2 ? min(kk, N2 - 1) : kk);
   };
-  auto load_plane = [&](Plane<R>& P, int kk) {
-    const double* base = a.u + (long long)uplane(kk) * sz;
+  auto load_plane = [&](Plane<T, R>& P, int kk) {
+    const T* base = a_u + (long long)uplane(kk) * sz;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const rsrc_t rs = plane_rsrc(base + c * a.sc, ubytes);
 #pragma unroll
-      for (int rr = 0; rr < R + 2; ++rr) P.v[c][rr] = ldb(rs, ucol, urow[rr]);
-      P.h[c] = ldb(rs, uhoff, 0);
+      for (int rr = 0; rr < R + 2; ++rr) P.v[c][rr] = ldb<T>(rs, ucol, urow[rr]);
+      P.h[c] = ldb<T>(rs, uhoff, 0);
     }
   };
-  auto load_p = [&](double (&P)[R + 3], double& PH, int kk) {
-    const rsrc_t rs = plane_rsrc(a.pI + (long long)(CORR == 2 ? min(kk, N2) : wrapi(kk - 1, n2)) * n0 * n1, qbytes);
+  auto load_p = [&](T (&P)[R + 3], T& PH, int kk) {
+    const rsrc_t rs = plane_rsrc(a_pI + (long long)(CORR == 2 ? min(kk, N2) : wrapi(kk - 1, n2)) * n0 * n1, qbytes);
 #pragma unroll
-    for (int rr = 0; rr < R + 3; ++rr) P[rr] = ldb(rs, qcol, qrow[rr]);
-    PH = ldb(rs, qhoff, 0);
+    for (int rr = 0; rr < R + 3; ++rr) P[rr] = ldb<T>(rs, qcol, qrow[rr]);
+    PH = ldb<T>(rs, qhoff, 0);
   };
   // u = u* - ∇p (applypressure!, operators.jl:225-233) for one register plane and its packed halo columns
-  auto correct = [&](Plane<R>& P, const double (&Pc)[R + 3], double PHc, const double (&Pn)[R + 3], double PHn) {
+  auto correct = [&](Plane<T, R>& P, const T (&Pc)[R + 3], T PHc, const T (&Pn)[R + 3], T PHn) {
     if (a.epi.self_in != 0.0) {
 #pragma unroll
       for (int c = 0; c < 3; ++c)
@@ -189,7 +219,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
     }
 #pragma unroll
     for (int rr = 0; rr < R + 2; ++rr) {
-      const double pc = Pc[rr];
+      const T pc = Pc[rr];
       P.v[0][rr] -= (next_h(pc, rdlane(PHc, 16 + rr)) - pc) * X.gs;
       P.v[1][rr] -= (Pc[rr + 1] - pc) * Y.gs;
       P.v[2][rr] -= (Pn[rr] - pc) * Z.gs;
@@ -199,11 +229,11 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
     P.h[2] -= (PHn - PHc) * Z.gs;
   };
 
-  double zprev[3][R];
-  auto zflux0 = [&](const Plane<R>& C, const Plane<R>& Nx) {  // upper-face z-fluxes of the plane below the chunk
+  T zprev[3][R];
+  auto zflux0 = [&](const Plane<T, R>& C, const Plane<T, R>& Nx) {  // upper-face z-fluxes of the plane below the chunk
 #pragma unroll
     for (int rr = 1; rr <= R; ++rr) {
-      const double Wc = C.v[2][rr];
+      const T Wc = C.v[2][rr];
       zprev[0][rr - 1] = flux(C.v[0][rr], Nx.v[0][rr], Wc, next_h(Wc, rdlane(C.h[2], 16 + rr)), Z.vo);
       zprev[1][rr - 1] = flux(C.v[1][rr], Nx.v[1][rr], Wc, C.v[2][rr + 1], Z.vo);
       zprev[2][rr - 1] = flux(Wc, Nx.v[2][rr], Wc, Nx.v[2][rr], Z.vs);
@@ -213,21 +243,21 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
   // output rows of this wavefront (clamped: rows / columns past the box are computed but never stored)
   unsigned orow[R];
 #pragma unroll
-  for (int rr = 0; rr < R; ++rr) orow[rr] = (unsigned)((min(jb0 + rr, n1 - 1) + 1) * N0) * 8u;
-  const unsigned ocol = (unsigned)(min(ci, n0 - 1) + 1) * 8u;
+  for (int rr = 0; rr < R; ++rr) orow[rr] = (unsigned)((min(jb0 + rr, n1 - 1) + 1) * N0) * EB;
+  const unsigned ocol = (unsigned)(min(ci, n0 - 1) + 1) * EB;
 
   // RK epilogue, first half: s = ustart + Σ_q coef_q k_q for all R rows of plane k.  Issued at the top of the plane so the
   // loads fly during the flux arithmetic (they used to sit right before the stores: one exposed round trip per row).
-  auto epi_load = [&](const Plane<R>& C, int k, double (&sacc)[3][R]) {
+  auto epi_load = [&](const Plane<T, R>& C, int k, T (&sacc)[3][R]) {
     const long long pk = (long long)k * sz;
     if (a.epi.ustart) {
-      const double* b = a.epi.ustart + pk;
-      const double c0 = 1.0 + a.epi.c0m1;  // exactly 1 in the k-basis
+      const T* b = static_cast<const T*>((const void*)a.epi.ustart) + pk;
+      const T c0 = (T)(1.0 + a.epi.c0m1);  // exactly 1 in the k-basis
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const rsrc_t rs = plane_rsrc(b + c * a.sc, ubytes);
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) sacc[c][rr] = c0 * ldb(rs, ocol, orow[rr]);
+        for (int rr = 0; rr < R; ++rr) sacc[c][rr] = c0 * ldb<T>(rs, ocol, orow[rr]);
       }
     } else {
 #pragma unroll
@@ -239,42 +269,42 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
 #pragma unroll
       for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) sacc[c][rr] += a.epi.self_in * (CORR ? C.raw[c][rr] : C.v[c][rr + 1]);
+        for (int rr = 0; rr < R; ++rr) sacc[c][rr] += (T)a.epi.self_in * (CORR ? C.raw[c][rr] : C.v[c][rr + 1]);
     }
     for (int q = 0; q < a.epi.n; ++q) {
-      const double* kq = a.epi.k[q] + pk;
-      const double cq = a.epi.coef[q];
+      const T* kq = static_cast<const T*>((const void*)a.epi.k[q]) + pk;
+      const T cq = (T)a.epi.coef[q];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const rsrc_t rs = plane_rsrc(kq + c * a.sc, ubytes);
-        double kv[R];
+        T kv[R];
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) kv[rr] = ldb(rs, ocol, orow[rr]);
+        for (int rr = 0; rr < R; ++rr) kv[rr] = ldb<T>(rs, ocol, orow[rr]);
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) sacc[c][rr] += cq * kv[rr];
       }
     }
   };
   // second half: u* = s + coef_self f, and k_i = f when a later stage needs it
-  auto emit = [&](int rr, int k, double fu, double fv, double fw, double s0, double s1, double s2) {
+  auto emit = [&](int rr, int k, T fu, T fv, T fw, T s0, T s1, T s2) {
     const long long pk = (long long)k * sz;
     const int j = jb0 + rr - 1;  // interior row
     if (xout && j < n1) {
       const unsigned rowb = orow[rr - 1], co = ocol;
       if (FUSE) {
         if (CORR && a.epi.ustart_out) {  // chained steps: s is the corrected stencil input = this step's ustart (no term was added to it)
-          double* w = a.epi.ustart_out + pk;
+          T* w = static_cast<T*>((void*)a.epi.ustart_out) + pk;
           stb(plane_rsrc(w, ubytes), co, rowb, s0);
           stb(plane_rsrc(w + a.sc, ubytes), co, rowb, s1);
           stb(plane_rsrc(w + 2 * a.sc, ubytes), co, rowb, s2);
         }
-        double* o = a.epi.ustar + pk;
-        stb(plane_rsrc(o, ubytes), co, rowb, s0 + a.epi.coef_self * fu);
-        stb(plane_rsrc(o + a.sc, ubytes), co, rowb, s1 + a.epi.coef_self * fv);
-        stb(plane_rsrc(o + 2 * a.sc, ubytes), co, rowb, s2 + a.epi.coef_self * fw);
+        T* o = static_cast<T*>((void*)a.epi.ustar) + pk;
+        stb(plane_rsrc(o, ubytes), co, rowb, s0 + (T)a.epi.coef_self * fu);
+        stb(plane_rsrc(o + a.sc, ubytes), co, rowb, s1 + (T)a.epi.coef_self * fv);
+        stb(plane_rsrc(o + 2 * a.sc, ubytes), co, rowb, s2 + (T)a.epi.coef_self * fw);
       }
       if (!FUSE || a.epi.write_k) {
-        double* o = a.F + pk;
+        T* o = a_F + pk;
         stb(plane_rsrc(o, ubytes), co, rowb, fu);
         stb(plane_rsrc(o + a.sc, ubytes), co, rowb, fv);
         stb(plane_rsrc(o + 2 * a.sc, ubytes), co, rowb, fw);
@@ -285,82 +315,82 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
   // One output plane.  C = plane k, Nx = plane k+1 (both complete, corrected).  As soon as a row of C has been consumed its
   // registers are re-loaded with the same row of plane `kload` (= k+2, the next plane this buffer has to hold), so the
   // prefetch of plane k+2 is in flight during the whole of plane k without a third register plane.
-  auto body = [&](Plane<R>& C, const Plane<R>& Nx, int k, int kload) {
-    const double* nb = a.u + (long long)uplane(kload) * sz;
+  auto body = [&](Plane<T, R>& C, const Plane<T, R>& Nx, int k, int kload) {
+    const T* nb = a_u + (long long)uplane(kload) * sz;
     const rsrc_t n0r = plane_rsrc(nb, ubytes), n1r = plane_rsrc(nb + a.sc, ubytes), n2r = plane_rsrc(nb + 2 * a.sc, ubytes);
-    const double ch0 = C.h[0], ch1 = C.h[1], ch2 = C.h[2];
-    double sacc[3][R];
+    const T ch0 = C.h[0], ch1 = C.h[1], ch2 = C.h[2];
+    T sacc[3][R];
     if (FUSE) epi_load(C, k, sacc);
-    double fyu_o = 0, fyv_o = 0, fyw_o = 0;
+    T fyu_o = 0, fyv_o = 0, fyw_o = 0;
 #pragma unroll
     for (int rr = 0; rr <= R; ++rr) {
-      const double Uc = C.v[0][rr], Vc = C.v[1][rr], Wc = C.v[2][rr];
+      const T Uc = C.v[0][rr], Vc = C.v[1][rr], Wc = C.v[2][rr];
       if (SKEL) {  // timing experiment: same loads, stores and epilogue, trivial arithmetic (tools/scan_flux64.sh)
         if (rr >= 1) {
-          const double fu = Uc + fyu_o + C.v[0][rr + 1] + Nx.v[0][rr] + zprev[0][rr - 1] + ch0;
-          const double fv = Vc + fyv_o + C.v[1][rr + 1] + Nx.v[1][rr] + zprev[1][rr - 1] + ch1;
-          const double fw = Wc + fyw_o + C.v[2][rr + 1] + Nx.v[2][rr] + zprev[2][rr - 1] + ch2;
-          emit(rr, k, fu, fv, fw, FUSE ? sacc[0][rr - 1] : 0.0, FUSE ? sacc[1][rr - 1] : 0.0, FUSE ? sacc[2][rr - 1] : 0.0);
+          const T fu = Uc + fyu_o + C.v[0][rr + 1] + Nx.v[0][rr] + zprev[0][rr - 1] + ch0;
+          const T fv = Vc + fyv_o + C.v[1][rr + 1] + Nx.v[1][rr] + zprev[1][rr - 1] + ch1;
+          const T fw = Wc + fyw_o + C.v[2][rr + 1] + Nx.v[2][rr] + zprev[2][rr - 1] + ch2;
+          emit(rr, k, fu, fv, fw, FUSE ? sacc[0][rr - 1] : (T)0, FUSE ? sacc[1][rr - 1] : (T)0, FUSE ? sacc[2][rr - 1] : (T)0);
         }
         fyu_o = Uc;
         fyv_o = Vc;
         fyw_o = Wc;
-        C.v[0][rr] = ldb(n0r, ucol, urow[rr]);
-        C.v[1][rr] = ldb(n1r, ucol, urow[rr]);
-        C.v[2][rr] = ldb(n2r, ucol, urow[rr]);
+        C.v[0][rr] = ldb<T>(n0r, ucol, urow[rr]);
+        C.v[1][rr] = ldb<T>(n1r, ucol, urow[rr]);
+        C.v[2][rr] = ldb<T>(n2r, ucol, urow[rr]);
         continue;
       }
-      const double Vn = next_h(Vc, rdlane(ch1, 16 + rr));
+      const T Vn = next_h(Vc, rdlane(ch1, 16 + rr));
       // y-fluxes through the face between rows rr and rr+1
-      const double fyu = flux(Uc, C.v[0][rr + 1], Vc, Vn, Y.vo);
-      const double fyv = flux(Vc, C.v[1][rr + 1], Vc, C.v[1][rr + 1], Y.vs);
-      const double fyw = flux(Wc, C.v[2][rr + 1], Vc, Nx.v[1][rr], Y.vo);
+      const T fyu = flux(Uc, C.v[0][rr + 1], Vc, Vn, Y.vo);
+      const T fyv = flux(Vc, C.v[1][rr + 1], Vc, C.v[1][rr + 1], Y.vs);
+      const T fyw = flux(Wc, C.v[2][rr + 1], Vc, Nx.v[1][rr], Y.vo);
       if (rr >= 1) {
-        const double Un = next_h(Uc, rdlane(ch0, 16 + rr)), Wn = next_h(Wc, rdlane(ch2, 16 + rr));
-        const double fxu = flux(Uc, Un, Uc, Un, X.vs);
-        const double fxv = flux(Vc, Vn, Uc, C.v[0][rr + 1], X.vo);
-        const double fxw = flux(Wc, Wn, Uc, Nx.v[0][rr], X.vo);
+        const T Un = next_h(Uc, rdlane(ch0, 16 + rr)), Wn = next_h(Wc, rdlane(ch2, 16 + rr));
+        const T fxu = flux(Uc, Un, Uc, Un, X.vs);
+        const T fxv = flux(Vc, Vn, Uc, C.v[0][rr + 1], X.vo);
+        const T fxw = flux(Wc, Wn, Uc, Nx.v[0][rr], X.vo);
         // left-face fluxes of lane 0 from the halo column x0-1 (all other lanes take their left neighbour's right face)
-        const double sU = rdlane(ch0, rr), sV = rdlane(ch1, rr), sW = rdlane(ch2, rr);
-        const double sUu = rdlane(ch0, rr + 1), sUn = rdlane(Nx.h[0], rr);
-        const double lxu = flux(sU, Uc, sU, Uc, X.vs);
-        const double lxv = flux(sV, Vc, sU, sUu, X.vo);
-        const double lxw = flux(sW, Wc, sU, sUn, X.vo);
-        double fu = (fxu - prev_h(fxu, lxu)) * X.rs;
-        double fv = (fxv - prev_h(fxv, lxv)) * X.ro;
-        double fw = (fxw - prev_h(fxw, lxw)) * X.ro;
+        const T sU = rdlane(ch0, rr), sV = rdlane(ch1, rr), sW = rdlane(ch2, rr);
+        const T sUu = rdlane(ch0, rr + 1), sUn = rdlane(Nx.h[0], rr);
+        const T lxu = flux(sU, Uc, sU, Uc, X.vs);
+        const T lxv = flux(sV, Vc, sU, sUu, X.vo);
+        const T lxw = flux(sW, Wc, sU, sUn, X.vo);
+        T fu = (fxu - prev_h(fxu, lxu)) * X.rs;
+        T fv = (fxv - prev_h(fxv, lxv)) * X.ro;
+        T fw = (fxw - prev_h(fxw, lxw)) * X.ro;
         fu += (fyu - fyu_o) * Y.ro;
         fv += (fyv - fyv_o) * Y.rs;
         fw += (fyw - fyw_o) * Y.ro;
-        const double zu = flux(Uc, Nx.v[0][rr], Wc, Wn, Z.vo);
-        const double zv = flux(Vc, Nx.v[1][rr], Wc, C.v[2][rr + 1], Z.vo);
-        const double zw = flux(Wc, Nx.v[2][rr], Wc, Nx.v[2][rr], Z.vs);
+        const T zu = flux(Uc, Nx.v[0][rr], Wc, Wn, Z.vo);
+        const T zv = flux(Vc, Nx.v[1][rr], Wc, C.v[2][rr + 1], Z.vo);
+        const T zw = flux(Wc, Nx.v[2][rr], Wc, Nx.v[2][rr], Z.vs);
         fu += (zu - zprev[0][rr - 1]) * Z.ro;
         fv += (zv - zprev[1][rr - 1]) * Z.ro;
         fw += (zw - zprev[2][rr - 1]) * Z.rs;
         zprev[0][rr - 1] = zu;
         zprev[1][rr - 1] = zv;
         zprev[2][rr - 1] = zw;
-        emit(rr, k, fu, fv, fw, FUSE ? sacc[0][rr - 1] : 0.0, FUSE ? sacc[1][rr - 1] : 0.0, FUSE ? sacc[2][rr - 1] : 0.0);
+        emit(rr, k, fu, fv, fw, FUSE ? sacc[0][rr - 1] : (T)0, FUSE ? sacc[1][rr - 1] : (T)0, FUSE ? sacc[2][rr - 1] : (T)0);
       }
       fyu_o = fyu;
       fyv_o = fyv;
       fyw_o = fyw;
       // row rr of plane k is dead: its registers receive plane `kload`
-      C.v[0][rr] = ldb(n0r, ucol, urow[rr]);
-      C.v[1][rr] = ldb(n1r, ucol, urow[rr]);
-      C.v[2][rr] = ldb(n2r, ucol, urow[rr]);
+      C.v[0][rr] = ldb<T>(n0r, ucol, urow[rr]);
+      C.v[1][rr] = ldb<T>(n1r, ucol, urow[rr]);
+      C.v[2][rr] = ldb<T>(n2r, ucol, urow[rr]);
     }
-    C.v[0][R + 1] = ldb(n0r, ucol, urow[R + 1]);
-    C.v[1][R + 1] = ldb(n1r, ucol, urow[R + 1]);
-    C.v[2][R + 1] = ldb(n2r, ucol, urow[R + 1]);
-    C.h[0] = ldb(n0r, uhoff, 0);
-    C.h[1] = ldb(n1r, uhoff, 0);
-    C.h[2] = ldb(n2r, uhoff, 0);
+    C.v[0][R + 1] = ldb<T>(n0r, ucol, urow[R + 1]);
+    C.v[1][R + 1] = ldb<T>(n1r, ucol, urow[R + 1]);
+    C.v[2][R + 1] = ldb<T>(n2r, ucol, urow[R + 1]);
+    C.h[0] = ldb<T>(n0r, uhoff, 0);
+    C.h[1] = ldb<T>(n1r, uhoff, 0);
+    C.h[2] = ldb<T>(n2r, uhoff, 0);
   };
 
   // Two register planes.  Loads past the chunk re-read plane k1 / p(k1+1) (cache hits) instead of branching.
-  Plane<R> P0, P1;
+  Plane<T, R> P0, P1;
   if (!CORR) {
     load_plane(P0, k0 - 1);
     load_plane(P1, k0);
@@ -377,7 +407,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
     }
   } else {
     // invariant at the top of iteration k: cur = corrected plane k, nxt = RAW plane k+1, Pa = p(k+1), Pb = p(k+2)
-    double Pa[R + 3], Pb[R + 3], Ha, Hb;
+    T Pa[R + 3], Pb[R + 3], Ha, Hb;
     load_p(Pa, Ha, k0 - 1);
     load_p(Pb, Hb, k0);
     load_plane(P0, k0 - 1);
@@ -426,25 +456,25 @@ Dir make_dir(const ins_grid* G, int d, double visc) {
   return r;
 }
 
-template <int R, int XW, bool FUSE, int NW>
+template <typename T, int R, int XW, bool FUSE, int NW>
 int launch_range(const ins_grid* G, FluxArgs& a, int corr_mode, hipStream_t s) {
   const unsigned nb = (unsigned)(8LL * a.ntx * ((a.nty + 7) / 8) * a.ntz);
   if (nb == 0) return INS_OK;
   const dim3 block(64, NW, 1);
-  if constexpr (NW <= 8 && R == 4) {
+  if constexpr (NW <= 8 && R == 4 && sizeof(T) == 8) {
     if (g_skel && corr_mode == 0) {
-      hipLaunchKernelGGL((k_flux64<R, XW, FUSE, 0, true, NW>), dim3(nb), block, (size_t)g_lds, s, a);
+      hipLaunchKernelGGL((k_flux64<T, R, XW, FUSE, 0, true, NW>), dim3(nb), block, (size_t)g_lds, s, a);
       INS_LAUNCH_CHECK();
       return INS_OK;
     }
   }
   if (corr_mode == 0)
-    hipLaunchKernelGGL((k_flux64<R, XW, FUSE, 0, false, NW>), dim3(nb), block, (size_t)g_lds, s, a);
+    hipLaunchKernelGGL((k_flux64<T, R, XW, FUSE, 0, false, NW>), dim3(nb), block, (size_t)g_lds, s, a);
   else if constexpr (FUSE && R <= 5) {
     if (corr_mode == 1)
-      hipLaunchKernelGGL((k_flux64<R, XW, true, 1, false, NW>), dim3(nb), block, (size_t)g_lds, s, a);
+      hipLaunchKernelGGL((k_flux64<T, R, XW, true, 1, false, NW>), dim3(nb), block, (size_t)g_lds, s, a);
     else
-      hipLaunchKernelGGL((k_flux64<R, XW, true, 2, false, NW>), dim3(nb), block, (size_t)g_lds, s, a);
+      hipLaunchKernelGGL((k_flux64<T, R, XW, true, 2, false, NW>), dim3(nb), block, (size_t)g_lds, s, a);
   } else {
     ins_set_error("in-kernel pressure correction needs the fused epilogue and <= 5 rows per thread");
     return INS_ERR_UNSUPPORTED;
@@ -455,7 +485,7 @@ int launch_range(const ins_grid* G, FluxArgs& a, int corr_mode, hipStream_t s) {
 
 // part 0: every plane; 1: the planes that read no ghost plane, [1 + ZB, nzl + 1 - ZB); 2: the two boundary ranges of ZB planes
 constexpr int ZB = 4;
-template <int R, int XW, bool FUSE, int NW = 4>
+template <typename T, int R, int XW, bool FUSE, int NW = 4>
 int launch(const ins_grid* G, FluxArgs& a, int corr_mode, int part, hipStream_t s) {
   const GridDev& g = G->g;
   a.ntx = cdiv(g.N[0] - 2, 64 * XW);
@@ -476,7 +506,7 @@ int launch(const ins_grid* G, FluxArgs& a, int corr_mode, int part, hipStream_t 
     a.kB = nzl + 1 - ZB;
   }
   a.ntz = part == 2 ? 2 : cdiv(a.k_hi - a.k_lo, a.zc);
-  return launch_range<R, XW, FUSE, NW>(G, a, corr_mode, s);
+  return launch_range<T, R, XW, FUSE, NW>(G, a, corr_mode, s);
 }
 
 }  // namespace
@@ -501,8 +531,8 @@ bool ins_flux64_supported(const ins_grid* G) {
 }
 
 // corr_mode 0: u has valid ghost volumes.  1 / 2: see k_flux64.  fuse: RK epilogue `epi`.
-int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, const RkEpi* epi, const double* pI, int corr_mode, hipStream_t s,
-                 int part) {
+template <typename T>
+static int flux64_dispatch(const ins_grid* G, double visc, const T* u, T* F, const RkEpi* epi, const T* pI, int corr_mode, hipStream_t s, int part) {
   const GridDev& g = G->g;
   FluxArgs a;
   memset(&a, 0, sizeof(a));
@@ -524,6 +554,8 @@ int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, con
   const int xw = xwo ? xwo : (waves_x >= 8 ? 2 : (waves_x >= 4 ? 4 : (waves_x >= 2 ? 2 : 1)));
   int rows = corr_mode ? (g_rows_corr ? g_rows_corr : 2) : (g_rows ? g_rows : 4);
   rows = std::min(std::max(rows, 2), corr_mode ? 5 : 6);
+  constexpr bool F32 = sizeof(T) == 4;  // the fp32 family is built for the default shapes only (2 rows correcting, 4 otherwise)
+  if (F32) rows = corr_mode ? 2 : 4;
   // Workgroup shape and z-chunk.  The wavefronts of a workgroup share halo rows / columns; a workgroup barrier per plane keeps them on
   // the same plane, so those shared lines are cache hits instead of HBM re-reads (512^3 plain K1, same box: 1.45 -> 1.37 ms with 4
   // wavefronts, 1.28 ms with 8 wavefronts = 128 x 16 cells per plane and workgroup: the flat-copy rate of that box, profiles/r02_k1_lab.txt;
@@ -559,23 +591,25 @@ int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, con
   if (rows != 2 && nw == 16) nw = 8;
   a.zc = zc;
   a.bar = ins_opt(OPT_INS_FLUX64_NOBAR) ? 0 : 1;
-#define INS_F64_CASE(RR, FUSE)                                                     \
-  if (rows == RR) {                                                                \
-    if constexpr (RR == 2) {                                                       \
-      if (nw == 16) {                                                              \
-        if (xw == 4) return launch<RR, 4, FUSE, 16>(G, a, corr_mode, part, s);     \
-        if (xw == 2) return launch<RR, 2, FUSE, 16>(G, a, corr_mode, part, s);     \
-        return launch<RR, 1, FUSE, 16>(G, a, corr_mode, part, s);                  \
-      }                                                                            \
-    }                                                                              \
-    if (nw >= 8) {                                                                 \
-      if (xw == 4) return launch<RR, 4, FUSE, 8>(G, a, corr_mode, part, s);        \
-      if (xw == 2) return launch<RR, 2, FUSE, 8>(G, a, corr_mode, part, s);        \
-      return launch<RR, 1, FUSE, 8>(G, a, corr_mode, part, s);                     \
-    }                                                                              \
-    if (xw == 4) return launch<RR, 4, FUSE>(G, a, corr_mode, part, s);             \
-    if (xw == 2) return launch<RR, 2, FUSE>(G, a, corr_mode, part, s);             \
-    return launch<RR, 1, FUSE>(G, a, corr_mode, part, s);                          \
+#define INS_F64_CASE(RR, FUSE)                                                        \
+  if constexpr (!F32 || RR == 2 || RR == 4) {                                         \
+    if (rows == RR) {                                                                 \
+      if constexpr (RR == 2 && !F32) {                                                \
+        if (nw == 16) {                                                               \
+          if (xw == 4) return launch<T, RR, 4, FUSE, 16>(G, a, corr_mode, part, s);   \
+          if (xw == 2) return launch<T, RR, 2, FUSE, 16>(G, a, corr_mode, part, s);   \
+          return launch<T, RR, 1, FUSE, 16>(G, a, corr_mode, part, s);                \
+        }                                                                             \
+      }                                                                               \
+      if (nw >= 8) {                                                                  \
+        if (xw == 4) return launch<T, RR, 4, FUSE, 8>(G, a, corr_mode, part, s);      \
+        if (xw == 2) return launch<T, RR, 2, FUSE, 8>(G, a, corr_mode, part, s);      \
+        return launch<T, RR, 1, FUSE, 8>(G, a, corr_mode, part, s);                   \
+      }                                                                               \
+      if (xw == 4) return launch<T, RR, 4, FUSE>(G, a, corr_mode, part, s);           \
+      if (xw == 2) return launch<T, RR, 2, FUSE>(G, a, corr_mode, part, s);           \
+      return launch<T, RR, 1, FUSE>(G, a, corr_mode, part, s);                        \
+    }                                                                                 \
   }
   if (epi) {
     INS_F64_CASE(2, true)
@@ -592,4 +626,14 @@ int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, con
   }
 #undef INS_F64_CASE
   return INS_ERR_INVALID;
+}
+
+int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, const RkEpi* epi, const double* pI, int corr_mode, hipStream_t s,
+                 int part) {
+  return flux64_dispatch<double>(G, visc, u, F, epi, pI, corr_mode, s, part);
+}
+// fp32 family (`_f32` entry points): same kernels instantiated for float; RkEpi's pointers are float arrays then
+int ins_k_flux64_f32(const ins_grid* G, double visc, const float* u, float* F, const RkEpi* epi, const float* pI, int corr_mode, hipStream_t s,
+                     int part) {
+  return flux64_dispatch<float>(G, visc, u, F, epi, pI, corr_mode, s, part);
 }

@@ -34,9 +34,9 @@ def c_kind(p):
     }
     if t in table:
         return table[t]
-    if re.fullmatch(r"ins_[a-z_]+_t\*\*", t):
+    if re.fullmatch(r"ins_[a-z0-9_]+_t\*\*", t):
         return "handle_out"
-    if re.fullmatch(r"ins_[a-z_]+_t\*", t):
+    if re.fullmatch(r"ins_[a-z0-9_]+_t\*", t):
         return "ptr"
     raise AssertionError(f"unclassified C parameter: {p!r} -> {t!r}")
 
