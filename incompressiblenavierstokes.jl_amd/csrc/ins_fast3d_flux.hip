@@ -140,14 +140,28 @@ __global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __r
 
   long long rowoff[R + 2];  // element offset of (row, column) inside a padded plane
   long long prow[R + 3];    // ... inside an unpadded pI plane (CORR only)
+  // CORR == 3 (masked grids, Periodic / Dirichlet sides): the stencil input is the previous stage's UNCORRECTED u* with its boundary data
+  // in place (apply_bc_u! has run on it) and pI is the PADDED pressure of that stage's projection.  Periodic directions are read
+  // through the periodic image (their ghost volumes hold uncorrected copies), the others at their padded index; the correction is
+  // applied to degrees of freedom only (applypressure!, operators.jl:225-233), so boundary data stays what apply_bc_u! wrote.
+  const bool perx = CORR == 3 && g.bc[0][0] == INS_BC_PERIODIC, pery = CORR == 3 && g.bc[1][0] == INS_BC_PERIODIC,
+             perz = CORR == 3 && g.bc[2][0] == INS_BC_PERIODIC;
+  const int colx = CORR == 3 ? (perx ? wrap(min(i, N0), n0) + 1 : ic) : 0;
+  auto rowy = [&](int j) { return pery ? wrap(min(j, N1 + 1), n1) + 1 : min(j, N1 - 1); };
+  auto planez = [&](int kk) { return perz ? wrap(min(kk, N2 + 1), n2) + 1 : min(max(kk, 0), N2 - 1); };
 #pragma unroll
   for (int rr = 0; rr < R + 2; ++rr) {
-    if (CORR)
+    if (CORR == 3)
+      rowoff[rr] = (long long)rowy(jb - 1 + rr) * N0 + colx;
+    else if (CORR)
       rowoff[rr] = (long long)(wrap(min(jb - 1 + rr, N1), n1) + 1) * N0 + (wrap(min(i, N0), n0) + 1);
     else
       rowoff[rr] = (long long)min(jb - 1 + rr, N1 - 1) * N0 + ic;
   }
-  if (CORR) {
+  if (CORR == 3) {
+#pragma unroll
+    for (int rr = 0; rr < R + 3; ++rr) prow[rr] = (long long)rowy(jb - 1 + rr) * N0 + colx;
+  } else if (CORR) {
 #pragma unroll
     // one index beyond the padded range is still a valid periodic image: the right ghost column / row / plane is
     // corrected with p of ITS right neighbour (image index 2)
@@ -156,14 +170,14 @@ __global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __r
 
   // kk = padded plane index (CORR 1: wrapped into the interior; CORR 2: ghost planes are valid, clamp the unused overshoot)
   auto load_plane = [&](Plane<R>& P, int kk) {
-    const double* base = u + (long long)(CORR == 1 ? wrap(kk, n2) + 1 : (CORR == 2 ? min(kk, N2 - 1) : kk)) * sz;
+    const double* base = u + (long long)(CORR == 3 ? planez(kk) : (CORR == 1 ? wrap(kk, n2) + 1 : (CORR == 2 ? min(kk, N2 - 1) : kk))) * sz;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int rr = 0; rr < R + 2; ++rr) P.v[c][rr] = base[c * g.sc + rowoff[rr]];
   };
   auto load_p = [&](double (&P)[R + 3], int kk) {
-    const double* base = pI + (long long)(CORR == 2 ? min(kk, N2) : wrap(kk, n2)) * n0 * n1;
+    const double* base = CORR == 3 ? pI + (long long)planez(kk) * sz : pI + (long long)(CORR == 2 ? min(kk, N2) : wrap(kk, n2)) * n0 * n1;
 #pragma unroll
     for (int rr = 0; rr < R + 3; ++rr) P[rr] = base[prow[rr]];
   };
@@ -171,6 +185,28 @@ __global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __r
   const Rec X = rx[UNIFORM ? 1 : min(i, N0 - 2)];
   // u = u* - ∇p for one register plane (padded plane index kk; Pc = p rows of plane kk, Pn = of plane kk+1)
   auto correct = [&](Plane<R>& P, const double (&Pc)[R + 3], const double (&Pn)[R + 3], int kk) {
+    if constexpr (CORR == 3) {
+      const int kz = planez(kk);  // the volume this register plane holds (image index in a periodic direction)
+      const Rec Zc = rz[min(max(kz, 1), N2 - 2)];
+      const Rec Xc = rx[min(max(colx, 1), N0 - 2)];
+      bool dx[3], dz[3];
+#pragma unroll
+      for (int al = 0; al < 3; ++al) {
+        dx[al] = colx >= g.iu_lo[al][0] && colx < g.iu_hi[al][0];
+        dz[al] = kz >= g.iu_lo[al][2] && kz < g.iu_hi[al][2];
+      }
+#pragma unroll
+      for (int rr = 0; rr < R + 2; ++rr) {
+        const int jy = rowy(jb - 1 + rr);
+        const Rec Y = ry[min(max(jy, 1), N1 - 2)];
+        const double pc = Pc[rr];
+        const double gx = (from_next(pc) - pc) * Xc.rs, gy = (Pc[rr + 1] - pc) * Y.rs, gz = (Pn[rr] - pc) * Zc.rs;
+        if (dx[0] && dz[0] && jy >= g.iu_lo[0][1] && jy < g.iu_hi[0][1]) P.v[0][rr] -= gx;
+        if (dx[1] && dz[1] && jy >= g.iu_lo[1][1] && jy < g.iu_hi[1][1]) P.v[1][rr] -= gy;
+        if (dx[2] && dz[2] && jy >= g.iu_lo[2][1] && jy < g.iu_hi[2][1]) P.v[2][rr] -= gz;
+      }
+      return;
+    }
     const Rec Z = rz[UNIFORM ? 1 : min(max(kk, 1), N2 - 2)];
 #pragma unroll
     for (int rr = 0; rr < R + 2; ++rr) {
@@ -447,7 +483,19 @@ static int launch_flux(const ins_grid* G, const double* u, double* F, const RkEp
   const int ntx = cdiv(g.N[0] - 2, xo * XW), nty = cdiv(g.N[1] - 2, (4 / XW) * reff), ntz = cdiv(g.N[2] - 2, zc);
   dim3 block(64, 4, 1);
   const unsigned nb = (unsigned)(8LL * ntx * ((nty + 7) / 8) * ntz);
-  if (corr) {
+  if (corr && corr_mode == 3) {  // masked / stretched grids with Periodic and Dirichlet sides: padded p, DOF-masked correction
+    if constexpr (FUSE) {
+      constexpr int R3 = R > 2 ? 2 : R;
+      const int nty3 = cdiv(g.N[1] - 2, (4 / XW) * R3), ntx3 = cdiv(g.N[0] - 2, (XOUT - 1) * XW);
+      const unsigned nb3 = (unsigned)(8LL * ntx3 * ((nty3 + 7) / 8) * ntz);
+      hipLaunchKernelGGL((k_momentum_flux<R3, false, true, XW, true, 3>), dim3(nb3), block, 0, s, g, r0, r1, r2, u, F, zc, ntx3, nty3, ntz, epi, pI, bar);
+      INS_LAUNCH_CHECK();
+      return INS_OK;
+    } else {
+      ins_set_error("in-kernel pressure correction needs the fused epilogue");
+      return INS_ERR_UNSUPPORTED;
+    }
+  } else if (corr) {
     if (!(FUSE && G->uniform_exact && !masked)) {
       ins_set_error("in-kernel pressure correction needs the fused path on an exactly uniform periodic grid");
       return INS_ERR_UNSUPPORTED;
@@ -531,6 +579,24 @@ int ins_k_momentum_rk_fused_corr(const ins_grid* G, double visc, const double* u
   int rc = ins_flux3d_prepare(G, visc, s);
   if (rc) return rc;
   return launch_flux_any<true>(G, ustar_prev, k_out, epi, pI, 1, s);
+}
+
+bool ins_fast3d_supported(const ins_grid* G);
+// Masked / stretched grids whose sides are all Periodic or Dirichlet (cavities, channels): ustar_prev is the previous stage's uncorrected
+// u* with apply_bc_u! applied, p_padded that stage's pressure (padded layout; only interior values and periodic images are read).
+bool ins_corr3_supported(const ins_grid* G) {
+  const GridDev& g = G->g;
+  if (g.D != 3 || !ins_fast3d_supported(G) || g.N[0] < 8 || g.N[1] < 8 || g.N[2] < 8) return false;
+  for (int a = 0; a < 3; ++a)
+    for (int sd = 0; sd < 2; ++sd)
+      if (g.bc[a][sd] != INS_BC_PERIODIC && g.bc[a][sd] != INS_BC_DIRICHLET) return false;
+  return true;
+}
+int ins_k_momentum_rk_fused_corr3(const ins_grid* G, double visc, const double* ustar_prev, const double* p_padded, double* k_out, const RkEpi& epi,
+                                  hipStream_t s) {
+  int rc = ins_flux3d_prepare(G, visc, s);
+  if (rc) return rc;
+  return launch_flux_any<true>(G, ustar_prev, k_out, epi, p_padded, 3, s);
 }
 
 // Slab flavour: z neighbours from ghost planes; p_ext = [1 plane below | local planes | 2 planes above] (unpadded in x, y).

@@ -246,6 +246,11 @@ int ins_k_momentum_rk_fused_corr(const ins_grid* G, double visc, const double* u
                                  hipStream_t s);
 int ins_k_momentum_rk_fused_corr_slab(const ins_grid* G, double visc, const double* ustar_prev, const double* p_ext, double* k_out,
                                       const RkEpi& epi, hipStream_t s, int part = 0);
+bool ins_corr3_supported(const ins_grid* G);
+int ins_k_momentum_rk_fused_corr3(const ins_grid* G, double visc, const double* ustar_prev, const double* p_padded, double* k_out, const RkEpi& epi,
+                                  hipStream_t s);
+bool ins_k_project_fdm_fused(const ins_poisson* ps);
+int ins_k_project_fdm_solve_only(const ins_grid* G, ins_poisson* ps, const double* u, double* p, hipStream_t s);
 int ins_k_project_periodic_fused_2d(const ins_grid* G, ins_poisson* ps, double* u, double* p, bool keep_p, hipStream_t s);
 bool ins_poisson_own2d(const ins_poisson* ps);
 int ins_k_project_periodic_solve_only(const ins_grid* G, ins_poisson* ps, const double* u, hipStream_t s);

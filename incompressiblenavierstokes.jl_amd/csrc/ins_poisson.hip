@@ -65,7 +65,7 @@ __device__ __forceinline__ int map_p(int I, int lo, int hi, int bcl, int bcr) { 
   return -2;
 }
 
-template <int D>
+template <int D, bool GRAD = true>
 __global__ __launch_bounds__(256) void k_unpack_grad_bc(GridDev g, double* __restrict__ u, double* __restrict__ p, const double* __restrict__ pI,
                                                         int n0, int n1, const double* __restrict__ shift) {
   const int I0 = g.ip_lo[0] - 1 + blockIdx.x * 64 + threadIdx.x;
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void k_unpack_grad_bc(GridDev g, double* __res
   const double pc = zero ? 0.0 : pI[q] - sh;
   const long long c = I[0] + I[1] * g.sx[1] + I[2] * g.sx[2];
   p[c] = pc;
+  if (!GRAD) return;  // solve only: the gradient-subtract is left to the next stage's stencil kernel (ins_fast3d_flux.hip, CORR = 3)
 #pragma unroll
   for (int a = 0; a < D; ++a) {
     bool dof = true;
@@ -1020,6 +1021,33 @@ extern "C" int ins_poisson_last_info(const ins_poisson_t* ps, int64_t* iteration
 }
 
 // project!(u, setup; psolver, p)                                                   pressure.jl:69-82
+// project! without its last statement: p <- solution of L p = Ω div(u) (padded, ghost pressures per apply_bc_p!), u untouched.
+// Direct solver inside its fused project form only (the caller checks ins_k_project_fdm_fused).
+bool ins_k_project_fdm_fused(const ins_poisson* ps) { return ps->kind == POISSON_FDM && !ins_opt(OPT_INS_DISABLE_FDM_FUSED); }
+int ins_k_project_fdm_solve_only(const ins_grid* G, ins_poisson* ps, const double* u, double* p, hipStream_t s) {
+  const GridDev& g = G->g;
+  int rc;
+  double* buf = ins_fdm_buffer(ps->fdm);
+  dim3 block(64, 4, 1), grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), g.D == 3 ? ps->np[2] : 1);
+  if (ins_fdm_takes_u(ps->fdm)) {
+    if ((rc = ins_fdm_solve(ps->fdm, s, G, u))) return rc;
+  } else {
+    if (g.D == 2)
+      hipLaunchKernelGGL(k_div_to_pI<2>, grid, block, 0, s, g, u, buf, ps->np[0], ps->np[1]);
+    else
+      hipLaunchKernelGGL(k_div_to_pI<3>, grid, block, 0, s, g, u, buf, ps->np[0], ps->np[1]);
+    INS_LAUNCH_CHECK();
+    if ((rc = ins_fdm_solve(ps->fdm, s))) return rc;
+  }
+  dim3 gridp(cdiv(ps->np[0] + 2, 64), cdiv(ps->np[1] + 2, 4), g.D == 3 ? ps->np[2] + 2 : 1);
+  if (g.D == 2)
+    hipLaunchKernelGGL((k_unpack_grad_bc<2, false>), gridp, block, 0, s, g, nullptr, p, (const double*)buf, ps->np[0], ps->np[1], ins_fdm_mean(ps->fdm));
+  else
+    hipLaunchKernelGGL((k_unpack_grad_bc<3, false>), gridp, block, 0, s, g, nullptr, p, (const double*)buf, ps->np[0], ps->np[1], ins_fdm_mean(ps->fdm));
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
 int ins_k_project(const ins_grid* G, ins_poisson* ps, double* u, double* p, hipStream_t s) {
   const GridDev& g = G->g;
   int rc;

@@ -402,9 +402,15 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
         INS_HIP_TRY(hipMalloc(&rk->ub[b], vbytes));
         INS_HIP_TRY(hipMemcpyAsync(rk->ub[b], u, vbytes, hipMemcpyDeviceToDevice, s));  // once: volumes no kernel ever writes
       }
+    // Masked grids with Periodic / Dirichlet sides and the direct solver: stages >= 2 read the previous stage's UNCORRECTED u* and its
+    // pressure and apply `u = u* - ∇p` in registers on the degrees of freedom (CORR = 3 of the 62-wide stage kernel), so between two
+    // stages the projection only solves for p: no gradient-subtract pass over u, no second ghost fill.  Same arithmetic per volume as
+    // project! + apply_bc_u! (boundary data is time-independent on this entry point); INS_DISABLE_INKERNEL_CORR restores them.
+    const bool incorr = tiled && ns > 1 && !ins_opt(OPT_INS_DISABLE_INKERNEL_CORR) && ins_corr3_supported(G) && ins_k_project_fdm_fused(rk->ps);
     double* cur = u;
     for (int i = 0; i < ns; ++i) {
-      if ((rc = ins_k_apply_bc_u(G, cur, 0, nullptr, s))) return rc;           // :19
+      const bool corr_in = incorr && i > 0;
+      if (!corr_in && (rc = ins_k_apply_bc_u(G, cur, 0, nullptr, s))) return rc;  // :19 (corr_in: `cur` got its boundary data at :48 already)
       double* out = (i == ns - 1 && ns > 1) ? u : rk->ub[i & 1];
       RkEpi epi;
       memset(&epi, 0, sizeof(epi));
@@ -433,8 +439,11 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
         INS_HIP_TRY(hipEventCreate(&e1));
         INS_HIP_TRY(hipEventRecord(e0, s));
       }
-      rc = tiled ? ins_k_momentum_rk_fused(G, visc, cur, rk->ku[i], epi, s)
-                 : (ins_flux2d_supported(G) ? ins_k_flux2d(G, visc, cur, rk->ku[i], &epi, s) : ins_k_momentum_rk_fused_generic(G, visc, cur, rk->ku[i], epi, s));
+      if (corr_in)
+        rc = ins_k_momentum_rk_fused_corr3(G, visc, cur, rk->p, rk->ku[i], epi, s);
+      else
+        rc = tiled ? ins_k_momentum_rk_fused(G, visc, cur, rk->ku[i], epi, s)
+                   : (ins_flux2d_supported(G) ? ins_k_flux2d(G, visc, cur, rk->ku[i], &epi, s) : ins_k_momentum_rk_fused_generic(G, visc, cur, rk->ku[i], epi, s));
       if (rc) return rc;   // :21, :35-38
       if (rk->profiling) {
         INS_HIP_TRY(hipEventRecord(e1, s));
@@ -443,7 +452,11 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
       }
       cur = out;
       if ((rc = ins_k_apply_bc_u(G, cur, 0, nullptr, s))) return rc;           // :48
-      if ((rc = ins_k_project(G, rk->ps, cur, rk->p, s))) return rc;            // :49
+      if (incorr && i < ns - 1)
+        rc = ins_k_project_fdm_solve_only(G, rk->ps, cur, rk->p, s);            // :49 without its gradient-subtract
+      else
+        rc = ins_k_project(G, rk->ps, cur, rk->p, s);                           // :49
+      if (rc) return rc;
     }
     if (ns == 1) INS_HIP_TRY(hipMemcpyAsync(u, rk->ub[0], vbytes, hipMemcpyDeviceToDevice, s));
     return ins_k_apply_bc_u(G, u, 0, nullptr, s);                              // :55

@@ -783,3 +783,136 @@ def test_direct_solver_cosine_grid_1024_projection(ins, oracle):
     assert np.abs(res).sum() < 1e-5 * np.abs(f[ip]).sum()  # cond(L) ~ 1e10..1e11 (observed 1.3e-7); dropped low modes: O(1)
     assert _flux_imbalance_ratio(ins, sp, solver, u_h, ip) < 1e-5
     assert np.abs(p[ip]).max() > 1e-2  # the pressure of this smooth field lives in the first cosine modes (0.29 at N = 256)
+
+
+# ------------------------------------------------------------------ masked grids: in-register pressure correction (config 5 path)
+def _numpy_fast_diagonalisation(o, so):
+    """The oracle's direct solve of `laplacian_mat` (pressure.jl:101-154, bordered when singular) for tensor-product grids by per-direction
+    eigen-decompositions in numpy — the sparse LU of oracle.psolver_direct is too slow beyond ~20k unknowns.  Independent of the device code
+    (dense numpy), and pinned to that LU on a small box by the caller."""
+    g = so.grid
+    D = g.D
+    ip = tuple(slice(lo, hi) for lo, hi in g.Ip)
+    L = o.laplacian_mat(so).toarray() if int(np.prod(g.Np)) <= 1500 else None
+    V, lam = [], []
+    for a in range(D):
+        lo, hi = g.Ip[a]
+        n = hi - lo
+        # 1-D factor Tα by probing the oracle's laplacian! with unit vectors along direction a (everything else one volume wide is not
+        # available, so build it from the definition: Ω/Δα ((p₊-p)/Δu[I] - (p-p₋)/Δu[I-1]) with apply_bc_p! ghosts, boundary branches of operators.jl:328-350)
+        T = np.zeros((n, n))
+        bl, br = so.boundary_conditions[a]
+        du = g.dxu[a]
+        for i in range(n):
+            I = lo + i
+            cr, cl = 1.0 / du[I], 1.0 / du[I - 1]
+            first, last = i == 0, i == n - 1
+            right = left = True
+            gl = gr = None
+            if first and isinstance(bl, o.PressureBC):
+                pass
+            elif last and isinstance(br, o.PressureBC):
+                pass
+            elif first and isinstance(bl, o.DirichletBC):
+                left = False
+            elif last and isinstance(br, o.DirichletBC):
+                right = False
+            else:
+                if first:
+                    gl = n - 1 if isinstance(bl, o.PeriodicBC) else i
+                if last:
+                    gr = 0 if isinstance(br, o.PeriodicBC) else i
+            if right:
+                T[i, i] -= cr
+                j = i + 1 if not last else gr
+                if j is not None:
+                    T[i, j] += cr
+            if left:
+                T[i, i] -= cl
+                j = i - 1 if not first else gl
+                if j is not None:
+                    T[i, j] += cl
+        dm = 1.0 / np.sqrt(g.dx[a][lo:hi])
+        l, W = np.linalg.eigh(dm[:, None] * T * dm[None, :])
+        V.append(dm[:, None] * W)
+        lam.append(l)
+    singular = not any(isinstance(b, o.PressureBC) for side in so.boundary_conditions for b in side)
+    lam = [l.copy() for l in lam]
+    if singular:
+        for l in lam:
+            l[np.argmin(np.abs(l))] = 0.0
+    S = lam[0].reshape(-1, 1, 1) + lam[1].reshape(1, -1, 1) + (lam[2].reshape(1, 1, -1) if D == 3 else 0.0)
+    if D == 2:
+        S = S[..., 0]
+    sub = "abc"[:D]
+
+    def psolve_(p):
+        f = p[ip].copy()
+        if singular:
+            f -= f.mean()
+        q = f
+        for a in range(D):
+            q = np.moveaxis(np.tensordot(V[a].T, q, axes=([1], [a])), 0, a)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            q = np.where(S == 0.0, 0.0, q / S)
+        for a in range(D):
+            q = np.moveaxis(np.tensordot(V[a], q, axes=([1], [a])), 0, a)
+        if singular:
+            q -= q.mean()
+        p[ip] = q
+        return p
+
+    return psolve_
+
+
+@pytest.mark.parametrize("geom", ["cavity", "channel", "allwalls"])
+@pytest.mark.parametrize("method", ["RK44", "Wray3"])
+def test_masked_inkernel_correction_matches_oracle(ins, oracle, geom, method):
+    """Mid-size (64 x 48 x 32) stretched boxes with Dirichlet / Periodic sides and the direct solver: stages >= 2 read the previous stage's
+    uncorrected u* and its pressure and apply the projection's gradient-subtract in registers on the degrees of freedom (62-wide stage
+    kernel, CORR = 3; csrc/ins_rk.hip).  Three steps against the oracle's stage loop (step_explicit_runge_kutta.jl:17-50 with
+    pressure.jl:69-82 after every stage; the oracle's direct solver in its fast-diagonalisation form, pinned above), and against the same
+    library with the correction left to project! (INS_DISABLE_INKERNEL_CORR)."""
+    from ins_amd import _lib
+
+    o = oracle
+    lid = (1.0, 0.2, 0.0)
+    Do, Po, Dp, Pp = o.DirichletBC, o.PeriodicBC, ins.DirichletBC, ins.PeriodicBC
+    if geom == "cavity":  # examples/LidDrivenCavity3D.jl: cosine x, y with a moving lid, periodic z
+        x = (o.cosine_grid(0.0, 1.0, 64), o.cosine_grid(0.0, 1.0, 48), np.linspace(-0.2, 0.2, 33))
+        bo = ((Do(), Do()), (Do(), Do(lid)), (Po(), Po()))
+        bp = ((Dp(), Dp()), (Dp(), Dp(lid)), (Pp(), Pp()))
+    elif geom == "channel":  # periodic x and z, tanh walls in y (Fourier x/z inside the direct solver)
+        x = (np.linspace(0.0, 2.0, 65), o.tanh_grid(0.0, 1.0, 48, 1.5), np.linspace(0.0, 1.0, 33))
+        bo = ((Po(), Po()), (Do(), Do()), (Po(), Po()))
+        bp = ((Pp(), Pp()), (Dp(), Dp()), (Pp(), Pp()))
+    else:  # walls everywhere, stretched in all three directions
+        x = (o.tanh_grid(0.0, 1.0, 64, 1.2), o.cosine_grid(0.0, 1.0, 48), o.tanh_grid(0.0, 0.5, 32, 1.1))
+        bo = ((Do(), Do()), (Do(), Do(lid)), (Do(), Do()))
+        bp = ((Dp(), Dp()), (Dp(), Dp(lid)), (Dp(), Dp()))
+    so = o.make_setup(x, bo, Re=200.0)
+    sp = ins.Setup(x=x, boundary_conditions=bp, Re=200.0)
+    g = so.grid
+    pso, psp = _numpy_fast_diagonalisation(o, so), ins.psolver_direct(sp)
+    X = [g.xp[a].reshape([-1 if b == a else 1 for b in range(3)]) for a in range(3)]
+    Lz = x[2][-1] - x[2][0]
+    u0 = np.zeros(g.N + (3,), order="F")
+    u0[..., 0] = 0.3 * np.sin(np.pi * X[0]) * np.cos(2 * np.pi * X[1]) * np.cos(2 * np.pi * X[2] / Lz)
+    u0[..., 1] = -0.2 * np.cos(np.pi * X[0]) * np.sin(np.pi * X[1]) + 0 * X[2]
+    u0[..., 2] = 0.1 * np.sin(2 * np.pi * X[0]) * np.sin(np.pi * X[1]) * np.sin(2 * np.pi * X[2] / Lz)
+    u0 = o.apply_bc_u(u0, 0.0, so)
+    u0 = o.project(u0, so, pso)
+    o.apply_bc_u_(u0, 0.0, so)
+    m, mo = getattr(ins.RKMethods, method)(), getattr(o, method)()
+    dt = 0.5 * o.get_cfl_timestep(u0, so)
+    want = o.solve_unsteady(so, (0.0, 3 * dt), u0, method=mo, psolver=pso, dt=dt)["u"]
+    mask = np.zeros(g.N + (3,), dtype=bool)
+    for a in range(3):
+        mask[tuple(slice(max(lo_ - 1, 0), min(hi_ + 1, n_)) for (lo_, hi_), n_ in zip(g.Iu[a], g.N)) + (a,)] = True
+    outs = {}
+    for key, opts in (("corr", {}), ("project", {"INS_DISABLE_INKERNEL_CORR": 1})):
+        with _lib.options(**opts):
+            (u, _, t), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 3 * dt), ustart=ins.from_numpy(sp, u0), method=m, psolver=psp, Δt=dt)
+            outs[key] = ins.to_numpy(u)
+        assert rell2(outs[key][mask], want[mask]) < STEP_TOL, key
+    assert rell2(outs["corr"][mask], outs["project"][mask]) < 1e-12

@@ -291,3 +291,34 @@ def test_lmwray3_equals_wray3_tableau(oracle):
         st = o.timestep_lmwray3_(st, 0.01, cache)
     assert np.allclose(st["u"], ref, rtol=1e-11, atol=1e-13)
     assert st["t"] == pytest.approx(0.02) and st["n"] == 2
+
+
+def _rell2(a, b):
+    return float(np.sqrt(np.sum((a - b) ** 2)) / max(np.sqrt(np.sum(b**2)), 1e-300))
+
+
+def test_numpy_fast_diagonalisation_is_the_oracles_direct_solver(oracle):
+    """Pins the helper above to oracle.psolver_direct (sparse LU of laplacian_mat, bordered when singular) on small boxes of the three mid-size
+    geometries, consistent and inconsistent right-hand sides."""
+    from tests.test_gpu_parity import _numpy_fast_diagonalisation as numpy_fast_diagonalisation
+
+    o = oracle
+    lid = (1.0, 0.2, 0.0)
+    D_, P_ = o.DirichletBC, o.PeriodicBC
+    for x, bcs in (
+        ((o.cosine_grid(0.0, 1.0, 8), o.cosine_grid(0.0, 1.0, 6), np.linspace(-0.2, 0.2, 5)), ((D_(), D_()), (D_(), D_(lid)), (P_(), P_()))),
+        ((np.linspace(0.0, 2.0, 7), o.tanh_grid(0.0, 1.0, 8, 1.5), np.linspace(0.0, 1.0, 5)), ((P_(), P_()), (D_(), D_()), (P_(), P_()))),
+        ((o.tanh_grid(0.0, 1.0, 8, 1.2), o.cosine_grid(0.0, 1.0, 6), o.tanh_grid(0.0, 0.5, 5, 1.1)), ((D_(), D_()), (D_(), D_(lid)), (D_(), D_()))),
+    ):
+        so = o.make_setup(x, bcs, Re=200.0)
+        g = so.grid
+        ip = tuple(slice(lo, hi) for lo, hi in g.Ip)
+        mine, ref = numpy_fast_diagonalisation(o, so), o.psolver_direct(so)
+        for seed in (1, 2):
+            f = fx.randn_field(g.N, seed)
+            a, b = mine(f.copy(order="F"))[ip], ref(f.copy(order="F"))[ip]
+            assert _rell2(a - a.mean(), b - b.mean()) < 1e-10
+
+
+
+
