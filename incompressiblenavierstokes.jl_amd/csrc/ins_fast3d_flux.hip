@@ -95,7 +95,7 @@ struct Plane {
 // CORR = 2: the same on a z-slab — x, y through the periodic image, z through exchanged ghost planes: `u` has valid z-ghost
 // planes of u*, and `pI` is the EXTENDED pressure buffer [1 ghost plane below | nzl local planes | 2 ghost planes above].
 template <int R, bool UNIFORM, bool MASKED, int XW, bool FUSE, int CORR>
-__global__ __launch_bounds__(256) void k_momentum_flux(GridDev g, const Rec* __restrict__ rx, const Rec* __restrict__ ry,
+__global__ __launch_bounds__(256, 2) void k_momentum_flux(GridDev g, const Rec* __restrict__ rx, const Rec* __restrict__ ry,
                                                        const Rec* __restrict__ rz, const double* __restrict__ u,
                                                        double* __restrict__ F, int zc, int ntx, int nty, int ntz, RkEpi epi,
                                                        const double* __restrict__ pI, int bar) {
