@@ -397,6 +397,117 @@ __global__ __launch_bounds__(256) void k_gradient_march(GridDev g, BoxMap L, int
   }
 }
 
+// 3-D, register rows (the stage kernel's formulation, ins_fast3d_flux.hip): lanes run along x (lanes 0 and 63 are halo columns, 62 outputs
+// per wavefront), every work-item keeps R + 2 rows of the three components of THREE planes in registers and marches through a z-chunk;
+// x neighbours come from DPP wave shifts, y neighbours from the work-item's own rows, z neighbours from the plane registers.  Per plane
+// a work-item issues 3 (R + 2) loads for R cells (R = 4: 4.6 per cell with the halo lanes) against ~40 for the plain kernel — the plain and
+// the LDS-ring kernels were bound by the vector-L1 / texture-addresser rate (250 M accesses per launch at 256³), not by HBM.
+// One barrier per plane keeps the four y-stacked wavefronts of a workgroup on one plane (shared halo rows are cache hits).
+__device__ __forceinline__ double lane_next(double v) {  // lane l receives lane l+1
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_prev(double v) {  // lane l receives lane l-1
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+constexpr int GR_XO = 62;
+template <int OP, int R>
+__global__ __launch_bounds__(256) void k_gradient_rows(GridDev g, BoxMap L, int zc, double par, const double* __restrict__ u, double* __restrict__ out) {
+  int seq = (int)(blockIdx.x >> 3);
+  const int tx = seq % L.ntx;
+  seq /= L.ntx;
+  const int ty = (int)(blockIdx.x & 7) * L.nty_l + seq % L.nty_l;
+  if (ty >= L.nty) return;  // whole workgroup
+  const int chunk = seq / L.nty_l;
+  const int lane = threadIdx.x, wy = threadIdx.y;
+  const int i = g.ip_lo[0] - 1 + tx * GR_XO + lane;  // lane 0 = left halo column
+  const int ic = min(i, g.N[0] - 1);
+  const int jb = g.ip_lo[1] + (ty * 4 + wy) * R;  // first output row of this wavefront
+  const int k0 = g.ip_lo[2] + chunk * zc, k1 = min(k0 + zc, g.ip_hi[2]);
+  const bool wave_on = i - lane < g.ip_hi[0] && jb < g.ip_hi[1];  // wave-uniform
+  const bool xout = lane >= 1 && lane <= GR_XO && i < g.ip_hi[0];
+  long long rowoff[R + 2];
+#pragma unroll
+  for (int rr = 0; rr < R + 2; ++rr) rowoff[rr] = (long long)min(jb - 1 + rr, g.N[1] - 1) * g.sx[1] + ic;
+  double P[3][3][R + 2];  // [plane slot][component][row]
+  auto load_plane = [&](double (&Q)[3][R + 2], int kk) {
+    const double* base = u + (long long)min(kk, g.N[2] - 1) * g.sx[2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int rr = 0; rr < R + 2; ++rr) Q[a][rr] = base[a * g.sc + rowoff[rr]];
+  };
+  // per-lane x metrics
+  const double rdx_x = g.rdx[0][ic], rux1 = g.rdxu[0][ic], rux0 = g.rdxu[0][max(ic - 1, 0)];
+  auto body = [&](const double (&M)[3][R + 2], const double (&C)[3][R + 2], const double (&N)[3][R + 2], int k) {
+    const double rdx_z = g.rdx[2][k], ruz1 = g.rdxu[2][k], ruz0 = g.rdxu[2][k - 1];
+#pragma unroll
+    for (int rr = 1; rr <= R; ++rr) {
+      const int j = jb - 1 + rr;
+      const int jc = min(j, g.N[1] - 2);
+      const double rdx_y = g.rdx[1][jc], ruy1 = g.rdxu[1][jc], ruy0 = g.rdxu[1][jc - 1];
+      // value of component a at offset (ox, oy, oz) from this cell
+      auto U = [&](int a, int ox, int oy, int oz) {
+        const double v = oz < 0 ? M[a][rr + oy] : (oz > 0 ? N[a][rr + oy] : C[a][rr + oy]);
+        return ox < 0 ? lane_prev(v) : (ox > 0 ? lane_next(v) : v);
+      };
+      auto at = [&](int a, int da, int sa_, int db, int sb_) {  // offsets sa_·e_da + sb_·e_db
+        const int ox = (da == 0 ? sa_ : 0) + (db == 0 ? sb_ : 0);
+        const int oy = (da == 1 ? sa_ : 0) + (db == 1 ? sb_ : 0);
+        const int oz = (da == 2 ? sa_ : 0) + (db == 2 ? sb_ : 0);
+        return U(a, ox, oy, oz);
+      };
+      const double rd[3] = {rdx_x, rdx_y, rdx_z}, r1s[3] = {rux1, ruy1, ruz1}, r0s[3] = {rux0, ruy0, ruz0};
+      double G[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          if (a == b) {
+            G[a][b] = (at(a, a, 0, b, 0) - at(a, a, 0, b, -1)) * rd[b];
+          } else {
+            const double r1 = r1s[b], r0 = r0s[b];
+            G[a][b] = ((at(a, a, 0, b, 1) - at(a, a, 0, b, 0)) * r1 + (at(a, a, -1, b, 1) - at(a, a, -1, b, 0)) * r1 +
+                       (at(a, a, 0, b, 0) - at(a, a, 0, b, -1)) * r0 + (at(a, a, -1, b, 0) - at(a, a, -1, b, -1)) * r0) /
+                      4;
+          }
+        }
+      if (xout && j < g.ip_hi[1]) {
+        const int I[3] = {i, j, k};
+        gradient_result<3, OP>(g, G, I, i + j * g.sx[1] + k * g.sx[2], par, out);
+      }
+    }
+  };
+  if (!wave_on) {  // keeps the workgroup's barrier count
+    for (int k = k0; k < k1; ++k) __builtin_amdgcn_s_barrier();
+    return;
+  }
+  // three plane slots (a fourth, loading plane k + 2 during plane k, measured slower: 144 more bytes of registers per lane cost more
+  // occupancy than the earlier loads gain — strain dissipation 0.207 -> 0.211 ms, smagtensor 0.449 -> 0.456 at 256^3)
+  load_plane(P[0], k0 - 1);
+  load_plane(P[1], k0);
+  int k = k0;
+  while (true) {  // rotation unrolled so that every register index is static
+    __builtin_amdgcn_s_barrier();
+    load_plane(P[2], k + 1);
+    body(P[0], P[1], P[2], k);
+    if (++k >= k1) break;
+    __builtin_amdgcn_s_barrier();
+    load_plane(P[0], k + 1);
+    body(P[1], P[2], P[0], k);
+    if (++k >= k1) break;
+    __builtin_amdgcn_s_barrier();
+    load_plane(P[1], k + 1);
+    body(P[2], P[0], P[1], k);
+    if (++k >= k1) break;
+  }
+}
+
 // --------------------------------------------------------------------------------------------
 // temperature equation
 // --------------------------------------------------------------------------------------------
@@ -538,6 +649,19 @@ int launch_gradient_op(const ins_grid* G, double par, const double* u, double* o
       Launch3 l = ip_launch(g);
       hipLaunchKernelGGL((k_gradient_op<2, OP>), l.grid, l.block, 0, s, g, BoxMap{l.ntx, l.nty, l.nty_l}, par, u, out);
     }
+  } else if (OP != 1 && ins_opt(OPT_INS_FIELDS_ROWS) >= 0 && g.ip_hi[0] - g.ip_lo[0] >= 32 && g.N[2] >= 4) {
+    // register rows + DPP (INS_FIELDS_ROWS=-1: the older kernels).  256^3: strain dissipation 0.282 -> 0.207 ms, smagtensor 0.460 -> 0.449;
+    // eig2 (its arithmetic dominates: 0.362 plain, 0.453 here) keeps the plain kernel
+    constexpr int R = 4;
+    const int nx = g.ip_hi[0] - g.ip_lo[0], ny = g.ip_hi[1] - g.ip_lo[1], nz = g.ip_hi[2] - g.ip_lo[2];
+    const int zc = ins_opt(OPT_INS_FIELDS_ZC) > 0 ? (int)ins_opt(OPT_INS_FIELDS_ZC) : (nz >= 128 ? 32 : (nz >= 32 ? 16 : (nz >= 8 ? 8 : nz)));
+    Launch3 l;
+    l.block = dim3(64, 4, 1);
+    l.ntx = (int)cdiv(nx, GR_XO);
+    l.nty = (int)cdiv(ny, 4 * R);
+    l.nty_l = (l.nty + 7) / 8;
+    l.grid = dim3(8u * l.ntx * l.nty_l * cdiv(nz, zc), 1, 1);
+    hipLaunchKernelGGL((k_gradient_rows<OP, R>), l.grid, l.block, 0, s, g, BoxMap{l.ntx, l.nty, l.nty_l}, zc, par, u, out);
   } else if (!march || OP == 1) {  // eig2: its arithmetic dominates; the plain kernel measured faster (0.35 vs 0.43 ms at 256^3)
     Launch3 l = ip_launch(g);
     hipLaunchKernelGGL((k_gradient_op<3, OP>), l.grid, l.block, 0, s, g, BoxMap{l.ntx, l.nty, l.nty_l}, par, u, out);

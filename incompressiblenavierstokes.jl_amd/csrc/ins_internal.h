@@ -64,6 +64,8 @@ void ins_set_error(const char* fmt, ...);
   X(INS_DISABLE_FDM_XYFFT)       \
   X(INS_DISABLE_OWNFFT)          \
   X(INS_FIELDS_NO_MARCH)         \
+  X(INS_FIELDS_ROWS)             \
+  X(INS_FIELDS_ZC)               \
   X(INS_DISABLE_FLUX2D)          \
   X(INS_DISABLE_FLUX64)          \
   X(INS_FLUX64_ROWS)             \
