@@ -50,9 +50,61 @@ struct ins_fdm {
   double* lyp = nullptr;    // λy in the digit-reversed order the own y pass leaves behind
   double* oyp = nullptr;    // Vyᵀ1 in that layout: sqrt(n1/hy) at position 0
   double* ytw = nullptr;
+  // Symmetric directions (cosine / tanh / uniform walls: Tα and Dα commute with the reflection i -> n-1-i): every eigenvector is even or odd, so
+  // with the modes ordered [even | odd] and the data folded into (f_i + f_{n-1-i} | f_i - f_{n-1-i}) a transform along that direction is two
+  // GEMMs of half the size — half the flops of the dense transform.  Vh[a]: the top halves of the reordered eigenvectors, (n/2) x n, column-major.
+  bool fold[3] = {false, false, false};
+  double* Vh[3] = {nullptr, nullptr, nullptr};
 };
 
 namespace {
+
+// out of place (in place the work-item of i would overwrite position n/2 + i, which the work-item of n/2 - 1 - i still has to read):
+// forward  (f_i, f_{n-1-i}) -> (f_i + f_{n-1-i} at i, f_i - f_{n-1-i} at n/2 + i), i < n/2, along every direction flagged in `mask`;
+// inverse  (e_i, o_i) -> (e_i + o_i at i, e_i - o_i at n-1-i).  One work-item per group of 2^k mirror images.
+__global__ __launch_bounds__(256) void k_fdm_fold(const double* __restrict__ x, double* __restrict__ y, int n0, int n1, int n2, int mask, int inverse) {
+  const int h0 = (mask & 1) ? n0 / 2 : n0, h1 = (mask & 2) ? n1 / 2 : n1, h2 = (mask & 4) ? n2 / 2 : n2;
+  const long long total = (long long)h0 * h1 * h2;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int i = (int)(t % h0);
+    const long long r = t / h0;
+    const int j = (int)(r % h1), k = (int)(r / h1);
+    // the two storage positions along each folded direction: natural layout (i, n-1-i), folded layout (i, n/2 + i)
+    const int ia[2] = {i, (mask & 1) ? (inverse ? n0 / 2 + i : n0 - 1 - i) : i}, ib[2] = {i, (mask & 1) ? (inverse ? n0 - 1 - i : n0 / 2 + i) : i};
+    const int ja[2] = {j, (mask & 2) ? (inverse ? n1 / 2 + j : n1 - 1 - j) : j}, jb[2] = {j, (mask & 2) ? (inverse ? n1 - 1 - j : n1 / 2 + j) : j};
+    const int ka[2] = {k, (mask & 4) ? (inverse ? n2 / 2 + k : n2 - 1 - k) : k}, kb[2] = {k, (mask & 4) ? (inverse ? n2 - 1 - k : n2 / 2 + k) : k};
+    const int c0 = (mask & 1) ? 2 : 1, c1 = (mask & 2) ? 2 : 1, c2 = (mask & 4) ? 2 : 1;
+    double v[2][2][2];
+    for (int c = 0; c < c2; ++c)
+      for (int b = 0; b < c1; ++b)
+        for (int a = 0; a < c0; ++a) v[c][b][a] = x[ia[a] + (long long)n0 * (ja[b] + (long long)n1 * ka[c])];
+    if (mask & 1)
+      for (int c = 0; c < c2; ++c)
+        for (int b = 0; b < c1; ++b) {
+          const double p = v[c][b][0], q = v[c][b][1];
+          v[c][b][0] = p + q;
+          v[c][b][1] = p - q;
+        }
+    if (mask & 2)
+      for (int c = 0; c < c2; ++c)
+        for (int a = 0; a < c0; ++a) {
+          const double p = v[c][0][a], q = v[c][1][a];
+          v[c][0][a] = p + q;
+          v[c][1][a] = p - q;
+        }
+    if (mask & 4)
+      for (int b = 0; b < c1; ++b)
+        for (int a = 0; a < c0; ++a) {
+          const double p = v[0][b][a], q = v[1][b][a];
+          v[0][b][a] = p + q;
+          v[1][b][a] = p - q;
+        }
+    for (int c = 0; c < c2; ++c)
+      for (int b = 0; b < c1; ++b)
+        for (int a = 0; a < c0; ++a) y[ib[a] + (long long)n0 * (jb[b] + (long long)n1 * kb[c])] = v[c][b][a];
+  }
+}
+
 
 // Singular systems (no PressureBC side) are handled in eigen-space, where both gauges are rank-one:
 //   mean(f) removal:  f - m·1  <=>  q - m·(Vᵀ1),  Vᵀ1 = ox ⊗ oy ⊗ oz,  and  Σ f = q[null] / null_scale  (V₀ is the constant vector);
@@ -147,6 +199,7 @@ int ins_fdm_destroy(ins_fdm* F) {
     if (F->V[a]) (void)hipFree(F->V[a]);
     if (F->lam[a]) (void)hipFree(F->lam[a]);
     if (F->ones[a]) (void)hipFree(F->ones[a]);
+    if (F->Vh[a]) (void)hipFree(F->Vh[a]);
   }
   if (F->a) (void)hipFree(F->a);
   if (F->b) (void)hipFree(F->b);
@@ -175,27 +228,72 @@ int ins_fdm_create(int D, const int n[3], const double* const V[3], const double
   for (int a = 0; ok && a < D; ++a) {
     F->n[a] = n[a];
     total *= n[a];
+    // Symmetric direction?  Every eigenvector even or odd under i -> n-1-i (to 1e-9 of its norm), as many even as odd ones (n even).
+    // Then the modes are reordered [even | odd] — eigenvalues, Vαᵀ1 and the null mode follow — and the top halves are kept for the half GEMMs.
+    const int na = n[a], hh = na / 2;
+    std::vector<int> perm(na);
+    for (int j = 0; j < na; ++j) perm[j] = j;
+    bool sym = na % 2 == 0 && na >= 8 && !ins_opt(OPT_INS_DISABLE_FDM_FOLD);
+    if (sym) {
+      std::vector<int> ev, od;
+      for (int j = 0; sym && j < na; ++j) {
+        const double* v = V[a] + (size_t)na * j;
+        double se = 0.0, so = 0.0, nn = 0.0;
+        for (int i = 0; i < na; ++i) {
+          se += (v[i] - v[na - 1 - i]) * (v[i] - v[na - 1 - i]);
+          so += (v[i] + v[na - 1 - i]) * (v[i] + v[na - 1 - i]);
+          nn += v[i] * v[i];
+        }
+        if (se <= 1e-18 * nn)
+          ev.push_back(j);
+        else if (so <= 1e-18 * nn)
+          od.push_back(j);
+        else
+          sym = false;
+      }
+      sym = sym && (int)ev.size() == hh && (int)od.size() == hh;
+      if (sym) {
+        for (int j = 0; j < hh; ++j) {
+          perm[j] = ev[j];
+          perm[hh + j] = od[j];
+        }
+      }
+    }
+    F->fold[a] = sym;
+    std::vector<double> Vs((size_t)na * na), lam_s(na);
+    for (int j = 0; j < na; ++j) {
+      lam_s[j] = lam[a][perm[j]];
+      for (int i = 0; i < na; ++i) Vs[i + (size_t)na * j] = V[a][i + (size_t)na * perm[j]];
+    }
+    const double* Va = Vs.data();
+    const double* la = lam_s.data();
     // Vαᵀ 1 and the null mode of this direction (largest eigenvalue, ~0 when the system is singular)
     std::vector<double> o(n[a], 0.0);
     int inull = 0;
     for (int j = 0; j < n[a]; ++j) {
-      for (int i = 0; i < n[a]; ++i) o[j] += V[a][i + (size_t)n[a] * j];
-      if (std::fabs(lam[a][j]) < std::fabs(lam[a][inull])) inull = j;
+      for (int i = 0; i < n[a]; ++i) o[j] += Va[i + (size_t)n[a] * j];
+      if (std::fabs(la[j]) < std::fabs(la[inull])) inull = j;
     }
     // Singular system: every direction's factor has the constant vector in its null space, so the eigenvalue of that mode IS zero; the
     // eigensolver returns it to ~eps·λmax.  It is stored as an exact 0, so that the scaling kernels recognise the ONE null mode of the
     // Kronecker sum by λx + λy + λz == 0 and nothing else: a magnitude threshold would have to sit between that noise (eps·λmax, λmax ~
     // 4/h_min²) and the lowest physical mode (~π²/L²), and on strongly stretched grids (cosine grid, N >= 1024) there is no such gap.
-    std::vector<double> lam_up(lam[a], lam[a] + n[a]);
+    std::vector<double> lam_up(la, la + n[a]);
     if (F->singular) lam_up[inull] = 0.0;
     ok = hipMalloc(&F->V[a], (size_t)n[a] * n[a] * 8) == hipSuccess && hipMalloc(&F->lam[a], (size_t)n[a] * 8) == hipSuccess &&
-         hipMemcpy(F->V[a], V[a], (size_t)n[a] * n[a] * 8, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(F->V[a], Va, (size_t)n[a] * n[a] * 8, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(F->lam[a], lam_up.data(), (size_t)n[a] * 8, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && sym) {
+      std::vector<double> top((size_t)hh * na);
+      for (int j = 0; j < na; ++j)
+        for (int i = 0; i < hh; ++i) top[i + (size_t)hh * j] = Va[i + (size_t)na * j];
+      ok = hipMalloc(&F->Vh[a], top.size() * 8) == hipSuccess && hipMemcpy(F->Vh[a], top.data(), top.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+    }
     for (int i = 0; i < n[a]; ++i) lmax = std::fmax(lmax, std::fabs(lam[a][i]));
     F->null_index += (long long)inull * (a == 0 ? 1 : (a == 1 ? n[0] : (long long)n[0] * n[1]));
-    F->null_scale *= V[a][(size_t)n[a] * inull];
+    F->null_scale *= Va[(size_t)n[a] * inull];
     F->null_i[a] = inull;
-    F->null_s[a] = V[a][(size_t)n[a] * inull];
+    F->null_s[a] = Va[(size_t)n[a] * inull];
     ok = ok && hipMalloc(&F->ones[a], (size_t)n[a] * 8) == hipSuccess &&
          hipMemcpy(F->ones[a], o.data(), (size_t)n[a] * 8, hipMemcpyHostToDevice) == hipSuccess;
   }
@@ -240,6 +338,7 @@ int ins_fdm_enable_zfft(ins_fdm* F, double hz, const double* lam_z_host) {
   if (rc) return rc;
   F->hz = hz;
   F->zfft = true;
+  F->fold[2] = false;
   return INS_OK;
 }
 
@@ -287,6 +386,7 @@ int ins_fdm_enable_xfft(ins_fdm* F, double hx, const double* lam_x_host) {
   F->null_i[0] = 0;
   F->null_s[0] = 1.0 / std::sqrt(hx * (double)n0);
   F->xfft = true;
+  F->fold[0] = F->fold[1] = false;  // the spectrum rows of this route are not folded (next: fold y there too)
   return INS_OK;
 }
 
@@ -350,12 +450,14 @@ int ins_fdm_enable_xyfft(ins_fdm* F, double hx, double hy, const double* lam_x_h
   F->null_index = (long long)F->null_i[2] * (2LL * kxs) * n1;
   F->null_scale = sx * sy * F->null_s[2];
   F->xyfft = true;
+  F->fold[0] = F->fold[1] = F->fold[2] = false;
   return INS_OK;
 }
 
 // in: f on the unpadded block (n0,n1,n2) in F->a; out: p in F->a
 // G, u given (only meaningful when ins_fdm_takes_u): the right-hand side Ω·div(u) is formed inside the x pass instead of being read from F->a
-int ins_fdm_solve(ins_fdm* F, hipStream_t s, const ins_grid* G, const double* u) {
+// folded_io: the caller wrote the right-hand side in folded form and reads the solution in folded form (project!: ins_poisson.hip)
+int ins_fdm_solve(ins_fdm* F, hipStream_t s, const ins_grid* G, const double* u, bool folded_io) {
   const int n0 = F->n[0], n1 = F->n[1], n2 = F->D == 3 ? F->n[2] : 1;
   const long long n01 = (long long)n0 * n1, total = n01 * n2;
   const double one = 1.0, zero = 0.0;
@@ -403,29 +505,77 @@ int ins_fdm_solve(ins_fdm* F, hipStream_t s, const ins_grid* G, const double* u)
     return ins_k_ownfft_xinv(y, x, n0, n1, n2, F->xtw, s, F->kxs);
   }
   const int nblk = (int)std::min<long long>((total + 255) / 256, 4096);
+  // Transforms along one direction; a symmetric direction (F->fold) runs as two GEMMs of half the size on the folded data.
+  auto gemm_x = [&](bool fwd, const double* in, double* out) -> int {
+    if (F->fold[0]) {
+      const int h = n0 / 2;
+      for (int part = 0; part < 2; ++part)
+        INS_BLAS_TRY(rocblas_dgemm(F->h, fwd ? rocblas_operation_transpose : rocblas_operation_none, rocblas_operation_none, h, n1 * n2, h, &one,
+                                   F->Vh[0] + (size_t)part * h * h, h, in + part * h, n0, &zero, out + part * h, n0));
+      return INS_OK;
+    }
+    INS_BLAS_TRY(rocblas_dgemm(F->h, fwd ? rocblas_operation_transpose : rocblas_operation_none, rocblas_operation_none, n0, n1 * n2, n0, &one, F->V[0], n0,
+                               in, n0, &zero, out, n0));
+    return INS_OK;
+  };
+  auto gemm_y = [&](bool fwd, const double* in, double* out) -> int {
+    const rocblas_operation opb = fwd ? rocblas_operation_none : rocblas_operation_transpose;
+    if (F->fold[1]) {
+      const int h = n1 / 2;
+      for (int part = 0; part < 2; ++part)
+        INS_BLAS_TRY(rocblas_dgemm_strided_batched(F->h, rocblas_operation_none, opb, n0, h, h, &one, in + (size_t)part * n0 * h, n0, n01,
+                                                   F->Vh[1] + (size_t)part * h * h, h, 0, &zero, out + (size_t)part * n0 * h, n0, n01, n2));
+      return INS_OK;
+    }
+    INS_BLAS_TRY(rocblas_dgemm_strided_batched(F->h, rocblas_operation_none, opb, n0, n1, n1, &one, in, n0, n01, F->V[1], n1, 0, &zero, out, n0, n01, n2));
+    return INS_OK;
+  };
+  auto gemm_z = [&](bool fwd, const double* in, double* out) -> int {
+    const rocblas_operation opb = fwd ? rocblas_operation_none : rocblas_operation_transpose;
+    if (F->fold[2]) {
+      const int h = n2 / 2;
+      for (int part = 0; part < 2; ++part)
+        INS_BLAS_TRY(rocblas_dgemm(F->h, rocblas_operation_none, opb, (int)n01, h, h, &one, in + (size_t)part * n01 * h, (int)n01,
+                                   F->Vh[2] + (size_t)part * h * h, h, &zero, out + (size_t)part * n01 * h, (int)n01));
+      return INS_OK;
+    }
+    INS_BLAS_TRY(rocblas_dgemm(F->h, rocblas_operation_none, opb, (int)n01, n2, n2, &one, in, (int)n01, F->V[2], n2, &zero, out, (int)n01));
+    return INS_OK;
+  };
+  const int fmask = (F->fold[0] ? 1 : 0) | (F->fold[1] ? 2 : 0) | ((F->D == 3 && F->fold[2]) ? 4 : 0);
+  const int nfold = (int)std::min<long long>((total / (fmask ? 2 : 1) + 255) / 256, 8192);
+  int rc;
+  // x: where the data is, y: the other buffer.  The fold and the unfold are out-of-place passes, so with them every branch below makes an even
+  // number of buffer changes and the result lands in F->a as without them.
+  if (fmask && !folded_io) {
+    hipLaunchKernelGGL(k_fdm_fold, dim3(nfold), dim3(256), 0, s, (const double*)x, y, n0, n1, n2, fmask, 0);
+    std::swap(x, y);
+  }
   // forward: q = (Vxᵀ ⊗ Vyᵀ ⊗ Vzᵀ) f
-  INS_BLAS_TRY(rocblas_dgemm(F->h, rocblas_operation_transpose, rocblas_operation_none, n0, n1 * n2, n0, &one, F->V[0], n0, x, n0, &zero, y, n0));
-  INS_BLAS_TRY(rocblas_dgemm_strided_batched(F->h, rocblas_operation_none, rocblas_operation_none, n0, n1, n1, &one, y, n0, n01, F->V[1], n1, 0,
-                                             &zero, x, n0, n01, n2));
+  if ((rc = gemm_x(true, x, y))) return rc;
+  if ((rc = gemm_y(true, y, x))) return rc;
   if (F->zfft) {  // x holds (Vxᵀ ⊗ Vyᵀ) f: the z transform, the scaling and the inverse z transform are one pass
     const long long idx_xy = F->null_i[0] + (long long)n0 * F->null_i[1];
     if (F->singular)
       hipLaunchKernelGGL(k_fdm_null_z, dim3(1), dim3(64), 0, s, x, idx_xy, n01, n2, 1.0 / (F->null_s[0] * F->null_s[1] * (double)total), F->sums);
     int nb = 0;
-    int rc = ins_k_fdm_z(x, n0, n1, n2, F->lam[0], F->lam[1], F->lzk, F->ones[0], F->ones[1], F->hz, F->lam_tol, F->singular ? 1 : 0, F->sums + 4096,
-                         F->zpart, F->ztw, &nb, s);
+    rc = ins_k_fdm_z(x, n0, n1, n2, F->lam[0], F->lam[1], F->lzk, F->ones[0], F->ones[1], F->hz, F->lam_tol, F->singular ? 1 : 0, F->sums + 4096,
+                     F->zpart, F->ztw, &nb, s);
     if (rc) return rc;
     if (F->singular) hipLaunchKernelGGL(k_fdm_mean_z, dim3(1), dim3(256), 0, s, F->zpart, nb, 1.0 / (double)total, F->sums);
     INS_LAUNCH_CHECK();
-    INS_BLAS_TRY(rocblas_dgemm_strided_batched(F->h, rocblas_operation_none, rocblas_operation_transpose, n0, n1, n1, &one, x, n0, n01, F->V[1], n1,
-                                               0, &zero, y, n0, n01, n2));
-    INS_BLAS_TRY(rocblas_dgemm(F->h, rocblas_operation_none, rocblas_operation_none, n0, n1 * n2, n0, &one, F->V[0], n0, y, n0, &zero, x, n0));
+    if ((rc = gemm_y(false, x, y))) return rc;
+    if ((rc = gemm_x(false, y, x))) return rc;
+    if (fmask && !folded_io) {
+      hipLaunchKernelGGL(k_fdm_fold, dim3(nfold), dim3(256), 0, s, (const double*)x, y, n0, n1, n2, fmask, 1);
+      std::swap(x, y);
+    }
+    INS_LAUNCH_CHECK();
     if (x != F->a) INS_HIP_TRY(hipMemcpyAsync(F->a, x, total * 8, hipMemcpyDeviceToDevice, s));
     return INS_OK;
   }
   if (F->D == 3) {
-    INS_BLAS_TRY(rocblas_dgemm(F->h, rocblas_operation_none, rocblas_operation_none, (int)n01, n2, n2, &one, x, (int)n01, F->V[2], n2, &zero, y,
-                               (int)n01));
+    if ((rc = gemm_z(true, x, y))) return rc;
     std::swap(x, y);
   }
   // x holds Vᵀf
@@ -436,19 +586,23 @@ int ins_fdm_solve(ins_fdm* F, hipStream_t s, const ins_grid* G, const double* u)
   INS_LAUNCH_CHECK();
   // backward: p = (Vx ⊗ Vy ⊗ Vz) q
   if (F->D == 3) {
-    INS_BLAS_TRY(rocblas_dgemm(F->h, rocblas_operation_none, rocblas_operation_transpose, (int)n01, n2, n2, &one, x, (int)n01, F->V[2], n2, &zero,
-                               y, (int)n01));
+    if ((rc = gemm_z(false, x, y))) return rc;
     std::swap(x, y);
   }
-  INS_BLAS_TRY(rocblas_dgemm_strided_batched(F->h, rocblas_operation_none, rocblas_operation_transpose, n0, n1, n1, &one, x, n0, n01, F->V[1], n1,
-                                             0, &zero, y, n0, n01, n2));
-  INS_BLAS_TRY(rocblas_dgemm(F->h, rocblas_operation_none, rocblas_operation_none, n0, n1 * n2, n0, &one, F->V[0], n0, y, n0, &zero, x, n0));
-  // x is F->a when D == 3 (two swaps) ... keep the result in F->a in every case
+  if ((rc = gemm_y(false, x, y))) return rc;
+  if ((rc = gemm_x(false, y, x))) return rc;
+  if (fmask && !folded_io) {
+    hipLaunchKernelGGL(k_fdm_fold, dim3(nfold), dim3(256), 0, s, (const double*)x, y, n0, n1, n2, fmask, 1);
+    std::swap(x, y);
+  }
+  INS_LAUNCH_CHECK();
+  // keep the result in F->a in every case
   if (x != F->a) INS_HIP_TRY(hipMemcpyAsync(F->a, x, total * 8, hipMemcpyDeviceToDevice, s));
   return INS_OK;
 }
 
 double* ins_fdm_buffer(ins_fdm* F) { return F->a; }
+int ins_fdm_fold_mask(const ins_fdm* F) { return (F->fold[0] ? 1 : 0) | (F->fold[1] ? 2 : 0) | (F->fold[2] ? 4 : 0); }
 
 // the solve starts with an x pass that can form Ω·div(u) itself (ins_fdm_solve(F, s, G, u))
 bool ins_fdm_takes_u(const ins_fdm* F) { return F->xfft || F->xyfft; }

@@ -82,6 +82,8 @@ void ins_set_error(const char* fmt, ...);
   X(INS_UNIFORM_BITWISE)         \
   X(INS_PHAT_DENSE)              \
   X(INS_DISABLE_FDM_FUSED)       \
+  X(INS_DISABLE_FDM_FOLD)        \
+  X(INS_DISABLE_FDM_FOLDFUSE)    \
   X(INS_DISABLE_INKERNEL_CORR)   \
   X(INS_RK_KEEP_K)               \
   X(INS_DISABLE_FUSED_RK)        \
@@ -155,7 +157,8 @@ int ins_fdm_destroy(ins_fdm* F);
 int ins_fdm_enable_zfft(ins_fdm* F, double hz, const double* lam_z_host);
 int ins_fdm_enable_xfft(ins_fdm* F, double hx, const double* lam_x_host);
 int ins_fdm_enable_xyfft(ins_fdm* F, double hx, double hy, const double* lam_x_host, const double* lam_y_host);
-int ins_fdm_solve(ins_fdm* F, hipStream_t s, const ins_grid* G = nullptr, const double* u = nullptr);
+int ins_fdm_solve(ins_fdm* F, hipStream_t s, const ins_grid* G = nullptr, const double* u = nullptr, bool folded_io = false);
+int ins_fdm_fold_mask(const ins_fdm* F);
 bool ins_fdm_takes_u(const ins_fdm* F);
 double* ins_fdm_buffer(ins_fdm* F);
 const double* ins_fdm_mean(ins_fdm* F);  // device scalar the consumer subtracts (singular systems), or nullptr

@@ -35,6 +35,77 @@ __global__ __launch_bounds__(256) void k_div_to_pI(GridDev g, const double* __re
   pI[ii + (long long)n0 * (jj + (long long)n1 * kk)] = d * om;
 }
 
+// The same right-hand side written in the FOLDED form of the direct solver's symmetric directions (csrc/ins_fdm.hip: e_i = f_i + f_{n-1-i} at i,
+// o_i = f_i - f_{n-1-i} at n/2 + i, i < n/2, along every direction of `mask`): a work-item evaluates the divergence at the 2^k mirror images
+// of its volume and writes their sums / differences, so the solver needs no fold pass of its own.
+template <int D>
+__global__ __launch_bounds__(256) void k_div_to_pI_fold(GridDev g, const double* __restrict__ u, double* __restrict__ pI, int n0, int n1, int n2, int mask) {
+  const int h0 = (mask & 1) ? n0 / 2 : n0, h1 = (mask & 2) ? n1 / 2 : n1, h2 = (D == 3 && (mask & 4)) ? n2 / 2 : n2;
+  const int ii = blockIdx.x * 64 + threadIdx.x;
+  const int jj = blockIdx.y * 4 + threadIdx.y;
+  const int kk = D == 3 ? (int)blockIdx.z : 0;
+  if (ii >= h0 || jj >= h1 || kk >= h2) return;
+  const int c0 = (mask & 1) ? 2 : 1, c1 = (mask & 2) ? 2 : 1, c2 = (D == 3 && (mask & 4)) ? 2 : 1;
+  double v[2][2][2];
+  for (int cz = 0; cz < c2; ++cz)
+    for (int cy = 0; cy < c1; ++cy)
+      for (int cx = 0; cx < c0; ++cx) {
+        const int pi = cx ? n0 - 1 - ii : ii, pj = cy ? n1 - 1 - jj : jj, pk = cz ? n2 - 1 - kk : kk;
+        const int I[3] = {g.ip_lo[0] + pi, g.ip_lo[1] + pj, D == 3 ? g.ip_lo[2] + pk : 0};
+        const long long c = I[0] + I[1] * g.sx[1] + I[2] * g.sx[2];
+        double d = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          const double* ua = u + a * g.sc;
+          d += (ua[c] - ua[c - g.sx[a]]) * g.rdx[a][I[a]];
+        }
+        double om = g.dx[0][I[0]] * g.dx[1][I[1]];
+        if (D == 3) om = om * g.dx[2][I[2]];
+        v[cz][cy][cx] = d * om;
+      }
+  if (mask & 1)
+    for (int cz = 0; cz < c2; ++cz)
+      for (int cy = 0; cy < c1; ++cy) {
+        const double p = v[cz][cy][0], q = v[cz][cy][1];
+        v[cz][cy][0] = p + q;
+        v[cz][cy][1] = p - q;
+      }
+  if (mask & 2)
+    for (int cz = 0; cz < c2; ++cz)
+      for (int cx = 0; cx < c0; ++cx) {
+        const double p = v[cz][0][cx], q = v[cz][1][cx];
+        v[cz][0][cx] = p + q;
+        v[cz][1][cx] = p - q;
+      }
+  if (D == 3 && (mask & 4))
+    for (int cy = 0; cy < c1; ++cy)
+      for (int cx = 0; cx < c0; ++cx) {
+        const double p = v[0][cy][cx], q = v[1][cy][cx];
+        v[0][cy][cx] = p + q;
+        v[1][cy][cx] = p - q;
+      }
+  for (int cz = 0; cz < c2; ++cz)
+    for (int cy = 0; cy < c1; ++cy)
+      for (int cx = 0; cx < c0; ++cx)
+        pI[(cx ? n0 / 2 + ii : ii) + (long long)n0 * ((cy ? n1 / 2 + jj : jj) + (long long)n1 * (cz ? n2 / 2 + kk : kk))] = v[cz][cy][cx];
+}
+
+// value of the solution at interior offsets (w0, w1, w2) when the solver's buffer holds it in folded form (inverse of the fold above)
+__device__ __forceinline__ double unfold_at(const double* __restrict__ pI, int w0, int w1, int w2, int n0, int n1, int n2, int mask) {
+  const bool f0 = mask & 1, f1 = mask & 2, f2 = mask & 4;
+  const int h0 = n0 / 2, h1 = n1 / 2, h2 = n2 / 2;
+  const int i = (f0 && w0 >= h0) ? n0 - 1 - w0 : w0, j = (f1 && w1 >= h1) ? n1 - 1 - w1 : w1, k = (f2 && w2 >= h2) ? n2 - 1 - w2 : w2;
+  const double s0 = (f0 && w0 >= h0) ? -1.0 : 1.0, s1 = (f1 && w1 >= h1) ? -1.0 : 1.0, s2 = (f2 && w2 >= h2) ? -1.0 : 1.0;
+  double acc = 0.0;
+  for (int cz = 0; cz < (f2 ? 2 : 1); ++cz)
+    for (int cy = 0; cy < (f1 ? 2 : 1); ++cy)
+      for (int cx = 0; cx < (f0 ? 2 : 1); ++cx) {
+        const double sg = (cx ? s0 : 1.0) * (cy ? s1 : 1.0) * (cz ? s2 : 1.0);
+        acc += sg * pI[(cx ? h0 + i : i) + (long long)n0 * ((cy ? h1 + j : j) + (long long)n1 * (cz ? h2 + k : k))];
+      }
+  return acc;
+}
+
 // copyto!(pI, view(p, Ip))  /  copyto!(view(p, Ip), pI)                        pressure.jl:320, 347
 template <int D, bool PACK>
 __global__ __launch_bounds__(256) void k_pack(GridDev g, double* __restrict__ p, double* __restrict__ pI, int n0, int n1,
@@ -67,7 +138,7 @@ __device__ __forceinline__ int map_p(int I, int lo, int hi, int bcl, int bcr) { 
 
 template <int D, bool GRAD = true>
 __global__ __launch_bounds__(256) void k_unpack_grad_bc(GridDev g, double* __restrict__ u, double* __restrict__ p, const double* __restrict__ pI,
-                                                        int n0, int n1, const double* __restrict__ shift) {
+                                                        int n0, int n1, const double* __restrict__ shift, int fmask = 0, int n2 = 1) {
   const int I0 = g.ip_lo[0] - 1 + blockIdx.x * 64 + threadIdx.x;
   const int I1 = g.ip_lo[1] - 1 + blockIdx.y * 4 + threadIdx.y;
   const int I2 = D == 3 ? g.ip_lo[2] - 1 + (int)blockIdx.z : 0;
@@ -87,7 +158,10 @@ __global__ __launch_bounds__(256) void k_unpack_grad_bc(GridDev g, double* __res
   long long q = 0;
 #pragma unroll
   for (int a = 0; a < D; ++a) q += (long long)(w[a] < 0 ? 0 : w[a]) * qs[a];
-  const double pc = zero ? 0.0 : pI[q] - sh;
+  auto val = [&](const int (&ww)[3], long long qq) {  // solution at interior offsets ww (flat index qq): unfolded on the fly when the solver kept it folded
+    return fmask ? unfold_at(pI, ww[0] < 0 ? 0 : ww[0], ww[1] < 0 ? 0 : ww[1], ww[2] < 0 ? 0 : ww[2], n0, n1, n2, fmask) : pI[qq];
+  };
+  const double pc = zero ? 0.0 : val(w, q) - sh;
   const long long c = I[0] + I[1] * g.sx[1] + I[2] * g.sx[2];
   p[c] = pc;
   if (!GRAD) return;  // solve only: the gradient-subtract is left to the next stage's stencil kernel (ins_fast3d_flux.hip, CORR = 3)
@@ -102,7 +176,9 @@ __global__ __launch_bounds__(256) void k_unpack_grad_bc(GridDev g, double* __res
 #pragma unroll
     for (int b = 0; b < D; ++b) zn = zn || (b != a && w[b] == -1);
     const long long qn = q + (long long)((wn < 0 ? 0 : wn) - (w[a] < 0 ? 0 : w[a])) * qs[a];  // direction a replaced, the others kept
-    const double pn = zn ? 0.0 : pI[qn] - sh;
+    int wnn[3] = {w[0], w[1], w[2]};
+    wnn[a] = wn;
+    const double pn = zn ? 0.0 : val(wnn, qn) - sh;
     u[a * g.sc + c] -= (pn - pc) * g.rdxu[a][I[a]];
   }
 }
@@ -1013,6 +1089,9 @@ extern "C" int ins_poisson_solve_f64(ins_poisson_t* ps, double* p, void* stream)
   return ins_k_poisson_solve(ps, p, as_stream(stream));
 }
 
+// experiment / test hook (not in the public header): which directions of a direct solver run as folded half-size GEMMs (bit a = direction a)
+extern "C" int ins_dbg_fdm_fold_mask(const ins_poisson_t* ps) { return (ps && ps->kind == POISSON_FDM) ? ins_fdm_fold_mask(ps->fdm) : -1; }
+
 extern "C" int ins_poisson_last_info(const ins_poisson_t* ps, int64_t* iterations, double* residual) {
   INS_REQUIRE(ps, "null argument");
   if (iterations) *iterations = ps->last_iter;
@@ -1024,26 +1103,46 @@ extern "C" int ins_poisson_last_info(const ins_poisson_t* ps, int64_t* iteration
 // project! without its last statement: p <- solution of L p = Ω div(u) (padded, ghost pressures per apply_bc_p!), u untouched.
 // Direct solver inside its fused project form only (the caller checks ins_k_project_fdm_fused).
 bool ins_k_project_fdm_fused(const ins_poisson* ps) { return ps->kind == POISSON_FDM && !ins_opt(OPT_INS_DISABLE_FDM_FUSED); }
+// Ω·div(u) into the direct solver's buffer; fm != 0: in the folded form of its symmetric directions (no separate fold pass)
+static int fdm_rhs(const ins_grid* G, ins_poisson* ps, const double* u, double* buf, int fm, hipStream_t s) {
+  const GridDev& g = G->g;
+  const dim3 block(64, 4, 1);
+  if (fm) {
+    const int n0 = ps->np[0], n1 = ps->np[1], n2 = g.D == 3 ? ps->np[2] : 1;
+    const dim3 grid(cdiv((fm & 1) ? n0 / 2 : n0, 64), cdiv((fm & 2) ? n1 / 2 : n1, 4), (g.D == 3 && (fm & 4)) ? n2 / 2 : n2);
+    if (g.D == 2)
+      hipLaunchKernelGGL(k_div_to_pI_fold<2>, grid, block, 0, s, g, u, buf, n0, n1, n2, fm);
+    else
+      hipLaunchKernelGGL(k_div_to_pI_fold<3>, grid, block, 0, s, g, u, buf, n0, n1, n2, fm);
+  } else {
+    const dim3 grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), g.D == 3 ? ps->np[2] : 1);
+    if (g.D == 2)
+      hipLaunchKernelGGL(k_div_to_pI<2>, grid, block, 0, s, g, u, buf, ps->np[0], ps->np[1]);
+    else
+      hipLaunchKernelGGL(k_div_to_pI<3>, grid, block, 0, s, g, u, buf, ps->np[0], ps->np[1]);
+  }
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
 int ins_k_project_fdm_solve_only(const ins_grid* G, ins_poisson* ps, const double* u, double* p, hipStream_t s) {
   const GridDev& g = G->g;
-  int rc;
+  int rc, fm = 0;
   double* buf = ins_fdm_buffer(ps->fdm);
   dim3 block(64, 4, 1), grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), g.D == 3 ? ps->np[2] : 1);
   if (ins_fdm_takes_u(ps->fdm)) {
     if ((rc = ins_fdm_solve(ps->fdm, s, G, u))) return rc;
   } else {
-    if (g.D == 2)
-      hipLaunchKernelGGL(k_div_to_pI<2>, grid, block, 0, s, g, u, buf, ps->np[0], ps->np[1]);
-    else
-      hipLaunchKernelGGL(k_div_to_pI<3>, grid, block, 0, s, g, u, buf, ps->np[0], ps->np[1]);
-    INS_LAUNCH_CHECK();
-    if ((rc = ins_fdm_solve(ps->fdm, s))) return rc;
+    fm = ins_opt(OPT_INS_DISABLE_FDM_FOLDFUSE) ? 0 : ins_fdm_fold_mask(ps->fdm);
+    if ((rc = fdm_rhs(G, ps, u, buf, fm, s))) return rc;
+    if ((rc = ins_fdm_solve(ps->fdm, s, nullptr, nullptr, fm != 0))) return rc;
   }
   dim3 gridp(cdiv(ps->np[0] + 2, 64), cdiv(ps->np[1] + 2, 4), g.D == 3 ? ps->np[2] + 2 : 1);
   if (g.D == 2)
-    hipLaunchKernelGGL((k_unpack_grad_bc<2, false>), gridp, block, 0, s, g, nullptr, p, (const double*)buf, ps->np[0], ps->np[1], ins_fdm_mean(ps->fdm));
+    hipLaunchKernelGGL((k_unpack_grad_bc<2, false>), gridp, block, 0, s, g, nullptr, p, (const double*)buf, ps->np[0], ps->np[1], ins_fdm_mean(ps->fdm), fm, 1);
   else
-    hipLaunchKernelGGL((k_unpack_grad_bc<3, false>), gridp, block, 0, s, g, nullptr, p, (const double*)buf, ps->np[0], ps->np[1], ins_fdm_mean(ps->fdm));
+    hipLaunchKernelGGL((k_unpack_grad_bc<3, false>), gridp, block, 0, s, g, nullptr, p, (const double*)buf, ps->np[0], ps->np[1], ins_fdm_mean(ps->fdm), fm,
+                       ps->np[2]);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -1070,22 +1169,20 @@ int ins_k_project(const ins_grid* G, ins_poisson* ps, double* u, double* p, hipS
   if (ps->kind == POISSON_FDM && !ins_opt(OPT_INS_DISABLE_FDM_FUSED)) {
     // direct solver: Ω·div(u) straight into the solver's buffer, and copy-back - mean + apply_bc_p! + applypressure! in one pass
     double* buf = ins_fdm_buffer(ps->fdm);
+    int fm = 0;
     dim3 block(64, 4, 1), grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), g.D == 3 ? ps->np[2] : 1);
     if (ins_fdm_takes_u(ps->fdm)) {  // periodic x: the divergence is formed inside the solver's x pass
       if ((rc = ins_fdm_solve(ps->fdm, s, G, u))) return rc;
     } else {
-      if (g.D == 2)
-        hipLaunchKernelGGL(k_div_to_pI<2>, grid, block, 0, s, g, u, buf, ps->np[0], ps->np[1]);
-      else
-        hipLaunchKernelGGL(k_div_to_pI<3>, grid, block, 0, s, g, u, buf, ps->np[0], ps->np[1]);
-      INS_LAUNCH_CHECK();
-      if ((rc = ins_fdm_solve(ps->fdm, s))) return rc;
+      fm = ins_opt(OPT_INS_DISABLE_FDM_FOLDFUSE) ? 0 : ins_fdm_fold_mask(ps->fdm);
+      if ((rc = fdm_rhs(G, ps, u, buf, fm, s))) return rc;
+      if ((rc = ins_fdm_solve(ps->fdm, s, nullptr, nullptr, fm != 0))) return rc;
     }
     dim3 gridp(cdiv(ps->np[0] + 2, 64), cdiv(ps->np[1] + 2, 4), g.D == 3 ? ps->np[2] + 2 : 1);
     if (g.D == 2)
-      hipLaunchKernelGGL(k_unpack_grad_bc<2>, gridp, block, 0, s, g, u, p, (const double*)buf, ps->np[0], ps->np[1], ins_fdm_mean(ps->fdm));
+      hipLaunchKernelGGL(k_unpack_grad_bc<2>, gridp, block, 0, s, g, u, p, (const double*)buf, ps->np[0], ps->np[1], ins_fdm_mean(ps->fdm), fm, 1);
     else
-      hipLaunchKernelGGL(k_unpack_grad_bc<3>, gridp, block, 0, s, g, u, p, (const double*)buf, ps->np[0], ps->np[1], ins_fdm_mean(ps->fdm));
+      hipLaunchKernelGGL(k_unpack_grad_bc<3>, gridp, block, 0, s, g, u, p, (const double*)buf, ps->np[0], ps->np[1], ins_fdm_mean(ps->fdm), fm, ps->np[2]);
     INS_LAUNCH_CHECK();
     return INS_OK;
   }

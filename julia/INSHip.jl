@@ -267,6 +267,28 @@ function laplacian_1d(setup, α)
 end
 
 """
+Eigen-decomposition of the symmetric 1-D factor.  On a symmetric grid (cosine, tanh, uniform walls) the matrix commutes with the reflection
+`i -> n+1-i`; its even and odd blocks `A ± B J` (A = M[1:h,1:h], B = M[1:h,h+1:n]) are decomposed separately, so every eigenvector is EXACTLY
+even or odd (the plain solver mixes the nearly degenerate wall-mode pairs of a strongly stretched grid) and the library runs that direction as
+two half-size GEMMs on folded data (csrc/ins_fdm.hip).  Same as `_eigh_even_odd` in incompressiblenavierstokes.jl_amd/pressure.py.
+"""
+function eigen_even_odd(M::Matrix{Float64})
+    n = size(M, 1)
+    R = reverse(reverse(M; dims = 1); dims = 2)
+    centro = iseven(n) && n >= 8 && isapprox(M, R; rtol = 1e-12, atol = 1e-12 * maximum(abs, M))
+    if !centro
+        E = eigen(Symmetric(M))
+        return E.values, E.vectors
+    end
+    h = n ÷ 2
+    Ms = (M + M' + R + R') / 4
+    A, BJ = Ms[1:h, 1:h], reverse(Ms[1:h, h+1:n]; dims = 2)
+    Ee, Eo = eigen(Symmetric(A + BJ)), eigen(Symmetric(A - BJ))
+    W = [Ee.vectors Eo.vectors; reverse(Ee.vectors; dims = 1) -reverse(Eo.vectors; dims = 1)] / sqrt(2)
+    [Ee.values; Eo.values], W
+end
+
+"""
 `psolver_direct` for `ROCArray`s (pressure.jl:101-154; same dispatch hook as ext/IncompressibleNavierStokesCUDSSExt.jl:18): fast
 diagonalisation of the separable Laplacian.  The generalised eigenpairs `Tα v = λ Dα v` of the 1-D factors are computed here once and
 handed to the library, which solves with six fp64 GEMMs on rocBLAS (Fourier passes in periodic uniform directions); singular systems
@@ -279,9 +301,9 @@ function psolver_direct(::ROCArray, setup)
         d = Array(setup.grid.Δ[α])[setup.grid.Ip.indices[α]]
         T = laplacian_1d(setup, α)
         S = Diagonal(d .^ -0.5)
-        E = eigen(Symmetric(S * T * S))
-        push!(V, S * E.vectors)      # column-major, V'DV = I
-        push!(λ, E.values)
+        vals, vecs = eigen_even_odd(Matrix(S * T * S))
+        push!(V, S * vecs)           # column-major, V'DV = I
+        push!(λ, vals)
     end
     Vp = [pointer(V[min(α, D)]) for α = 1:3]
     λp = [pointer(λ[min(α, D)]) for α = 1:3]
