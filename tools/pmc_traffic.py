@@ -26,7 +26,7 @@ for k in sorted(set(fe) | set(wr)):
     if rd + wt < 1e-3:
         continue
     out["per_kernel"][k] = {"launches": len(f), "hbm_read_GB": rd, "hbm_write_GB": wt, "hbm_total_GB": rd + wt}
-stage = [v for k, v in out["per_kernel"].items() if re.match(r"k_flux64<\d+,\d+,true,", k)]  # <R, XW, FUSE, CORR, SKEL>
+stage = [v for k, v in out["per_kernel"].items() if re.match(r"k_flux64<(double,)?\d+,\d+,true,", k)]  # <T, R, XW, FUSE, CORR, SKEL, NW>
 if stage:
     n = sum(v["launches"] for v in stage)
     out["per_kernel"]["stage kernel, RK44 step average"] = {"hbm_total_GB": sum(v["hbm_total_GB"] * v["launches"] for v in stage) / n, "launches": n}
