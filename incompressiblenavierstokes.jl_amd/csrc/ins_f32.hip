@@ -4,8 +4,10 @@
 // Scope: all-periodic uniform boxes, 2-D and 3-D — the configuration the reference's own Float32 example runs (spectral pressure solver).
 //   K1 (momentum!)          : the 64-outputs-per-wavefront stage kernel of ins_flux64.hip instantiated for float (wide 3-D boxes: half
 //                             the bytes of the fp64 kernel at the same memory rate), a plain one-cell-per-work-item kernel elsewhere;
-//   spectral projection     : Ω·div(u) with the periodic image of u (no ghost fill needed) -> hipFFT R2C -> symbol -> C2R -> padded p with
-//                             periodic ghosts -> u -= ∇p -> periodic ghosts of u;
+//   spectral projection     : 3-D power-of-two boxes: the library's five fused fp64 passes, the right-hand side Ω·div(u) formed from the float field
+//                             inside the x pass (ins_fft.hip, SRC = 5) — a mixed-precision projection whose pressure is more accurate than a
+//                             float solve; other boxes: Ω·div(u) -> hipFFT R2C -> symbol -> C2R; then padded p with periodic ghosts,
+//                             u -= ∇p, periodic ghosts of u;
 //   explicit RK             : the stage loop of step_explicit_runge_kutta.jl:4-59 on those kernels, the stage combination as K1's epilogue
 //                             on wide 3-D boxes.
 // Arrays are the reference layout with Float32 elements.  The grid handle is the fp64 one (metrics are computed in double and rounded
@@ -16,6 +18,9 @@
 #include "ins_internal.h"
 
 bool ins_flux64_supported(const ins_grid* G);
+bool ins_k_spectral_own3d(const ins_poisson* ps);
+int ins_k_spectral_solve_from_u32(ins_poisson* ps, const float* u32, hipStream_t s);
+const double* ins_k_spectral_pI(const ins_poisson* ps);
 int ins_k_flux64_f32(const ins_grid* G, double visc, const float* u, float* F, const RkEpi* epi, const float* pI, int corr_mode, hipStream_t s,
                      int part = 0);
 
@@ -27,6 +32,10 @@ struct ins_poisson32 {
   hipfftComplex* phat = nullptr;
   float* ahat[3] = {nullptr, nullptr, nullptr};
   int np[3] = {1, 1, 1}, kmax[3] = {1, 1, 1};
+  // 3-D power-of-two boxes: project! solves its pressure equation with the library's fused fp64 passes (right-hand side formed from the
+  // float field inside the x pass, five passes instead of hipFFT's 3-D plans + separate kernels; the pressure is MORE accurate than a float
+  // solve would give).  512^3 RK44 step: 26.9 ms with hipFFT's float plans -> see DESIGN.md §5.
+  ins_poisson* ps64 = nullptr;
 };
 
 struct ins_rk32 {
@@ -37,6 +46,7 @@ struct ins_rk32 {
   std::vector<float*> ku;
   float* ub[2] = {nullptr, nullptr};
   float* p = nullptr;
+  float* pu = nullptr;  // unpadded float copy of the stage pressure (in-register correction of the next stage's stencil kernel)
 };
 
 namespace {
@@ -157,13 +167,13 @@ __global__ __launch_bounds__(256) void k32_symbol(hipfftComplex* __restrict__ ph
 }
 
 // p (padded, with periodic ghosts) <- pI; one work-item per padded volume                pressure.jl:347, boundary_conditions.jl:306-318
-template <int D>
-__global__ __launch_bounds__(256) void k32_pad(Box32 b, const float* __restrict__ pI, float* __restrict__ p) {
+template <int D, typename S = float>
+__global__ __launch_bounds__(256) void k32_pad(Box32 b, const S* __restrict__ pI, float* __restrict__ p) {
   const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = D == 3 ? (int)blockIdx.z : 0;
   if (i >= b.N[0] || j >= b.N[1]) return;
   auto w = [](int I, int n) { return I == 0 ? n - 1 : (I == n + 1 ? 0 : I - 1); };
   const long long q = w(i, b.n[0]) + (long long)b.n[0] * (w(j, b.n[1]) + (long long)b.n[1] * (D == 3 ? w(k, b.n[2]) : 0));
-  p[i + j * b.sx[1] + k * b.sx[2]] = pI[q];
+  p[i + j * b.sx[1] + k * b.sx[2]] = (float)pI[q];
 }
 
 // u[I, a] -= (p[I + e_a] - p[I]) / h_a on the interior                                    operators.jl:225-233
@@ -189,6 +199,10 @@ __global__ __launch_bounds__(256) void k32_combine(long long n, const float* __r
     for (int q = 0; q < cb.n; ++q) v += cb.coef[q] * cb.k[q][t];
     out[t] = v;
   }
+}
+
+__global__ __launch_bounds__(256) void k32_cvt(long long n, const double* __restrict__ a, float* __restrict__ b) {
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) b[t] = (float)a[t];
 }
 
 dim3 grid_over(const Box32& b, bool padded) {
@@ -237,6 +251,7 @@ extern "C" int ins_poisson_destroy_f32(ins_poisson32_t* ps) {
   if (ps->phat) (void)hipFree(ps->phat);
   for (float* a : ps->ahat)
     if (a) (void)hipFree(a);
+  if (ps->ps64) (void)ins_poisson_destroy(ps->ps64);
   delete ps;
   return INS_OK;
 }
@@ -291,6 +306,15 @@ extern "C" int ins_poisson_spectral_create_f32(const ins_grid_t* G, ins_poisson3
     ins_poisson_destroy_f32(ps);
     return INS_ERR_FFT;
   }
+  if (g.D == 3 && !ins_opt(OPT_INS_F32_HIPFFT_PROJECT)) {  // the fused fp64 passes for project! where they exist (power-of-two sides)
+    ins_poisson* p64 = nullptr;
+    if (ins_poisson_spectral_create(G, &p64) == INS_OK) {
+      if (ins_k_spectral_own3d(p64))
+        ps->ps64 = p64;
+      else
+        (void)ins_poisson_destroy(p64);
+    }
+  }
   *out = ps;
   return INS_OK;
 }
@@ -319,6 +343,13 @@ extern "C" int ins_project_f32(const ins_grid_t* G, ins_poisson32_t* ps, float* 
   hipStream_t s = as_stream(stream);
   const Box32 b = box_of(G);
   int rc;
+  if (ps->ps64) {
+    if ((rc = ins_k_spectral_solve_from_u32(ps->ps64, u, s))) return rc;
+    hipLaunchKernelGGL((k32_pad<3, double>), grid_over(b, true), dim3(64, 4), 0, s, b, ins_k_spectral_pI(ps->ps64), p);
+    hipLaunchKernelGGL(k32_applypressure<3>, grid_over(b, false), dim3(64, 4), 0, s, b, u, p);
+    INS_LAUNCH_CHECK();
+    return bc_periodic(G, u, b.D, s);
+  }
   if (b.D == 2) {
     hipLaunchKernelGGL(k32_div<2>, grid_over(b, false), dim3(64, 4), 0, s, b, u, ps->pI);
   } else {
@@ -371,6 +402,7 @@ extern "C" int ins_rk_destroy_f32(ins_rk32_t* rk) {
   for (float* b : rk->ub)
     if (b) (void)hipFree(b);
   if (rk->p) (void)hipFree(rk->p);
+  if (rk->pu) (void)hipFree(rk->pu);
   delete rk;
   return INS_OK;
 }
@@ -411,6 +443,13 @@ extern "C" int ins_rk_step_f32(ins_rk32_t* rk, float visc, float* u, float dt, v
   const bool wide = ins_flux64_supported(G);
   int rc;
   if ((rc = bc_periodic(G, u, D, s))) return rc;                                // :19
+  // Wide power-of-two boxes: the fp64 path's stage structure (csrc/ins_rk.hip) in float — stages >= 2 read the previous stage's UNCORRECTED u* and
+  // its pressure and apply u = u* - ∇p in registers (flux64<float, CORR = 1>), the solve forms Ω·div(u*) from the float field inside its x
+  // pass; only the last stage materialises u (padded p, gradient-subtract, ghosts).
+  const bool incorr = wide && rk->ps->ps64 && ns > 1 && G->uniform_exact && G->g.N[0] >= 8 && G->g.N[1] >= 8 && G->g.N[2] >= 8 &&
+                      !ins_opt(OPT_INS_DISABLE_INKERNEL_CORR);
+  const long long ncell_in = (long long)(G->g.N[0] - 2) * (G->g.N[1] - 2) * (G->g.N[2] - 2);
+  if (incorr && !rk->pu) INS_HIP_TRY(hipMalloc(&rk->pu, ncell_in * sizeof(float)));
   float* cur = u;
   for (int i = 0; i < ns; ++i) {
     float* outp = (i == ns - 1 && ns > 1) ? u : rk->ub[i & 1];
@@ -429,7 +468,7 @@ extern "C" int ins_rk_step_f32(ins_rk32_t* rk, float visc, float* u, float dt, v
       epi.coef_self = (double)dt * rk->A[i * ns + i];
       epi.ustart = i == 0 ? nullptr : reinterpret_cast<const double*>(u);
       epi.ustar = reinterpret_cast<double*>(outp);
-      if ((rc = ins_k_flux64_f32(G, (double)visc, cur, rk->ku[i], &epi, nullptr, 0, s))) return rc;   // :21, :35-38
+      if ((rc = ins_k_flux64_f32(G, (double)visc, cur, rk->ku[i], &epi, (incorr && i > 0) ? rk->pu : nullptr, (incorr && i > 0) ? 1 : 0, s))) return rc;   // :21, :35-38
     } else {
       if ((rc = ins_momentum_f32(G, visc, cur, rk->ku[i], s))) return rc;       // :21
       Comb32 cb;
@@ -444,7 +483,14 @@ extern "C" int ins_rk_step_f32(ins_rk32_t* rk, float visc, float* u, float dt, v
       hipLaunchKernelGGL(k32_combine, dim3((unsigned)std::min<long long>((nvec + 255) / 256, 8192)), dim3(256), 0, s, nvec, u, outp, cb);  // :35-38
       INS_LAUNCH_CHECK();
     }
-    if ((rc = ins_project_f32(G, rk->ps, outp, rk->p, s))) return rc;           // :48-49 (periodic images: no ghost fill before)
+    if (incorr && i < ns - 1) {  // solve only: p (unpadded, float) for the next stage's in-register correction
+      if ((rc = ins_k_spectral_solve_from_u32(rk->ps->ps64, outp, s))) return rc;
+      hipLaunchKernelGGL(k32_cvt, dim3((unsigned)std::min<long long>((ncell_in + 255) / 256, 8192)), dim3(256), 0, s, ncell_in,
+                         ins_k_spectral_pI(rk->ps->ps64), rk->pu);
+      INS_LAUNCH_CHECK();
+    } else if ((rc = ins_project_f32(G, rk->ps, outp, rk->p, s))) {             // :48-49 (periodic images: no ghost fill before)
+      return rc;
+    }
     cur = outp;
   }
   if (ns == 1) INS_HIP_TRY(hipMemcpyAsync(u, rk->ub[0], nvec * sizeof(float), hipMemcpyDeviceToDevice, s));

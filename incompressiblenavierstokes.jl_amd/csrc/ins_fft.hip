@@ -223,6 +223,19 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
       const int j = min(j0 + row, n1 - 1);
       if (SRC == 0) {
         v[q] = src[i + (long long)N * (j + (long long)n1 * kz)];
+      } else if (SRC == 5) {
+        // as SRC 1, from a FLOAT velocity field (the `_f32` family solves its pressure equation with these fp64 passes, ins_f32.hip):
+        // differences and metrics in double from the float values
+        const float* sf = reinterpret_cast<const float*>(src);
+        const int I0 = i + 1, I1 = j + 1, I2 = kz + 1;
+        const long long c = I0 + I1 * g.sx[1] + I2 * g.sx[2];
+        const long long cx = I0 == 1 ? c + (long long)(g.N[0] - 3) : c - 1;
+        const long long cy = I1 == 1 ? c + (long long)(g.N[1] - 3) * g.sx[1] : c - g.sx[1];
+        const long long cz = I2 == 1 ? c + (long long)(g.N[2] - 3) * g.sx[2] : c - g.sx[2];
+        double d = ((double)sf[c] - (double)sf[cx]) * g.rdx[0][I0];
+        d += ((double)sf[g.sc + c] - (double)sf[g.sc + cy]) * g.rdx[1][I1];
+        d += ((double)sf[2 * g.sc + c] - (double)sf[2 * g.sc + cz]) * g.rdx[2][I2];
+        v[q] = d * (g.dx[0][I0] * g.dx[1][I1] * g.dx[2][I2]);
       } else if (SRC == 4) {
         // Ω · div(u) at the pressure point (i, j, kz) of a grid with walls: the ghost volumes of u are valid (k_div_to_pI<3, false>)
         const int I0 = g.ip_lo[0] + i, I1 = g.ip_lo[1] + j, I2 = g.ip_lo[2] + kz;
@@ -468,7 +481,9 @@ int launch_xfwd(const GridDev& g, const double* src, int from_u, double2* out, i
   constexpr int NP = N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N);
   constexpr size_t lds = ((size_t)NP * N + N) * sizeof(double2);
   dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
-  if (from_u == 4)
+  if (from_u == 5)
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 5>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0);
+  else if (from_u == 4)
     hipLaunchKernelGGL((k_xfwd<LOGN, NP, 4>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0);
   else if (from_u == 3)
     hipLaunchKernelGGL((k_xfwd<LOGN, NP, 3>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0);

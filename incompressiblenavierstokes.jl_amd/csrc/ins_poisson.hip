@@ -701,7 +701,7 @@ extern "C" int ins_poisson_spectral_create(const ins_grid_t* G, ins_poisson_t** 
 }
 
 // pI -> pI through the five own passes; from_u != nullptr: the right-hand side Ω·div(u) is formed inside pass 1
-static int ownfft_transform(ins_poisson* ps, const double* from_u, hipStream_t s) {
+static int ownfft_transform(ins_poisson* ps, const double* from_u, hipStream_t s, int src_code = 1) {
   const int n0 = ps->np[0], n1 = ps->np[1], n2 = ps->np[2], kxn = ps->kmax[0], kxs = ps->kxs;
   double* ph = reinterpret_cast<double*>(ps->phat);
   int rc;
@@ -710,7 +710,7 @@ static int ownfft_transform(ins_poisson* ps, const double* from_u, hipStream_t s
     if ((rc = ins_k_zsolve(ph, n1, (long long)kxs, ps->ahat[0], kxn, ps->ahat[2], ps->ahat[1], ps->tw, 1.0 / ((double)n0 * n1), true, s, kxs))) return rc;
     return ins_k_ownfft_xinv(ph, ps->pI, n0, n1, 1, ps->tw_x, s, kxs);
   }
-  if ((rc = ins_k_ownfft_xfwd(ps->grid, from_u ? from_u : ps->pI, from_u != nullptr, ph, n0, n1, n2, ps->tw_x, s, kxs))) return rc;
+  if ((rc = ins_k_ownfft_xfwd(ps->grid, from_u ? from_u : ps->pI, from_u ? src_code : 0, ph, n0, n1, n2, ps->tw_x, s, kxs))) return rc;
   if ((rc = ins_k_ownfft_y(ph, kxn, n1, n2, ps->tw_y, false, s, kxs))) return rc;
   const double inv_n = 1.0 / ((double)n0 * n1 * n2);
   if ((rc = ins_k_zsolve(ph, n2, (long long)kxs * n1, ps->ahat[0], kxn, ps->ahat[1], ps->ahat[2], ps->tw, inv_n, true, s, kxs))) return rc;
@@ -1246,6 +1246,14 @@ int ins_k_project_periodic_solve_only(const ins_grid* G, ins_poisson* ps, const 
   INS_LAUNCH_CHECK();
   return spectral_transform(ps, s);
 }
+
+// The `_f32` family's pressure equation on power-of-two boxes: right-hand side Ω·div(u) from the FLOAT field u32 (periodic images), the five fp64
+// passes, solution in ps->pI (double, unpadded).  false: this solver has no own passes (the caller keeps hipFFT).
+bool ins_k_spectral_own3d(const ins_poisson* ps) { return ps->kind == POISSON_SPECTRAL && ps->ownfft && ps->grid->g.D == 3; }
+int ins_k_spectral_solve_from_u32(ins_poisson* ps, const float* u32, hipStream_t s) {
+  return ownfft_transform(ps, reinterpret_cast<const double*>(u32), s, 5);
+}
+const double* ins_k_spectral_pI(const ins_poisson* ps) { return ps->pI; }
 
 extern "C" int ins_project_f64(const ins_grid_t* G, ins_poisson_t* ps, double* u, double* p, void* stream) {
   INS_REQUIRE(G && ps && u && p, "null argument");
