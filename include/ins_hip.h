@@ -158,6 +158,10 @@ int ins_poisson_cg_set_comm(ins_poisson_t* ps, ins_comm_t* comm);
  * pressure.jl:133-140 is solved (mean(f) removed, null mode dropped, mean(p[Ip]) = 0).  Asynchronous. */
 int ins_poisson_fdm_create(const ins_grid_t* grid, const double* const* V, const double* const* lam, ins_poisson_t** out);
 int ins_poisson_destroy(ins_poisson_t* ps);
+/* Which transform engine a spectral solver was planned on: *engine = 1 when all of its passes are this library's own kernels
+ * (power-of-two sides and 192 / 384 = 3 * 2^m, csrc/ins_fft.hip), 2 when rocFFT 2-D plans feed the own fused z pass, 0 when every transform
+ * is a rocFFT plan (pressure.jl:316 leaves the choice to the FFT library).  Other solver kinds: *engine = -1. */
+int ins_poisson_fft_engine(const ins_poisson_t* ps, int32_t* engine);
 /* poisson!(psolver, p) = psolver(p)        pressure.jl:22: solves L p = f in place on the padded array.
  * Spectral: asynchronous.  CG: blocking (the reference reads residuals on the host, pressure.jl:244,275). */
 int ins_poisson_solve_f64(ins_poisson_t* ps, double* p, void* stream);

@@ -25,19 +25,31 @@ __device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_doub
 __device__ __forceinline__ double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }
 __device__ __forceinline__ double2 mul_pi(double2 a) { return make_double2(-a.y, a.x); }
 
-// Storage position of frequency k after the DIF stages (radix-2 first when log2 N is odd, then radix 4):
-// inverse of freq_of_pos() in ins_zsolve.hip.
+// Transform lengths.  The template parameter LOGN of everything below is a SIZE CODE: codes < 32 are log2 N of a power of two; code
+// 32 + m stands for N = 3 * 2^m (a radix-3 stage in front of the power-of-two stages: 192 = 3 * 64, 384 = 3 * 128), so that boxes with
+// such sides run on these passes too instead of rocFFT (pressure.jl:316 plans any even n).
+constexpr int fft_r3(int code) { return code >= 32 ? 3 : 1; }
+constexpr int fft_lg(int code) { return code & 31; }                           // log2 of the power-of-two part
+constexpr int fft_len(int code) { return fft_r3(code) << fft_lg(code); }
+
+// Storage position of frequency k after the DIF stages (radix 3 first for the 3 * 2^m lengths, then radix 2 when the remaining log2 is odd,
+// then radix 4): inverse of freq_of_pos() in ins_zsolve.hip.
 template <int LOGN>
 __host__ __device__ __forceinline__ int pos_of_freq(int k) {
-  constexpr bool ODD = LOGN & 1;
-  int p = 0, L = 1 << LOGN;
+  constexpr int LG = fft_lg(LOGN), R3 = fft_r3(LOGN);
+  constexpr bool ODD = LG & 1;
+  int p = 0, L = 1 << LG;
+  if (R3 == 3) {
+    p = (k % 3) * L;
+    k /= 3;
+  }
   if (ODD) {
     p += (k & 1) * (L / 2);
     k >>= 1;
     L /= 2;
   }
 #pragma unroll
-  for (int s = 0; s < LOGN / 2; ++s) {
+  for (int s = 0; s < LG / 2; ++s) {
     p += (k & 3) * (L / 4);
     k >>= 2;
     L /= 4;
@@ -48,29 +60,55 @@ __host__ __device__ __forceinline__ int pos_of_freq(int k) {
 // In-place transforms of NC independent lines held in LDS; element (r, c) lives at buf[r*SR + c*SC].
 // RFAST: consecutive work-items take consecutive butterflies of one line (x layout, SR == 1) instead of the
 // same butterfly of consecutive lines (y/z layout, SC == 1) — keeps LDS accesses unit-stride in both layouts.
+// radix-3 butterfly, forward (w = e^{-2πi/3}) / inverse (conjugate)
+template <bool INV>
+__device__ __forceinline__ void bfly3(double2& x0, double2& x1, double2& x2) {
+  constexpr double h = 0.86602540378443864676;  // sqrt(3)/2
+  const double2 t1 = cadd(x1, x2), d = csub(x1, x2);
+  const double2 t2 = make_double2(x0.x - 0.5 * t1.x, x0.y - 0.5 * t1.y);
+  const double2 t3 = INV ? make_double2(-h * d.y, h * d.x) : make_double2(h * d.y, -h * d.x);  // (+-i) sqrt(3)/2 (x1 - x2)
+  x0 = cadd(x0, t1);
+  x1 = cadd(t2, t3);
+  x2 = csub(t2, t3);
+}
+
 template <int LOGN, int NC, int SR, int SC, bool RFAST>
 __device__ __forceinline__ void fft_dif(double2* __restrict__ buf, const double2* __restrict__ tw, int t) {
-  constexpr int N = 1 << LOGN;
-  constexpr bool ODD = LOGN & 1;
-  int L = N;
+  constexpr int N = fft_len(LOGN), R3 = fft_r3(LOGN), M = N / R3;  // M: the power-of-two sub-length
+  constexpr bool ODD = fft_lg(LOGN) & 1;
+  if (R3 == 3) {  // N = 3 M: one radix-3 stage over the whole line, then the three sub-blocks of length M run the stages below side by side
+    for (int w = t; w < M * NC; w += 256) {
+      const int c = RFAST ? w / M : w % NC, j = RFAST ? w % M : w / NC;
+      double2* x = buf + c * SC;
+      double2 a0 = x[j * SR], a1 = x[(j + M) * SR], a2 = x[(j + 2 * M) * SR];
+      bfly3<false>(a0, a1, a2);
+      x[j * SR] = a0;
+      x[(j + M) * SR] = cmul(a1, tw[j]);
+      x[(j + 2 * M) * SR] = cmul(a2, tw[2 * j]);
+    }
+    __syncthreads();
+  }
+  int L = M;
   if (ODD) {
     for (int w = t; w < (N / 2) * NC; w += 256) {
-      const int c = RFAST ? w / (N / 2) : w % NC, j = RFAST ? w % (N / 2) : w / NC;
-      double2* x = buf + c * SC;
-      const double2 a0 = x[j * SR], a1 = x[(j + N / 2) * SR];
+      const int c = RFAST ? w / (N / 2) : w % NC, jj = RFAST ? w % (N / 2) : w / NC;
+      const int sub = jj / (M / 2), j = jj - sub * (M / 2);
+      double2* x = buf + c * SC + sub * M * SR;
+      const double2 a0 = x[j * SR], a1 = x[(j + M / 2) * SR];
       x[j * SR] = cadd(a0, a1);
-      x[(j + N / 2) * SR] = cmul(csub(a0, a1), tw[j]);
+      x[(j + M / 2) * SR] = cmul(csub(a0, a1), tw[j * R3]);  // W_M^j = W_N^(R3 j)
     }
-    L = N / 2;
+    L = M / 2;
     __syncthreads();
   }
 #pragma unroll 1
   for (; L >= 4; L >>= 2) {
     const int Q = L / 4, step = N / L;
     for (int w = t; w < (N / 4) * NC; w += 256) {
-      const int c = RFAST ? w / (N / 4) : w % NC, b = RFAST ? w % (N / 4) : w / NC;
+      const int c = RFAST ? w / (N / 4) : w % NC, bb = RFAST ? w % (N / 4) : w / NC;
+      const int sub = bb / (M / 4), b = bb - sub * (M / 4);
       const int g = b / Q, j = b - g * Q;
-      double2* x = buf + c * SC + (g * L + j) * SR;
+      double2* x = buf + c * SC + (sub * M + g * L + j) * SR;
       const double2 a0 = x[0], a1 = x[Q * SR], a2 = x[2 * Q * SR], a3 = x[3 * Q * SR];
       const double2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
       double2 y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
@@ -91,15 +129,16 @@ __device__ __forceinline__ void fft_dif(double2* __restrict__ buf, const double2
 
 template <int LOGN, int NC, int SR, int SC, bool RFAST>
 __device__ __forceinline__ void fft_dit(double2* __restrict__ buf, const double2* __restrict__ tw, int t) {
-  constexpr int N = 1 << LOGN;
-  constexpr bool ODD = LOGN & 1;
+  constexpr int N = fft_len(LOGN), R3 = fft_r3(LOGN), M = N / R3;
+  constexpr bool ODD = fft_lg(LOGN) & 1;
 #pragma unroll 1
-  for (int L = 4; L <= (ODD ? N / 2 : N); L <<= 2) {
+  for (int L = 4; L <= (ODD ? M / 2 : M); L <<= 2) {
     const int Q = L / 4, step = N / L;
     for (int w = t; w < (N / 4) * NC; w += 256) {
-      const int c = RFAST ? w / (N / 4) : w % NC, b = RFAST ? w % (N / 4) : w / NC;
+      const int c = RFAST ? w / (N / 4) : w % NC, bb = RFAST ? w % (N / 4) : w / NC;
+      const int sub = bb / (M / 4), b = bb - sub * (M / 4);
       const int g = b / Q, j = b - g * Q;
-      double2* x = buf + c * SC + (g * L + j) * SR;
+      double2* x = buf + c * SC + (sub * M + g * L + j) * SR;
       double2 x0 = x[0], x1 = x[Q * SR], x2 = x[2 * Q * SR], x3 = x[3 * Q * SR];
       if (L > 4) {
         const double2 w1 = tw[j * step], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
@@ -117,11 +156,24 @@ __device__ __forceinline__ void fft_dit(double2* __restrict__ buf, const double2
   }
   if (ODD) {
     for (int w = t; w < (N / 2) * NC; w += 256) {
-      const int c = RFAST ? w / (N / 2) : w % NC, j = RFAST ? w % (N / 2) : w / NC;
-      double2* x = buf + c * SC;
-      const double2 x0 = x[j * SR], x1 = cmulc(x[(j + N / 2) * SR], tw[j]);
+      const int c = RFAST ? w / (N / 2) : w % NC, jj = RFAST ? w % (N / 2) : w / NC;
+      const int sub = jj / (M / 2), j = jj - sub * (M / 2);
+      double2* x = buf + c * SC + sub * M * SR;
+      const double2 x0 = x[j * SR], x1 = cmulc(x[(j + M / 2) * SR], tw[j * R3]);
       x[j * SR] = cadd(x0, x1);
-      x[(j + N / 2) * SR] = csub(x0, x1);
+      x[(j + M / 2) * SR] = csub(x0, x1);
+    }
+    __syncthreads();
+  }
+  if (R3 == 3) {
+    for (int w = t; w < M * NC; w += 256) {
+      const int c = RFAST ? w / M : w % NC, j = RFAST ? w % M : w / NC;
+      double2* x = buf + c * SC;
+      double2 a0 = x[j * SR], a1 = cmulc(x[(j + M) * SR], tw[j]), a2 = cmulc(x[(j + 2 * M) * SR], tw[2 * j]);
+      bfly3<true>(a0, a1, a2);
+      x[j * SR] = a0;
+      x[(j + M) * SR] = a1;
+      x[(j + 2 * M) * SR] = a2;
     }
     __syncthreads();
   }
@@ -141,7 +193,7 @@ struct PackMap {
 
 template <int LOGN, int TK, bool INVERSE, bool PACKED>
 __global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kxn, int kxs, const double2* __restrict__ tw_g, PackMap pm) {
-  constexpr int N = 1 << LOGN;
+  constexpr int N = fft_len(LOGN);
   extern __shared__ double2 lds_dyn[];
   double2* buf = lds_dyn;          // [N][TK]
   double2* tw = lds_dyn + N * TK;  // [N]
@@ -201,7 +253,7 @@ __global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kx
 template <int LOGN, int NP, int SRC>
 __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restrict__ src, double2* __restrict__ out, int n1,
                                               const double2* __restrict__ tw_g, int kxs, int kz0) {
-  constexpr int N = 1 << LOGN;
+  constexpr int N = fft_len(LOGN);
   constexpr int KXN = N / 2 + 1;
   extern __shared__ double2 lds_dyn[];
   double2* buf = lds_dyn;          // [NP][N]
@@ -282,7 +334,7 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
     const int j = j0 + 2 * p;
     if (j >= n1) continue;
     const double2 zk = buf[p * N + pos_of_freq<LOGN>(s)];
-    const double2 zm = buf[p * N + pos_of_freq<LOGN>((N - s) & (N - 1))];
+    const double2 zm = buf[p * N + pos_of_freq<LOGN>((N - s) % N)];
     const double2 a = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
     const double2 b = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
     const long long o = s + (long long)kxs * (j + (long long)n1 * kz);
@@ -297,7 +349,7 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
 template <int LOGN, int NP>
 __global__ __launch_bounds__(256) void k_xinv(const double2* __restrict__ in, double* __restrict__ pI, int n1,
                                               const double2* __restrict__ tw_g, int kxs) {
-  constexpr int N = 1 << LOGN;
+  constexpr int N = fft_len(LOGN);
   constexpr int KXN = N / 2 + 1;
   extern __shared__ double2 lds_dyn[];
   double2* buf = lds_dyn;
@@ -366,7 +418,7 @@ struct FdmZArgs {
 
 template <int LOGN, int TK>
 __global__ __launch_bounds__(256) void k_fdm_z(FdmZArgs a, const double2* __restrict__ tw_g) {
-  constexpr int N = 1 << LOGN;
+  constexpr int N = fft_len(LOGN);
   extern __shared__ double2 lds_dyn[];
   double2* buf = lds_dyn;          // [N][TK]
   double2* tw = lds_dyn + N * TK;  // [N]
@@ -397,7 +449,7 @@ __global__ __launch_bounds__(256) void k_fdm_z(FdmZArgs a, const double2* __rest
     if (ln >= a.nl) continue;
     const int m = (int)(ln % a.n0h), j = (int)(ln / a.n0h);
     const int ia = 2 * m, ib = ia + 1;
-    const int pk = pos_of_freq<LOGN>(k), pm = pos_of_freq<LOGN>((N - k) & (N - 1));
+    const int pk = pos_of_freq<LOGN>(k), pm = pos_of_freq<LOGN>((N - k) % N);
     const double2 zk = buf[pk * TK + c], zm = buf[pm * TK + c];
     const bool self = k == 0 || k == N / 2;
     double2 A = self ? make_double2(zk.x, 0.0) : make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
@@ -448,8 +500,8 @@ int set_lds(K kernel, size_t lds) {
 
 template <int LOGN>
 int launch_y(double2* data, int kxn, int kxs, int nplanes, const double2* tw, bool inverse, const PackMap* pm, hipStream_t s) {
-  constexpr int N = 1 << LOGN;
-  constexpr int TK = N <= 256 ? 16 : (N == 512 ? 8 : 4);  // 256-B segments per row where LDS allows (<= 80 KB tiles)
+  constexpr int N = fft_len(LOGN);
+  constexpr int TK = N <= 256 ? 16 : (N <= 512 ? 8 : 4);  // 256-B segments per row where LDS allows (<= 80 KB tiles)
   constexpr size_t lds = ((size_t)N * TK + N) * sizeof(double2);
   dim3 grid((kxn + TK - 1) / TK, nplanes);
   PackMap none{nullptr, 1, 1, 1};
@@ -477,8 +529,8 @@ int launch_y(double2* data, int kxn, int kxs, int nplanes, const double2* tw, bo
 
 template <int LOGN>
 int launch_xfwd(const GridDev& g, const double* src, int from_u, double2* out, int n1, int n2, const double2* tw, int kxs, hipStream_t s, int kz0) {
-  constexpr int N = 1 << LOGN;
-  constexpr int NP = N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N);
+  constexpr int N = fft_len(LOGN);
+  constexpr int NP = fft_r3(LOGN) == 3 ? 768 / N : (N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N));  // 2 NP N a multiple of 256
   constexpr size_t lds = ((size_t)NP * N + N) * sizeof(double2);
   dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
   if (from_u == 5)
@@ -499,8 +551,8 @@ int launch_xfwd(const GridDev& g, const double* src, int from_u, double2* out, i
 
 template <int LOGN>
 int launch_xinv(const double2* in, double* pI, int n1, int n2, const double2* tw, int kxs, hipStream_t s) {
-  constexpr int N = 1 << LOGN;
-  constexpr int NP = N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N);
+  constexpr int N = fft_len(LOGN);
+  constexpr int NP = fft_r3(LOGN) == 3 ? 768 / N : (N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N));  // 2 NP N a multiple of 256
   constexpr size_t lds = ((size_t)NP * N + N) * sizeof(double2);
   dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
   hipLaunchKernelGGL((k_xinv<LOGN, NP>), grid, dim3(256), lds, s, in, pI, n1, tw, kxs);
@@ -519,29 +571,46 @@ int launch_xinv(const double2* in, double* pI, int n1, int n2, const double2* tw
     case 256: return CALL(8);               \
     case 512: return CALL(9);               \
     case 1024: return CALL(10);             \
+    case 192: return CALL(32 + 6);          \
+    case 384: return CALL(32 + 7);          \
   }                                         \
   ins_set_error("own FFT: unsupported length %d", n); \
   return INS_ERR_UNSUPPORTED;
 
-bool ins_ownfft_supported(const int np[3]) {
+bool ins_ownfft_supported(const int np[3]) {  // power-of-two boxes (slab and 2-D paths)
   if (ins_opt(OPT_INS_DISABLE_OWNFFT)) return false;
   for (int a = 0; a < 3; ++a)
     if (np[a] < 16 || np[a] > 1024 || (np[a] & (np[a] - 1))) return false;
   return ins_zsolve_supported(np[2]);
 }
+// single-GPU 3-D solver: sides of 3 * 2^m (192, 384) run on the own passes too (a radix-3 stage in front; INS_OWNFFT_POW2_ONLY keeps rocFFT for them)
+bool ins_ownfft_supported_mixed(const int np[3]) {
+  if (ins_opt(OPT_INS_DISABLE_OWNFFT)) return false;
+  for (int a = 0; a < 3; ++a) {
+    const bool pow2 = np[a] >= 16 && np[a] <= 1024 && !(np[a] & (np[a] - 1));
+    const bool r3 = (np[a] == 192 || np[a] == 384) && !ins_opt(OPT_INS_OWNFFT_POW2_ONLY);
+    if (!pow2 && !r3) return false;
+  }
+  return ins_zsolve_supported(np[2]);
+}
 
 // ây permuted to the digit-reversed storage order that pass 2 leaves behind: out[pos] = ay[freq(pos)].
 void ins_ownfft_permute_symbol(int n, const double* ay, double* out) {
-  int logn = 0;
-  while ((1 << logn) < n) ++logn;
+  const int r3 = (n % 3 == 0) ? 3 : 1, m = n / r3;
+  int logm = 0;
+  while ((1 << logm) < m) ++logm;
   for (int k = 0; k < n; ++k) {
-    int p = 0, kk = k, L = n;
-    if (logn & 1) {
+    int p = 0, kk = k, L = m;
+    if (r3 == 3) {
+      p = (kk % 3) * m;
+      kk /= 3;
+    }
+    if (logm & 1) {
       p += (kk & 1) * (L / 2);
       kk >>= 1;
       L /= 2;
     }
-    for (int s = 0; s < logn / 2; ++s) {
+    for (int s = 0; s < logm / 2; ++s) {
       p += (kk & 3) * (L / 4);
       kk >>= 2;
       L /= 4;

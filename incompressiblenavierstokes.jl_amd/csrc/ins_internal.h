@@ -63,6 +63,7 @@ void ins_set_error(const char* fmt, ...);
   X(INS_DISABLE_FDM_XFFT)        \
   X(INS_DISABLE_FDM_XYFFT)       \
   X(INS_DISABLE_OWNFFT)          \
+  X(INS_OWNFFT_POW2_ONLY)        \
   X(INS_FIELDS_NO_MARCH)         \
   X(INS_FIELDS_ROWS)             \
   X(INS_FIELDS_ZC)               \
@@ -270,6 +271,7 @@ int ins_fft_make_real_plans(hipfftHandle* fwd, hipfftHandle* inv, int rank, int*
 void ins_fft_solver_released();
 bool ins_zsolve_supported(int nz);
 bool ins_ownfft_supported(const int np[3]);
+bool ins_ownfft_supported_mixed(const int np[3]);
 void ins_ownfft_permute_symbol(int n, const double* ay, double* out);
 // kxs: row stride of phat in complex elements (0 = dense, n0/2+1); a multiple of 8 keeps the y/z tiles 128-B aligned
 // n2 planes starting at interior plane kz0

@@ -640,7 +640,7 @@ extern "C" int ins_poisson_spectral_create(const ins_grid_t* G, ins_poisson_t** 
     ins_poisson_destroy(ps);
     return code;
   };
-  ps->ownfft = D == 3 && ins_ownfft_supported(ps->np);
+  ps->ownfft = D == 3 && ins_ownfft_supported_mixed(ps->np);
   // 2-D power-of-two boxes: own x passes around the fused solve kernel run along y (FFT · symbol · inverse FFT in one pass):
   // three kernels instead of rocFFT's eight plus its three staging copies per solve
   const int np2[3] = {ps->np[0], 16, ps->np[1]};
@@ -963,6 +963,15 @@ extern "C" int ins_poisson_cg_bordered(ins_poisson_t* ps, int enable) {
   INS_REQUIRE(ps, "null argument");
   INS_REQUIRE(ps->kind == POISSON_CG, "bordered mode applies to the CG solver only");
   ps->bordered = enable != 0;
+  return INS_OK;
+}
+
+extern "C" int ins_poisson_fft_engine(const ins_poisson_t* ps, int32_t* engine) {
+  if (!ps || !engine) {
+    ins_set_error("ins_poisson_fft_engine: null argument");
+    return INS_ERR_INVALID;
+  }
+  *engine = ps->kind != POISSON_SPECTRAL ? -1 : (ps->ownfft ? 1 : (ps->zfused ? 2 : 0));
   return INS_OK;
 }
 

@@ -215,10 +215,38 @@ __device__ __forceinline__ void dft4(double2& x0, double2& x1, double2& x2, doub
   x3 = csub(t1, t3);
 }
 // y[k] = sum_n x[n] w^(nk), w = exp(-+2 pi i / R), in place, natural order in and out
+template <bool INV>
+__device__ __forceinline__ void dft3(double2& x0, double2& x1, double2& x2) {
+  constexpr double h = 0.86602540378443864676;  // sqrt(3)/2
+  const double2 t1 = cadd(x1, x2), d = csub(x1, x2);
+  const double2 t2 = make_double2(x0.x - 0.5 * t1.x, x0.y - 0.5 * t1.y);
+  const double2 t3 = INV ? make_double2(-h * d.y, h * d.x) : make_double2(h * d.y, -h * d.x);  // (-+i) sqrt(3)/2 (x1 - x2)
+  x0 = cadd(x0, t1);
+  x1 = cadd(t2, t3);
+  x2 = csub(t2, t3);
+}
 template <int R, bool INV>
 __device__ __forceinline__ void dft(double2 (&x)[R]) {
   if constexpr (R == 4) {
     dft4<INV>(x[0], x[1], x[2], x[3]);
+  } else if constexpr (R == 3) {
+    dft3<INV>(x[0], x[1], x[2]);
+  } else if constexpr (R == 6) {
+    // even / odd thirds (radix 3 each), then the radix-2 combination with W6^k
+    dft3<INV>(x[0], x[2], x[4]);
+    dft3<INV>(x[1], x[3], x[5]);
+    constexpr double h = 0.86602540378443864676;
+    const double2 o1 = x[3], o2 = x[5];
+    // W6^1 = (1 -+ i sqrt3)/2, W6^2 = (-1 -+ i sqrt3)/2
+    const double2 w1 = INV ? make_double2(0.5 * o1.x - h * o1.y, 0.5 * o1.y + h * o1.x) : make_double2(0.5 * o1.x + h * o1.y, 0.5 * o1.y - h * o1.x);
+    const double2 w2 = INV ? make_double2(-0.5 * o2.x - h * o2.y, -0.5 * o2.y + h * o2.x) : make_double2(-0.5 * o2.x + h * o2.y, -0.5 * o2.y - h * o2.x);
+    const double2 e0 = x[0], e1 = x[2], e2 = x[4], w0 = x[1];
+    x[0] = cadd(e0, w0);
+    x[3] = csub(e0, w0);
+    x[1] = cadd(e1, w1);
+    x[4] = csub(e1, w1);
+    x[2] = cadd(e2, w2);
+    x[5] = csub(e2, w2);
   } else {
     static_assert(R == 8, "radix");
     // even / odd halves (radix 4 each), then the radix-2 combination with W8^k
@@ -248,7 +276,12 @@ __device__ __forceinline__ void twiddle(double2 (&x)[R], double2 w1) {
   const double2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
   x[1] = cmul(x[1], w1);
   x[2] = cmul(x[2], w2);
-  x[3] = cmul(x[3], w3);
+  if constexpr (R >= 4) x[3] = cmul(x[3], w3);
+  if constexpr (R == 6) {
+    const double2 w4 = cmul(w2, w2), w5 = cmul(w4, w1);
+    x[4] = cmul(x[4], w4);
+    x[5] = cmul(x[5], w5);
+  }
   if constexpr (R == 8) {
     const double2 w4 = cmul(w2, w2), w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
     x[4] = cmul(x[4], w4);
@@ -262,9 +295,9 @@ template <int LOGN, int TK, int NT>
 __global__ __launch_bounds__(NT) void k_zsolve3(double2* __restrict__ data, long long nl, const double* __restrict__ ax, int kxn,
                                                 const double* __restrict__ ay, const double* __restrict__ az,
                                                 const double2* __restrict__ tw_g, double inv_n, int zero_mean, int kxs, int skel, int ntiles) {
-  constexpr int N = 1 << LOGN;
-  constexpr int R1 = N / 64, R2 = 8, R3 = 8;  // 256 = 4 x 8 x 8, 512 = 8 x 8 x 8
-  static_assert(R1 == 4 || R1 == 8, "nz = 256 or 512");
+  constexpr int N = LOGN >= 32 ? 3 << (LOGN & 31) : 1 << LOGN;  // size code as in ins_fft.hip: 32 + m stands for 3 * 2^m
+  constexpr int R1 = N / 64, R2 = 8, R3 = 8;  // 256 = 4 x 8 x 8, 512 = 8 x 8 x 8, 192 = 3 x 8 x 8, 384 = 6 x 8 x 8
+  static_assert(R1 == 4 || R1 == 8 || R1 == 3 || R1 == 6, "nz = 192, 256, 384 or 512");
   constexpr int L2 = N / R1;                  // block length of pass 2 (64)
   extern __shared__ double2 lds_dyn[];
   double2* buf = lds_dyn;          // [N][TK], swizzled
@@ -272,8 +305,10 @@ __global__ __launch_bounds__(NT) void k_zsolve3(double2* __restrict__ data, long
   const int t = threadIdx.x;
   auto at = [&](int n, int c) -> double2& { return buf[(n ^ ((n >> 3) & 1)) * TK + c]; };
   for (int m = t; m < N; m += NT) tw[m] = tw_g[m];
-  constexpr int B1 = (N / R1) * TK / NT, B2 = (N / R2) * TK / NT, B3 = (N / R3) * TK / NT;  // transforms per work-item and pass
-  static_assert(B1 >= 1 && B2 >= 1 && B3 >= 1 && NT % TK == 0, "tile shape");
+  constexpr int RPI = NT / TK;  // transforms of one line column started per sweep of the workgroup
+  constexpr int B1 = (N / R1 + RPI - 1) / RPI, B2 = (N / R2 + RPI - 1) / RPI, B3 = (N / R3 + RPI - 1) / RPI;  // sweeps per pass
+  constexpr bool G2 = (N / R2) % RPI != 0;  // 192 / 384: the last sweep of passes 2 and 3 is partial
+  static_assert((N / R1) % RPI == 0 && NT % TK == 0, "tile shape");
   const int c = t % TK;  // NT is a multiple of TK: a work-item keeps its line column in every pass
   auto is_live = [&](long long line) { return line < nl && (int)(line % kxs) < kxn; };  // padding columns of a row (kx >= kxn) hold nothing
   // The workgroup is persistent: tiles blockIdx.x, blockIdx.x + gridDim.x, ...; the pass-1 loads of the next tile are issued as soon as the
@@ -318,6 +353,7 @@ __global__ __launch_bounds__(NT) void k_zsolve3(double2* __restrict__ data, long
 #pragma unroll
       for (int i = 0; i < B2; ++i) {
         const int b = t / TK + i * (NT / TK), g1 = b / (L2 / R2), j = b % (L2 / R2);
+        if (G2 && b >= N / R2) break;
         double2 x[R2];
 #pragma unroll
         for (int q = 0; q < R2; ++q) x[q] = at(g1 * L2 + j + q * (L2 / R2), c);
@@ -331,6 +367,7 @@ __global__ __launch_bounds__(NT) void k_zsolve3(double2* __restrict__ data, long
 #pragma unroll
       for (int i = 0; i < B3; ++i) {
         const int g = t / TK + i * (NT / TK);
+        if (G2 && g >= N / R3) break;
         double2 x[R3];
 #pragma unroll
         for (int q = 0; q < R3; ++q) x[q] = at(g * R3 + q, c);
@@ -353,6 +390,7 @@ __global__ __launch_bounds__(NT) void k_zsolve3(double2* __restrict__ data, long
 #pragma unroll
       for (int i = 0; i < B2; ++i) {
         const int b = t / TK + i * (NT / TK), g1 = b / (L2 / R2), j = b % (L2 / R2);
+        if (G2 && b >= N / R2) break;
         double2 x[R2];
 #pragma unroll
         for (int q = 0; q < R2; ++q) x[q] = at(g1 * L2 + j + q * (L2 / R2), c);
@@ -386,7 +424,8 @@ template <int LOGN, int TK, int NT>
 int launch_zsolve3(double2* data, long long nl, const double* ax, int kxn, const double* ay, const double* az, const double2* tw,
                    double inv_n, bool zero_mean, hipStream_t s, int kxs) {
   const int ntiles = (int)((nl + TK - 1) / TK);
-  constexpr size_t lds = ((size_t)(1 << LOGN) * TK + (1 << LOGN)) * sizeof(double2);
+  constexpr int N = LOGN >= 32 ? 3 << (LOGN & 31) : 1 << LOGN;
+  constexpr size_t lds = ((size_t)N * TK + N) * sizeof(double2);
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
     INS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_zsolve3<LOGN, TK, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -429,6 +468,7 @@ int launch_zsolve(double2* data, long long nl, const double* ax, int kxn, const 
 
 bool ins_zsolve_supported(int nz) {
   if (ins_opt(OPT_INS_DISABLE_ZSOLVE)) return false;
+  if ((nz == 192 || nz == 384) && !ins_opt(OPT_INS_OWNFFT_POW2_ONLY)) return true;  // 3 x 8 x 8 and 6 x 8 x 8 in the three-pass kernel
   return nz >= 16 && nz <= 1024 && (nz & (nz - 1)) == 0;
 }
 
@@ -472,6 +512,8 @@ int ins_k_zsolve(double* data, int nz, long long nl, const double* ax, int kxn, 
     case 32: return launch_zsolve<5, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
     case 64: return launch_zsolve<6, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
     case 128: return launch_zsolve<7, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+    case 192: return launch_zsolve3<32 + 6, 8, 256>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+    case 384: return launch_zsolve3<32 + 7, 8, 256>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
     case 256:
       if (!ins_opt(OPT_INS_ZSOLVE_RADIX4)) {
         return launch_zsolve3<8, 8, 256>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);

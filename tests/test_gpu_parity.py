@@ -434,10 +434,11 @@ def test_full_size_256_properties(ins):
     assert float((lhs - rhs).abs().max()) < 1e-9 * float(rhs.abs().max())
 
 
-@pytest.mark.parametrize("nz", [16, 32, 64, 128, 256, 512, 1024])
+@pytest.mark.parametrize("nz", [16, 32, 64, 128, 192, 256, 384, 512, 1024])
 def test_fused_z_pass_matches_oracle(ins, oracle, nz):
     """The custom z kernel (DIF FFT · symbol · DIT inverse FFT, csrc/ins_zsolve.hip) for every supported nz,
-    including the odd-log2 sizes that take the extra radix-2 stage; ragged line count (kxn*ny not a tile multiple)."""
+    including the odd-log2 sizes that take the extra radix-2 stage and 192 / 384 (3 x 8 x 8, 6 x 8 x 8 in the three-pass
+    kernel); ragged line count (kxn*ny not a tile multiple)."""
     o = oracle
     n = (10, 6, nz)
     so = fx.setup_periodic(o, n, D=3)
@@ -483,15 +484,22 @@ def test_lmwray3_and_right_hand_side_match_oracle(ins, oracle, geom):
 
 
 @pytest.mark.parametrize("n", [(16, 16, 16), (32, 16, 64), (128, 32, 16), (64, 128, 32), (256, 16, 16), (16, 256, 32),
-                               (512, 16, 16), (16, 512, 16), (1024, 16, 16), (16, 1024, 16)])
+                               (512, 16, 16), (16, 512, 16), (1024, 16, 16), (16, 1024, 16),
+                               (192, 16, 16), (16, 192, 32), (16, 16, 192), (384, 16, 16), (16, 384, 16), (32, 16, 384), (192, 384, 192)])
 def test_own_fft_passes_match_oracle(ins, oracle, n):
-    """All-own-kernel spectral solve on power-of-two boxes (csrc/ins_fft.hip: paired-row real x transform, digit-reversed
-    y pass, fused z pass) — every supported length incl. the odd-log2 ones, in each direction; both the generic
-    psolver(p) entry and the fused projection (right-hand side formed inside the x pass)."""
+    """All-own-kernel spectral solve (csrc/ins_fft.hip: paired-row real x transform, digit-reversed y pass, fused z pass) —
+    every supported length incl. the odd-log2 ones and 192 / 384 (a radix-3 stage in front of the power-of-two stages), in each
+    direction; both the generic psolver(p) entry and the fused projection (right-hand side formed inside the x pass)."""
+    import ctypes
+    from ins_amd import _lib
+
     o = oracle
     so = fx.setup_periodic(o, n, D=3)
     sp = mirror(ins, so, o)
     pso, psp = o.psolver_spectral(so), ins.psolver_spectral(sp)
+    engine = ctypes.c_int32(-2)
+    _lib.call("ins_poisson_fft_engine", psp.handle, ctypes.byref(engine))
+    assert engine.value == 1  # no rocFFT plan in this solver
     f = fx.randn_field(so.grid.N, 23)
     ip = tuple(slice(lo, hi) for lo, hi in so.grid.Ip)
     f[ip] -= f[ip].mean()
@@ -551,7 +559,7 @@ def test_flux64_momentum_matches_oracle(ins, oracle, n):
     assert relmax(got, o.momentum(u_h, None, 0.0, so)) < OP_TOL
 
 
-@pytest.mark.parametrize("n", [(96, 10, 8), (128, 16, 12), (200, 8, 6), (66, 10, 4), (130, 14, 10)])  # even: spectral solver
+@pytest.mark.parametrize("n", [(96, 10, 8), (128, 16, 12), (200, 8, 6), (66, 10, 4), (130, 14, 10), (192, 16, 16)])  # even: spectral solver; last: own 3 * 2^m passes
 @pytest.mark.parametrize("method", ["RK44", "Wray3"])
 def test_flux64_rk_steps_match_oracle(ins, oracle, n, method):
     """Fused stage kernels: first stage (RK epilogue) and the in-register pressure correction of the later stages, on boxes
