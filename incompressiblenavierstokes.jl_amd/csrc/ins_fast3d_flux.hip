@@ -472,7 +472,7 @@ static int launch_flux(const ins_grid* G, const double* u, double* F, const RkEp
   const Rec* r0 = reinterpret_cast<const Rec*>(G->rec_dev);
   const Rec* r1 = r0 + g.N[0];
   const Rec* r2 = r1 + g.N[1];
-  const int zc = g_zchunk ? g_zchunk : (g.N[2] >= 384 ? 8 : 4);
+  const int zc = g_zchunk ? g_zchunk : ((g.N[2] >= 384 || (pI && corr_mode == 3 && g.N[2] >= 128)) ? 8 : 4);
   const int bar = ins_opt(OPT_INS_FLUX_BAR) ? 1 : 0;  // measured neutral on the masked cavity kernel (6.31 vs 6.37 ms/step): off by default
   const bool corr = pI != nullptr;
   const bool masked = !G->all_dof;
@@ -520,8 +520,14 @@ static int launch_flux(const ins_grid* G, const double* u, double* F, const RkEp
 template <bool FUSE>
 static int launch_flux_any(const ins_grid* G, const double* u, double* F, const RkEpi& epi, const double* pI, int corr_mode, hipStream_t s) {
   // wavefronts side by side in x: 4 when the row needs >= 8 of them, else 2 (fewer mostly-empty workgroups)
-  const int waves_x = cdiv(G->g.N[0] - 2, XOUT);
-  const int xw = g_xw ? g_xw : (waves_x >= 8 ? 4 : (waves_x >= 2 ? 2 : 1));
+  // (the correcting kernels produce one column less per wavefront; a 256-wide row then takes 5 wavefronts, and workgroups of 2 or 4 side by
+  // side would launch 6 or 8: the side-by-side count is the largest of 4, 2, 1 that wastes no wavefront — cavity 256^3: 6.26 -> 6.05 ms/step)
+  const int waves_x = cdiv(G->g.N[0] - 2, pI ? XOUT - 1 : XOUT);
+  int xw = g_xw;
+  if (!xw) {
+    xw = waves_x >= 8 ? 4 : (waves_x >= 2 ? 2 : 1);
+    while (xw > 1 && cdiv(waves_x, xw) * xw > waves_x) xw >>= 1;
+  }
   const int rows = g_rows ? g_rows : 4;  // rows per thread (masked / correcting variants cap themselves at 3: registers)
 #define INS_FLUX_CASE(RR)                                                          \
   if (rows == RR) {                                                                \

@@ -84,6 +84,7 @@ void ins_set_error(const char* fmt, ...);
   X(INS_PHAT_DENSE)              \
   X(INS_DISABLE_FDM_FUSED)       \
   X(INS_DISABLE_FDM_FOLD)        \
+  X(INS_DISABLE_FDM_UNFOLD4)     \
   X(INS_DISABLE_FDM_FOLDFUSE)    \
   X(INS_DISABLE_INKERNEL_CORR)   \
   X(INS_RK_KEEP_K)               \

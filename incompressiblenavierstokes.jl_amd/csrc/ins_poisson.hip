@@ -38,54 +38,80 @@ __global__ __launch_bounds__(256) void k_div_to_pI(GridDev g, const double* __re
 // The same right-hand side written in the FOLDED form of the direct solver's symmetric directions (csrc/ins_fdm.hip: e_i = f_i + f_{n-1-i} at i,
 // o_i = f_i - f_{n-1-i} at n/2 + i, i < n/2, along every direction of `mask`): a work-item evaluates the divergence at the 2^k mirror images
 // of its volume and writes their sums / differences, so the solver needs no fold pass of its own.
-template <int D>
-__global__ __launch_bounds__(256) void k_div_to_pI_fold(GridDev g, const double* __restrict__ u, double* __restrict__ pI, int n0, int n1, int n2, int mask) {
-  const int h0 = (mask & 1) ? n0 / 2 : n0, h1 = (mask & 2) ? n1 / 2 : n1, h2 = (D == 3 && (mask & 4)) ? n2 / 2 : n2;
+template <int D, int MASK>  // MASK is a template parameter: the image loops unroll and v[][][] stays in registers (run-time bounds put it in scratch: 176 -> ? us at 256^3)
+__global__ __launch_bounds__(256) void k_div_to_pI_fold(GridDev g, const double* __restrict__ u, double* __restrict__ pI, int n0, int n1, int n2) {
+  constexpr int c0 = (MASK & 1) ? 2 : 1, c1 = (MASK & 2) ? 2 : 1, c2 = (D == 3 && (MASK & 4)) ? 2 : 1;
+  const int h0 = c0 == 2 ? n0 / 2 : n0, h1 = c1 == 2 ? n1 / 2 : n1, h2 = c2 == 2 ? n2 / 2 : n2;
   const int ii = blockIdx.x * 64 + threadIdx.x;
   const int jj = blockIdx.y * 4 + threadIdx.y;
   const int kk = D == 3 ? (int)blockIdx.z : 0;
   if (ii >= h0 || jj >= h1 || kk >= h2) return;
-  const int c0 = (mask & 1) ? 2 : 1, c1 = (mask & 2) ? 2 : 1, c2 = (D == 3 && (mask & 4)) ? 2 : 1;
-  double v[2][2][2];
+  double v[c2][c1][c0];
+  // metrics of the images: one read per direction and image instead of one per volume
+  double rd[3][2], dd[3][2];
+  int Ia[3][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    Ia[0][m] = g.ip_lo[0] + (m ? n0 - 1 - ii : ii);
+    Ia[1][m] = g.ip_lo[1] + (m ? n1 - 1 - jj : jj);
+    Ia[2][m] = D == 3 ? g.ip_lo[2] + (m ? n2 - 1 - kk : kk) : 0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      if (m >= (a == 0 ? c0 : (a == 1 ? c1 : c2))) continue;
+      rd[a][m] = g.rdx[a][Ia[a][m]];
+      dd[a][m] = g.dx[a][Ia[a][m]];
+    }
+  }
+#pragma unroll
   for (int cz = 0; cz < c2; ++cz)
+#pragma unroll
     for (int cy = 0; cy < c1; ++cy)
+#pragma unroll
       for (int cx = 0; cx < c0; ++cx) {
-        const int pi = cx ? n0 - 1 - ii : ii, pj = cy ? n1 - 1 - jj : jj, pk = cz ? n2 - 1 - kk : kk;
-        const int I[3] = {g.ip_lo[0] + pi, g.ip_lo[1] + pj, D == 3 ? g.ip_lo[2] + pk : 0};
-        const long long c = I[0] + I[1] * g.sx[1] + I[2] * g.sx[2];
+        const int m[3] = {cx, cy, cz};
+        const long long c = Ia[0][cx] + Ia[1][cy] * g.sx[1] + Ia[2][cz] * g.sx[2];
         double d = 0.0;
 #pragma unroll
         for (int a = 0; a < D; ++a) {
           const double* ua = u + a * g.sc;
-          d += (ua[c] - ua[c - g.sx[a]]) * g.rdx[a][I[a]];
+          d += (ua[c] - ua[c - g.sx[a]]) * rd[a][m[a]];
         }
-        double om = g.dx[0][I[0]] * g.dx[1][I[1]];
-        if (D == 3) om = om * g.dx[2][I[2]];
+        double om = dd[0][cx] * dd[1][cy];
+        if (D == 3) om = om * dd[2][cz];
         v[cz][cy][cx] = d * om;
       }
-  if (mask & 1)
+  if (c0 == 2)
+#pragma unroll
     for (int cz = 0; cz < c2; ++cz)
+#pragma unroll
       for (int cy = 0; cy < c1; ++cy) {
-        const double p = v[cz][cy][0], q = v[cz][cy][1];
+        const double p = v[cz][cy][0], q = v[cz][cy][c0 - 1];
         v[cz][cy][0] = p + q;
-        v[cz][cy][1] = p - q;
+        v[cz][cy][c0 - 1] = p - q;
       }
-  if (mask & 2)
+  if (c1 == 2)
+#pragma unroll
     for (int cz = 0; cz < c2; ++cz)
+#pragma unroll
       for (int cx = 0; cx < c0; ++cx) {
-        const double p = v[cz][0][cx], q = v[cz][1][cx];
+        const double p = v[cz][0][cx], q = v[cz][c1 - 1][cx];
         v[cz][0][cx] = p + q;
-        v[cz][1][cx] = p - q;
+        v[cz][c1 - 1][cx] = p - q;
       }
-  if (D == 3 && (mask & 4))
+  if (c2 == 2)
+#pragma unroll
     for (int cy = 0; cy < c1; ++cy)
+#pragma unroll
       for (int cx = 0; cx < c0; ++cx) {
-        const double p = v[0][cy][cx], q = v[1][cy][cx];
+        const double p = v[0][cy][cx], q = v[c2 - 1][cy][cx];
         v[0][cy][cx] = p + q;
-        v[1][cy][cx] = p - q;
+        v[c2 - 1][cy][cx] = p - q;
       }
+#pragma unroll
   for (int cz = 0; cz < c2; ++cz)
+#pragma unroll
     for (int cy = 0; cy < c1; ++cy)
+#pragma unroll
       for (int cx = 0; cx < c0; ++cx)
         pI[(cx ? n0 / 2 + ii : ii) + (long long)n0 * ((cy ? n1 / 2 + jj : jj) + (long long)n1 * (cz ? n2 / 2 + kk : kk))] = v[cz][cy][cx];
 }
@@ -180,6 +206,96 @@ __global__ __launch_bounds__(256) void k_unpack_grad_bc(GridDev g, double* __res
     wnn[a] = wn;
     const double pn = zn ? 0.0 : val(wnn, qn) - sh;
     u[a * g.sc + c] -= (pn - pc) * g.rdxu[a][I[a]];
+  }
+}
+
+// The same pass for a 3-D solution kept FOLDED along x and / or y (z unfolded): a work-item owns the 2 or 4 mirror images of its volume,
+// so each folded value is read once for all of them (the kernel above gathers 2^k values per pressure it needs: 16 per volume with the
+// gradient).  Neighbours: six such reads — (i±1, j), (i, j±1), (i, j, k+1) — serve all images (the +x neighbour of the image n0-1-i is
+// the image of i-1).  Ghost pressures are written by the owner of the adjacent interior volume, composed over the directions as map_p does.
+template <bool GRAD>
+__global__ __launch_bounds__(256) void k_unfold_grad3(GridDev g, double* __restrict__ u, double* __restrict__ p, const double* __restrict__ pI,
+                                                      int n0, int n1, int n2, const double* __restrict__ shift, int fmask) {
+  const bool fx = fmask & 1, fy = fmask & 2;
+  const int h0 = fx ? n0 / 2 : n0, h1 = fy ? n1 / 2 : n1;
+  const int ii = blockIdx.x * 64 + threadIdx.x, jj = blockIdx.y * 4 + threadIdx.y, kk = (int)blockIdx.z;
+  if (ii >= h0 || jj >= h1) return;
+  const double sh = shift ? *shift : 0.0;
+  const long long s1 = n0, s2 = (long long)n0 * n1;
+  struct Q {
+    double v[2][2];  // [image in y][image in x]
+  };
+  auto fetch = [&](int i, int j, int k) {
+    const double* b = pI + i + s1 * j + s2 * k;
+    const double a = b[0], bx = fx ? b[h0] : 0.0, cy = fy ? b[s1 * h1] : 0.0, d = (fx && fy) ? b[h0 + s1 * h1] : 0.0;
+    Q q;  // the summation order of unfold_at
+    q.v[0][0] = ((a + bx) + cy) + d - sh;
+    q.v[0][1] = ((a - bx) + cy) - d - sh;
+    q.v[1][0] = ((a + bx) - cy) - d - sh;
+    q.v[1][1] = ((a - bx) - cy) + d - sh;
+    return q;
+  };
+  const Q c = fetch(ii, jj, kk);
+  Q xp = c, xm = c, yp = c, ym = c, zp = c;
+  const bool perz = g.bc[2][0] == INS_BC_PERIODIC;
+  if (GRAD) {
+    if (ii + 1 < h0) xp = fetch(ii + 1, jj, kk);
+    if (fx && ii >= 1) xm = fetch(ii - 1, jj, kk);
+    if (jj + 1 < h1) yp = fetch(ii, jj + 1, kk);
+    if (fy && jj >= 1) ym = fetch(ii, jj - 1, kk);
+    if (kk + 1 < n2 || perz) zp = fetch(ii, jj, kk + 1 < n2 ? kk + 1 : 0);
+  }
+  // (no side is a PressureBC here — the host routes those grids to the kernel above —, so a pressure just outside the box is the copy of the
+  // adjacent interior value behind a Symmetric side and is read by no DOF behind a Dirichlet one)
+#pragma unroll
+  for (int my = 0; my < 2; ++my) {
+    if (my && !fy) break;
+#pragma unroll
+    for (int mx = 0; mx < 2; ++mx) {
+      if (mx && !fx) break;
+      const int w[3] = {mx ? n0 - 1 - ii : ii, my ? n1 - 1 - jj : jj, kk};
+      const int n[3] = {n0, n1, n2};
+      const int I[3] = {g.ip_lo[0] + w[0], g.ip_lo[1] + w[1], g.ip_lo[2] + w[2]};
+      const double pc = c.v[my][mx];
+      // ---- p: the volume itself and every ghost volume that takes its value (or zero) from it
+      int tgt[3][3], nt[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        nt[a] = 1;
+        tgt[a][0] = I[a];
+        if (w[a] == 0) {
+          if (g.bc[a][1] == INS_BC_PERIODIC) tgt[a][nt[a]++] = g.ip_hi[a];
+          if (g.bc[a][0] == INS_BC_SYMMETRIC) tgt[a][nt[a]++] = g.ip_lo[a] - 1;
+        }
+        if (w[a] == n[a] - 1 && nt[a] < 3) {
+          if (g.bc[a][0] == INS_BC_PERIODIC) tgt[a][nt[a]++] = g.ip_lo[a] - 1;
+          if (g.bc[a][1] == INS_BC_SYMMETRIC) tgt[a][nt[a]++] = g.ip_hi[a];
+        }
+      }
+      for (int t2 = 0; t2 < nt[2]; ++t2)
+        for (int t1 = 0; t1 < nt[1]; ++t1)
+          for (int t0 = 0; t0 < nt[0]; ++t0) p[tgt[0][t0] + tgt[1][t1] * g.sx[1] + tgt[2][t2] * g.sx[2]] = pc;
+      if (!GRAD) continue;
+      // ---- u -= ∇p on the degrees of freedom of this volume
+      double pn[3];
+      if (mx == 0)
+        pn[0] = ii + 1 < h0 ? xp.v[my][0] : (fx ? c.v[my][1] : pc);
+      else
+        pn[0] = ii >= 1 ? xm.v[my][1] : pc;
+      if (my == 0)
+        pn[1] = jj + 1 < h1 ? yp.v[0][mx] : (fy ? c.v[1][mx] : pc);
+      else
+        pn[1] = jj >= 1 ? ym.v[1][mx] : pc;
+      pn[2] = (kk + 1 < n2 || perz) ? zp.v[my][mx] : pc;
+      const long long cc = I[0] + I[1] * g.sx[1] + I[2] * g.sx[2];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        bool dof = true;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) dof = dof && I[b] >= g.iu_lo[a][b] && I[b] < g.iu_hi[a][b];
+        if (dof) u[a * g.sc + cc] -= (pn[a] - pc) * g.rdxu[a][I[a]];
+      }
+    }
   }
 }
 
@@ -1119,10 +1235,26 @@ static int fdm_rhs(const ins_grid* G, ins_poisson* ps, const double* u, double* 
   if (fm) {
     const int n0 = ps->np[0], n1 = ps->np[1], n2 = g.D == 3 ? ps->np[2] : 1;
     const dim3 grid(cdiv((fm & 1) ? n0 / 2 : n0, 64), cdiv((fm & 2) ? n1 / 2 : n1, 4), (g.D == 3 && (fm & 4)) ? n2 / 2 : n2);
-    if (g.D == 2)
-      hipLaunchKernelGGL(k_div_to_pI_fold<2>, grid, block, 0, s, g, u, buf, n0, n1, n2, fm);
-    else
-      hipLaunchKernelGGL(k_div_to_pI_fold<3>, grid, block, 0, s, g, u, buf, n0, n1, n2, fm);
+#define INS_DIVFOLD(DD, MM) \
+  case MM: hipLaunchKernelGGL((k_div_to_pI_fold<DD, MM>), grid, block, 0, s, g, u, buf, n0, n1, n2); break;
+    if (g.D == 2) {
+      switch (fm & 3) {
+        INS_DIVFOLD(2, 1)
+        INS_DIVFOLD(2, 2)
+        INS_DIVFOLD(2, 3)
+      }
+    } else {
+      switch (fm & 7) {
+        INS_DIVFOLD(3, 1)
+        INS_DIVFOLD(3, 2)
+        INS_DIVFOLD(3, 3)
+        INS_DIVFOLD(3, 4)
+        INS_DIVFOLD(3, 5)
+        INS_DIVFOLD(3, 6)
+        INS_DIVFOLD(3, 7)
+      }
+    }
+#undef INS_DIVFOLD
   } else {
     const dim3 grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), g.D == 3 ? ps->np[2] : 1);
     if (g.D == 2)
@@ -1134,11 +1266,41 @@ static int fdm_rhs(const ins_grid* G, ins_poisson* ps, const double* u, double* 
   return INS_OK;
 }
 
-int ins_k_project_fdm_solve_only(const ins_grid* G, ins_poisson* ps, const double* u, double* p, hipStream_t s) {
+// copy-back (- mean) + apply_bc_p! (+ applypressure! when u != nullptr) from the direct solver's buffer, folded (fm) or not
+static int fdm_unpack(const ins_grid* G, ins_poisson* ps, double* u, double* p, const double* buf, int fm, hipStream_t s) {
   const GridDev& g = G->g;
+  const dim3 block(64, 4, 1);
+  const int n0 = ps->np[0], n1 = ps->np[1], n2 = g.D == 3 ? ps->np[2] : 1;
+  bool pressure_side = false;  // a PressureBC puts a DOF of u into the ghost layer: the general kernel covers it
+  for (int a = 0; a < g.D; ++a) pressure_side = pressure_side || g.bc[a][0] == INS_BC_PRESSURE || g.bc[a][1] == INS_BC_PRESSURE;
+  if (g.D == 3 && fm && !(fm & 4) && !pressure_side && !((fm & 1) && (n0 & 1)) && !((fm & 2) && (n1 & 1)) && !ins_opt(OPT_INS_DISABLE_FDM_UNFOLD4)) {
+    const dim3 grid(cdiv((fm & 1) ? n0 / 2 : n0, 64), cdiv((fm & 2) ? n1 / 2 : n1, 4), n2);
+    if (u)
+      hipLaunchKernelGGL(k_unfold_grad3<true>, grid, block, 0, s, g, u, p, buf, n0, n1, n2, ins_fdm_mean(ps->fdm), fm);
+    else
+      hipLaunchKernelGGL(k_unfold_grad3<false>, grid, block, 0, s, g, u, p, buf, n0, n1, n2, ins_fdm_mean(ps->fdm), fm);
+    INS_LAUNCH_CHECK();
+    return INS_OK;
+  }
+  const dim3 gridp(cdiv(n0 + 2, 64), cdiv(n1 + 2, 4), g.D == 3 ? n2 + 2 : 1);
+  if (g.D == 2) {
+    if (u)
+      hipLaunchKernelGGL((k_unpack_grad_bc<2, true>), gridp, block, 0, s, g, u, p, buf, n0, n1, ins_fdm_mean(ps->fdm), fm, 1);
+    else
+      hipLaunchKernelGGL((k_unpack_grad_bc<2, false>), gridp, block, 0, s, g, u, p, buf, n0, n1, ins_fdm_mean(ps->fdm), fm, 1);
+  } else {
+    if (u)
+      hipLaunchKernelGGL((k_unpack_grad_bc<3, true>), gridp, block, 0, s, g, u, p, buf, n0, n1, ins_fdm_mean(ps->fdm), fm, n2);
+    else
+      hipLaunchKernelGGL((k_unpack_grad_bc<3, false>), gridp, block, 0, s, g, u, p, buf, n0, n1, ins_fdm_mean(ps->fdm), fm, n2);
+  }
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+int ins_k_project_fdm_solve_only(const ins_grid* G, ins_poisson* ps, const double* u, double* p, hipStream_t s) {
   int rc, fm = 0;
   double* buf = ins_fdm_buffer(ps->fdm);
-  dim3 block(64, 4, 1), grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), g.D == 3 ? ps->np[2] : 1);
   if (ins_fdm_takes_u(ps->fdm)) {
     if ((rc = ins_fdm_solve(ps->fdm, s, G, u))) return rc;
   } else {
@@ -1146,14 +1308,7 @@ int ins_k_project_fdm_solve_only(const ins_grid* G, ins_poisson* ps, const doubl
     if ((rc = fdm_rhs(G, ps, u, buf, fm, s))) return rc;
     if ((rc = ins_fdm_solve(ps->fdm, s, nullptr, nullptr, fm != 0))) return rc;
   }
-  dim3 gridp(cdiv(ps->np[0] + 2, 64), cdiv(ps->np[1] + 2, 4), g.D == 3 ? ps->np[2] + 2 : 1);
-  if (g.D == 2)
-    hipLaunchKernelGGL((k_unpack_grad_bc<2, false>), gridp, block, 0, s, g, nullptr, p, (const double*)buf, ps->np[0], ps->np[1], ins_fdm_mean(ps->fdm), fm, 1);
-  else
-    hipLaunchKernelGGL((k_unpack_grad_bc<3, false>), gridp, block, 0, s, g, nullptr, p, (const double*)buf, ps->np[0], ps->np[1], ins_fdm_mean(ps->fdm), fm,
-                       ps->np[2]);
-  INS_LAUNCH_CHECK();
-  return INS_OK;
+  return fdm_unpack(G, ps, nullptr, p, buf, fm, s);
 }
 
 int ins_k_project(const ins_grid* G, ins_poisson* ps, double* u, double* p, hipStream_t s) {
@@ -1179,7 +1334,6 @@ int ins_k_project(const ins_grid* G, ins_poisson* ps, double* u, double* p, hipS
     // direct solver: Ω·div(u) straight into the solver's buffer, and copy-back - mean + apply_bc_p! + applypressure! in one pass
     double* buf = ins_fdm_buffer(ps->fdm);
     int fm = 0;
-    dim3 block(64, 4, 1), grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), g.D == 3 ? ps->np[2] : 1);
     if (ins_fdm_takes_u(ps->fdm)) {  // periodic x: the divergence is formed inside the solver's x pass
       if ((rc = ins_fdm_solve(ps->fdm, s, G, u))) return rc;
     } else {
@@ -1187,13 +1341,7 @@ int ins_k_project(const ins_grid* G, ins_poisson* ps, double* u, double* p, hipS
       if ((rc = fdm_rhs(G, ps, u, buf, fm, s))) return rc;
       if ((rc = ins_fdm_solve(ps->fdm, s, nullptr, nullptr, fm != 0))) return rc;
     }
-    dim3 gridp(cdiv(ps->np[0] + 2, 64), cdiv(ps->np[1] + 2, 4), g.D == 3 ? ps->np[2] + 2 : 1);
-    if (g.D == 2)
-      hipLaunchKernelGGL(k_unpack_grad_bc<2>, gridp, block, 0, s, g, u, p, (const double*)buf, ps->np[0], ps->np[1], ins_fdm_mean(ps->fdm), fm, 1);
-    else
-      hipLaunchKernelGGL(k_unpack_grad_bc<3>, gridp, block, 0, s, g, u, p, (const double*)buf, ps->np[0], ps->np[1], ins_fdm_mean(ps->fdm), fm, ps->np[2]);
-    INS_LAUNCH_CHECK();
-    return INS_OK;
+    return fdm_unpack(G, ps, u, p, buf, fm, s);
   }
   if ((rc = ins_k_divergence(G, u, p, s))) return rc;
   if ((rc = ins_k_scalewithvolume(G, p, s))) return rc;
