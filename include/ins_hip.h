@@ -202,6 +202,9 @@ int ins_rk_profile_read(ins_rk_t* rk, double* momentum_ms, int64_t* momentum_lau
  * NULL removes it.  With a force the steps of ins_rk_steps_f64 are not chained. */
 int ins_rk_set_bodyforce(ins_rk_t* rk, const double* force);
 int ins_rk_pressure(const ins_rk_t* rk, double** p);
+/* The cache array ku[i] of ode_method_cache (time_steppers.jl).  It holds the stage force k_i only on the k-basis paths (INS_RK_KEEP_K=1
+ * selects them everywhere); the fused stage loops work in the stage-velocity basis, where the periodic loop leaves the arrays untouched
+ * and the wall-bounded loop uses them for its uncorrected stage velocities. */
 int ins_rk_stage_force(const ins_rk_t* rk, int i, double** ku);
 
 /* ---------------------------------------------------------------------------------- step-adjacent field operators

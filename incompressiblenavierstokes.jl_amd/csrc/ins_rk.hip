@@ -407,23 +407,48 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
     // stages the projection only solves for p: no gradient-subtract pass over u, no second ghost fill.  Same arithmetic per volume as
     // project! + apply_bc_u! (boundary data is time-independent on this entry point); INS_DISABLE_INKERNEL_CORR restores them.
     const bool incorr = tiled && ns > 1 && !ins_opt(OPT_INS_DISABLE_INKERNEL_CORR) && ins_corr3_supported(G) && ins_k_project_fdm_fused(rk->ps);
+    // Stage-velocity basis, as on the periodic path (rk_step_fused_periodic): with the in-kernel correction the uncorrected stage velocities
+    // V_m (boundary data applied) stay in memory as the next stencil's input, so the stage combination is written in terms of them and no
+    // k_j is stored or read (RK44: 360 instead of 432 B per cell and step through the stage kernels; on volumes that are no DOF every term
+    // holds the same boundary value and the weights sum to one).  The ku arrays serve as the V_m buffers; INS_RK_KEEP_K=1 restores the k-basis.
+    bool vbasis = incorr && !ins_opt(OPT_INS_RK_KEEP_K);
+    for (int i = 0; vbasis && i < ns; ++i) vbasis = rk->A[i * ns + i] != 0.0;
     double* cur = u;
     for (int i = 0; i < ns; ++i) {
       const bool corr_in = incorr && i > 0;
       if (!corr_in && (rc = ins_k_apply_bc_u(G, cur, 0, nullptr, s))) return rc;  // :19 (corr_in: `cur` got its boundary data at :48 already)
-      double* out = (i == ns - 1 && ns > 1) ? u : rk->ub[i & 1];
+      double* out = (i == ns - 1 && ns > 1) ? u : (vbasis ? rk->ku[i] : rk->ub[i & 1]);
       RkEpi epi;
       memset(&epi, 0, sizeof(epi));
-      for (int j = 0; j < i; ++j) {
-        const double coef = dt * rk->A[i * ns + j];
-        if (coef == 0.0) continue;
-        epi.coef[epi.n] = coef;
-        epi.k[epi.n] = rk->ku[j];
-        ++epi.n;
+      if (vbasis) {
+        double beta[INS_MAX_STAGES];
+        for (int m = i - 1; m >= 0; --m) {  // β_i · A[0:i,0:i] = A[i,0:i], A lower triangular
+          double v = rk->A[i * ns + m];
+          for (int j = m + 1; j < i; ++j) v -= beta[j] * rk->A[j * ns + m];
+          beta[m] = v / rk->A[m * ns + m];
+        }
+        for (int m = 0; m < i; ++m) {
+          if (beta[m] == 0.0) continue;
+          epi.c0m1 -= beta[m];
+          epi.coef[epi.n] = beta[m];
+          epi.k[epi.n] = rk->ku[m];
+          ++epi.n;
+        }
+      } else {
+        for (int j = 0; j < i; ++j) {
+          const double coef = dt * rk->A[i * ns + j];
+          if (coef == 0.0) continue;
+          epi.coef[epi.n] = coef;
+          epi.k[epi.n] = rk->ku[j];
+          ++epi.n;
+        }
+        for (int i2 = i + 1; i2 < ns; ++i2)
+          if (rk->A[i2 * ns + i] != 0.0) epi.write_k = 1;
       }
-      if (rk->force) {
-        double cf = 0.0;
-        for (int j = 0; j <= i; ++j) cf += dt * rk->A[i * ns + j];
+      if (rk->force) {  // k_j = F_j + f: the V_m already hold their share of f (stage-velocity basis)
+        double cf = dt * rk->A[i * ns + i];
+        if (!vbasis)
+          for (int j = 0; j < i; ++j) cf += dt * rk->A[i * ns + j];
         epi.coef[epi.n] = cf;
         epi.k[epi.n] = rk->force;
         ++epi.n;
@@ -431,8 +456,6 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
       epi.coef_self = dt * rk->A[i * ns + i];
       epi.ustart = (i == 0) ? nullptr : u;
       epi.ustar = out;
-      for (int i2 = i + 1; i2 < ns; ++i2)
-        if (rk->A[i2 * ns + i] != 0.0) epi.write_k = 1;
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (rk->profiling) {
         INS_HIP_TRY(hipEventCreate(&e0));
