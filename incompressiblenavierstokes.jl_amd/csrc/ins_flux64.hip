@@ -124,7 +124,9 @@ struct Plane {
 // NW wavefronts per workgroup: XW side by side in x, NW/XW stacked in y.  CORR as in ins_fast3d_flux.hip: 0 = `u` has valid ghost volumes;
 // 1 = `u` is the previous stage's uncorrected u* (interior only), pI its unpadded pressure, every neighbour through the
 // periodic image; 2 = z-slab: x, y periodic images, z through exchanged ghost planes, pI = [1 | nzl | 2] extended buffer.
-template <typename T, int R, int XW, bool FUSE, int CORR, bool SKEL = false, int NW = 4>
+// EXTRA (extended stage loop, ins_rk_ext.hip): epi.extra is a vector field added to the stage force before it is used and stored
+// (k_i = F_i + closure(u_i) + gravity(temp_i), step_explicit_runge_kutta.jl:21-34).
+template <typename T, int R, int XW, bool FUSE, int CORR, bool SKEL = false, int NW = 4, bool EXTRA = false>
 __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a) {
   constexpr unsigned EB = (unsigned)sizeof(T);  // element bytes
   const T* const a_u = static_cast<const T*>(a.u);
@@ -248,8 +250,18 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
 
   // RK epilogue, first half: s = ustart + Σ_q coef_q k_q for all R rows of plane k.  Issued at the top of the plane so the
   // loads fly during the flux arithmetic (they used to sit right before the stores: one exposed round trip per row).
+  T eacc[3][EXTRA ? R : 1];
   auto epi_load = [&](const Plane<T, R>& C, int k, T (&sacc)[3][R]) {
     const long long pk = (long long)k * sz;
+    if constexpr (EXTRA) {
+      const T* b = static_cast<const T*>((const void*)a.epi.extra) + pk;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const rsrc_t rs = plane_rsrc(b + c * a.sc, ubytes);
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) eacc[c][rr] = ldb<T>(rs, ocol, orow[rr]);
+      }
+    }
     if (a.epi.ustart) {
       const T* b = static_cast<const T*>((const void*)a.epi.ustart) + pk;
       const T c0 = (T)(1.0 + a.epi.c0m1);  // exactly 1 in the k-basis
@@ -288,6 +300,11 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
   // second half: u* = s + coef_self f, and k_i = f when a later stage needs it
   auto emit = [&](int rr, int k, T fu, T fv, T fw, T s0, T s1, T s2) {
     const long long pk = (long long)k * sz;
+    if constexpr (EXTRA) {
+      fu += eacc[0][rr - 1];
+      fv += eacc[1][rr - 1];
+      fw += eacc[2][rr - 1];
+    }
     const int j = jb0 + rr - 1;  // interior row
     if (xout && j < n1) {
       const unsigned rowb = orow[rr - 1], co = ocol;
@@ -468,6 +485,17 @@ int launch_range(const ins_grid* G, FluxArgs& a, int corr_mode, hipStream_t s) {
       return INS_OK;
     }
   }
+  if (a.epi.extra) {
+    if constexpr (FUSE && R == 2 && NW == 4 && sizeof(T) == 8) {
+      if (corr_mode == 0) {
+        hipLaunchKernelGGL((k_flux64<T, R, XW, true, 0, false, NW, true>), dim3(nb), block, (size_t)g_lds, s, a);
+        INS_LAUNCH_CHECK();
+        return INS_OK;
+      }
+    }
+    ins_set_error("stage kernel with an extra force term: fp64, fused epilogue, 2 rows, 4 wavefronts, no in-kernel correction");
+    return INS_ERR_UNSUPPORTED;
+  }
   if (corr_mode == 0)
     hipLaunchKernelGGL((k_flux64<T, R, XW, FUSE, 0, false, NW>), dim3(nb), block, (size_t)g_lds, s, a);
   else if constexpr (FUSE && R <= 5) {
@@ -589,6 +617,11 @@ static int flux64_dispatch(const ins_grid* G, double visc, const T* u, T* F, con
     zc = n2 >= 256 && small_plane ? 64 : (n2 >= 128 ? 32 : (n2 >= 64 ? 16 : (n2 >= 32 ? 8 : 4)));
   }
   if (rows != 2 && nw == 16) nw = 8;
+  if (epi && epi->extra) {  // one instantiation serves the extended stage loop
+    rows = 2;
+    nw = 4;
+    if (!zco) zc = n2 >= 128 ? 32 : (n2 >= 64 ? 16 : (n2 >= 32 ? 8 : 4));
+  }
   a.zc = zc;
   a.bar = ins_opt(OPT_INS_FLUX64_NOBAR) ? 0 : 1;
 #define INS_F64_CASE(RR, FUSE)                                                        \

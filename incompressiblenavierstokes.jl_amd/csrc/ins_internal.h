@@ -231,6 +231,7 @@ struct RkEpi {
   const double* ustart;     // nullptr: ustart is the stencil input itself (first stage)
   double* ustar;            // stage velocity out (interior volumes only)
   double* ustart_out;       // optional (first stage of a chained step, ustart == nullptr): the corrected stencil input is stored here
+  const double* extra;      // optional vector field added to the stage force before it is used and stored (closure term, gravity: ins_rk_ext.hip)
 };
 
 

@@ -237,11 +237,11 @@ __global__ __launch_bounds__(256) void k_unfold_grad3(GridDev g, double* __restr
   };
   const Q c = fetch(ii, jj, kk);
   Q xp = c, xm = c, yp = c, ym = c, zp = c;
-  const bool perz = g.bc[2][0] == INS_BC_PERIODIC;
+  const bool perx = g.bc[0][0] == INS_BC_PERIODIC, pery = g.bc[1][0] == INS_BC_PERIODIC, perz = g.bc[2][0] == INS_BC_PERIODIC;
   if (GRAD) {
-    if (ii + 1 < h0) xp = fetch(ii + 1, jj, kk);
+    if (ii + 1 < h0 || (!fx && perx)) xp = fetch(ii + 1 < h0 ? ii + 1 : 0, jj, kk);  // unfolded periodic direction: the image of the first volume
     if (fx && ii >= 1) xm = fetch(ii - 1, jj, kk);
-    if (jj + 1 < h1) yp = fetch(ii, jj + 1, kk);
+    if (jj + 1 < h1 || (!fy && pery)) yp = fetch(ii, jj + 1 < h1 ? jj + 1 : 0, kk);
     if (fy && jj >= 1) ym = fetch(ii, jj - 1, kk);
     if (kk + 1 < n2 || perz) zp = fetch(ii, jj, kk + 1 < n2 ? kk + 1 : 0);
   }
@@ -278,14 +278,16 @@ __global__ __launch_bounds__(256) void k_unfold_grad3(GridDev g, double* __restr
       if (!GRAD) continue;
       // ---- u -= ∇p on the degrees of freedom of this volume
       double pn[3];
+      // (past the last volume of a direction: the first volume's value when it is periodic — folded: image 0 of this work-item's own
+      // values —, the copy pc behind a Symmetric side, unread behind a Dirichlet one)
       if (mx == 0)
-        pn[0] = ii + 1 < h0 ? xp.v[my][0] : (fx ? c.v[my][1] : pc);
+        pn[0] = ii + 1 < h0 ? xp.v[my][0] : (fx ? c.v[my][1] : (perx ? xp.v[my][0] : pc));
       else
-        pn[0] = ii >= 1 ? xm.v[my][1] : pc;
+        pn[0] = ii >= 1 ? xm.v[my][1] : (perx ? c.v[my][0] : pc);
       if (my == 0)
-        pn[1] = jj + 1 < h1 ? yp.v[0][mx] : (fy ? c.v[1][mx] : pc);
+        pn[1] = jj + 1 < h1 ? yp.v[0][mx] : (fy ? c.v[1][mx] : (pery ? yp.v[0][mx] : pc));
       else
-        pn[1] = jj >= 1 ? ym.v[1][mx] : pc;
+        pn[1] = jj >= 1 ? ym.v[1][mx] : (pery ? c.v[0][mx] : pc);
       pn[2] = (kk + 1 < n2 || perz) ? zp.v[my][mx] : pc;
       const long long cc = I[0] + I[1] * g.sx[1] + I[2] * g.sx[2];
 #pragma unroll

@@ -1,0 +1,229 @@
+// Native stage loop that carries the temperature equation and the Smagorinsky closure:
+// timestep!(method::ExplicitRungeKuttaMethod, stepper, Δt) with `temp` and / or `closure_model` set
+// (step_explicit_runge_kutta.jl:4-59), boundary data time-independent.  Per stage i
+//   apply_bc_u!, apply_bc_temp!                                                       :19-20
+//   ku[i] = momentum(u, temp) = convection-diffusion + body force + gravity(temp)      :21   (operators.jl:967-976)
+//   ktemp[i] = convection_diffusion_temp(u, temp) + dissipation(u)                     :23-27
+//   ku[i] += closure(u, θ) = divoftensor(apply_bc_p(smagtensor(u, θ)))                 :31-34 (operators.jl:1294-1305)
+//   u = ustart + Σ_j Δt A[i,j] ku[j],  temp = tempstart + Σ_j Δt A[i,j] ktemp[j]        :35-44
+//   apply_bc_u!, project!                                                              :48-49
+// and apply_bc_u!, apply_bc_temp! at the end (:55-56).  The host mirror drove exactly this from Python with one C-ABI call per
+// operator; here the loop is one call, and on periodic uniform 3-D boxes with the spectral solver it runs on the fused kernels of the
+// plain path: the closure term and gravity go into ONE vector field E_i that the stage kernel adds to its force in registers
+// (RkEpi::extra: k_i = F_i + E_i is what is combined and stored — no axpy pass, no combine pass, no snapshot copy), the divergence is
+// formed inside the solver's x pass and the gradient-subtract fills the ghost volumes (ins_k_project_periodic_fused).  The in-register
+// pressure correction of the plain path does not apply: closure and temperature kernels need the corrected stage velocity in memory.
+#include <cstring>
+#include <vector>
+
+#include "ins_internal.h"
+
+int ins_k_momentum_generic(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s);
+int ins_k_momentum_fast3d_opts(const ins_grid* G, double visc, const double* u, double* F, bool zero_shell, hipStream_t s);
+int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s);
+int ins_k_project_periodic_fused(const ins_grid* G, ins_poisson* ps, double* u, double* p, bool keep_p, hipStream_t s);
+int ins_k_project(const ins_grid* G, ins_poisson* ps, double* u, double* p, hipStream_t s);
+bool ins_fast3d_supported(const ins_grid* G);
+bool ins_flux64_supported(const ins_grid* G);
+
+struct ins_rk_ext {
+  int closure = 0;  // 0 none, 1 Smagorinsky
+  double theta = 0.0;
+  bool temp_on = false;
+  ins_temperature_desc_t td;
+  double* sigma = nullptr;      // D(D+1)/2 scalar fields
+  double* E = nullptr;          // closure term + gravity (vector field)
+  double* diff = nullptr;       // scratch of dissipation! (vector field)
+  double* tempstart = nullptr;  // scalar
+  std::vector<double*> ktemp;   // nstage scalars
+};
+
+void ins_rk_ext_free(ins_rk_ext* e) {
+  if (!e) return;
+  for (double* p : {e->sigma, e->E, e->diff, e->tempstart})
+    if (p) (void)hipFree(p);
+  for (double* p : e->ktemp)
+    if (p) (void)hipFree(p);
+  delete e;
+}
+
+static ins_rk_ext* ext_of(ins_rk* rk) {
+  if (!rk->ext) rk->ext = new ins_rk_ext();
+  return rk->ext;
+}
+
+extern "C" int ins_rk_set_closure(ins_rk_t* rk, int32_t kind, double theta) {
+  INS_REQUIRE(rk, "null argument");
+  INS_REQUIRE(kind == 0 || kind == 1, "closure kind: 0 (none) or 1 (Smagorinsky)");
+  ins_rk_ext* e = ext_of(rk);
+  e->closure = kind;
+  e->theta = theta;
+  return INS_OK;
+}
+
+extern "C" int ins_rk_set_temperature(ins_rk_t* rk, const ins_temperature_desc_t* desc) {
+  INS_REQUIRE(rk, "null argument");
+  ins_rk_ext* e = ext_of(rk);
+  e->temp_on = desc != nullptr;
+  if (desc) {
+    INS_REQUIRE(desc->gdir >= 0 && desc->gdir < rk->grid->g.D, "gdir out of range");
+    e->td = *desc;
+  }
+  return INS_OK;
+}
+
+static int zalloc(double** p, size_t bytes, hipStream_t s) {
+  if (*p) return INS_OK;
+  INS_HIP_TRY(hipMalloc(p, bytes));
+  INS_HIP_TRY(hipMemsetAsync(*p, 0, bytes, s));
+  return INS_OK;
+}
+
+extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double* temp, double t, double dt, void* stream) {
+  INS_REQUIRE(rk && u, "null argument");
+  ins_rk_ext* e = rk->ext;
+  const bool closure = e && e->closure == 1, with_temp = e && e->temp_on;
+  INS_REQUIRE(with_temp == (temp != nullptr), "a temperature field needs ins_rk_set_temperature and vice versa");
+  if (!closure && !with_temp) return ins_rk_step_f64(rk, visc, u, t, dt, nullptr, stream);
+  const ins_grid* G = rk->grid;
+  const GridDev& g = G->g;
+  hipStream_t s = as_stream(stream);
+  const int ns = rk->nstage, D = g.D;
+  const size_t sbytes = (size_t)G->ncell * sizeof(double), vbytes = sbytes * D;
+  int rc;
+  if (closure && (rc = zalloc(&e->sigma, sbytes * (D * (D + 1) / 2), s))) return rc;
+  if ((rc = zalloc(&e->E, vbytes, s))) return rc;
+  if (with_temp) {
+    if ((rc = zalloc(&e->tempstart, sbytes, s))) return rc;
+    if (e->td.dodissipation && (rc = zalloc(&e->diff, vbytes, s))) return rc;
+    if ((int)e->ktemp.size() < ns) e->ktemp.resize(ns, nullptr);
+    for (int i = 0; i < ns; ++i)
+      if ((rc = zalloc(&e->ktemp[i], sbytes, s))) return rc;
+    INS_HIP_TRY(hipMemcpyAsync(e->tempstart, temp, sbytes, hipMemcpyDeviceToDevice, s));  // state_copyto!(xstart, x)   :14
+  }
+  const ins_temperature_desc_t& td = e->td;
+  auto bc_temp = [&]() { return with_temp ? ins_apply_bc_temp_f64(G, td.bc, td.val, nullptr, temp, stream) : INS_OK; };
+  // E = closure(v, θ) (+ gravity(temp)); on return every DOF of E holds the term, everything else stays zero
+  auto extra_terms = [&](const double* v, double* Eout, bool overwrite) -> int {
+    int r;
+    if (closure) {
+      if ((r = ins_smagtensor_f64(G, e->theta, v, e->sigma, stream))) return r;
+      for (int q = 0; q < D * (D + 1) / 2; ++q)
+        if ((r = ins_k_apply_bc_p(G, e->sigma + (size_t)q * G->ncell, s))) return r;  // apply_bc_p!(σ, 0, setup)   operators.jl:1302
+      if ((r = ins_divoftensor_f64(G, e->sigma, Eout, stream))) return r;               // writes Iu[α]
+    } else if (overwrite) {
+      INS_HIP_TRY(hipMemsetAsync(Eout + (size_t)td.gdir * G->ncell, 0, sbytes, s));
+    }
+    if (with_temp && (r = ins_gravity_f64(G, td.gdir, td.a2, temp, Eout, stream))) return r;  // += α2 avg(temp) on Iu[gdir]
+    return INS_OK;
+  };
+  auto temp_rhs = [&](const double* v, int i) -> int {
+    if (!with_temp) return INS_OK;
+    int r;
+    INS_HIP_TRY(hipMemsetAsync(e->ktemp[i], 0, sbytes, s));
+    if ((r = ins_convection_diffusion_temp_f64(G, td.a4, v, temp, e->ktemp[i], stream))) return r;
+    if (td.dodissipation && (r = ins_dissipation_f64(G, visc, td.diss_coef, v, e->diff, e->ktemp[i], stream))) return r;
+    return INS_OK;
+  };
+  auto temp_combine = [&](int i) -> int {
+    if (!with_temp) return INS_OK;
+    double coefs[INS_MAX_STAGES];
+    const double* ks[INS_MAX_STAGES];
+    int n = 0;
+    for (int j = 0; j <= i; ++j) {
+      coefs[n] = dt * rk->A[i * ns + j];
+      ks[n] = e->ktemp[j];
+      ++n;
+    }
+    return ins_combine_scalar_f64(G, e->tempstart, temp, n, coefs, ks, stream);
+  };
+
+  bool fused = !ins_opt(OPT_INS_DISABLE_FUSED_RK) && !ins_opt(OPT_INS_DISABLE_EXT_FUSED) && D == 3 && G->all_periodic && G->all_dof &&
+               rk->ps->kind == POISSON_SPECTRAL && ins_fast3d_supported(G) && ins_flux64_supported(G);
+  for (int a = 0; fused && a < 3; ++a) fused = rk->ps->np[a] >= 2;
+
+  if (fused) {
+    for (int b = 0; b < 2; ++b)
+      if ((rc = zalloc(&rk->ub[b], vbytes, s))) return rc;
+    if ((rc = ins_k_apply_bc_u(G, u, 0, nullptr, s))) return rc;
+    if ((rc = bc_temp())) return rc;
+    const double* in = u;
+    for (int i = 0; i < ns; ++i) {
+      double* out = (i == ns - 1 && ns > 1) ? u : rk->ub[i & 1];
+      if ((rc = extra_terms(in, e->E, true))) return rc;
+      if ((rc = temp_rhs(in, i))) return rc;
+      RkEpi epi;
+      memset(&epi, 0, sizeof(epi));
+      for (int j = 0; j < i; ++j) {
+        const double coef = dt * rk->A[i * ns + j];
+        if (coef == 0.0) continue;
+        epi.coef[epi.n] = coef;
+        epi.k[epi.n] = rk->ku[j];
+        ++epi.n;
+      }
+      for (int i2 = i + 1; i2 < ns; ++i2)
+        if (rk->A[i2 * ns + i] != 0.0) epi.write_k = 1;
+      if (rk->force) {  // k_j = F_j + E_j is stored without the steady force f: it enters with Δt Σ_{j<=i} A[i,j]
+        double cf = 0.0;
+        for (int j = 0; j <= i; ++j) cf += dt * rk->A[i * ns + j];
+        epi.coef[epi.n] = cf;
+        epi.k[epi.n] = rk->force;
+        ++epi.n;
+      }
+      epi.coef_self = dt * rk->A[i * ns + i];
+      epi.ustart = (i == 0) ? nullptr : u;
+      epi.ustar = out;
+      epi.extra = e->E;
+      if ((rc = ins_k_momentum_rk_fused(G, visc, in, rk->ku[i], epi, s))) return rc;
+      if ((rc = temp_combine(i))) return rc;
+      if ((rc = ins_k_project_periodic_fused(G, rk->ps, out, rk->p, i == ns - 1, s))) return rc;
+      if ((rc = bc_temp())) return rc;
+      in = out;
+    }
+    if (ns == 1) INS_HIP_TRY(hipMemcpyAsync(u, rk->ub[0], vbytes, hipMemcpyDeviceToDevice, s));
+    return INS_OK;
+  }
+
+  // any grid: the reference's kernel sequence
+  INS_HIP_TRY(hipMemcpyAsync(rk->ustart, u, vbytes, hipMemcpyDeviceToDevice, s));
+  for (int i = 0; i < ns; ++i) {
+    if ((rc = ins_k_apply_bc_u(G, u, 0, nullptr, s))) return rc;
+    if ((rc = bc_temp())) return rc;
+    rc = ins_fast3d_supported(G) ? ins_k_momentum_fast3d_opts(G, visc, u, rk->ku[i], false, s) : ins_k_momentum_generic(G, visc, u, rk->ku[i], s);
+    if (rc) return rc;
+    if (with_temp && (rc = ins_gravity_f64(G, td.gdir, td.a2, temp, rk->ku[i], stream))) return rc;
+    if ((rc = temp_rhs(u, i))) return rc;
+    if (closure) {
+      if ((rc = ins_smagtensor_f64(G, e->theta, u, e->sigma, stream))) return rc;
+      for (int q = 0; q < D * (D + 1) / 2; ++q)
+        if ((rc = ins_k_apply_bc_p(G, e->sigma + (size_t)q * G->ncell, s))) return rc;
+      if ((rc = ins_divoftensor_f64(G, e->sigma, e->E, stream))) return rc;
+      const double one = 1.0;
+      const double* ks[1] = {e->E};
+      if ((rc = ins_combine_f64(G, rk->ku[i], rk->ku[i], 1, &one, ks, stream))) return rc;  // ku[i] += m(u, θ)
+    }
+    double coefs[INS_MAX_STAGES + 1];
+    const double* ks[INS_MAX_STAGES + 1];
+    int n = 0;
+    double cf = 0.0;
+    for (int j = 0; j <= i; ++j) {
+      const double c = dt * rk->A[i * ns + j];
+      cf += c;
+      if (c == 0.0) continue;
+      coefs[n] = c;
+      ks[n] = rk->ku[j];
+      ++n;
+    }
+    if (rk->force && n < INS_MAX_STAGES) {
+      coefs[n] = cf;
+      ks[n] = rk->force;
+      ++n;
+    }
+    if ((rc = ins_combine_f64(G, rk->ustart, u, n, coefs, ks, stream))) return rc;
+    if ((rc = temp_combine(i))) return rc;
+    if ((rc = ins_k_apply_bc_u(G, u, 0, nullptr, s))) return rc;
+    if ((rc = ins_k_project(G, rk->ps, u, rk->p, s))) return rc;
+  }
+  if ((rc = ins_k_apply_bc_u(G, u, 0, nullptr, s))) return rc;
+  return bc_temp();
+}
