@@ -245,6 +245,27 @@ int ins_tensorbasis_f64(const ins_grid_t* grid, const double* u, double* B, doub
 int ins_combine_scalar_f64(const ins_grid_t* grid, const double* base, double* out, int nterms, const double* coefs,
                            const double* const* ks, void* stream);
 
+/* ---------------------------------------------------------------------------------- extended stage loop
+ * timestep!(method, stepper, Δt) with the temperature equation and / or the Smagorinsky closure carried inside the native loop
+ * (step_explicit_runge_kutta.jl:4-59 with `temp` and `closure_model`; boundary data time-independent).  The host mirror used to drive
+ * this loop operator by operator; csrc/ins_rk_ext.hip runs it as one call and, on periodic uniform 3-D boxes with the spectral solver,
+ * on the fused stage / projection kernels (closure term + gravity enter the stage kernel as one extra force field). */
+typedef struct ins_temperature_desc {
+  double a2;            /* gravity!: F[:, gdir] += α2 avg(temp)                        operators.jl:914-931 */
+  double a4;            /* convection_diffusion_temp!: α4                               operators.jl:712-737 */
+  double diss_coef;     /* dissipation!: Re·α1/γ                                        operators.jl:791-814 */
+  int32_t gdir;         /* 0-based */
+  int32_t dodissipation;
+  int32_t bc[6];        /* bc[2β+side] = INS_BC_* of setup.temperature.boundary_conditions */
+  double val[6];        /* Dirichlet constants */
+} ins_temperature_desc_t;
+/* NULL removes the temperature equation from the cache's loop. */
+int ins_rk_set_temperature(ins_rk_t* rk, const ins_temperature_desc_t* desc);
+/* kind 0: no closure; 1: smagorinsky_closure(setup) with constant θ (operators.jl:1294-1305). */
+int ins_rk_set_closure(ins_rk_t* rk, int32_t kind, double theta);
+/* One step; `temp` (scalar field, nullable exactly when no temperature equation is set) is advanced with u.  Asynchronous. */
+int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double* temp, double t, double dt, void* stream);
+
 /* observespectrum(state; setup, npoint, a)   processors.jl:303-332.  The index sets of spectral_stuff (utils.jl:49-108) are built
  * on the host: bin i sums the modes inds[offsets[i] .. offsets[i+1]), each a 0-based column-major position in the K = Np .÷ 2
  * array of retained non-negative wavenumbers.  ins_spectrum_f64 writes ehat[0 .. nbin) (DEVICE): per component one ghost strip,

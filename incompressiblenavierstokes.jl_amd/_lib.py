@@ -101,6 +101,9 @@ SIGNATURES = {
     "ins_rk_set_bodyforce": (C.c_int, [vp, vp]),
     "ins_rk_pressure": (C.c_int, [vp, C.POINTER(vp)]),
     "ins_rk_stage_force": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+    "ins_rk_set_temperature": (C.c_int, [vp, vp]),
+    "ins_rk_set_closure": (C.c_int, [vp, C.c_int32, C.c_double]),
+    "ins_rk_step_ext_f64": (C.c_int, [vp, C.c_double, vp, vp, C.c_double, C.c_double, vp]),
     "ins_stage_momentum_f64": (C.c_int, [vp, C.c_double, vp, vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), C.c_double, vp]),
     "ins_stage_momentum_corr_f64": (C.c_int, [vp, C.c_double, vp, vp, vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), C.c_double, vp]),
     "ins_stage_momentum_corr_part_f64": (C.c_int, [vp, C.c_double, vp, vp, vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), C.c_double, C.c_double, C.c_double, vp, C.c_int, vp]),

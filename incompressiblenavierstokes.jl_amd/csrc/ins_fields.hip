@@ -552,6 +552,52 @@ __global__ __launch_bounds__(256) void k_dissipation_interp(GridDev g, BoxMap L,
   diss[c] += d;
 }
 
+// One stage of the temperature equation in one pass (extended stage loop, ins_rk_ext.hip; step_explicit_runge_kutta.jl:23-27, 39-44):
+//   ktemp_i = convection_diffusion_temp(u, temp) + coef · Σ_β (w_β[I-e_β] + w_β[I]) / 2        (w = u · diffusion(u), stored by the stage kernel)
+//   temp_out = tempstart + Σ_j c_j ktemp_j + c_self ktemp_i
+// instead of fill!, convection_diffusion_temp!, diffusion!, the interpolation kernel and the combination (five passes).  temp_out is another
+// array than temp (neighbours of temp are read here).
+struct TempStage {
+  int n;
+  double coef[INS_MAX_STAGES];
+  const double* k[INS_MAX_STAGES];
+  double c_self;
+  const double* tempstart;
+  double* ktemp_out;  // nullable: no later stage reads ktemp_i
+  double* temp_out;
+};
+template <int D>
+__global__ __launch_bounds__(256) void k_temp_stage(GridDev g, BoxMap L, double a4, double coef, const double* __restrict__ u, const double* __restrict__ temp,
+                                                    const double* __restrict__ w, TempStage ts) {
+  INS_BOX_INDEX(g.ip_lo[0], g.ip_lo[1], g.ip_lo[2], g.ip_hi[0], g.ip_hi[1]);
+  const double tc = temp[c];
+  double acc = 0.0, d = 0.0;
+#pragma unroll
+  for (int b = 0; b < D; ++b) {
+    const long long sb = g.sx[b];
+    const double* ub = u + b * g.sc;
+    const double u1 = ub[c - sb], u2 = ub[c];
+    const double dT1 = (tc - temp[c - sb]) * g.rdxu[b][I[b] - 1];
+    const double dT2 = (temp[c + sb] - tc) * g.rdxu[b][I[b]];
+    const double uT1 = u1 * avg_at(g, temp, c - sb, I[b] - 1, b);
+    const double uT2 = u2 * avg_at(g, temp, c, I[b], b);
+    acc += (-(uT2 - uT1) + a4 * (dT2 - dT1)) * g.rdx[b][I[b]];
+    if (w) {
+      // diffusion! writes the DOFs of u only and dissipation! starts from fill!(diff, 0) (operators.jl:793-794): the lower-face term of the
+      // first volume of a direction reads a ghost volume of `diff`, i.e. zero — also in a periodic direction (not its periodic image)
+      const double* wb = w + b * g.sc;
+      const double wm = I[b] - 1 >= g.iu_lo[b][b] ? wb[c - sb] : 0.0;
+      d += coef * (wm + wb[c]) / 2;
+    }
+  }
+  acc += d;
+  double t = ts.tempstart[c];
+  for (int q = 0; q < ts.n; ++q) t += ts.coef[q] * ts.k[q][c];
+  t += ts.c_self * acc;
+  if (ts.ktemp_out) ts.ktemp_out[c] = acc;
+  ts.temp_out[c] = t;
+}
+
 // gravity!  (F[:, gdir] += α2 avg(temp))   over the whole Iu[gdir]                     operators.jl:914-931
 template <int D>
 __global__ __launch_bounds__(256) void k_gravity(GridDev g, BoxMap L, int gdir, double a2, const double* __restrict__ temp, double* __restrict__ F) {
@@ -752,6 +798,27 @@ extern "C" int ins_apply_bc_temp_f64(const ins_grid_t* G, const int32_t* bc, con
       hipLaunchKernelGGL(k_bc_temp<3>, grid, dim3(256), 0, as_stream(stream), g, temp, be, t);
     INS_LAUNCH_CHECK();
   }
+  return INS_OK;
+}
+
+// internal (ins_rk_ext.hip): w nullable (no dissipation term); ks / coefs: the previous ktemp_j with non-zero coefficient
+int ins_k_temp_stage(const ins_grid* G, double a4, double coef, const double* u, const double* temp, const double* w, const double* tempstart, int n,
+                     const double* coefs, const double* const* ks, double c_self, double* ktemp_out, double* temp_out, hipStream_t s) {
+  const GridDev& g = G->g;
+  TempStage ts;
+  ts.n = 0;
+  for (int q = 0; q < n && ts.n < INS_MAX_STAGES; ++q) {
+    if (coefs[q] == 0.0) continue;
+    ts.coef[ts.n] = coefs[q];
+    ts.k[ts.n] = ks[q];
+    ++ts.n;
+  }
+  ts.c_self = c_self;
+  ts.tempstart = tempstart;
+  ts.ktemp_out = ktemp_out;
+  ts.temp_out = temp_out;
+  Launch3 l = ip_launch(g);
+  INS_LAUNCH_D(k_temp_stage, l, s, a4, coef, u, temp, w, ts);
   return INS_OK;
 }
 

@@ -251,15 +251,33 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
   // RK epilogue, first half: s = ustart + Σ_q coef_q k_q for all R rows of plane k.  Issued at the top of the plane so the
   // loads fly during the flux arithmetic (they used to sit right before the stores: one exposed round trip per row).
   T eacc[3][EXTRA ? R : 1];
+  T gacc[EXTRA ? R : 1];  // gravity!: α2 avg(temp) at the gdir-face (operators.jl:914-931; uniform grid: the plain mean)
+  T Pz[3][EXTRA ? R : 1];  // the output rows of plane k-1 (for the Laplacian behind epi.wout)
+  const T nux = X.vs * X.rs, nuy = Y.vs * Y.rs, nuz = Z.vs * Z.rs;  // ν/Δ² per direction (4ν/Δ · ¼/Δ: exact scalings)
   auto epi_load = [&](const Plane<T, R>& C, int k, T (&sacc)[3][R]) {
     const long long pk = (long long)k * sz;
     if constexpr (EXTRA) {
-      const T* b = static_cast<const T*>((const void*)a.epi.extra) + pk;
+      if (a.epi.extra) {
+        const T* b = static_cast<const T*>((const void*)a.epi.extra) + pk;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const rsrc_t rs = plane_rsrc(b + c * a.sc, ubytes);
+        for (int c = 0; c < 3; ++c) {
+          const rsrc_t rs = plane_rsrc(b + c * a.sc, ubytes);
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) eacc[c][rr] = ldb<T>(rs, ocol, orow[rr]);
+          for (int rr = 0; rr < R; ++rr) eacc[c][rr] = ldb<T>(rs, ocol, orow[rr]);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int rr = 0; rr < R; ++rr) eacc[c][rr] = 0;
+      }
+      if (a.epi.gtemp) {  // temp is a padded scalar field with valid ghost volumes (apply_bc_temp! has run)
+        const T* tb = static_cast<const T*>((const void*)a.epi.gtemp) + pk;
+        const int gd = a.epi.gdir;
+        const rsrc_t r0 = plane_rsrc(tb, ubytes), r1 = plane_rsrc(gd == 2 ? tb + sz : tb, ubytes);
+        const unsigned dcol = gd == 0 ? EB : 0u, drow = gd == 1 ? (unsigned)N0 * EB : 0u;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) gacc[rr] = (T)a.epi.ga2 * ((T)0.5 * (ldb<T>(r0, ocol, orow[rr]) + ldb<T>(r1, ocol + dcol, orow[rr] + drow)));
       }
     }
     if (a.epi.ustart) {
@@ -304,6 +322,12 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
       fu += eacc[0][rr - 1];
       fv += eacc[1][rr - 1];
       fw += eacc[2][rr - 1];
+      if (a.epi.gtemp) {
+        const T gv = gacc[rr - 1];
+        if (a.epi.gdir == 0) fu += gv;
+        if (a.epi.gdir == 1) fv += gv;
+        if (a.epi.gdir == 2) fw += gv;
+      }
     }
     const int j = jb0 + rr - 1;  // interior row
     if (xout && j < n1) {
@@ -339,6 +363,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
     T sacc[3][R];
     if (FUSE) epi_load(C, k, sacc);
     T fyu_o = 0, fyv_o = 0, fyw_o = 0;
+    T Uo = 0, Vo = 0, Wo = 0;  // row rr - 1 of this plane (EXTRA: its registers already hold the next plane)
 #pragma unroll
     for (int rr = 0; rr <= R; ++rr) {
       const T Uc = C.v[0][rr], Vc = C.v[1][rr], Wc = C.v[2][rr];
@@ -388,11 +413,36 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
         zprev[0][rr - 1] = zu;
         zprev[1][rr - 1] = zv;
         zprev[2][rr - 1] = zw;
+        if constexpr (EXTRA) {
+          // w_α = u_α · diffusion(u)_α at this volume (dissipation!, operators.jl:791-797): the seven-point Laplacian from values already in
+          // registers (x: wave shifts, y: the rows above / below, z: plane k+1 and the saved plane k-1)
+          if (a.epi.wout) {
+            const T Up = prev_h(Uc, sU), Vp = prev_h(Vc, sV), Wp = prev_h(Wc, sW);
+            const T wu = Uc * ((Un + Up - 2 * Uc) * nux + (C.v[0][rr + 1] + Uo - 2 * Uc) * nuy + (Nx.v[0][rr] + Pz[0][rr - 1] - 2 * Uc) * nuz);
+            const T wv = Vc * ((Vn + Vp - 2 * Vc) * nux + (C.v[1][rr + 1] + Vo - 2 * Vc) * nuy + (Nx.v[1][rr] + Pz[1][rr - 1] - 2 * Vc) * nuz);
+            const T ww = Wc * ((Wn + Wp - 2 * Wc) * nux + (C.v[2][rr + 1] + Wo - 2 * Wc) * nuy + (Nx.v[2][rr] + Pz[2][rr - 1] - 2 * Wc) * nuz);
+            const int j = jb0 + rr - 1;
+            if (xout && j < n1) {
+              T* w = static_cast<T*>((void*)a.epi.wout) + (long long)k * sz;
+              stb(plane_rsrc(w, ubytes), ocol, orow[rr - 1], wu);
+              stb(plane_rsrc(w + a.sc, ubytes), ocol, orow[rr - 1], wv);
+              stb(plane_rsrc(w + 2 * a.sc, ubytes), ocol, orow[rr - 1], ww);
+            }
+          }
+          Pz[0][rr - 1] = Uc;
+          Pz[1][rr - 1] = Vc;
+          Pz[2][rr - 1] = Wc;
+        }
         emit(rr, k, fu, fv, fw, FUSE ? sacc[0][rr - 1] : (T)0, FUSE ? sacc[1][rr - 1] : (T)0, FUSE ? sacc[2][rr - 1] : (T)0);
       }
       fyu_o = fyu;
       fyv_o = fyv;
       fyw_o = fyw;
+      if constexpr (EXTRA) {
+        Uo = Uc;
+        Vo = Vc;
+        Wo = Wc;
+      }
       // row rr of plane k is dead: its registers receive plane `kload`
       C.v[0][rr] = ldb<T>(n0r, ucol, urow[rr]);
       C.v[1][rr] = ldb<T>(n1r, ucol, urow[rr]);
@@ -412,6 +462,12 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
     load_plane(P0, k0 - 1);
     load_plane(P1, k0);
     zflux0(P0, P1);
+    if constexpr (EXTRA) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) Pz[c][rr] = P0.v[c][rr + 1];
+    }
     load_plane(P0, min(k0 + 1, k1));
     int k = k0;
     while (true) {
@@ -485,7 +541,7 @@ int launch_range(const ins_grid* G, FluxArgs& a, int corr_mode, hipStream_t s) {
       return INS_OK;
     }
   }
-  if (a.epi.extra) {
+  if (a.epi.extra || a.epi.gtemp || a.epi.wout) {
     if constexpr (FUSE && R == 2 && NW == 4 && sizeof(T) == 8) {
       if (corr_mode == 0) {
         hipLaunchKernelGGL((k_flux64<T, R, XW, true, 0, false, NW, true>), dim3(nb), block, (size_t)g_lds, s, a);
@@ -617,7 +673,7 @@ static int flux64_dispatch(const ins_grid* G, double visc, const T* u, T* F, con
     zc = n2 >= 256 && small_plane ? 64 : (n2 >= 128 ? 32 : (n2 >= 64 ? 16 : (n2 >= 32 ? 8 : 4)));
   }
   if (rows != 2 && nw == 16) nw = 8;
-  if (epi && epi->extra) {  // one instantiation serves the extended stage loop
+  if (epi && (epi->extra || epi->gtemp || epi->wout)) {  // one instantiation serves the extended stage loop
     rows = 2;
     nw = 4;
     if (!zco) zc = n2 >= 128 ? 32 : (n2 >= 64 ? 16 : (n2 >= 32 ? 8 : 4));

@@ -88,6 +88,7 @@ void ins_set_error(const char* fmt, ...);
   X(INS_DISABLE_FDM_FOLDFUSE)    \
   X(INS_DISABLE_INKERNEL_CORR)   \
   X(INS_RK_KEEP_K)               \
+  X(INS_DISABLE_EXT_FUSED)       \
   X(INS_DISABLE_FUSED_RK)        \
   X(INS_DISABLE_STEP_CHAIN)      \
   X(INS_ZSOLVE_SKEL)             \
@@ -202,6 +203,8 @@ struct ins_poisson {
   ins_fdm* fdm = nullptr;
 };
 
+struct ins_rk_ext;  // temperature equation / closure state of the extended stage loop (ins_rk_ext.hip)
+void ins_rk_ext_free(ins_rk_ext* e);
 struct ins_rk {
   const ins_grid* grid;
   ins_poisson* ps;
@@ -213,6 +216,7 @@ struct ins_rk {
   double* ub[2] = {nullptr, nullptr};  // ping-pong stage velocities of the fused path
   std::vector<double*> vb;
   const double* force = nullptr;  // steady body force field (caller-owned), ins_rk_set_bodyforce             // all uncorrected stage velocities V_0..V_{s-2} (stage-velocity basis, ins_rk.hip)
+  ins_rk_ext* ext = nullptr;
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;  // (start, stop) pairs around momentum launches
 };
@@ -231,7 +235,11 @@ struct RkEpi {
   const double* ustart;     // nullptr: ustart is the stencil input itself (first stage)
   double* ustar;            // stage velocity out (interior volumes only)
   double* ustart_out;       // optional (first stage of a chained step, ustart == nullptr): the corrected stencil input is stored here
-  const double* extra;      // optional vector field added to the stage force before it is used and stored (closure term, gravity: ins_rk_ext.hip)
+  const double* extra;      // optional vector field added to the stage force before it is used and stored (closure term: ins_rk_ext.hip)
+  const double* gtemp;      // optional temperature field: gravity! is added to component gdir of the stage force (ga2 = α2)
+  double ga2;
+  int gdir;
+  double* wout;             // optional: w_α = u_α · diffusion(u)_α of the stencil input is stored here (dissipation!, ins_rk_ext.hip)
 };
 
 

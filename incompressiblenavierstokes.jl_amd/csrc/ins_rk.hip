@@ -65,7 +65,7 @@ extern "C" int ins_combine_scalar_f64(const ins_grid_t* G, const double* base, d
 }
 
 static int combine_n(long long nvec, const double* base, double* out, int nterms, const double* coefs, const double* const* ks, void* stream) {
-  INS_REQUIRE(nterms >= 0 && nterms <= INS_MAX_STAGES && (nterms == 0 || (coefs && ks)), "bad stage terms");
+  INS_REQUIRE(nterms >= 0 && nterms <= INS_MAX_STAGES + 1 && (nterms == 0 || (coefs && ks)), "bad stage terms");
   Combine cb;
   cb.n = 0;
   for (int q = 0; q < nterms; ++q) {
@@ -119,6 +119,7 @@ extern "C" int ins_rk_destroy(ins_rk_t* rk) {
   for (double* b : rk->ub)
     if (b) (void)hipFree(b);
   for (hipEvent_t e : rk->prof_events) (void)hipEventDestroy(e);
+  ins_rk_ext_free(rk->ext);
   delete rk;
   return INS_OK;
 }

@@ -25,6 +25,8 @@ int ins_k_project_periodic_fused(const ins_grid* G, ins_poisson* ps, double* u, 
 int ins_k_project(const ins_grid* G, ins_poisson* ps, double* u, double* p, hipStream_t s);
 bool ins_fast3d_supported(const ins_grid* G);
 bool ins_flux64_supported(const ins_grid* G);
+int ins_k_temp_stage(const ins_grid* G, double a4, double coef, const double* u, const double* temp, const double* w, const double* tempstart, int n,
+                     const double* coefs, const double* const* ks, double c_self, double* ktemp_out, double* temp_out, hipStream_t s);
 
 struct ins_rk_ext {
   int closure = 0;  // 0 none, 1 Smagorinsky
@@ -35,12 +37,14 @@ struct ins_rk_ext {
   double* E = nullptr;          // closure term + gravity (vector field)
   double* diff = nullptr;       // scratch of dissipation! (vector field)
   double* tempstart = nullptr;  // scalar
+  double* w = nullptr;          // u · diffusion(u) (vector field, written by the stage kernel; fused path)
+  double* tb[2] = {nullptr, nullptr};  // stage temperatures (fused path)
   std::vector<double*> ktemp;   // nstage scalars
 };
 
 void ins_rk_ext_free(ins_rk_ext* e) {
   if (!e) return;
-  for (double* p : {e->sigma, e->E, e->diff, e->tempstart})
+  for (double* p : {e->sigma, e->E, e->diff, e->tempstart, e->w, e->tb[0], e->tb[1]})
     if (p) (void)hipFree(p);
   for (double* p : e->ktemp)
     if (p) (void)hipFree(p);
@@ -71,6 +75,10 @@ extern "C" int ins_rk_set_temperature(ins_rk_t* rk, const ins_temperature_desc_t
   }
   return INS_OK;
 }
+
+static long long g_fused_steps = 0;
+// test hook: how many steps took the fused path (periodic uniform 3-D boxes, spectral solver)
+extern "C" long long ins_dbg_ext_fused_steps(void) { return g_fused_steps; }
 
 static int zalloc(double** p, size_t bytes, hipStream_t s) {
   if (*p) return INS_OK;
@@ -103,20 +111,6 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
   }
   const ins_temperature_desc_t& td = e->td;
   auto bc_temp = [&]() { return with_temp ? ins_apply_bc_temp_f64(G, td.bc, td.val, nullptr, temp, stream) : INS_OK; };
-  // E = closure(v, θ) (+ gravity(temp)); on return every DOF of E holds the term, everything else stays zero
-  auto extra_terms = [&](const double* v, double* Eout, bool overwrite) -> int {
-    int r;
-    if (closure) {
-      if ((r = ins_smagtensor_f64(G, e->theta, v, e->sigma, stream))) return r;
-      for (int q = 0; q < D * (D + 1) / 2; ++q)
-        if ((r = ins_k_apply_bc_p(G, e->sigma + (size_t)q * G->ncell, s))) return r;  // apply_bc_p!(σ, 0, setup)   operators.jl:1302
-      if ((r = ins_divoftensor_f64(G, e->sigma, Eout, stream))) return r;               // writes Iu[α]
-    } else if (overwrite) {
-      INS_HIP_TRY(hipMemsetAsync(Eout + (size_t)td.gdir * G->ncell, 0, sbytes, s));
-    }
-    if (with_temp && (r = ins_gravity_f64(G, td.gdir, td.a2, temp, Eout, stream))) return r;  // += α2 avg(temp) on Iu[gdir]
-    return INS_OK;
-  };
   auto temp_rhs = [&](const double* v, int i) -> int {
     if (!with_temp) return INS_OK;
     int r;
@@ -143,15 +137,30 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
   for (int a = 0; fused && a < 3; ++a) fused = rk->ps->np[a] >= 2;
 
   if (fused) {
+    // Periodic uniform 3-D box, spectral solver.  Per stage: [closure kernels ->] stage kernel (convection-diffusion + closure field + gravity
+    // from temp in registers, RK combination, and w = u · diffusion(u) as a by-product) -> one temperature kernel (its right-hand side and its
+    // RK combination) -> the five solver passes -> gradient-subtract with ghost fill -> temperature ghost fill.
+    ++g_fused_steps;
     for (int b = 0; b < 2; ++b)
       if ((rc = zalloc(&rk->ub[b], vbytes, s))) return rc;
+    if (with_temp) {
+      for (int b = 0; b < 2; ++b)
+        if ((rc = zalloc(&e->tb[b], sbytes, s))) return rc;
+      if (td.dodissipation && (rc = zalloc(&e->w, vbytes, s))) return rc;
+    }
     if ((rc = ins_k_apply_bc_u(G, u, 0, nullptr, s))) return rc;
     if ((rc = bc_temp())) return rc;
     const double* in = u;
+    const double* tin = temp;
     for (int i = 0; i < ns; ++i) {
       double* out = (i == ns - 1 && ns > 1) ? u : rk->ub[i & 1];
-      if ((rc = extra_terms(in, e->E, true))) return rc;
-      if ((rc = temp_rhs(in, i))) return rc;
+      double* tout = with_temp ? ((i == ns - 1 && ns > 1) ? temp : e->tb[i & 1]) : nullptr;
+      if (closure) {
+        if ((rc = ins_smagtensor_f64(G, e->theta, in, e->sigma, stream))) return rc;
+        for (int q = 0; q < D * (D + 1) / 2; ++q)
+          if ((rc = ins_k_apply_bc_p(G, e->sigma + (size_t)q * G->ncell, s))) return rc;  // apply_bc_p!(σ, 0, setup)   operators.jl:1302
+        if ((rc = ins_divoftensor_f64(G, e->sigma, e->E, stream))) return rc;
+      }
       RkEpi epi;
       memset(&epi, 0, sizeof(epi));
       for (int j = 0; j < i; ++j) {
@@ -173,14 +182,38 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
       epi.coef_self = dt * rk->A[i * ns + i];
       epi.ustart = (i == 0) ? nullptr : u;
       epi.ustar = out;
-      epi.extra = e->E;
+      epi.extra = closure ? e->E : nullptr;
+      if (with_temp) {
+        epi.gtemp = tin;
+        epi.ga2 = td.a2;
+        epi.gdir = td.gdir;
+        epi.wout = td.dodissipation ? e->w : nullptr;
+      }
       if ((rc = ins_k_momentum_rk_fused(G, visc, in, rk->ku[i], epi, s))) return rc;
-      if ((rc = temp_combine(i))) return rc;
+      if (with_temp) {
+        double coefs[INS_MAX_STAGES];
+        const double* ks[INS_MAX_STAGES];
+        int n = 0;
+        for (int j = 0; j < i; ++j) {
+          coefs[n] = dt * rk->A[i * ns + j];
+          ks[n] = e->ktemp[j];
+          ++n;
+        }
+        bool later = false;
+        for (int i2 = i + 1; i2 < ns; ++i2) later = later || rk->A[i2 * ns + i] != 0.0;
+        if ((rc = ins_k_temp_stage(G, td.a4, td.diss_coef, in, tin, td.dodissipation ? e->w : nullptr, e->tempstart, n, coefs, ks, dt * rk->A[i * ns + i],
+                                   later ? e->ktemp[i] : nullptr, tout, s)))
+          return rc;
+      }
       if ((rc = ins_k_project_periodic_fused(G, rk->ps, out, rk->p, i == ns - 1, s))) return rc;
-      if ((rc = bc_temp())) return rc;
+      if (with_temp && (rc = ins_apply_bc_temp_f64(G, td.bc, td.val, nullptr, tout, stream))) return rc;
       in = out;
+      tin = tout;
     }
-    if (ns == 1) INS_HIP_TRY(hipMemcpyAsync(u, rk->ub[0], vbytes, hipMemcpyDeviceToDevice, s));
+    if (ns == 1) {
+      INS_HIP_TRY(hipMemcpyAsync(u, rk->ub[0], vbytes, hipMemcpyDeviceToDevice, s));
+      if (with_temp) INS_HIP_TRY(hipMemcpyAsync(temp, e->tb[0], sbytes, hipMemcpyDeviceToDevice, s));
+    }
     return INS_OK;
   }
 
@@ -214,7 +247,7 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
       ks[n] = rk->ku[j];
       ++n;
     }
-    if (rk->force && n < INS_MAX_STAGES) {
+    if (rk->force) {
       coefs[n] = cf;
       ks[n] = rk->force;
       ++n;

@@ -394,6 +394,7 @@ def smagorinsky_closure(setup):
             _lib.call("ins_apply_bc_p_f64", setup.handle, C.c_void_p(base + 8 * ncell * q), setup.stream)
         return divoftensor_(s, σ, setup)
 
+    closure._ins_closure, closure._ins_setup = "smagorinsky", setup  # lets timestep_ run it inside the native stage loop (ins_rk_set_closure)
     return closure
 
 

@@ -1,6 +1,7 @@
 """Explicit Runge-Kutta time stepping (time_steppers/methods.jl, RKMethods.jl,
 step_explicit_runge_kutta.jl, time_stepper_caches.jl), host side."""
 import ctypes as C
+import os
 from dataclasses import dataclass
 from fractions import Fraction
 from types import SimpleNamespace
@@ -226,6 +227,38 @@ def _host_driven(setup, temp):
     return temp is not None or setup.closure_model is not None or (setup.bodyforce is not None and not setup.issteadybodyforce) or setup.needs_bc_planes
 
 
+class _TempDesc(C.Structure):
+    """ins_temperature_desc_t (include/ins_hip.h)"""
+
+    _fields_ = [("a2", C.c_double), ("a4", C.c_double), ("diss_coef", C.c_double), ("gdir", C.c_int32), ("dodissipation", C.c_int32),
+                ("bc", C.c_int32 * 6), ("val", C.c_double * 6)]
+
+
+def _native_ext(setup, temp, θ):
+    """The native extended stage loop (csrc/ins_rk_ext.hip) serves the temperature equation and the Smagorinsky closure when nothing
+    else needs the host between the kernels: returns (closure kind, θ, temperature descriptor or None), or None for the host loop."""
+    if setup.needs_bc_planes or (setup.bodyforce is not None and not setup.issteadybodyforce):
+        return None
+    m = setup.closure_model
+    kind = 0
+    if m is not None:
+        if getattr(m, "_ins_closure", None) != "smagorinsky" or getattr(m, "_ins_setup", None) is not setup or not np.isscalar(θ):
+            return None  # a user callable: only the host can evaluate it
+        kind = 1
+    desc = None
+    if temp is not None:
+        from .operators import _temp_bc_args
+
+        T = setup.temperature
+        codes, vals, planes, _ = _temp_bc_args(setup, 0.0)
+        if planes is not None:
+            return None  # callable temperature boundary data
+        desc = _TempDesc(a2=T.α2, a4=T.α4, diss_coef=setup.Re * T.α1 / T.γ, gdir=int(T.gdir), dodissipation=int(T.dodissipation))
+        for q in range(6):
+            desc.bc[q], desc.val[q] = codes[q], vals[q]
+    return kind, float(θ) if kind else 0.0, desc
+
+
 def _temp_rhs_(ktemp, diff, u, temp, setup):
     """ktemp = convection_diffusion_temp + dissipation (step_explicit_runge_kutta.jl:23-27)"""
     ktemp.zero_()
@@ -359,7 +392,16 @@ def timestep_(method, stepper, Δt, *, θ=None, cache):
         _native_force(cache, setup)
         _lib.call("ins_rk_step_f64", cache.handle, 1.0 / setup.Re, setup.ptr(u, True), float(t), float(Δt), None, setup.stream)
         return create_stepper(method, setup=setup, psolver=psolver, u=u, temp=None, t=stepper.t + method.c[-1] * Δt, n=n + 1)
-    # host-driven stage loop (time-dependent boundary data, body force, closure model, temperature equation)
+    ext = None if os.environ.get("INS_HOST_STAGE_LOOP") else _native_ext(setup, temp, θ)
+    if ext is not None:  # temperature equation / Smagorinsky closure inside the native loop
+        kind, th, desc = ext
+        _native_force(cache, setup)
+        _lib.call("ins_rk_set_closure", cache.handle, kind, th)
+        _lib.call("ins_rk_set_temperature", cache.handle, C.byref(desc) if desc is not None else None)
+        _lib.call("ins_rk_step_ext_f64", cache.handle, 1.0 / setup.Re, setup.ptr(u, True), setup.ptr(temp, False) if temp is not None else None,
+                  float(t), float(Δt), setup.stream)
+        return create_stepper(method, setup=setup, psolver=psolver, u=u, temp=temp, t=stepper.t + method.c[-1] * Δt, n=n + 1)
+    # host-driven stage loop (time-dependent boundary data, unsteady body force, user closure model)
     A, c = method.A, method.c
     ns = len(method.b)
     m = setup.closure_model

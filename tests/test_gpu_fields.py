@@ -204,6 +204,61 @@ def test_steppers_with_closure_model_match_oracle(ins, oracle, geom, method):
     assert rell2(u, st["u"]) < STEP_TOL
 
 
+@pytest.mark.parametrize("n,what,gdir,diss", [((72, 10, 8), "temp", 1, True), ((72, 10, 8), "temp", 0, False), ((130, 10, 12), "temp", 2, True),
+                                              ((72, 10, 8), "temp", 1, False), ((72, 10, 8), "temp", 2, False), ((72, 10, 8), "temp", 0, True),
+                                              ((72, 10, 8), "smag", 1, True), ((130, 10, 12), "both", 2, True)])
+@pytest.mark.parametrize("method", ["RK44", "Wray3"])
+def test_fused_extended_stage_loop_matches_oracle(ins, oracle, n, what, gdir, diss, method):
+    """The native stage loop with the temperature equation and / or the Smagorinsky closure on boxes that take its fused path
+    (csrc/ins_rk_ext.hip: gravity and w = u · diffusion(u) inside the 64-wide stage kernel, one temperature kernel per stage), against the
+    oracle's operator-by-operator loop; the same runs with INS_DISABLE_EXT_FUSED (the reference's kernel sequence) agree to rounding."""
+    import ctypes
+
+    from ins_amd import _lib
+
+    o = oracle
+
+    def run(fused):
+        so = fx.setup_periodic(o, n, D=3)
+        if what in ("temp", "both"):
+            T = o.temperature_equation(Pr=0.71, Ra=1e6, Ge=0.1, boundary_conditions=temp_bcs(o, so, "any"), gdir=gdir, dodissipation=diss)
+            so.temperature = T
+            sp = mirror(ins, so, o)
+            sp.temperature = mirror_temp(ins, o, T)
+            so.Re = sp.Re = 1.0 / T.a1
+        else:
+            sp = mirror(ins, so, o)
+        if what in ("smag", "both"):
+            so.closure_model = o.smagorinsky_closure(so)
+            sp.closure_model = ins.smagorinsky_closure(sp)
+        ps_h, ps_d = o.psolver_spectral(so), ins.psolver_spectral(sp)
+        g = so.grid
+        u0 = o.project(o.apply_bc_u(0.1 * fx.randn_field(g.N + (3,), 11), 0.0, so), so, ps_h)
+        o.apply_bc_u_(u0, 0.0, so)
+        th = o.apply_bc_temp(0.5 + 0.1 * fx.randn_field(g.N, 4), 0.0, so) if so.temperature is not None else None
+        theta = 0.17 if so.closure_model is not None else None
+        mo, md = getattr(o, method)(), getattr(ins.RKMethods, method)()
+        st = dict(setup=so, psolver=ps_h, u=u0.copy(order="F"), temp=None if th is None else th.copy(order="F"), t=0.0, n=0)
+        cache = o.ode_method_cache_ext(mo, so)
+        for _ in range(3):
+            st = o.timestep_ext_(mo, st, 2e-3, cache, theta)
+        lib = _lib.load()
+        lib.ins_dbg_ext_fused_steps.restype = ctypes.c_longlong
+        before = lib.ins_dbg_ext_fused_steps()
+        with _lib.options(INS_DISABLE_EXT_FUSED=0 if fused else 1):
+            (u_d, t_d, _), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 6e-3), ustart=ins.from_numpy(sp, u0), tempstart=None if th is None else ins.from_numpy(sp, th),
+                                                  method=md, psolver=ps_d, Δt=2e-3, θ=theta)
+        assert lib.ins_dbg_ext_fused_steps() - before == (3 if fused else 0)
+        return st, ins.to_numpy(u_d), None if t_d is None else ins.to_numpy(t_d)
+
+    st, u, temp = run(True)
+    assert rell2(u, st["u"]) < STEP_TOL
+    if temp is not None:
+        assert rell2(temp, st["temp"]) < STEP_TOL
+    _, u2, temp2 = run(False)
+    assert rell2(u2, u) < 1e-12 and (temp is None or rell2(temp2, temp) < 1e-12)
+
+
 @pytest.mark.parametrize("geom", ["periodic2d", "periodic3d", "periodic3d_wide"])
 def test_energy_spectrum_matches_oracle(ins, oracle, geom):
     o = oracle
