@@ -673,6 +673,120 @@ __global__ __launch_bounds__(256) void k_divoftensor(GridDev g, BoxMap L, const 
   }
 }
 
+// divoftensor! in the register-row formulation of k_gradient_rows (3-D): lanes along x (lanes 0 and 63 are halo columns), R + 2 rows per
+// work-item, march through a z-chunk.  What a volume needs of each stress component is small — σxx: I, I+ex; σyy: I, I+ey; σzz: I, I+ez;
+// σxy: the 3 x 3 (x, y) neighbourhood in its own plane; σxz, σyz: three planes — so a work-item holds 11 R + 9 values and loads 6 R + 5 per
+// plane for 3 R results (R = 4: 2.4 loads per result; the plain kernel issues 10 per result and ran at the vector-L1 rate: 0.68 ms at 256³).
+// Same expressions in the same order as k_divoftensor.  Needs every DOF inside [1, N - 1) (no PressureBC side: the host checks).
+template <int R>
+__global__ __launch_bounds__(256) void k_divoftensor_rows(GridDev g, BoxMap L, int zc, const double* __restrict__ sig, double* __restrict__ s) {
+  int seq = (int)(blockIdx.x >> 3);
+  const int tx = seq % L.ntx;
+  seq /= L.ntx;
+  const int ty = (int)(blockIdx.x & 7) * L.nty_l + seq % L.nty_l;
+  if (ty >= L.nty) return;  // whole workgroup
+  const int chunk = seq / L.nty_l;
+  const int lane = threadIdx.x, wy = threadIdx.y;
+  const int N0 = g.N[0], N1 = g.N[1], N2 = g.N[2];
+  const int i = tx * GR_XO + lane;  // lane 0 = left halo column (outputs start at volume 1)
+  const int ic = min(i, N0 - 1);
+  const int jb = 1 + (ty * 4 + wy) * R;  // first output row of this wavefront
+  const int k0 = 1 + chunk * zc, k1 = min(k0 + zc, N2 - 1);
+  const bool wave_on = i - lane < N0 - 1 && jb < N1 - 1;  // wave-uniform
+  if (!wave_on) {  // keeps the workgroup's barrier count
+    for (int k = k0; k < k1; ++k) __builtin_amdgcn_s_barrier();
+    return;
+  }
+  const bool xout = lane >= 1 && lane <= GR_XO && i < N0 - 1;
+  long long rowoff[R + 2];
+#pragma unroll
+  for (int rr = 0; rr < R + 2; ++rr) rowoff[rr] = (long long)min(jb - 1 + rr, N1 - 1) * g.sx[1] + ic;
+  const double* sxx = sig + sym_index<3>(0, 0) * g.sc;
+  const double* syy = sig + sym_index<3>(1, 1) * g.sc;
+  const double* szz = sig + sym_index<3>(2, 2) * g.sc;
+  const double* sxy = sig + sym_index<3>(0, 1) * g.sc;
+  const double* sxz = sig + sym_index<3>(0, 2) * g.sc;
+  const double* syz = sig + sym_index<3>(1, 2) * g.sc;
+  // rows: index rr = 0 .. R + 1 is row jb - 1 + rr; outputs are rr = 1 .. R
+  double XX[R + 2], YY[R + 2], XY[R + 2];          // plane k (XX: rows 1..R used, YY: 1..R+1)
+  double ZZ[2][R + 2], XZ[3][R + 2], YZ[3][R + 2];  // planes k (, k-1), k+1 (ZZ, XZ: rows 1..R used)
+  auto ld = [&](const double* comp, int kk, int rr) { return comp[(long long)min(kk, N2 - 1) * g.sx[2] + rowoff[rr]]; };
+  auto load_upper = [&](int kk) {  // plane kk into the upper slots
+#pragma unroll
+    for (int rr = 1; rr <= R; ++rr) {
+      ZZ[1][rr] = ld(szz, kk, rr);
+      XZ[2][rr] = ld(sxz, kk, rr);
+    }
+#pragma unroll
+    for (int rr = 0; rr < R + 2; ++rr) YZ[2][rr] = ld(syz, kk, rr);
+  };
+  auto load_own = [&](int kk) {
+#pragma unroll
+    for (int rr = 1; rr <= R; ++rr) XX[rr] = ld(sxx, kk, rr);
+#pragma unroll
+    for (int rr = 1; rr <= R + 1; ++rr) YY[rr] = ld(syy, kk, rr);
+#pragma unroll
+    for (int rr = 0; rr < R + 2; ++rr) XY[rr] = ld(sxy, kk, rr);
+  };
+  auto rotate = [&]() {
+#pragma unroll
+    for (int rr = 0; rr < R + 2; ++rr) {
+      ZZ[0][rr] = ZZ[1][rr];
+      XZ[0][rr] = XZ[1][rr];
+      XZ[1][rr] = XZ[2][rr];
+      YZ[0][rr] = YZ[1][rr];
+      YZ[1][rr] = YZ[2][rr];
+    }
+  };
+  bool dofx[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) dofx[a] = i >= g.iu_lo[a][0] && i < g.iu_hi[a][0];
+  const double rux = g.rdxu[0][ic], rdx_x = g.rdx[0][ic];
+  // planes k0 - 1 and k0 into the lower / middle slots
+  load_upper(k0 - 1);
+  rotate();
+  load_upper(k0);
+  rotate();
+  for (int k = k0; k < k1; ++k) {
+    __builtin_amdgcn_s_barrier();  // the y-stacked wavefronts stay on one plane: their shared halo rows are cache hits
+    load_upper(k + 1);
+    load_own(k);
+    const double ruz = g.rdxu[2][k], rdx_z = g.rdx[2][k];
+    bool dofz[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) dofz[a] = k >= g.iu_lo[a][2] && k < g.iu_hi[a][2];
+#pragma unroll
+    for (int rr = 1; rr <= R; ++rr) {
+      const int j = jb - 1 + rr;
+      const int jc = min(j, N1 - 2);
+      const double ruy = g.rdxu[1][jc], rdx_y = g.rdx[1][jc];
+      // s_x: σxx along x; σxy: (I, I+ey, I+ex+ey, I+ex) - (I-ey, I, I+ex-ey, I+ex) over 4; σxz likewise with z
+      const double xy_c = XY[rr], xy_u = XY[rr + 1], xy_d = XY[rr - 1];
+      const double xz_c = XZ[1][rr], xz_u = XZ[2][rr], xz_d = XZ[0][rr];
+      double ax = (lane_next(XX[rr]) - XX[rr]) * rux;
+      ax += ((xy_c + xy_u + lane_next(xy_u) + lane_next(xy_c)) / 4 - (xy_d + xy_c + lane_next(xy_d) + lane_next(xy_c)) / 4) * rdx_y;
+      ax += ((xz_c + xz_u + lane_next(xz_u) + lane_next(xz_c)) / 4 - (xz_d + xz_c + lane_next(xz_d) + lane_next(xz_c)) / 4) * rdx_z;
+      // s_y: σxy: (I, I+ex, I+ey+ex, I+ey) - (I-ex, I, I+ey-ex, I+ey) over 4; σyy along y; σyz with z
+      const double yz_c = YZ[1][rr], yz_u = YZ[2][rr], yz_d = YZ[0][rr], yz_cn = YZ[1][rr + 1], yz_un = YZ[2][rr + 1], yz_dn = YZ[0][rr + 1];
+      double ay = ((xy_c + lane_next(xy_c) + lane_next(xy_u) + xy_u) / 4 - (lane_prev(xy_c) + xy_c + lane_prev(xy_u) + xy_u) / 4) * rdx_x;
+      ay += (YY[rr + 1] - YY[rr]) * ruy;
+      ay += ((yz_c + yz_u + yz_un + yz_cn) / 4 - (yz_d + yz_c + yz_dn + yz_cn) / 4) * rdx_z;
+      // s_z: σxz: (I, I+ex, I+ez+ex, I+ez) - (I-ex, I, I+ez-ex, I+ez) over 4; σyz: (I, I+ey, I+ez+ey, I+ez) - (I-ey, I, I+ez-ey, I+ez) over 4; σzz along z
+      const double yz_cd = YZ[1][rr - 1], yz_ud = YZ[2][rr - 1];
+      double az = ((xz_c + lane_next(xz_c) + lane_next(xz_u) + xz_u) / 4 - (lane_prev(xz_c) + xz_c + lane_prev(xz_u) + xz_u) / 4) * rdx_x;
+      az += ((yz_c + yz_cn + yz_un + yz_u) / 4 - (yz_cd + yz_c + yz_ud + yz_u) / 4) * rdx_y;
+      az += (ZZ[1][rr] - ZZ[0][rr]) * ruz;
+      if (xout && j < N1 - 1) {
+        const long long c = i + j * g.sx[1] + k * g.sx[2];
+        if (dofx[0] && dofz[0] && j >= g.iu_lo[0][1] && j < g.iu_hi[0][1]) s[c] = ax;
+        if (dofx[1] && dofz[1] && j >= g.iu_lo[1][1] && j < g.iu_hi[1][1]) s[g.sc + c] = ay;
+        if (dofx[2] && dofz[2] && j >= g.iu_lo[2][1] && j < g.iu_hi[2][1]) s[2 * g.sc + c] = az;
+      }
+    }
+    rotate();
+  }
+}
+
 #define INS_LAUNCH_D(KERNEL, L, S, ...)                                                \
   do {                                                                                  \
     if (g.D == 2)                                                                       \
@@ -698,7 +812,10 @@ int launch_gradient_op(const ins_grid* G, double par, const double* u, double* o
   } else if (OP != 1 && ins_opt(OPT_INS_FIELDS_ROWS) >= 0 && g.ip_hi[0] - g.ip_lo[0] >= 32 && g.N[2] >= 4) {
     // register rows + DPP (INS_FIELDS_ROWS=-1: the older kernels).  256^3: strain dissipation 0.282 -> 0.207 ms, smagtensor 0.460 -> 0.449;
     // eig2 (its arithmetic dominates: 0.362 plain, 0.453 here) keeps the plain kernel
-    constexpr int R = 4;
+    // rows per work-item: 4 (strain dissipation), 2 for the stress tensor (six results per cell: with 4 rows the kernel needs all 256 VGPRs
+    // and more); INS_FIELDS_ROWS = 2, 3, 4 overrides
+    const int ro = (int)ins_opt(OPT_INS_FIELDS_ROWS);
+    const int R = (ro >= 2 && ro <= 4) ? ro : (OP == 2 ? 2 : 4);
     const int nx = g.ip_hi[0] - g.ip_lo[0], ny = g.ip_hi[1] - g.ip_lo[1], nz = g.ip_hi[2] - g.ip_lo[2];
     const int zc = ins_opt(OPT_INS_FIELDS_ZC) > 0 ? (int)ins_opt(OPT_INS_FIELDS_ZC) : (nz >= 128 ? 32 : (nz >= 32 ? 16 : (nz >= 8 ? 8 : nz)));
     Launch3 l;
@@ -707,7 +824,12 @@ int launch_gradient_op(const ins_grid* G, double par, const double* u, double* o
     l.nty = (int)cdiv(ny, 4 * R);
     l.nty_l = (l.nty + 7) / 8;
     l.grid = dim3(8u * l.ntx * l.nty_l * cdiv(nz, zc), 1, 1);
-    hipLaunchKernelGGL((k_gradient_rows<OP, R>), l.grid, l.block, 0, s, g, BoxMap{l.ntx, l.nty, l.nty_l}, zc, par, u, out);
+    if (R == 2)
+      hipLaunchKernelGGL((k_gradient_rows<OP, 2>), l.grid, l.block, 0, s, g, BoxMap{l.ntx, l.nty, l.nty_l}, zc, par, u, out);
+    else if (R == 3)
+      hipLaunchKernelGGL((k_gradient_rows<OP, 3>), l.grid, l.block, 0, s, g, BoxMap{l.ntx, l.nty, l.nty_l}, zc, par, u, out);
+    else
+      hipLaunchKernelGGL((k_gradient_rows<OP, 4>), l.grid, l.block, 0, s, g, BoxMap{l.ntx, l.nty, l.nty_l}, zc, par, u, out);
   } else if (!march || OP == 1) {  // eig2: its arithmetic dominates; the plain kernel measured faster (0.35 vs 0.43 ms at 256^3)
     Launch3 l = ip_launch(g);
     hipLaunchKernelGGL((k_gradient_op<3, OP>), l.grid, l.block, 0, s, g, BoxMap{l.ntx, l.nty, l.nty_l}, par, u, out);
@@ -861,6 +983,23 @@ extern "C" int ins_smagtensor_f64(const ins_grid_t* G, double theta, const doubl
 extern "C" int ins_divoftensor_f64(const ins_grid_t* G, const double* sig, double* s, void* stream) {
   INS_REQUIRE(G && sig && s, "null argument");
   const GridDev& g = G->g;
+  bool inside = g.D == 3 && g.N[0] - 2 >= 32 && g.N[2] >= 4 && ins_opt(OPT_INS_FIELDS_ROWS) >= 0;
+  for (int a = 0; inside && a < 3; ++a)
+    for (int b = 0; b < 3; ++b) inside = inside && g.iu_lo[a][b] >= 1 && g.iu_hi[a][b] <= g.N[b] - 1;
+  if (inside) {  // register rows + DPP (256^3: 0.68 -> ? ms); a PressureBC side puts DOFs into the ghost layer: plain kernel
+    constexpr int R = 4;
+    const int nx = g.N[0] - 2, ny = g.N[1] - 2, nz = g.N[2] - 2;
+    const int zc = ins_opt(OPT_INS_FIELDS_ZC) > 0 ? (int)ins_opt(OPT_INS_FIELDS_ZC) : (nz >= 128 ? 32 : (nz >= 32 ? 16 : (nz >= 8 ? 8 : nz)));
+    Launch3 l;
+    l.block = dim3(64, 4, 1);
+    l.ntx = (int)cdiv(nx, GR_XO);
+    l.nty = (int)cdiv(ny, 4 * R);
+    l.nty_l = (l.nty + 7) / 8;
+    l.grid = dim3(8u * l.ntx * l.nty_l * cdiv(nz, zc), 1, 1);
+    hipLaunchKernelGGL((k_divoftensor_rows<R>), l.grid, l.block, 0, as_stream(stream), g, BoxMap{l.ntx, l.nty, l.nty_l}, zc, sig, s);
+    INS_LAUNCH_CHECK();
+    return INS_OK;
+  }
   Launch3 l = box_launch(g.N[0], g.N[1], g.D == 3 ? g.N[2] : 1);
   INS_LAUNCH_D(k_divoftensor, l, as_stream(stream), sig, s);
   return INS_OK;
