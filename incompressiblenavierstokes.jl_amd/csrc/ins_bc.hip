@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void k_bc_u(GridDev g, double* __restrict__ u,
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void k_bc_p(GridDev g, double* __restrict__ p, int be) {
+__global__ __launch_bounds__(256) void k_bc_p(GridDev g, double* __restrict__ p, int be, long long fstride = 0) {
+  p += (long long)blockIdx.z * fstride;  // several scalar fields in one launch (the stress components of the closure, ins_k_apply_bc_p_fields)
   const int o0 = be == 0 ? 1 : 0;
   const int o1 = be == 2 ? 1 : 2;
   const int q0 = blockIdx.x * 256 + threadIdx.x;
@@ -143,22 +144,24 @@ int ins_k_apply_bc_u(const ins_grid* G, double* u, int dudt, const double* const
   return INS_OK;
 }
 
-int ins_k_apply_bc_p(const ins_grid* G, double* p, hipStream_t s) {
+// apply_bc_p! on nf scalar fields laid out back to back (field f at p + f·ncell): one launch per direction for all of them
+int ins_k_apply_bc_p_fields(const ins_grid* G, double* p, int nf, hipStream_t s) {
   const GridDev& g = G->g;
   for (int be = 0; be < g.D; ++be) {
     const int l = g.bc[be][0], r = g.bc[be][1];
     const bool noop = (l == INS_BC_DIRICHLET || l == INS_BC_HALO) && (r == INS_BC_DIRICHLET || r == INS_BC_HALO);
     if (noop) continue;
     const int o0 = be == 0 ? 1 : 0, o1 = be == 2 ? 1 : 2;
-    dim3 grid(cdiv(g.N[o0], 256), g.D == 3 ? g.N[o1] : 1, 1);
+    dim3 grid(cdiv(g.N[o0], 256), g.D == 3 ? g.N[o1] : 1, nf);
     if (g.D == 2)
-      hipLaunchKernelGGL(k_bc_p<2>, grid, dim3(256), 0, s, g, p, be);
+      hipLaunchKernelGGL(k_bc_p<2>, grid, dim3(256), 0, s, g, p, be, G->ncell);
     else
-      hipLaunchKernelGGL(k_bc_p<3>, grid, dim3(256), 0, s, g, p, be);
+      hipLaunchKernelGGL(k_bc_p<3>, grid, dim3(256), 0, s, g, p, be, G->ncell);
     INS_LAUNCH_CHECK();
   }
   return INS_OK;
 }
+int ins_k_apply_bc_p(const ins_grid* G, double* p, hipStream_t s) { return ins_k_apply_bc_p_fields(G, p, 1, s); }
 
 // op: 0 sum(a*b), 1 max|a|, 2 min(a), 3 sum(a), 4 sum(a*a).  Blocking.
 int ins_k_reduce(const ins_grid* G, int op, const double* a, const double* b, const int lo[3], const int hi[3], double* out,

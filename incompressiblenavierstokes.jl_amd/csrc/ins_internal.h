@@ -248,6 +248,7 @@ struct RkEpi {
 // ------------------------------------------------------------------------------------------------
 int ins_k_apply_bc_u(const ins_grid* grid, double* u, int dudt, const double* const* planes, hipStream_t s);
 int ins_k_apply_bc_p(const ins_grid* grid, double* p, hipStream_t s);
+int ins_k_apply_bc_p_fields(const ins_grid* grid, double* p, int nf, hipStream_t s);
 int ins_k_momentum(const ins_grid* grid, double visc, const double* u, double* F, hipStream_t s);
 int ins_k_divergence(const ins_grid* grid, const double* u, double* div, hipStream_t s);
 int ins_k_diffusion_overwrite(const ins_grid* grid, double visc, const double* u, double* F, hipStream_t s);

@@ -400,9 +400,10 @@ __global__ __launch_bounds__(256) void k_grad_ghost(GridDev g, double* __restric
     }
   }
 }
+// uin: the uncorrected field (u itself for the in-place form; another array keeps the uncorrected stage velocity intact: ins_rk_ext.hip)
 template <bool KEEP_P>
-__global__ __launch_bounds__(256) void k_grad_ghost3(GridDev g, double* __restrict__ u, double* __restrict__ p,
-                                                     const double* __restrict__ pI, int n0, int n1, int n2) {
+__global__ __launch_bounds__(256) void k_grad_ghost3(GridDev g, double* u, double* __restrict__ p, const double* __restrict__ pI, int n0, int n1, int n2,
+                                                     const double* uin) {
   const int ii = blockIdx.x * 64 + threadIdx.x;
   const int jj = blockIdx.y * 4 + threadIdx.y;
   const int kk = blockIdx.z;
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(256) void k_grad_ghost3(GridDev g, double* __restri
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const long long qn = (w[a] + 1 < n[a]) ? q + qs[a] : q - (long long)(n[a] - 1) * qs[a];
-    un[a] = u[a * g.sc + c] - (pI[qn] - pc) * g.rdxu[a][I[a]];
+    un[a] = uin[a * g.sc + c] - (pI[qn] - pc) * g.rdxu[a][I[a]];
     img[a] = I[a] == 1 ? g.N[a] - 1 : (I[a] == g.N[a] - 2 ? 0 : -1);
   }
 #pragma unroll
@@ -1354,10 +1355,12 @@ int ins_k_project(const ins_grid* G, ins_poisson* ps, double* u, double* p, hipS
 
 // project! for the fused periodic RK stage: u holds valid INTERIOR values only; on return its interior is
 // divergence-free and its ghost volumes are filled.  3-D, all-periodic, spectral solver.
-int ins_k_project_periodic_fused(const ins_grid* G, ins_poisson* ps, double* u, double* p, bool keep_p, hipStream_t s) {
+// uout != nullptr: u stays as it is (uncorrected) and the corrected field with its ghost volumes goes to uout.
+int ins_k_project_periodic_fused(const ins_grid* G, ins_poisson* ps, double* u, double* p, bool keep_p, hipStream_t s, double* uout) {
   const GridDev& g = G->g;
   dim3 block(64, 4, 1), grid(cdiv(ps->np[0], 64), cdiv(ps->np[1], 4), ps->np[2]);
   int rc;
+  double* dst = uout ? uout : u;
   if (ps->ownfft) {  // K2 lives inside the x-forward pass
     rc = ownfft_transform(ps, u, s);
   } else {
@@ -1367,9 +1370,9 @@ int ins_k_project_periodic_fused(const ins_grid* G, ins_poisson* ps, double* u, 
   }
   if (rc) return rc;
   if (keep_p)
-    hipLaunchKernelGGL(k_grad_ghost3<true>, grid, block, 0, s, g, u, p, ps->pI, ps->np[0], ps->np[1], ps->np[2]);
+    hipLaunchKernelGGL(k_grad_ghost3<true>, grid, block, 0, s, g, dst, p, ps->pI, ps->np[0], ps->np[1], ps->np[2], (const double*)u);
   else
-    hipLaunchKernelGGL(k_grad_ghost3<false>, grid, block, 0, s, g, u, p, ps->pI, ps->np[0], ps->np[1], ps->np[2]);
+    hipLaunchKernelGGL(k_grad_ghost3<false>, grid, block, 0, s, g, dst, p, ps->pI, ps->np[0], ps->np[1], ps->np[2], (const double*)u);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }

@@ -12,7 +12,7 @@ bool ins_fast3d_supported(const ins_grid* G);
 bool ins_flux64_supported(const ins_grid* G);
 
 int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s);
-int ins_k_project_periodic_fused(const ins_grid* G, ins_poisson* ps, double* u, double* p, bool keep_p, hipStream_t s);
+int ins_k_project_periodic_fused(const ins_grid* G, ins_poisson* ps, double* u, double* p, bool keep_p, hipStream_t s, double* uout = nullptr);
 
 int ins_k_momentum(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s) {
   if (ins_fast3d_supported(G)) return ins_k_momentum_fast3d(G, visc, u, F, s);

@@ -21,7 +21,7 @@
 int ins_k_momentum_generic(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s);
 int ins_k_momentum_fast3d_opts(const ins_grid* G, double visc, const double* u, double* F, bool zero_shell, hipStream_t s);
 int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s);
-int ins_k_project_periodic_fused(const ins_grid* G, ins_poisson* ps, double* u, double* p, bool keep_p, hipStream_t s);
+int ins_k_project_periodic_fused(const ins_grid* G, ins_poisson* ps, double* u, double* p, bool keep_p, hipStream_t s, double* uout = nullptr);
 int ins_k_project(const ins_grid* G, ins_poisson* ps, double* u, double* p, hipStream_t s);
 bool ins_fast3d_supported(const ins_grid* G);
 bool ins_flux64_supported(const ins_grid* G);
@@ -150,31 +150,53 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
     }
     if ((rc = ins_k_apply_bc_u(G, u, 0, nullptr, s))) return rc;
     if ((rc = bc_temp())) return rc;
+    // Stage-velocity basis (rk_step_fused_periodic): the projection writes the corrected field to another array, so the uncorrected stage
+    // velocities V_m stay in memory (in the ku arrays) and no k_j is stored or read; INS_RK_KEEP_K=1 restores the k-basis.
+    bool vbasis = ns > 1 && !ins_opt(OPT_INS_RK_KEEP_K);
+    for (int i = 0; vbasis && i < ns; ++i) vbasis = rk->A[i * ns + i] != 0.0;
     const double* in = u;
     const double* tin = temp;
     for (int i = 0; i < ns; ++i) {
-      double* out = (i == ns - 1 && ns > 1) ? u : rk->ub[i & 1];
-      double* tout = with_temp ? ((i == ns - 1 && ns > 1) ? temp : e->tb[i & 1]) : nullptr;
+      const bool last = i == ns - 1 && ns > 1;
+      double* out = last ? u : (vbasis ? rk->ku[i] : rk->ub[i & 1]);      // what the stage kernel writes (uncorrected)
+      double* corrected = last ? u : rk->ub[i & 1];                        // what the projection leaves (with ghost volumes)
+      double* tout = with_temp ? (last ? temp : e->tb[i & 1]) : nullptr;
       if (closure) {
         if ((rc = ins_smagtensor_f64(G, e->theta, in, e->sigma, stream))) return rc;
-        for (int q = 0; q < D * (D + 1) / 2; ++q)
-          if ((rc = ins_k_apply_bc_p(G, e->sigma + (size_t)q * G->ncell, s))) return rc;  // apply_bc_p!(σ, 0, setup)   operators.jl:1302
+        if ((rc = ins_k_apply_bc_p_fields(G, e->sigma, D * (D + 1) / 2, s))) return rc;  // apply_bc_p!(σ, 0, setup)   operators.jl:1302
         if ((rc = ins_divoftensor_f64(G, e->sigma, e->E, stream))) return rc;
       }
       RkEpi epi;
       memset(&epi, 0, sizeof(epi));
-      for (int j = 0; j < i; ++j) {
-        const double coef = dt * rk->A[i * ns + j];
-        if (coef == 0.0) continue;
-        epi.coef[epi.n] = coef;
-        epi.k[epi.n] = rk->ku[j];
-        ++epi.n;
+      if (vbasis) {
+        double beta[INS_MAX_STAGES];
+        for (int m = i - 1; m >= 0; --m) {  // β_i · A[0:i,0:i] = A[i,0:i], A lower triangular
+          double v = rk->A[i * ns + m];
+          for (int j = m + 1; j < i; ++j) v -= beta[j] * rk->A[j * ns + m];
+          beta[m] = v / rk->A[m * ns + m];
+        }
+        for (int m = 0; m < i; ++m) {
+          if (beta[m] == 0.0) continue;
+          epi.c0m1 -= beta[m];
+          epi.coef[epi.n] = beta[m];
+          epi.k[epi.n] = rk->ku[m];
+          ++epi.n;
+        }
+      } else {
+        for (int j = 0; j < i; ++j) {
+          const double coef = dt * rk->A[i * ns + j];
+          if (coef == 0.0) continue;
+          epi.coef[epi.n] = coef;
+          epi.k[epi.n] = rk->ku[j];
+          ++epi.n;
+        }
+        for (int i2 = i + 1; i2 < ns; ++i2)
+          if (rk->A[i2 * ns + i] != 0.0) epi.write_k = 1;
       }
-      for (int i2 = i + 1; i2 < ns; ++i2)
-        if (rk->A[i2 * ns + i] != 0.0) epi.write_k = 1;
-      if (rk->force) {  // k_j = F_j + E_j is stored without the steady force f: it enters with Δt Σ_{j<=i} A[i,j]
-        double cf = 0.0;
-        for (int j = 0; j <= i; ++j) cf += dt * rk->A[i * ns + j];
+      if (rk->force) {  // the steady force f is not part of what is stored: Δt A[i,i] f on top of the V_m, Δt Σ_{j<=i} A[i,j] f on top of the k_j
+        double cf = dt * rk->A[i * ns + i];
+        if (!vbasis)
+          for (int j = 0; j < i; ++j) cf += dt * rk->A[i * ns + j];
         epi.coef[epi.n] = cf;
         epi.k[epi.n] = rk->force;
         ++epi.n;
@@ -205,9 +227,9 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
                                    later ? e->ktemp[i] : nullptr, tout, s)))
           return rc;
       }
-      if ((rc = ins_k_project_periodic_fused(G, rk->ps, out, rk->p, i == ns - 1, s))) return rc;
+      if ((rc = ins_k_project_periodic_fused(G, rk->ps, out, rk->p, i == ns - 1, s, corrected == out ? nullptr : corrected))) return rc;
       if (with_temp && (rc = ins_apply_bc_temp_f64(G, td.bc, td.val, nullptr, tout, stream))) return rc;
-      in = out;
+      in = corrected;
       tin = tout;
     }
     if (ns == 1) {
@@ -228,8 +250,7 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
     if ((rc = temp_rhs(u, i))) return rc;
     if (closure) {
       if ((rc = ins_smagtensor_f64(G, e->theta, u, e->sigma, stream))) return rc;
-      for (int q = 0; q < D * (D + 1) / 2; ++q)
-        if ((rc = ins_k_apply_bc_p(G, e->sigma + (size_t)q * G->ncell, s))) return rc;
+      if ((rc = ins_k_apply_bc_p_fields(G, e->sigma, D * (D + 1) / 2, s))) return rc;
       if ((rc = ins_divoftensor_f64(G, e->sigma, e->E, stream))) return rc;
       const double one = 1.0;
       const double* ks[1] = {e->E};
