@@ -809,13 +809,12 @@ int launch_gradient_op(const ins_grid* G, double par, const double* u, double* o
       Launch3 l = ip_launch(g);
       hipLaunchKernelGGL((k_gradient_op<2, OP>), l.grid, l.block, 0, s, g, BoxMap{l.ntx, l.nty, l.nty_l}, par, u, out);
     }
-  } else if (OP != 1 && ins_opt(OPT_INS_FIELDS_ROWS) >= 0 && g.ip_hi[0] - g.ip_lo[0] >= 32 && g.N[2] >= 4) {
+  } else if ((OP != 1 || ins_opt(OPT_INS_FIELDS_ROWS) >= 2) && ins_opt(OPT_INS_FIELDS_ROWS) >= 0 && g.ip_hi[0] - g.ip_lo[0] >= 32 && g.N[2] >= 4) {
     // register rows + DPP (INS_FIELDS_ROWS=-1: the older kernels).  256^3: strain dissipation 0.282 -> 0.207 ms, smagtensor 0.460 -> 0.449;
     // eig2 (its arithmetic dominates: 0.362 plain, 0.453 here) keeps the plain kernel
-    // rows per work-item: 4 (strain dissipation), 2 for the stress tensor (six results per cell: with 4 rows the kernel needs all 256 VGPRs
-    // and more); INS_FIELDS_ROWS = 2, 3, 4 overrides
+    // rows per work-item: 2 (with 4 rows the stress-tensor kernel needs all 256 VGPRs and runs one wavefront per SIMD); INS_FIELDS_ROWS = 2, 3, 4 overrides
     const int ro = (int)ins_opt(OPT_INS_FIELDS_ROWS);
-    const int R = (ro >= 2 && ro <= 4) ? ro : (OP == 2 ? 2 : 4);
+    const int R = (ro >= 2 && ro <= 4) ? ro : 2;  // 256^3: strain dissipation 0.202 (4 rows) -> 0.186 ms, smagtensor 0.45 -> 0.33; eig2 (only with INS_FIELDS_ROWS set) is slower here: 0.40-0.47 vs 0.36 plain
     const int nx = g.ip_hi[0] - g.ip_lo[0], ny = g.ip_hi[1] - g.ip_lo[1], nz = g.ip_hi[2] - g.ip_lo[2];
     const int zc = ins_opt(OPT_INS_FIELDS_ZC) > 0 ? (int)ins_opt(OPT_INS_FIELDS_ZC) : (nz >= 128 ? 32 : (nz >= 32 ? 16 : (nz >= 8 ? 8 : nz)));
     Launch3 l;

@@ -372,21 +372,30 @@ function apply_bc_temp!(temp::RA, t, setup; kwargs...)
     isempty(keep) || AMDGPU.synchronize()
     temp
 end
-# smagorinsky_closure(setup): Ïƒ as D(D+1)/2 scalar fields [xx, yy, (zz), xy, (xz, yz)]
+# smagorinsky_closure(setup): Ïƒ as D(D+1)/2 scalar fields [xx, yy, (zz), xy, (xz, yz)].  A callable struct, so that `timestep!` can tell this
+# closure from a user function and carry it inside the native stage loop (ins_rk_set_closure).
+struct HipSmagorinsky{S,A,B}
+    setup::S
+    Ïƒ::A
+    s::B
+end
 function smagorinsky_closure(setup::ROCSetup)
     D = setup.grid.dimension()
     ns = D * (D + 1) Ã· 2
     Ïƒ = similar(setup.grid.x[1], Float64, (setup.grid.N..., ns)); fill!(Ïƒ, 0)
-    s = IncompressibleNavierStokes.vectorfield(setup)
+    HipSmagorinsky(setup, Ïƒ, IncompressibleNavierStokes.vectorfield(setup))
+end
+function (m::HipSmagorinsky)(u, Î¸)
+    (; setup, Ïƒ, s) = m
+    D = setup.grid.dimension()
+    ns = D * (D + 1) Ã· 2
     ncell = prod(setup.grid.N)
-    function closure(u, Î¸)
-        check(ccall((:ins_smagtensor_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), Î¸, pointer(u), pointer(Ïƒ), stream()))
-        for q = 0:ns-1   # apply_bc_p!(Ïƒ, 0, setup) component by component (operators.jl:1296)
-            check(ccall((:ins_apply_bc_p_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), pointer(Ïƒ) + 8 * ncell * q, stream()))
-        end
-        check(ccall((:ins_divoftensor_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), pointer(Ïƒ), pointer(s), stream()))
-        s
+    check(ccall((:ins_smagtensor_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), Î¸, pointer(u), pointer(Ïƒ), stream()))
+    for q = 0:ns-1   # apply_bc_p!(Ïƒ, 0, setup) component by component (operators.jl:1296)
+        check(ccall((:ins_apply_bc_p_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), pointer(Ïƒ) + 8 * ncell * q, stream()))
     end
+    check(ccall((:ins_divoftensor_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), pointer(Ïƒ), pointer(s), stream()))
+    s
 end
 # observespectrum: shells from spectral_stuff (host), everything else on the device
 function spectrum_handle(setup; kwargs...)
@@ -422,6 +431,25 @@ function native!(cache::HipRKCache, method, setup, psolver)
     cache.psolver = psolver
     cache.h = h[]
 end
+# ins_temperature_desc_t (include/ins_hip.h): the scalars of `temperature_equation` (setup.jl:48-87) the native stage loop needs
+struct TempDesc
+    a2::Float64
+    a4::Float64
+    diss_coef::Float64
+    gdir::Int32
+    dodissipation::Int32
+    bc::NTuple{6,Int32}
+    val::NTuple{6,Float64}
+end
+function tempdesc(setup)
+    T = setup.temperature
+    D = setup.grid.dimension()
+    bcs = T.boundary_conditions
+    code(Î², s) = Î² <= D ? Int32(bccode(bcs[Î²][s])) : Int32(0)
+    value(Î², s) = (Î² <= D && bcs[Î²][s] isa DirichletBC && bcs[Î²][s].u isa Number) ? Float64(bcs[Î²][s].u) : 0.0
+    TempDesc(T.Î±2, T.Î±4, setup.Re * T.Î±1 / T.Î³, T.gdir - 1, T.dodissipation ? 1 : 0,
+             ntuple(q -> code((q + 1) Ã· 2, 2 - q % 2), 6), ntuple(q -> value((q + 1) Ã· 2, 2 - q % 2), 6))
+end
 # A stepper (create_stepper: (; setup, psolver, u, temp, t, n), step_explicit_runge_kutta.jl:1-2) whose pressure solver is the library's
 const HipStepper = NamedTuple{N,<:Tuple{Any,HipPSolver,Vararg{Any}}} where {N}
 function timestep!(method::ExplicitRungeKuttaMethod, stepper::HipStepper, Î”t; Î¸ = nothing, cache::HipRKCache)
@@ -429,8 +457,27 @@ function timestep!(method::ExplicitRungeKuttaMethod, stepper::HipStepper, Î”t; Î
     # The fused native step is valid only without closure model / temperature / unsteady body force and with time-independent boundary
     # data (SURVEY.md Â§8b caveat); otherwise the reference's own stage loop runs, on the operator-level methods above, so user callbacks
     # can run between kernels.  A steady body force rides inside the native stage kernels (ins_rk_set_bodyforce).
-    native = isnothing(setup.closure_model) && isnothing(temp) && (isnothing(setup.bodyforce) || setup.issteadybodyforce) &&
-             !any(isclosure, Iterators.flatten(setup.boundary_conditions))
+    steady = (isnothing(setup.bodyforce) || setup.issteadybodyforce) && !any(isclosure, Iterators.flatten(setup.boundary_conditions))
+    native = steady && isnothing(setup.closure_model) && isnothing(temp)
+    # The temperature equation and this glue's Smagorinsky closure (constant Î¸) ride inside the native stage loop (ins_rk_step_ext_f64)
+    ext = steady && !native && (isnothing(setup.closure_model) || (setup.closure_model isa HipSmagorinsky && Î¸ isa Real)) &&
+          (isnothing(temp) || !any(b -> b isa DirichletBC && !(isnothing(b.u) || b.u isa Number), Iterators.flatten(setup.temperature.boundary_conditions)))
+    if ext
+        h = native!(cache, method, setup, psolver)
+        check(ccall((:ins_rk_set_bodyforce, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), h,
+                    isnothing(setup.bodyforce) ? Ptr{Float64}(C_NULL) : pointer(setup.bodyforce)))
+        check(ccall((:ins_rk_set_closure, lib), Cint, (Ptr{Cvoid}, Cint, Cdouble), h, isnothing(setup.closure_model) ? 0 : 1,
+                    isnothing(setup.closure_model) ? 0.0 : Float64(Î¸)))
+        if isnothing(temp)
+            check(ccall((:ins_rk_set_temperature, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h, C_NULL))
+        else
+            desc = Ref(tempdesc(setup))
+            GC.@preserve desc check(ccall((:ins_rk_set_temperature, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h, Base.unsafe_convert(Ptr{Cvoid}, desc)))
+        end
+        check(ccall((:ins_rk_step_ext_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble, Ptr{Cvoid}),
+                    h, 1 / setup.Re, pointer(u), isnothing(temp) ? Ptr{Float64}(C_NULL) : pointer(temp), t, Î”t, stream()))
+        return IncompressibleNavierStokes.create_stepper(method; setup, psolver, u, temp, t = t + method.c[end] * Î”t, n = n + 1)
+    end
     if !native
         isnothing(cache.ref) && (cache.ref = invoke(ode_method_cache, Tuple{ExplicitRungeKuttaMethod,Any}, method, setup))
         return invoke(timestep!, Tuple{ExplicitRungeKuttaMethod,Any,Any}, method, stepper, Î”t; Î¸, cache = cache.ref)

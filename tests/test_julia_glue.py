@@ -136,6 +136,25 @@ def test_griddesc_mirrors_the_c_struct():
     assert jfields == cfields
 
 
+def test_tempdesc_mirrors_the_c_struct():
+    hdr = open(HEADER).read()
+    body = re.search(r"typedef struct ins_temperature_desc \{(.*?)\} ins_temperature_desc_t;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    cfields = []
+    for decl in filter(None, (d.strip() for d in body.split(";"))):
+        m = re.fullmatch(r"(int32_t|double)\s+([A-Za-z0-9_]+)(?:\[(\d+)\])?", decl)
+        assert m, decl
+        cfields.append((m.group(2), {"int32_t": "Int32", "double": "Float64"}[m.group(1)], int(m.group(3) or 1)))
+    src = open(GLUE).read()
+    jbody = re.search(r"struct TempDesc\n(.*?)\nend", src, flags=re.S).group(1)
+    jfields = []
+    for ln in jbody.splitlines():
+        name, typ = ln.strip().split("::")
+        m = re.fullmatch(r"NTuple\{(\d+),(.+)\}", typ)
+        jfields.append((name, m.group(2), int(m.group(1))) if m else (name, typ, 1))
+    assert jfields == cfields
+
+
 COVERED = [  # "methods divergence!, pressuregradient!, applypressure!, convection!, diffusion!, convectiondiffusion!, momentum!,
     # laplacian!, scalewithvolume!, apply_bc_u!, apply_bc_p!, project!, psolver_spectral, psolver_cg, timestep!" + what §8f added
     "divergence!", "pressuregradient!", "applypressure!", "convection!", "diffusion!", "convectiondiffusion!", "momentum!", "laplacian!",
