@@ -21,14 +21,7 @@
 
 #include "ins_internal.h"
 
-// One record per (direction d, index idx); 16 doubles = 128 B so a record is one aligned scalar burst.
-//   vs = ν·mdx[d][idx+1]   diffusion coefficient of the upper d-face for the d-component   (Δb, α == β)
-//   vo = ν·mdxu[d][idx]    ... for the other components                                     (Δb, α != β)
-//   a[β], b[β] = ½A₂[β][d][idx], ½A₁[β][d][idx+1]   half weights of component β read along d
-//   rs = 1/Δu[d][idx], ro = 1/Δ[d][idx]              control-volume width reciprocals (α == β / α != β)
-struct Rec {
-  double vs, vo, a0, b0, a1, b1, a2, b2, rs, ro, pad[6];
-};
+// (struct Rec, the per-direction metric record, lives in ins_internal.h: ins_flux64m.hip reads the same tables)
 
 namespace {
 
@@ -570,8 +563,14 @@ int ins_k_momentum_flux3d(const ins_grid* G, double visc, const double* u, doubl
 }
 
 // K1 + K6: k_i = momentum(u_in) (stored when epi.write_k) and the stage velocity u* (interior) in one pass.
+// 64 outputs per wavefront on stretched / masked grids (ins_flux64m.hip)
+bool ins_flux64m_supported(const ins_grid* G);
+int ins_k_flux64m(const ins_grid* G, double visc, const double* u, double* k_out, const RkEpi& epi, const double* p_padded, hipStream_t s);
+
 int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s) {
   if (ins_flux64_supported(G)) return ins_k_flux64(G, visc, u_in, k_out, &epi, nullptr, 0, s);
+  // (the non-correcting 64-wide masked kernel is opt-in: INS_FLUX64M_FIRST=1; at 256^3 the 62-wide one with 3 rows per thread is faster, 0.29 vs 0.38 ms)
+  if (ins_opt(OPT_INS_FLUX64M_FIRST) && ins_flux64m_supported(G)) return ins_k_flux64m(G, visc, u_in, k_out, epi, nullptr, s);
   int rc = ins_flux3d_prepare(G, visc, s);
   if (rc) return rc;
   return launch_flux_any<true>(G, u_in, k_out, epi, nullptr, 0, s);
@@ -600,6 +599,7 @@ bool ins_corr3_supported(const ins_grid* G) {
 }
 int ins_k_momentum_rk_fused_corr3(const ins_grid* G, double visc, const double* ustar_prev, const double* p_padded, double* k_out, const RkEpi& epi,
                                   hipStream_t s) {
+  if (ins_flux64m_supported(G)) return ins_k_flux64m(G, visc, ustar_prev, k_out, epi, p_padded, s);
   int rc = ins_flux3d_prepare(G, visc, s);
   if (rc) return rc;
   return launch_flux_any<true>(G, ustar_prev, k_out, epi, p_padded, 3, s);

@@ -68,6 +68,12 @@ void ins_set_error(const char* fmt, ...);
   X(INS_FIELDS_ROWS)             \
   X(INS_FIELDS_ZC)               \
   X(INS_DISABLE_FLUX2D)          \
+  X(INS_DISABLE_FLUX64M)         \
+  X(INS_FLUX64M_ZC)              \
+  X(INS_FLUX64M_NOBAR)           \
+  X(INS_FLUX64M_XW)              \
+  X(INS_FLUX64M_ROWS)            \
+  X(INS_FLUX64M_FIRST)           \
   X(INS_DISABLE_FLUX64)          \
   X(INS_FLUX64_ROWS)             \
   X(INS_FLUX64_ROWS_CORR)        \
@@ -219,6 +225,16 @@ struct ins_rk {
   ins_rk_ext* ext = nullptr;
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;  // (start, stop) pairs around momentum launches
+};
+
+// Metric records of the flux-form stage kernels on stretched / masked grids (ins_fast3d_flux.hip builds them per viscosity: ins_flux3d_prepare;
+// ins_flux64m.hip reads the same tables).  One record per (direction d, index idx); 16 doubles = 128 B so a record is one aligned scalar burst.
+//   vs = ν·mdx[d][idx+1]   diffusion coefficient of the upper d-face for the d-component   (Δb, α == β)
+//   vo = ν·mdxu[d][idx]    ... for the other components                                     (Δb, α != β)
+//   a[β], b[β] = ½A₂[β][d][idx], ½A₁[β][d][idx+1]   half weights of component β read along d
+//   rs = 1/Δu[d][idx], ro = 1/Δ[d][idx]              control-volume width reciprocals (α == β / α != β)
+struct Rec {
+  double vs, vo, a0, b0, a1, b1, a2, b2, rs, ro, pad[6];
 };
 
 // Runge-Kutta stage epilogue fused behind the stencil (K1 + K6): with f = momentum(u) still in registers,

@@ -875,10 +875,11 @@ def _numpy_fast_diagonalisation(o, so):
 
 @pytest.mark.parametrize("geom", ["cavity", "channel", "allwalls"])
 @pytest.mark.parametrize("method", ["RK44", "Wray3"])
-def test_masked_inkernel_correction_matches_oracle(ins, oracle, geom, method):
-    """Mid-size (64 x 48 x 32) stretched boxes with Dirichlet / Periodic sides and the direct solver: stages >= 2 read the previous stage's
-    uncorrected u* and its pressure and apply the projection's gradient-subtract in registers on the degrees of freedom (62-wide stage
-    kernel, CORR = 3; csrc/ins_rk.hip).  Three steps against the oracle's stage loop (step_explicit_runge_kutta.jl:17-50 with
+@pytest.mark.parametrize("nx", [64, 72, 136])  # 64: the 62-wide stage kernel; 72, 136: the 64-wide one (csrc/ins_flux64m.hip; a full + a partial wavefront, three wavefronts)
+def test_masked_inkernel_correction_matches_oracle(ins, oracle, geom, method, nx):
+    """Mid-size (nx x 48 x 32) stretched boxes with Dirichlet / Periodic sides and the direct solver: stages >= 2 read the previous stage's
+    uncorrected u* and its pressure and apply the projection's gradient-subtract in registers on the degrees of freedom (stage kernels
+    with CORR = 3; csrc/ins_rk.hip).  Three steps against the oracle's stage loop (step_explicit_runge_kutta.jl:17-50 with
     pressure.jl:69-82 after every stage; the oracle's direct solver in its fast-diagonalisation form, pinned above), and against the same
     library with the correction left to project! (INS_DISABLE_INKERNEL_CORR)."""
     from ins_amd import _lib
@@ -887,15 +888,15 @@ def test_masked_inkernel_correction_matches_oracle(ins, oracle, geom, method):
     lid = (1.0, 0.2, 0.0)
     Do, Po, Dp, Pp = o.DirichletBC, o.PeriodicBC, ins.DirichletBC, ins.PeriodicBC
     if geom == "cavity":  # examples/LidDrivenCavity3D.jl: cosine x, y with a moving lid, periodic z
-        x = (o.cosine_grid(0.0, 1.0, 64), o.cosine_grid(0.0, 1.0, 48), np.linspace(-0.2, 0.2, 33))
+        x = (o.cosine_grid(0.0, 1.0, nx), o.cosine_grid(0.0, 1.0, 48), np.linspace(-0.2, 0.2, 33))
         bo = ((Do(), Do()), (Do(), Do(lid)), (Po(), Po()))
         bp = ((Dp(), Dp()), (Dp(), Dp(lid)), (Pp(), Pp()))
     elif geom == "channel":  # periodic x and z, tanh walls in y (Fourier x/z inside the direct solver)
-        x = (np.linspace(0.0, 2.0, 65), o.tanh_grid(0.0, 1.0, 48, 1.5), np.linspace(0.0, 1.0, 33))
+        x = (np.linspace(0.0, 2.0, nx + 1), o.tanh_grid(0.0, 1.0, 48, 1.5), np.linspace(0.0, 1.0, 33))
         bo = ((Po(), Po()), (Do(), Do()), (Po(), Po()))
         bp = ((Pp(), Pp()), (Dp(), Dp()), (Pp(), Pp()))
     else:  # walls everywhere, stretched in all three directions
-        x = (o.tanh_grid(0.0, 1.0, 64, 1.2), o.cosine_grid(0.0, 1.0, 48), o.tanh_grid(0.0, 0.5, 32, 1.1))
+        x = (o.tanh_grid(0.0, 1.0, nx, 1.2), o.cosine_grid(0.0, 1.0, 48), o.tanh_grid(0.0, 0.5, 32, 1.1))
         bo = ((Do(), Do()), (Do(), Do(lid)), (Do(), Do()))
         bp = ((Dp(), Dp()), (Dp(), Dp(lid)), (Dp(), Dp()))
     so = o.make_setup(x, bo, Re=200.0)
