@@ -566,17 +566,35 @@ struct TempStage {
   double* ktemp_out;  // nullable: no later stage reads ktemp_i
   double* temp_out;
 };
+// pI != nullptr (all-periodic boxes): u is the UNCORRECTED stage velocity (interior volumes only) and pI the unpadded pressure of its projection;
+// the two face velocities a volume needs are corrected here, u = u* - ∇p through the periodic image (applypressure!, operators.jl:225-233), so
+// the stage loop needs no gradient-subtract pass between its stages.
 template <int D>
 __global__ __launch_bounds__(256) void k_temp_stage(GridDev g, BoxMap L, double a4, double coef, const double* __restrict__ u, const double* __restrict__ temp,
-                                                    const double* __restrict__ w, TempStage ts) {
+                                                    const double* __restrict__ w, TempStage ts, const double* __restrict__ pI) {
   INS_BOX_INDEX(g.ip_lo[0], g.ip_lo[1], g.ip_lo[2], g.ip_hi[0], g.ip_hi[1]);
   const double tc = temp[c];
   double acc = 0.0, d = 0.0;
+  const int n[3] = {g.ip_hi[0] - g.ip_lo[0], g.ip_hi[1] - g.ip_lo[1], D == 3 ? g.ip_hi[2] - g.ip_lo[2] : 1};
+  const long long qs[3] = {1, n[0], (long long)n[0] * n[1]};
+  const long long q = (I[0] - g.ip_lo[0]) + qs[1] * (I[1] - g.ip_lo[1]) + (D == 3 ? qs[2] * (I[2] - g.ip_lo[2]) : 0);
+  const double pc = pI ? pI[q] : 0.0;
 #pragma unroll
   for (int b = 0; b < D; ++b) {
     const long long sb = g.sx[b];
     const double* ub = u + b * g.sc;
-    const double u1 = ub[c - sb], u2 = ub[c];
+    double u1, u2;
+    if (pI) {
+      const int w0 = I[b] - g.ip_lo[b];
+      const bool first = w0 == 0, lastv = w0 == n[b] - 1;
+      const double pp = pI[lastv ? q - (long long)(n[b] - 1) * qs[b] : q + qs[b]];
+      const double pm = pI[first ? q + (long long)(n[b] - 1) * qs[b] : q - qs[b]];
+      u2 = ub[c] - (pp - pc) * g.rdxu[b][I[b]];
+      u1 = ub[first ? c + (long long)(n[b] - 1) * sb : c - sb] - (pc - pm) * g.rdxu[b][first ? g.ip_hi[b] - 1 : I[b] - 1];
+    } else {
+      u1 = ub[c - sb];
+      u2 = ub[c];
+    }
     const double dT1 = (tc - temp[c - sb]) * g.rdxu[b][I[b] - 1];
     const double dT2 = (temp[c + sb] - tc) * g.rdxu[b][I[b]];
     const double uT1 = u1 * avg_at(g, temp, c - sb, I[b] - 1, b);
@@ -924,7 +942,7 @@ extern "C" int ins_apply_bc_temp_f64(const ins_grid_t* G, const int32_t* bc, con
 
 // internal (ins_rk_ext.hip): w nullable (no dissipation term); ks / coefs: the previous ktemp_j with non-zero coefficient
 int ins_k_temp_stage(const ins_grid* G, double a4, double coef, const double* u, const double* temp, const double* w, const double* tempstart, int n,
-                     const double* coefs, const double* const* ks, double c_self, double* ktemp_out, double* temp_out, hipStream_t s) {
+                     const double* coefs, const double* const* ks, double c_self, double* ktemp_out, double* temp_out, hipStream_t s, const double* pI) {
   const GridDev& g = G->g;
   TempStage ts;
   ts.n = 0;
@@ -939,7 +957,7 @@ int ins_k_temp_stage(const ins_grid* G, double a4, double coef, const double* u,
   ts.ktemp_out = ktemp_out;
   ts.temp_out = temp_out;
   Launch3 l = ip_launch(g);
-  INS_LAUNCH_D(k_temp_stage, l, s, a4, coef, u, temp, w, ts);
+  INS_LAUNCH_D(k_temp_stage, l, s, a4, coef, u, temp, w, ts, pI);
   return INS_OK;
 }
 

@@ -438,6 +438,12 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
     load_p(Pa, Ha, k0 + 1);
     correct(P1, Pb, Hb, Pa, Ha);
     zflux0(P0, P1);
+    if constexpr (EXTRA) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) Pz[c][rr] = P0.v[c][rr + 1];
+    }
     load_plane(P0, min(k0 + 1, k1));
     load_p(Pb, Hb, min(k0 + 2, k1 + 1));
     int k = k0;
@@ -497,8 +503,13 @@ int launch_range(const ins_grid* G, FluxArgs& a, int corr_mode, hipStream_t s) {
         INS_LAUNCH_CHECK();
         return INS_OK;
       }
+      if (corr_mode == 1) {
+        hipLaunchKernelGGL((k_flux64<T, R, XW, true, 1, false, NW, true>), dim3(nb), block, (size_t)g_lds, s, a);
+        INS_LAUNCH_CHECK();
+        return INS_OK;
+      }
     }
-    ins_set_error("stage kernel with an extra force term: fp64, fused epilogue, 2 rows, 4 wavefronts, no in-kernel correction");
+    ins_set_error("stage kernel with an extra force term: fp64, fused epilogue, 2 rows, 4 wavefronts, no slab correction");
     return INS_ERR_UNSUPPORTED;
   }
   if (corr_mode == 0)

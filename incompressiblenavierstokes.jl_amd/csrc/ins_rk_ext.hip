@@ -26,7 +26,9 @@ int ins_k_project(const ins_grid* G, ins_poisson* ps, double* u, double* p, hipS
 bool ins_fast3d_supported(const ins_grid* G);
 bool ins_flux64_supported(const ins_grid* G);
 int ins_k_temp_stage(const ins_grid* G, double a4, double coef, const double* u, const double* temp, const double* w, const double* tempstart, int n,
-                     const double* coefs, const double* const* ks, double c_self, double* ktemp_out, double* temp_out, hipStream_t s);
+                     const double* coefs, const double* const* ks, double c_self, double* ktemp_out, double* temp_out, hipStream_t s, const double* pI);
+int ins_k_momentum_rk_fused_corr(const ins_grid* G, double visc, const double* ustar_prev, const double* pI, double* k_out, const RkEpi& epi, hipStream_t s);
+int ins_k_project_periodic_solve_only(const ins_grid* G, ins_poisson* ps, const double* u, hipStream_t s);
 
 struct ins_rk_ext {
   int closure = 0;  // 0 none, 1 Smagorinsky
@@ -154,13 +156,18 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
     // velocities V_m stay in memory (in the ku arrays) and no k_j is stored or read; INS_RK_KEEP_K=1 restores the k-basis.
     bool vbasis = ns > 1 && !ins_opt(OPT_INS_RK_KEEP_K);
     for (int i = 0; vbasis && i < ns; ++i) vbasis = rk->A[i * ns + i] != 0.0;
+    // Without a closure every consumer of the stage velocity can correct it on the fly (the stage kernel as on the plain path, the temperature
+    // kernel for its two face velocities), so the gradient-subtract pass runs for the last stage only; the closure kernels need the corrected
+    // field with its ghost volumes in memory.
+    const bool incorr = vbasis && !closure && !ins_opt(OPT_INS_DISABLE_INKERNEL_CORR) && g.N[0] >= 8 && g.N[1] >= 8 && g.N[2] >= 8;
     const double* in = u;
     const double* tin = temp;
     for (int i = 0; i < ns; ++i) {
       const bool last = i == ns - 1 && ns > 1;
       double* out = last ? u : (vbasis ? rk->ku[i] : rk->ub[i & 1]);      // what the stage kernel writes (uncorrected)
-      double* corrected = last ? u : rk->ub[i & 1];                        // what the projection leaves (with ghost volumes)
+      double* corrected = (last || incorr) ? out : rk->ub[i & 1];          // what the projection leaves (K4 route: with ghost volumes)
       double* tout = with_temp ? (last ? temp : e->tb[i & 1]) : nullptr;
+      const bool corr_in = incorr && i > 0;  // `in` is the uncorrected V_{i-1}, ps->pI its pressure
       if (closure) {
         if ((rc = ins_smagtensor_f64(G, e->theta, in, e->sigma, stream))) return rc;
         if ((rc = ins_k_apply_bc_p_fields(G, e->sigma, D * (D + 1) / 2, s))) return rc;  // apply_bc_p!(σ, 0, setup)   operators.jl:1302
@@ -178,6 +185,10 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
         for (int m = 0; m < i; ++m) {
           if (beta[m] == 0.0) continue;
           epi.c0m1 -= beta[m];
+          if (corr_in && m == i - 1) {  // V_{i-1} is this stage's stencil input: its uncorrected value is taken from registers
+            epi.self_in = beta[m];
+            continue;
+          }
           epi.coef[epi.n] = beta[m];
           epi.k[epi.n] = rk->ku[m];
           ++epi.n;
@@ -211,7 +222,8 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
         epi.gdir = td.gdir;
         epi.wout = td.dodissipation ? e->w : nullptr;
       }
-      if ((rc = ins_k_momentum_rk_fused(G, visc, in, rk->ku[i], epi, s))) return rc;
+      rc = corr_in ? ins_k_momentum_rk_fused_corr(G, visc, in, rk->ps->pI, rk->ku[i], epi, s) : ins_k_momentum_rk_fused(G, visc, in, rk->ku[i], epi, s);
+      if (rc) return rc;
       if (with_temp) {
         double coefs[INS_MAX_STAGES];
         const double* ks[INS_MAX_STAGES];
@@ -224,10 +236,14 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
         bool later = false;
         for (int i2 = i + 1; i2 < ns; ++i2) later = later || rk->A[i2 * ns + i] != 0.0;
         if ((rc = ins_k_temp_stage(G, td.a4, td.diss_coef, in, tin, td.dodissipation ? e->w : nullptr, e->tempstart, n, coefs, ks, dt * rk->A[i * ns + i],
-                                   later ? e->ktemp[i] : nullptr, tout, s)))
+                                   later ? e->ktemp[i] : nullptr, tout, s, corr_in ? rk->ps->pI : nullptr)))
           return rc;
       }
-      if ((rc = ins_k_project_periodic_fused(G, rk->ps, out, rk->p, i == ns - 1, s, corrected == out ? nullptr : corrected))) return rc;
+      if (incorr && i < ns - 1)
+        rc = ins_k_project_periodic_solve_only(G, rk->ps, out, s);
+      else
+        rc = ins_k_project_periodic_fused(G, rk->ps, out, rk->p, i == ns - 1, s, corrected == out ? nullptr : corrected);
+      if (rc) return rc;
       if (with_temp && (rc = ins_apply_bc_temp_f64(G, td.bc, td.val, nullptr, tout, stream))) return rc;
       in = corrected;
       tin = tout;
