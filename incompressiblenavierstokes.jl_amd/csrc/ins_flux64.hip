@@ -54,6 +54,8 @@ struct FluxArgs {  // field pointers are T* of the kernel instantiation (RkEpi's
   int bar;  // one workgroup barrier per plane: the y-stacked wavefronts of a workgroup stay on the same plane (their shared halo rows are then cache hits)
   Dir X, Y, Z;
   RkEpi epi;
+  int tm;      // temperature stage inside the kernel (EXTRA instantiation, CORR = 0)
+  TempEpi te;
 };
 
 // 4 × face flux:  4ν(up - uc)/Δb - (uc + up)(ub0 + ub1)        [ν(up - uc)/Δb - ½(uc + up)·½(ub0 + ub1), times 4]
@@ -68,6 +70,15 @@ struct Plane {
   T v[3][R + 2];
   T h[3];  // packed halo columns: lane r = row r of column x0-1, lane 16+r = row r of column x0+64
   T raw[3][R];  // CORR: the output rows before the pressure correction (a term of the stage-velocity basis, ins_rk.hip)
+};
+
+// temperature rows of a register plane (EXTRA, a.tm): T rides along as a fourth component; vm1 = the y-component at the row BELOW the halo
+// row (the Laplacian of v at the halo row needs it: dissipation! reads u·diffusion(u) of the volume below)
+template <typename T, int R>
+struct TExt {
+  T t[R + 2];
+  T th;  // packed halo columns of T
+  T vm1;
 };
 
 // NW wavefronts per workgroup: XW side by side in x, NW/XW stacked in y.  CORR as in ins_fast3d_flux.hip: 0 = `u` has valid ghost volumes;
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
   {
     const int r = lane & 7, grp = (lane >> 3) & 3;
     const int ru = r <= R + 1 ? r : 0;
-    const int colu = (grp == 2) ? pcol_of(x0 + 64) : pcol_of(x0 - 1);
+    const int colu = (grp == 2) ? pcol_of(x0 + 64) : ((EXTRA && grp == 1) ? pcol_of(x0 - 2) : pcol_of(x0 - 1));  // EXTRA: lanes 8..15 hold column x0-2
     uhoff = (unsigned)(prow_of(jb0 - 1 + ru) * N0 + colu) * EB;
     if (CORR) {
       const int rq = r <= R + 2 ? r : 0;
@@ -153,6 +164,15 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
       for (int rr = 0; rr < R + 2; ++rr) P.v[c][rr] = ldb<T>(rs, ucol, urow[rr]);
       P.h[c] = ldb<T>(rs, uhoff, 0);
     }
+  };
+  const unsigned urowm1 = (unsigned)(prow_of(jb0 - 2) * N0) * EB;
+  auto load_text = [&](TExt<T, R>& E, int kk) {
+    const long long po = (long long)uplane(kk) * sz;
+    const rsrc_t rt = plane_rsrc(static_cast<const T*>((const void*)a.te.temp) + po, ubytes);
+#pragma unroll
+    for (int rr = 0; rr < R + 2; ++rr) E.t[rr] = ldb<T>(rt, ucol, urow[rr]);
+    E.th = ldb<T>(rt, uhoff, 0);
+    E.vm1 = ldb<T>(plane_rsrc(a_u + po + a.sc, ubytes), ucol, urowm1);
   };
   auto load_p = [&](T (&P)[R + 3], T& PH, int kk) {
     const rsrc_t rs = plane_rsrc(a_pI + (long long)(CORR == 2 ? min(kk, N2) : wrapi(kk - 1, n2)) * n0 * n1, qbytes);
@@ -305,14 +325,37 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
   // One output plane.  C = plane k, Nx = plane k+1 (both complete, corrected).  As soon as a row of C has been consumed its
   // registers are re-loaded with the same row of plane `kload` (= k+2, the next plane this buffer has to hold), so the
   // prefetch of plane k+2 is in flight during the whole of plane k without a third register plane.
-  auto body = [&](Plane<T, R>& C, const Plane<T, R>& Nx, int k, int kload) {
+  // temperature stage (EXTRA, a.tm): state carried from plane to plane
+  T Tz[EXTRA ? R : 1];      // T of plane k-1 at the output rows
+  T wwprev[EXTRA ? R : 1];  // w·diffusion(w) of plane k-1 at the output rows (zero below the first plane: operators.jl:793-807 reads a ghost of `diff`)
+  T PzV0 = 0;               // v at the halo row of plane k-1
+  T hU_prev = 0;            // packed halo columns of u, plane k-1
+  auto body = [&](Plane<T, R>& C, const Plane<T, R>& Nx, TExt<T, R>& CT, const TExt<T, R>& NT, int k, int kload) {
     const T* nb = a_u + (long long)uplane(kload) * sz;
     const rsrc_t n0r = plane_rsrc(nb, ubytes), n1r = plane_rsrc(nb + a.sc, ubytes), n2r = plane_rsrc(nb + 2 * a.sc, ubytes);
     const T ch0 = C.h[0], ch1 = C.h[1], ch2 = C.h[2];
     T sacc[3][R];
     if (FUSE) epi_load(C, k, sacc);
+    const bool tm = EXTRA && a.tm;
+    const rsrc_t ntr = plane_rsrc(static_cast<const T*>((const void*)a.te.temp) + (long long)uplane(kload) * sz, ubytes);
+    T tacc[EXTRA ? R : 1];
+    const T cth = CT.th;
+    if constexpr (EXTRA) {
+      if (tm) {  // temp_out = tempstart + Σ_j coef_j ktemp_j + c_self ktemp_i: the loads fly during the flux arithmetic
+        const long long pk = (long long)k * sz;
+        const rsrc_t rs0 = plane_rsrc(static_cast<const T*>((const void*)a.te.tempstart) + pk, ubytes);
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) tacc[rr] = ldb<T>(rs0, ocol, orow[rr]);
+        for (int q = 0; q < a.te.n; ++q) {
+          const rsrc_t rq = plane_rsrc(static_cast<const T*>((const void*)a.te.k[q]) + pk, ubytes);
+#pragma unroll
+          for (int rr = 0; rr < R; ++rr) tacc[rr] += (T)a.te.coef[q] * ldb<T>(rq, ocol, orow[rr]);
+        }
+      }
+    }
     T fyu_o = 0, fyv_o = 0, fyw_o = 0;
     T Uo = 0, Vo = 0, Wo = 0;  // row rr - 1 of this plane (EXTRA: its registers already hold the next plane)
+    T To = 0, wv_o = 0;        // T and v·diffusion(v) of row rr - 1
 #pragma unroll
     for (int rr = 0; rr <= R; ++rr) {
       const T Uc = C.v[0][rr], Vc = C.v[1][rr], Wc = C.v[2][rr];
@@ -365,17 +408,47 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
         if constexpr (EXTRA) {
           // w_α = u_α · diffusion(u)_α at this volume (dissipation!, operators.jl:791-797): the seven-point Laplacian from values already in
           // registers (x: wave shifts, y: the rows above / below, z: plane k+1 and the saved plane k-1)
-          if (a.epi.wout) {
+          if (a.epi.wout || tm) {
             const T Up = prev_h(Uc, sU), Vp = prev_h(Vc, sV), Wp = prev_h(Wc, sW);
             const T wu = Uc * ((Un + Up - 2 * Uc) * nux + (C.v[0][rr + 1] + Uo - 2 * Uc) * nuy + (Nx.v[0][rr] + Pz[0][rr - 1] - 2 * Uc) * nuz);
             const T wv = Vc * ((Vn + Vp - 2 * Vc) * nux + (C.v[1][rr + 1] + Vo - 2 * Vc) * nuy + (Nx.v[1][rr] + Pz[1][rr - 1] - 2 * Vc) * nuz);
             const T ww = Wc * ((Wn + Wp - 2 * Wc) * nux + (C.v[2][rr + 1] + Wo - 2 * Wc) * nuy + (Nx.v[2][rr] + Pz[2][rr - 1] - 2 * Wc) * nuz);
             const int j = jb0 + rr - 1;
-            if (xout && j < n1) {
+            if (a.epi.wout && xout && j < n1) {
               T* w = static_cast<T*>((void*)a.epi.wout) + (long long)k * sz;
               stb(plane_rsrc(w, ubytes), ocol, orow[rr - 1], wu);
               stb(plane_rsrc(w + a.sc, ubytes), ocol, orow[rr - 1], wv);
               stb(plane_rsrc(w + 2 * a.sc, ubytes), ocol, orow[rr - 1], ww);
+            }
+            if (tm) {
+              // ---- temperature stage at this volume.  Lower-face terms of dissipation!: the left neighbour's w_x by a wave shift — lane 0
+              // takes it from the halo column x0-1, whose Laplacian is formed from wave-uniform values (columns x0-2, x0-1 of the packed
+              // halo, lane 0's own column, the halo columns of planes k±1) —, the row below from the previous iteration, the plane below
+              // from the previous plane; all of them zero below the first volume of a direction (a ghost volume of `diff`).
+              T wuL = 0;
+              if (x0 > 0) {
+                const T U0 = rdlane(Uc, 0), Um2 = rdlane(ch0, 8 + rr), sUd = rdlane(ch0, rr - 1), sUp = rdlane(hU_prev, rr);
+                wuL = sU * ((U0 + Um2 - 2 * sU) * nux + (sUu + sUd - 2 * sU) * nuy + (sUn + sUp - 2 * sU) * nuz);
+              }
+              const T dc = (T)a.te.dcoef;
+              const T dd = dc * (prev_h(wu, wuL) + wu) / 2 + dc * (wv_o + wv) / 2 + dc * (wwprev[rr - 1] + ww) / 2;
+              // convection_diffusion_temp! (operators.jl:723-737) on the uniform grid: avg = mean, Δ = Δu
+              const T Tc = CT.t[rr];
+              const T Txp = next_h(Tc, rdlane(cth, 16 + rr)), Txm = prev_h(Tc, rdlane(cth, rr));
+              const T Typ = CT.t[rr + 1], Tym = To, Tzp = NT.t[rr], Tzm = Tz[rr - 1];
+              const T a4 = (T)a.te.a4;
+              T cd = (-(Uc * ((Tc + Txp) / 2) - Up * ((Txm + Tc) / 2)) + a4 * ((Txp - Tc) * X.gs - (Tc - Txm) * X.gs)) * X.gs;
+              cd += (-(Vc * ((Tc + Typ) / 2) - Vo * ((Tym + Tc) / 2)) + a4 * ((Typ - Tc) * Y.gs - (Tc - Tym) * Y.gs)) * Y.gs;
+              cd += (-(Wc * ((Tc + Tzp) / 2) - Pz[2][rr - 1] * ((Tzm + Tc) / 2)) + a4 * ((Tzp - Tc) * Z.gs - (Tc - Tzm) * Z.gs)) * Z.gs;
+              const T kt = cd + dd;
+              if (xout && j < n1) {
+                const long long pk = (long long)k * sz;
+                if (a.te.ktemp_out) stb(plane_rsrc(static_cast<T*>((void*)a.te.ktemp_out) + pk, ubytes), ocol, orow[rr - 1], kt);
+                stb(plane_rsrc(static_cast<T*>((void*)a.te.temp_out) + pk, ubytes), ocol, orow[rr - 1], tacc[rr - 1] + (T)a.te.c_self * kt);
+              }
+              wv_o = wv;
+              wwprev[rr - 1] = ww;
+              Tz[rr - 1] = Tc;
             }
           }
           Pz[0][rr - 1] = Uc;
@@ -388,6 +461,15 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
       fyv_o = fyv;
       fyw_o = fyw;
       if constexpr (EXTRA) {
+        if (tm) {
+          if (rr == 0) {  // v·diffusion(v) at the halo row (the row below the first output row; a ghost row of `diff` when it is row -1 of the box)
+            const T Vp = prev_h(Vc, rdlane(ch1, 0));
+            wv_o = jb0 > 0 ? Vc * ((Vn + Vp - 2 * Vc) * nux + (C.v[1][1] + CT.vm1 - 2 * Vc) * nuy + (Nx.v[1][0] + PzV0 - 2 * Vc) * nuz) : (T)0;
+            PzV0 = Vc;
+          }
+          To = CT.t[rr];
+          CT.t[rr] = ldb<T>(ntr, ucol, urow[rr]);
+        }
         Uo = Uc;
         Vo = Vc;
         Wo = Wc;
@@ -403,10 +485,19 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
     C.h[0] = ldb<T>(n0r, uhoff, 0);
     C.h[1] = ldb<T>(n1r, uhoff, 0);
     C.h[2] = ldb<T>(n2r, uhoff, 0);
+    if constexpr (EXTRA) {
+      if (tm) {
+        hU_prev = ch0;
+        CT.t[R + 1] = ldb<T>(ntr, ucol, urow[R + 1]);
+        CT.th = ldb<T>(ntr, uhoff, 0);
+        CT.vm1 = ldb<T>(n1r, ucol, urowm1);
+      }
+    }
   };
 
   // Two register planes.  Loads past the chunk re-read plane k1 / p(k1+1) (cache hits) instead of branching.
   Plane<T, R> P0, P1;
+  TExt<T, R> TE0, TE1;
   if (!CORR) {
     load_plane(P0, k0 - 1);
     load_plane(P1, k0);
@@ -416,15 +507,33 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
       for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) Pz[c][rr] = P0.v[c][rr + 1];
+      if (a.tm) {
+        load_text(TE0, k0 - 1);
+        load_text(TE1, k0);
+        PzV0 = P0.v[1][0];
+        hU_prev = P0.h[0];
+        // w·diffusion(w) of plane k0-1 (zero when that is the ghost plane): its z-neighbour below, plane k0-2, is read here once per chunk
+        const rsrc_t rw = plane_rsrc(a_u + (long long)uplane(max(k0 - 2, 0)) * sz + 2 * a.sc, ubytes);
+#pragma unroll
+        for (int rr = 1; rr <= R; ++rr) {
+          const T Wc = P0.v[2][rr], Wm2 = ldb<T>(rw, ucol, urow[rr]);
+          const T Wn = next_h(Wc, rdlane(P0.h[2], 16 + rr)), Wp = prev_h(Wc, rdlane(P0.h[2], rr));
+          wwprev[rr - 1] = k0 > 1 ? Wc * ((Wn + Wp - 2 * Wc) * nux + (P0.v[2][rr + 1] + P0.v[2][rr - 1] - 2 * Wc) * nuy + (P1.v[2][rr] + Wm2 - 2 * Wc) * nuz) : (T)0;
+          Tz[rr - 1] = TE0.t[rr];
+        }
+      }
     }
     load_plane(P0, min(k0 + 1, k1));
+    if constexpr (EXTRA) {
+      if (a.tm) load_text(TE0, min(k0 + 1, k1));
+    }
     int k = k0;
     while (true) {
       if (a.bar) __builtin_amdgcn_s_barrier();
-      body(P1, P0, k, min(k + 2, k1));
+      body(P1, P0, TE1, TE0, k, min(k + 2, k1));
       if (++k >= k1) break;
       if (a.bar) __builtin_amdgcn_s_barrier();
-      body(P0, P1, k, min(k + 2, k1));
+      body(P0, P1, TE0, TE1, k, min(k + 2, k1));
       if (++k >= k1) break;
     }
   } else {
@@ -451,12 +560,12 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
       if (a.bar) __builtin_amdgcn_s_barrier();
       correct(P0, Pa, Ha, Pb, Hb);  // plane k+1 with p(k+1), p(k+2)
       load_p(Pa, Ha, min(k + 3, k1 + 1));
-      body(P1, P0, k, min(k + 2, k1));
+      body(P1, P0, TE1, TE0, k, min(k + 2, k1));
       if (++k >= k1) break;
       if (a.bar) __builtin_amdgcn_s_barrier();
       correct(P1, Pb, Hb, Pa, Ha);
       load_p(Pb, Hb, min(k + 3, k1 + 1));
-      body(P0, P1, k, min(k + 2, k1));
+      body(P0, P1, TE0, TE1, k, min(k + 2, k1));
       if (++k >= k1) break;
     }
   }
@@ -496,7 +605,11 @@ int launch_range(const ins_grid* G, FluxArgs& a, int corr_mode, hipStream_t s) {
       return INS_OK;
     }
   }
-  if (a.epi.extra || a.epi.gtemp || a.epi.wout) {
+  if (a.tm && corr_mode != 0) {
+    ins_set_error("temperature stage inside the stage kernel: no in-kernel pressure correction");
+    return INS_ERR_UNSUPPORTED;
+  }
+  if (a.epi.extra || a.epi.gtemp || a.epi.wout || a.tm) {
     if constexpr (FUSE && R == 2 && NW == 4 && sizeof(T) == 8) {
       if (corr_mode == 0) {
         hipLaunchKernelGGL((k_flux64<T, R, XW, true, 0, false, NW, true>), dim3(nb), block, (size_t)g_lds, s, a);
@@ -592,6 +705,11 @@ static int flux64_dispatch(const ins_grid* G, double visc, const T* u, T* F, con
   a.Y = make_dir(G, 1, visc);
   a.Z = make_dir(G, 2, visc);
   if (epi) a.epi = *epi;
+  if (epi && epi->tstage) {
+    a.te = *epi->tstage;
+    a.tm = 1;
+    a.epi.tstage = nullptr;
+  }
   const int waves_x = cdiv(g.N[0] - 2, 64);
   // wavefronts side by side: 4 for 256-wide rows (2.85 vs 2.90 ms/step with 2), 2 for 512-wide ones (23.7 vs 24.3 ms/step)
   const int xwo = (corr_mode && ins_opt(OPT_INS_FLUX64_XW_CORR)) ? (int)ins_opt(OPT_INS_FLUX64_XW_CORR) : g_xw;
@@ -633,7 +751,7 @@ static int flux64_dispatch(const ins_grid* G, double visc, const T* u, T* F, con
     zc = n2 >= 256 && small_plane ? 64 : (n2 >= 128 ? 32 : (n2 >= 64 ? 16 : (n2 >= 32 ? 8 : 4)));
   }
   if (rows != 2 && nw == 16) nw = 8;
-  if (epi && (epi->extra || epi->gtemp || epi->wout)) {  // one instantiation serves the extended stage loop
+  if (epi && (epi->extra || epi->gtemp || epi->wout || epi->tstage)) {  // one instantiation serves the extended stage loop
     rows = 2;
     nw = 4;
     if (!zco) zc = n2 >= 128 ? 32 : (n2 >= 64 ? 16 : (n2 >= 32 ? 8 : 4));

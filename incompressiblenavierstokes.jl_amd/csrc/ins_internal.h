@@ -95,6 +95,7 @@ void ins_set_error(const char* fmt, ...);
   X(INS_DISABLE_INKERNEL_CORR)   \
   X(INS_RK_KEEP_K)               \
   X(INS_DISABLE_EXT_FUSED)       \
+  X(INS_EXT_TEMP_SPLIT)          \
   X(INS_DISABLE_FUSED_RK)        \
   X(INS_DISABLE_STEP_CHAIN)      \
   X(INS_ZSOLVE_SKEL)             \
@@ -256,6 +257,20 @@ struct RkEpi {
   double ga2;
   int gdir;
   double* wout;             // optional: w_α = u_α · diffusion(u)_α of the stencil input is stored here (dissipation!, ins_rk_ext.hip)
+  const struct TempEpi* tstage;  // optional (HOST pointer, read at launch): the temperature equation's stage inside the stage kernel
+};
+
+// One stage of the temperature equation carried by the 64-wide stage kernel (ins_flux64.hip, EXTRA; step_explicit_runge_kutta.jl:23-27, 39-44):
+//   ktemp_i = convection_diffusion_temp(u, temp) + dissipation(u),   temp_out = tempstart + Σ_j coef_j k_j + c_self ktemp_i
+struct TempEpi {
+  const double* temp;       // T_i, padded, ghost volumes valid
+  const double* tempstart;
+  double* temp_out;         // T_{i+1}: another array than temp
+  double* ktemp_out;        // nullable
+  int n;
+  double coef[INS_MAX_STAGES];
+  const double* k[INS_MAX_STAGES];
+  double c_self, a4, dcoef;  // Δt A[i,i];  α4;  Re·α1/γ (0: no dissipation term)
 };
 
 

@@ -159,7 +159,11 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
     // Without a closure every consumer of the stage velocity can correct it on the fly (the stage kernel as on the plain path, the temperature
     // kernel for its two face velocities), so the gradient-subtract pass runs for the last stage only; the closure kernels need the corrected
     // field with its ghost volumes in memory.
-    const bool incorr = vbasis && !closure && !ins_opt(OPT_INS_DISABLE_INKERNEL_CORR) && g.N[0] >= 8 && g.N[1] >= 8 && g.N[2] >= 8;
+    // The temperature stage itself rides inside the stage kernel (TempEpi: T as a fourth register component, the lower-face dissipation terms
+    // from the halo column / halo row / previous plane); INS_EXT_TEMP_SPLIT=1 keeps it as a kernel of its own (then without a closure the
+    // gradient-subtract passes between the stages can go, see above).
+    const bool tin_kernel = with_temp && !ins_opt(OPT_INS_EXT_TEMP_SPLIT);
+    const bool incorr = vbasis && !closure && !tin_kernel && !ins_opt(OPT_INS_DISABLE_INKERNEL_CORR) && g.N[0] >= 8 && g.N[1] >= 8 && g.N[2] >= 8;
     const double* in = u;
     const double* tin = temp;
     for (int i = 0; i < ns; ++i) {
@@ -216,15 +220,37 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
       epi.ustart = (i == 0) ? nullptr : u;
       epi.ustar = out;
       epi.extra = closure ? e->E : nullptr;
+      TempEpi te;
       if (with_temp) {
         epi.gtemp = tin;
         epi.ga2 = td.a2;
         epi.gdir = td.gdir;
-        epi.wout = td.dodissipation ? e->w : nullptr;
+        if (tin_kernel) {
+          memset(&te, 0, sizeof(te));
+          te.temp = tin;
+          te.tempstart = e->tempstart;
+          te.temp_out = tout;
+          bool later = false;
+          for (int i2 = i + 1; i2 < ns; ++i2) later = later || rk->A[i2 * ns + i] != 0.0;
+          te.ktemp_out = later ? e->ktemp[i] : nullptr;
+          for (int j = 0; j < i; ++j) {
+            const double c = dt * rk->A[i * ns + j];
+            if (c == 0.0) continue;
+            te.coef[te.n] = c;
+            te.k[te.n] = e->ktemp[j];
+            ++te.n;
+          }
+          te.c_self = dt * rk->A[i * ns + i];
+          te.a4 = td.a4;
+          te.dcoef = td.dodissipation ? td.diss_coef : 0.0;
+          epi.tstage = &te;
+        } else {
+          epi.wout = td.dodissipation ? e->w : nullptr;
+        }
       }
       rc = corr_in ? ins_k_momentum_rk_fused_corr(G, visc, in, rk->ps->pI, rk->ku[i], epi, s) : ins_k_momentum_rk_fused(G, visc, in, rk->ku[i], epi, s);
       if (rc) return rc;
-      if (with_temp) {
+      if (with_temp && !tin_kernel) {
         double coefs[INS_MAX_STAGES];
         const double* ks[INS_MAX_STAGES];
         int n = 0;

@@ -210,7 +210,7 @@ def test_steppers_with_closure_model_match_oracle(ins, oracle, geom, method):
 @pytest.mark.parametrize("method", ["RK44", "Wray3"])
 def test_fused_extended_stage_loop_matches_oracle(ins, oracle, n, what, gdir, diss, method):
     """The native stage loop with the temperature equation and / or the Smagorinsky closure on boxes that take its fused path
-    (csrc/ins_rk_ext.hip: gravity and w = u · diffusion(u) inside the 64-wide stage kernel, one temperature kernel per stage), against the
+    (csrc/ins_rk_ext.hip: gravity and the whole temperature stage inside the 64-wide stage kernel), against the
     oracle's operator-by-operator loop; the same runs with INS_DISABLE_EXT_FUSED (the reference's kernel sequence) agree to rounding."""
     import ctypes
 
@@ -218,7 +218,7 @@ def test_fused_extended_stage_loop_matches_oracle(ins, oracle, n, what, gdir, di
 
     o = oracle
 
-    def run(fused):
+    def run(fused, **opts):
         so = fx.setup_periodic(o, n, D=3)
         if what in ("temp", "both"):
             T = o.temperature_equation(Pr=0.71, Ra=1e6, Ge=0.1, boundary_conditions=temp_bcs(o, so, "any"), gdir=gdir, dodissipation=diss)
@@ -245,7 +245,7 @@ def test_fused_extended_stage_loop_matches_oracle(ins, oracle, n, what, gdir, di
         lib = _lib.load()
         lib.ins_dbg_ext_fused_steps.restype = ctypes.c_longlong
         before = lib.ins_dbg_ext_fused_steps()
-        with _lib.options(INS_DISABLE_EXT_FUSED=0 if fused else 1):
+        with _lib.options(INS_DISABLE_EXT_FUSED=0 if fused else 1, **opts):
             (u_d, t_d, _), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 6e-3), ustart=ins.from_numpy(sp, u0), tempstart=None if th is None else ins.from_numpy(sp, th),
                                                   method=md, psolver=ps_d, Δt=2e-3, θ=theta)
         assert lib.ins_dbg_ext_fused_steps() - before == (3 if fused else 0)
@@ -257,6 +257,9 @@ def test_fused_extended_stage_loop_matches_oracle(ins, oracle, n, what, gdir, di
         assert rell2(temp, st["temp"]) < STEP_TOL
     _, u2, temp2 = run(False)
     assert rell2(u2, u) < 1e-12 and (temp is None or rell2(temp2, temp) < 1e-12)
+    if temp is not None:  # the temperature stage as a kernel of its own (and, without a closure, no gradient-subtract pass between the stages)
+        _, u3, temp3 = run(True, INS_EXT_TEMP_SPLIT=1)
+        assert rell2(u3, u) < 1e-12 and rell2(temp3, temp) < 1e-12
 
 
 @pytest.mark.parametrize("geom", ["periodic2d", "periodic3d", "periodic3d_wide"])
