@@ -51,6 +51,7 @@ struct FluxArgs {  // field pointers are T* of the kernel instantiation (RkEpi's
   // plane range of this launch: chunk t covers [k_lo + t zc, min(.. + zc, k_hi)); kB > 0: two chunks, [k_lo, k_lo + zc) and [kB, kB + zc)
   // (the host runs the planes that read no ghost plane beside the halo exchange, then the two thin boundary ranges)
   int k_lo, k_hi, kB;
+  int nt;   // cache-policy experiment on the result stores (INS_FLUX64_NT)
   int bar;  // one workgroup barrier per plane: the y-stacked wavefronts of a workgroup stay on the same plane (their shared halo rows are then cache hits)
   Dir X, Y, Z;
   RkEpi epi;
@@ -285,6 +286,27 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
     }
   };
   // second half: u* = s + coef_self f, and k_i = f when a later stage needs it
+  // the three components of one result (INS_FLUX64_NT: cache-policy bits on these stores, an experiment)
+  auto st3 = [&](T* o, unsigned co, unsigned rowb, T v0, T v1, T v2) {
+    const rsrc_t r0 = plane_rsrc(o, ubytes), r1 = plane_rsrc(o + a.sc, ubytes), r2 = plane_rsrc(o + 2 * a.sc, ubytes);
+    if (a.nt == 0) {
+      stb(r0, co, rowb, v0);
+      stb(r1, co, rowb, v1);
+      stb(r2, co, rowb, v2);
+    } else if (a.nt == 1) {
+      stb_aux<2>(r0, co, rowb, v0);
+      stb_aux<2>(r1, co, rowb, v1);
+      stb_aux<2>(r2, co, rowb, v2);
+    } else if (a.nt == 2) {
+      stb_aux<17>(r0, co, rowb, v0);
+      stb_aux<17>(r1, co, rowb, v1);
+      stb_aux<17>(r2, co, rowb, v2);
+    } else {
+      stb_aux<19>(r0, co, rowb, v0);
+      stb_aux<19>(r1, co, rowb, v1);
+      stb_aux<19>(r2, co, rowb, v2);
+    }
+  };
   auto emit = [&](int rr, int k, T fu, T fv, T fw, T s0, T s1, T s2) {
     const long long pk = (long long)k * sz;
     if constexpr (EXTRA) {
@@ -309,16 +331,9 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
           stb(plane_rsrc(w + 2 * a.sc, ubytes), co, rowb, s2);
         }
         T* o = static_cast<T*>((void*)a.epi.ustar) + pk;
-        stb(plane_rsrc(o, ubytes), co, rowb, s0 + (T)a.epi.coef_self * fu);
-        stb(plane_rsrc(o + a.sc, ubytes), co, rowb, s1 + (T)a.epi.coef_self * fv);
-        stb(plane_rsrc(o + 2 * a.sc, ubytes), co, rowb, s2 + (T)a.epi.coef_self * fw);
+        st3(o, co, rowb, s0 + (T)a.epi.coef_self * fu, s1 + (T)a.epi.coef_self * fv, s2 + (T)a.epi.coef_self * fw);
       }
-      if (!FUSE || a.epi.write_k) {
-        T* o = a_F + pk;
-        stb(plane_rsrc(o, ubytes), co, rowb, fu);
-        stb(plane_rsrc(o + a.sc, ubytes), co, rowb, fv);
-        stb(plane_rsrc(o + 2 * a.sc, ubytes), co, rowb, fw);
-      }
+      if (!FUSE || a.epi.write_k) st3(a_F + pk, co, rowb, fu, fv, fw);
     }
   };
 
@@ -758,6 +773,7 @@ static int flux64_dispatch(const ins_grid* G, double visc, const T* u, T* F, con
   }
   a.zc = zc;
   a.bar = ins_opt(OPT_INS_FLUX64_NOBAR) ? 0 : 1;
+  a.nt = (int)ins_opt(OPT_INS_FLUX64_NT);
 #define INS_F64_CASE(RR, FUSE)                                                        \
   if constexpr (!F32 || RR == 2 || RR == 4) {                                         \
     if (rows == RR) {                                                                 \

@@ -83,6 +83,7 @@ void ins_set_error(const char* fmt, ...);
   X(INS_FLUX64_LDS)              \
   X(INS_FLUX64_SKEL)             \
   X(INS_FLUX64_NW)               \
+  X(INS_FLUX64_NT)               \
   X(INS_FLUX64_NOBAR)            \
   X(INS_FLUX64_MINTILES)         \
   X(INS_FLUX64_XW_CORR)          \

@@ -209,93 +209,145 @@ __global__ __launch_bounds__(256) void k_unpack_grad_bc(GridDev g, double* __res
   }
 }
 
-// The same pass for a 3-D solution kept FOLDED along x and / or y (z unfolded): a work-item owns the 2 or 4 mirror images of its volume,
-// so each folded value is read once for all of them (the kernel above gathers 2^k values per pressure it needs: 16 per volume with the
-// gradient).  Neighbours: six such reads — (i±1, j), (i, j±1), (i, j, k+1) — serve all images (the +x neighbour of the image n0-1-i is
-// the image of i-1).  Ghost pressures are written by the owner of the adjacent interior volume, composed over the directions as map_p does.
+// The same pass for a 3-D solution kept FOLDED along any subset of its directions: a work-item owns the 2, 4 or 8 mirror images of its volume,
+// so each folded value is read once for all of them (the kernel above gathers 2^k values per pressure it needs: 32 per volume with the
+// gradient when all three directions are folded).  Neighbours: six more such reads — (i±1, j, k), (i, j±1, k), (i, j, k±1) — serve all
+// images (the +x neighbour of the image n0-1-i is the image of i-1).  Ghost pressures are written by the owner of the adjacent interior
+// volume, composed over the directions as map_p does.
+struct UnfoldQ {
+  double v[2][2][2];  // [image in z][image in y][image in x]
+};
 template <bool GRAD>
 __global__ __launch_bounds__(256) void k_unfold_grad3(GridDev g, double* __restrict__ u, double* __restrict__ p, const double* __restrict__ pI,
                                                       int n0, int n1, int n2, const double* __restrict__ shift, int fmask) {
-  const bool fx = fmask & 1, fy = fmask & 2;
-  const int h0 = fx ? n0 / 2 : n0, h1 = fy ? n1 / 2 : n1;
-  const int ii = blockIdx.x * 64 + threadIdx.x, jj = blockIdx.y * 4 + threadIdx.y, kk = (int)blockIdx.z;
-  if (ii >= h0 || jj >= h1) return;
+  const bool f[3] = {(fmask & 1) != 0, (fmask & 2) != 0, (fmask & 4) != 0};
+  const int n[3] = {n0, n1, n2};
+  const int h[3] = {f[0] ? n0 / 2 : n0, f[1] ? n1 / 2 : n1, f[2] ? n2 / 2 : n2};
+  const int id[3] = {(int)(blockIdx.x * 64 + threadIdx.x), (int)(blockIdx.y * 4 + threadIdx.y), (int)blockIdx.z};
+  if (id[0] >= h[0] || id[1] >= h[1]) return;
   const double sh = shift ? *shift : 0.0;
   const long long s1 = n0, s2 = (long long)n0 * n1;
-  struct Q {
-    double v[2][2];  // [image in y][image in x]
-  };
+  const long long hs[3] = {h[0], s1 * h[1], s2 * h[2]};  // offset of the odd half along each direction
   auto fetch = [&](int i, int j, int k) {
     const double* b = pI + i + s1 * j + s2 * k;
-    const double a = b[0], bx = fx ? b[h0] : 0.0, cy = fy ? b[s1 * h1] : 0.0, d = (fx && fy) ? b[h0 + s1 * h1] : 0.0;
-    Q q;  // the summation order of unfold_at
-    q.v[0][0] = ((a + bx) + cy) + d - sh;
-    q.v[0][1] = ((a - bx) + cy) - d - sh;
-    q.v[1][0] = ((a + bx) - cy) - d - sh;
-    q.v[1][1] = ((a - bx) - cy) + d - sh;
+    double a[2][2][2];
+#pragma unroll
+    for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+      for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) {
+          const bool have = (!cx || f[0]) && (!cy || f[1]) && (!cz || f[2]);
+          a[cz][cy][cx] = have ? b[(cx ? hs[0] : 0) + (cy ? hs[1] : 0) + (cz ? hs[2] : 0)] : 0.0;
+        }
+    UnfoldQ q;  // the summation order of unfold_at: odd-half terms that do not exist are exact zeros
+#pragma unroll
+    for (int mz = 0; mz < 2; ++mz)
+#pragma unroll
+      for (int my = 0; my < 2; ++my)
+#pragma unroll
+        for (int mx = 0; mx < 2; ++mx) {
+          double acc = 0.0;
+#pragma unroll
+          for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+            for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+              for (int cx = 0; cx < 2; ++cx) {
+                const bool neg = ((mx & cx) ^ (my & cy) ^ (mz & cz)) != 0;
+                acc += neg ? -a[cz][cy][cx] : a[cz][cy][cx];
+              }
+          q.v[mz][my][mx] = acc - sh;
+        }
     return q;
   };
-  const Q c = fetch(ii, jj, kk);
-  Q xp = c, xm = c, yp = c, ym = c, zp = c;
-  const bool perx = g.bc[0][0] == INS_BC_PERIODIC, pery = g.bc[1][0] == INS_BC_PERIODIC, perz = g.bc[2][0] == INS_BC_PERIODIC;
+  const UnfoldQ c = fetch(id[0], id[1], id[2]);
+  UnfoldQ P[3] = {c, c, c}, M[3] = {c, c, c};  // the neighbours at index + 1 / index - 1 along each direction
+  bool per[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) per[a] = g.bc[a][0] == INS_BC_PERIODIC;
   if (GRAD) {
-    if (ii + 1 < h0 || (!fx && perx)) xp = fetch(ii + 1 < h0 ? ii + 1 : 0, jj, kk);  // unfolded periodic direction: the image of the first volume
-    if (fx && ii >= 1) xm = fetch(ii - 1, jj, kk);
-    if (jj + 1 < h1 || (!fy && pery)) yp = fetch(ii, jj + 1 < h1 ? jj + 1 : 0, kk);
-    if (fy && jj >= 1) ym = fetch(ii, jj - 1, kk);
-    if (kk + 1 < n2 || perz) zp = fetch(ii, jj, kk + 1 < n2 ? kk + 1 : 0);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      int q[3] = {id[0], id[1], id[2]};
+      if (id[a] + 1 < h[a] || (!f[a] && per[a])) {  // unfolded periodic direction: past the last volume comes the first
+        q[a] = id[a] + 1 < h[a] ? id[a] + 1 : 0;
+        P[a] = fetch(q[0], q[1], q[2]);
+      }
+      if (f[a] && id[a] >= 1) {
+        q[a] = id[a] - 1;
+        M[a] = fetch(q[0], q[1], q[2]);
+      }
+    }
   }
   // (no side is a PressureBC here — the host routes those grids to the kernel above —, so a pressure just outside the box is the copy of the
   // adjacent interior value behind a Symmetric side and is read by no DOF behind a Dirichlet one)
 #pragma unroll
-  for (int my = 0; my < 2; ++my) {
-    if (my && !fy) break;
+  for (int mz = 0; mz < 2; ++mz) {
+    if (mz && !f[2]) break;
 #pragma unroll
-    for (int mx = 0; mx < 2; ++mx) {
-      if (mx && !fx) break;
-      const int w[3] = {mx ? n0 - 1 - ii : ii, my ? n1 - 1 - jj : jj, kk};
-      const int n[3] = {n0, n1, n2};
-      const int I[3] = {g.ip_lo[0] + w[0], g.ip_lo[1] + w[1], g.ip_lo[2] + w[2]};
-      const double pc = c.v[my][mx];
-      // ---- p: the volume itself and every ghost volume that takes its value (or zero) from it
-      int tgt[3][3], nt[3];
+    for (int my = 0; my < 2; ++my) {
+      if (my && !f[1]) break;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        nt[a] = 1;
-        tgt[a][0] = I[a];
-        if (w[a] == 0) {
-          if (g.bc[a][1] == INS_BC_PERIODIC) tgt[a][nt[a]++] = g.ip_hi[a];
-          if (g.bc[a][0] == INS_BC_SYMMETRIC) tgt[a][nt[a]++] = g.ip_lo[a] - 1;
+      for (int mx = 0; mx < 2; ++mx) {
+        if (mx && !f[0]) break;
+        const int m[3] = {mx, my, mz};
+        int w[3], I[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          w[a] = m[a] ? n[a] - 1 - id[a] : id[a];
+          I[a] = g.ip_lo[a] + w[a];
         }
-        if (w[a] == n[a] - 1 && nt[a] < 3) {
-          if (g.bc[a][0] == INS_BC_PERIODIC) tgt[a][nt[a]++] = g.ip_lo[a] - 1;
-          if (g.bc[a][1] == INS_BC_SYMMETRIC) tgt[a][nt[a]++] = g.ip_hi[a];
+        const double pc = c.v[mz][my][mx];
+        // ---- p: the volume itself and every ghost volume that takes its value from it
+        int tgt[3][3], nt[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          nt[a] = 1;
+          tgt[a][0] = I[a];
+          if (w[a] == 0) {
+            if (g.bc[a][1] == INS_BC_PERIODIC) tgt[a][nt[a]++] = g.ip_hi[a];
+            if (g.bc[a][0] == INS_BC_SYMMETRIC) tgt[a][nt[a]++] = g.ip_lo[a] - 1;
+          }
+          if (w[a] == n[a] - 1 && nt[a] < 3) {
+            if (g.bc[a][0] == INS_BC_PERIODIC) tgt[a][nt[a]++] = g.ip_lo[a] - 1;
+            if (g.bc[a][1] == INS_BC_SYMMETRIC) tgt[a][nt[a]++] = g.ip_hi[a];
+          }
         }
-      }
-      for (int t2 = 0; t2 < nt[2]; ++t2)
-        for (int t1 = 0; t1 < nt[1]; ++t1)
-          for (int t0 = 0; t0 < nt[0]; ++t0) p[tgt[0][t0] + tgt[1][t1] * g.sx[1] + tgt[2][t2] * g.sx[2]] = pc;
-      if (!GRAD) continue;
-      // ---- u -= ∇p on the degrees of freedom of this volume
-      double pn[3];
-      // (past the last volume of a direction: the first volume's value when it is periodic — folded: image 0 of this work-item's own
-      // values —, the copy pc behind a Symmetric side, unread behind a Dirichlet one)
-      if (mx == 0)
-        pn[0] = ii + 1 < h0 ? xp.v[my][0] : (fx ? c.v[my][1] : (perx ? xp.v[my][0] : pc));
-      else
-        pn[0] = ii >= 1 ? xm.v[my][1] : (perx ? c.v[my][0] : pc);
-      if (my == 0)
-        pn[1] = jj + 1 < h1 ? yp.v[0][mx] : (fy ? c.v[1][mx] : (pery ? yp.v[0][mx] : pc));
-      else
-        pn[1] = jj >= 1 ? ym.v[1][mx] : (pery ? c.v[0][mx] : pc);
-      pn[2] = (kk + 1 < n2 || perz) ? zp.v[my][mx] : pc;
-      const long long cc = I[0] + I[1] * g.sx[1] + I[2] * g.sx[2];
+        for (int t2 = 0; t2 < nt[2]; ++t2)
+          for (int t1 = 0; t1 < nt[1]; ++t1)
+            for (int t0 = 0; t0 < nt[0]; ++t0) p[tgt[0][t0] + tgt[1][t1] * g.sx[1] + tgt[2][t2] * g.sx[2]] = pc;
+        if (!GRAD) continue;
+        // ---- u -= ∇p on the degrees of freedom of this volume.  The neighbour at coordinate + 1 along a: image 0 — the next index (or, past
+        // the middle of a folded direction, image 1 of this work-item's own values); image 1 — image 1 of the previous index; past the last
+        // volume: the first volume's value when the direction is periodic, the copy pc behind a Symmetric side, unread behind a Dirichlet one.
+        const long long cc = I[0] + I[1] * g.sx[1] + I[2] * g.sx[2];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        bool dof = true;
+        for (int a = 0; a < 3; ++a) {
+          int mm[3] = {mx, my, mz};
+          double pn;
+          if (m[a] == 0) {
+            if (id[a] + 1 < h[a]) {
+              pn = P[a].v[mm[2]][mm[1]][mm[0]];
+            } else if (f[a]) {
+              mm[a] = 1;
+              pn = c.v[mm[2]][mm[1]][mm[0]];
+            } else {
+              pn = per[a] ? P[a].v[mm[2]][mm[1]][mm[0]] : pc;
+            }
+          } else {
+            if (id[a] >= 1) {
+              pn = M[a].v[mm[2]][mm[1]][mm[0]];
+            } else {
+              mm[a] = 0;
+              pn = per[a] ? c.v[mm[2]][mm[1]][mm[0]] : pc;
+            }
+          }
+          bool dof = true;
 #pragma unroll
-        for (int b = 0; b < 3; ++b) dof = dof && I[b] >= g.iu_lo[a][b] && I[b] < g.iu_hi[a][b];
-        if (dof) u[a * g.sc + cc] -= (pn[a] - pc) * g.rdxu[a][I[a]];
+          for (int b = 0; b < 3; ++b) dof = dof && I[b] >= g.iu_lo[a][b] && I[b] < g.iu_hi[a][b];
+          if (dof) u[a * g.sc + cc] -= (pn - pc) * g.rdxu[a][I[a]];
+        }
       }
     }
   }
@@ -1276,8 +1328,8 @@ static int fdm_unpack(const ins_grid* G, ins_poisson* ps, double* u, double* p, 
   const int n0 = ps->np[0], n1 = ps->np[1], n2 = g.D == 3 ? ps->np[2] : 1;
   bool pressure_side = false;  // a PressureBC puts a DOF of u into the ghost layer: the general kernel covers it
   for (int a = 0; a < g.D; ++a) pressure_side = pressure_side || g.bc[a][0] == INS_BC_PRESSURE || g.bc[a][1] == INS_BC_PRESSURE;
-  if (g.D == 3 && fm && !(fm & 4) && !pressure_side && !((fm & 1) && (n0 & 1)) && !((fm & 2) && (n1 & 1)) && !ins_opt(OPT_INS_DISABLE_FDM_UNFOLD4)) {
-    const dim3 grid(cdiv((fm & 1) ? n0 / 2 : n0, 64), cdiv((fm & 2) ? n1 / 2 : n1, 4), n2);
+  if (g.D == 3 && fm && !pressure_side && !((fm & 1) && (n0 & 1)) && !((fm & 2) && (n1 & 1)) && !((fm & 4) && (n2 & 1)) && !ins_opt(OPT_INS_DISABLE_FDM_UNFOLD4)) {
+    const dim3 grid(cdiv((fm & 1) ? n0 / 2 : n0, 64), cdiv((fm & 2) ? n1 / 2 : n1, 4), (fm & 4) ? n2 / 2 : n2);
     if (u)
       hipLaunchKernelGGL(k_unfold_grad3<true>, grid, block, 0, s, g, u, p, buf, n0, n1, n2, ins_fdm_mean(ps->fdm), fm);
     else

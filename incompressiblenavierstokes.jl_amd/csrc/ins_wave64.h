@@ -51,6 +51,18 @@ __device__ __forceinline__ void stb(rsrc_t r, unsigned voff, unsigned soff, doub
   v.y = (unsigned)__double2hiint(x);
   __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
+// the same with the cache-policy bits of the instruction (aux: 1 = sc0, 2 = nt, 16 = sc1): an experiment switch (INS_FLUX64_NT)
+template <int AUX>
+__device__ __forceinline__ void stb_aux(rsrc_t r, unsigned voff, unsigned soff, double x) {
+  v2u v;
+  v.x = (unsigned)__double2loint(x);
+  v.y = (unsigned)__double2hiint(x);
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void stb_aux(rsrc_t r, unsigned voff, unsigned soff, float x) {
+  __builtin_amdgcn_raw_buffer_store_b32((unsigned)__float_as_int(x), r, voff, soff, AUX);
+}
 __device__ __forceinline__ void stb(rsrc_t r, unsigned voff, unsigned soff, float x) {
   __builtin_amdgcn_raw_buffer_store_b32((unsigned)__float_as_int(x), r, voff, soff, 0);
 }
