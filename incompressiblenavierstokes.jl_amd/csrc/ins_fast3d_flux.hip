@@ -26,7 +26,7 @@
 namespace {
 
 __global__ __launch_bounds__(256) void k_build_recs(GridDev g, double visc, Rec* __restrict__ r0, Rec* __restrict__ r1,
-                                                    Rec* __restrict__ r2) {
+                                                    Rec* __restrict__ r2, int diffusion_only) {
   const int d = blockIdx.y;
   Rec* out = d == 0 ? r0 : (d == 1 ? r1 : r2);
   const int n = g.N[d];
@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void k_build_recs(GridDev g, double visc, Rec*
     r.rs = g.rdxu[d][idx];
     r.ro = g.rdx[d][idx];
     for (int q = 0; q < 6; ++q) r.pad[q] = 0.0;
+    if (diffusion_only) r.a0 = r.b0 = r.a1 = r.b1 = r.a2 = r.b2 = 0.0;  // the convective part of every face flux is then exactly zero
     out[idx] = r;
   }
 }
@@ -280,6 +281,13 @@ __global__ __launch_bounds__(256, 2) void k_momentum_flux(GridDev g, const Rec* 
       }
       if (xout && j <= N1 - 2) {
         const long long c = i + (long long)j * N0 + (long long)k * sz;
+        if constexpr (FUSE && CORR == 0) {
+          if (epi.extra) {  // the stage force is F + E (closure term, gravity: ins_rk_ext.hip); E is zero off the degrees of freedom
+            fu += epi.extra[c];
+            fv += epi.extra[c + g.sc];
+            fw += epi.extra[c + 2 * g.sc];
+          }
+        }
         if (FUSE) {
           double su, sv, sw;
           if (epi.ustart) {
@@ -452,7 +460,7 @@ int ins_flux3d_prepare(const ins_grid* G, double visc, hipStream_t s) {
     Rec* r1 = r0 + g.N[0];
     Rec* r2 = r1 + g.N[1];
     const int nmax = std::max(g.N[0], std::max(g.N[1], g.N[2]));
-    hipLaunchKernelGGL(k_build_recs, dim3(cdiv(nmax, 256), 3), dim3(256), 0, s, g, visc, r0, r1, r2);
+    hipLaunchKernelGGL(k_build_recs, dim3(cdiv(nmax, 256), 3), dim3(256), 0, s, g, visc, r0, r1, r2, 0);
     INS_LAUNCH_CHECK();
     M->rec_visc = visc;
   }
@@ -460,9 +468,10 @@ int ins_flux3d_prepare(const ins_grid* G, double visc, hipStream_t s) {
 }
 
 template <int R, int XW, bool FUSE>
-static int launch_flux(const ins_grid* G, const double* u, double* F, const RkEpi& epi, const double* pI, int corr_mode, hipStream_t s) {
+static int launch_flux(const ins_grid* G, const double* u, double* F, const RkEpi& epi, const double* pI, int corr_mode, hipStream_t s,
+                       const void* recs = nullptr) {
   const GridDev& g = G->g;
-  const Rec* r0 = reinterpret_cast<const Rec*>(G->rec_dev);
+  const Rec* r0 = reinterpret_cast<const Rec*>(recs ? recs : G->rec_dev);
   const Rec* r1 = r0 + g.N[0];
   const Rec* r2 = r1 + g.N[1];
   const int zc = g_zchunk ? g_zchunk : ((g.N[2] >= 384 || (pI && corr_mode == 3 && g.N[2] >= 128)) ? 8 : 4);
@@ -511,7 +520,8 @@ static int launch_flux(const ins_grid* G, const double* u, double* F, const RkEp
 }
 
 template <bool FUSE>
-static int launch_flux_any(const ins_grid* G, const double* u, double* F, const RkEpi& epi, const double* pI, int corr_mode, hipStream_t s) {
+static int launch_flux_any(const ins_grid* G, const double* u, double* F, const RkEpi& epi, const double* pI, int corr_mode, hipStream_t s,
+                           const void* recs = nullptr) {
   // wavefronts side by side in x: 4 when the row needs >= 8 of them, else 2 (fewer mostly-empty workgroups)
   // (the correcting kernels produce one column less per wavefront; a 256-wide row then takes 5 wavefronts, and workgroups of 2 or 4 side by
   // side would launch 6 or 8: the side-by-side count is the largest of 4, 2, 1 that wastes no wavefront — cavity 256^3: 6.26 -> 6.05 ms/step)
@@ -524,9 +534,9 @@ static int launch_flux_any(const ins_grid* G, const double* u, double* F, const 
   const int rows = g_rows ? g_rows : 4;  // rows per thread (masked / correcting variants cap themselves at 3: registers)
 #define INS_FLUX_CASE(RR)                                                          \
   if (rows == RR) {                                                                \
-    if (xw == 4) return launch_flux<RR, 4, FUSE>(G, u, F, epi, pI, corr_mode, s);  \
-    if (xw == 2) return launch_flux<RR, 2, FUSE>(G, u, F, epi, pI, corr_mode, s);  \
-    return launch_flux<RR, 1, FUSE>(G, u, F, epi, pI, corr_mode, s);               \
+    if (xw == 4) return launch_flux<RR, 4, FUSE>(G, u, F, epi, pI, corr_mode, s, recs);  \
+    if (xw == 2) return launch_flux<RR, 2, FUSE>(G, u, F, epi, pI, corr_mode, s, recs);  \
+    return launch_flux<RR, 1, FUSE>(G, u, F, epi, pI, corr_mode, s, recs);               \
   }
   INS_FLUX_CASE(2)
   INS_FLUX_CASE(3)
@@ -562,6 +572,38 @@ int ins_k_momentum_flux3d(const ins_grid* G, double visc, const double* u, doubl
   return INS_OK;
 }
 
+// fill!(F, 0) + diffusion!(F, u) (operators.jl:537-573) on the tiled kernel: the same face-flux sweep with records whose interpolation weights are
+// zero, so every face flux is its diffusive part alone (dissipation! needs diffusion(u) as a field of its own: ins_rk_ext.hip, ins_fields.hip).
+// zero_shell: also zero the ghost shell of F (a caller's array; the library's own scratch fields keep theirs zero).
+bool ins_fast3d_supported(const ins_grid* G);
+int ins_k_diffusion_flux3d(const ins_grid* G, double visc, const double* u, double* F, bool zero_shell, hipStream_t s) {
+  const GridDev& g = G->g;
+  if (!ins_fast3d_supported(G)) return INS_ERR_UNSUPPORTED;
+  ins_grid* M = const_cast<ins_grid*>(G);
+  if (!M->rec_diff_dev) {
+    const size_t n = (size_t)g.N[0] + g.N[1] + g.N[2];
+    INS_HIP_TRY(hipMalloc(&M->rec_diff_dev, n * sizeof(Rec)));
+    M->rec_diff_visc = -1.0;
+  }
+  if (M->rec_diff_visc != visc) {
+    Rec* r0 = reinterpret_cast<Rec*>(M->rec_diff_dev);
+    Rec* r1 = r0 + g.N[0];
+    Rec* r2 = r1 + g.N[1];
+    const int nmax = std::max(g.N[0], std::max(g.N[1], g.N[2]));
+    hipLaunchKernelGGL(k_build_recs, dim3(cdiv(nmax, 256), 3), dim3(256), 0, s, g, visc, r0, r1, r2, 1);
+    INS_LAUNCH_CHECK();
+    M->rec_diff_visc = visc;
+  }
+  RkEpi epi;
+  memset(&epi, 0, sizeof(epi));
+  int rc = launch_flux_any<false>(G, u, F, epi, nullptr, 0, s, M->rec_diff_dev);
+  if (rc || !zero_shell) return rc;
+  const long long total = 2LL * ((long long)g.N[0] * g.N[1] + (long long)g.N[0] * g.N[2] + (long long)g.N[1] * g.N[2]);
+  hipLaunchKernelGGL(k_zero_shell, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048)), dim3(256), 0, s, g, F);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
 // K1 + K6: k_i = momentum(u_in) (stored when epi.write_k) and the stage velocity u* (interior) in one pass.
 // 64 outputs per wavefront on stretched / masked grids (ins_flux64m.hip)
 bool ins_flux64m_supported(const ins_grid* G);
@@ -570,7 +612,7 @@ int ins_k_flux64m(const ins_grid* G, double visc, const double* u, double* k_out
 int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s) {
   if (ins_flux64_supported(G)) return ins_k_flux64(G, visc, u_in, k_out, &epi, nullptr, 0, s);
   // (the non-correcting 64-wide masked kernel is opt-in: INS_FLUX64M_FIRST=1; at 256^3 the 62-wide one with 3 rows per thread is faster, 0.29 vs 0.38 ms)
-  if (ins_opt(OPT_INS_FLUX64M_FIRST) && ins_flux64m_supported(G)) return ins_k_flux64m(G, visc, u_in, k_out, epi, nullptr, s);
+  if (ins_opt(OPT_INS_FLUX64M_FIRST) && !epi.extra && ins_flux64m_supported(G)) return ins_k_flux64m(G, visc, u_in, k_out, epi, nullptr, s);
   int rc = ins_flux3d_prepare(G, visc, s);
   if (rc) return rc;
   return launch_flux_any<true>(G, u_in, k_out, epi, nullptr, 0, s);

@@ -190,6 +190,7 @@ extern "C" int ins_grid_destroy(ins_grid_t* G) {
   if (G->dev) (void)hipFree(G->dev);
   if (G->red_dev) (void)hipFree(G->red_dev);
   if (G->rec_dev) (void)hipFree(G->rec_dev);
+  if (G->rec_diff_dev) (void)hipFree(G->rec_diff_dev);
   if (G->red_host) (void)hipHostFree(G->red_host);
   delete G;
   return INS_OK;

@@ -155,6 +155,8 @@ struct ins_grid {
   bool uniform_exact = false;  // all metric records bitwise identical over the used index range
   void* rec_dev = nullptr;     // flux-kernel metric records (ins_fast3d_flux.hip), built lazily
   double rec_visc = -1.0;
+  void* rec_diff_dev = nullptr;  // the same records with zero interpolation weights: the flux kernels then evaluate diffusion!(F, u) alone
+  double rec_diff_visc = -1.0;
   // scratch for blocking reductions
   double* red_dev = nullptr;
   double* red_host = nullptr;  // pinned

@@ -26,7 +26,10 @@ int ins_k_project(const ins_grid* G, ins_poisson* ps, double* u, double* p, hipS
 bool ins_fast3d_supported(const ins_grid* G);
 bool ins_flux64_supported(const ins_grid* G);
 int ins_k_temp_stage(const ins_grid* G, double a4, double coef, const double* u, const double* temp, const double* w, const double* tempstart, int n,
-                     const double* coefs, const double* const* ks, double c_self, double* ktemp_out, double* temp_out, hipStream_t s, const double* pI);
+                     const double* coefs, const double* const* ks, double c_self, double* ktemp_out, double* temp_out, hipStream_t s, const double* pI,
+                     const double* diff = nullptr);
+int ins_k_diffusion_overwrite(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s);
+int ins_k_diffusion_flux3d(const ins_grid* G, double visc, const double* u, double* F, bool zero_shell, hipStream_t s);
 int ins_k_momentum_rk_fused_corr(const ins_grid* G, double visc, const double* ustar_prev, const double* pI, double* k_out, const RkEpi& epi, hipStream_t s);
 int ins_k_project_periodic_solve_only(const ins_grid* G, ins_poisson* ps, const double* u, hipStream_t s);
 
@@ -78,7 +81,8 @@ extern "C" int ins_rk_set_temperature(ins_rk_t* rk, const ins_temperature_desc_t
   return INS_OK;
 }
 
-static long long g_fused_steps = 0;
+static long long g_fused_steps = 0, g_tiled_steps = 0;
+extern "C" long long ins_dbg_ext_tiled_steps(void) { return g_tiled_steps; }
 // test hook: how many steps took the fused path (periodic uniform 3-D boxes, spectral solver)
 extern "C" long long ins_dbg_ext_fused_steps(void) { return g_fused_steps; }
 
@@ -279,6 +283,91 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
       if (with_temp) INS_HIP_TRY(hipMemcpyAsync(temp, e->tb[0], sbytes, hipMemcpyDeviceToDevice, s));
     }
     return INS_OK;
+  }
+
+  // 3-D grids the tiled stage kernels take (walls, stretched grids, any solver): K1 + K6 + the extra force field in one stage kernel (the caller's u
+  // is ustart for the whole step, stage velocities ping-pong in two library buffers: no snapshot copy, no combination pass, no axpy), one
+  // temperature kernel per stage (right-hand side from (u, temp, diffusion(u)) + its RK combination), full projection after every stage.
+  if (!ins_opt(OPT_INS_DISABLE_FUSED_RK) && !ins_opt(OPT_INS_DISABLE_EXT_FUSED) && D == 3 && ins_fast3d_supported(G)) {
+    for (int b = 0; b < 2; ++b)
+      if (!rk->ub[b]) {
+        INS_HIP_TRY(hipMalloc(&rk->ub[b], vbytes));
+        INS_HIP_TRY(hipMemcpyAsync(rk->ub[b], u, vbytes, hipMemcpyDeviceToDevice, s));  // once: volumes no kernel ever writes
+      }
+    if (with_temp) {
+      for (int b = 0; b < 2; ++b)
+        if (!e->tb[b]) {
+          INS_HIP_TRY(hipMalloc(&e->tb[b], sbytes));
+          INS_HIP_TRY(hipMemcpyAsync(e->tb[b], temp, sbytes, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    ++g_tiled_steps;
+    double* cur = u;
+    double* tin = temp;
+    for (int i = 0; i < ns; ++i) {
+      const bool last = i == ns - 1 && ns > 1;
+      double* out = last ? u : rk->ub[i & 1];
+      double* tout = with_temp ? (last ? temp : e->tb[i & 1]) : nullptr;
+      if ((rc = ins_k_apply_bc_u(G, cur, 0, nullptr, s))) return rc;                                         // :19
+      if (with_temp && (rc = ins_apply_bc_temp_f64(G, td.bc, td.val, nullptr, tin, stream))) return rc;      // :20
+      if (closure) {
+        if ((rc = ins_smagtensor_f64(G, e->theta, cur, e->sigma, stream))) return rc;
+        if ((rc = ins_k_apply_bc_p_fields(G, e->sigma, D * (D + 1) / 2, s))) return rc;
+        if ((rc = ins_divoftensor_f64(G, e->sigma, e->E, stream))) return rc;
+      } else {
+        INS_HIP_TRY(hipMemsetAsync(e->E + (size_t)td.gdir * G->ncell, 0, sbytes, s));
+      }
+      if (with_temp && (rc = ins_gravity_f64(G, td.gdir, td.a2, tin, e->E, stream))) return rc;
+      if (with_temp && td.dodissipation && (rc = ins_k_diffusion_flux3d(G, visc, cur, e->diff, false, s))) return rc;  // e->diff: shell zero since its allocation
+      RkEpi epi;
+      memset(&epi, 0, sizeof(epi));
+      for (int j = 0; j < i; ++j) {
+        const double coef = dt * rk->A[i * ns + j];
+        if (coef == 0.0) continue;
+        epi.coef[epi.n] = coef;
+        epi.k[epi.n] = rk->ku[j];
+        ++epi.n;
+      }
+      for (int i2 = i + 1; i2 < ns; ++i2)
+        if (rk->A[i2 * ns + i] != 0.0) epi.write_k = 1;
+      if (rk->force) {
+        double cf = 0.0;
+        for (int j = 0; j <= i; ++j) cf += dt * rk->A[i * ns + j];
+        epi.coef[epi.n] = cf;
+        epi.k[epi.n] = rk->force;
+        ++epi.n;
+      }
+      epi.coef_self = dt * rk->A[i * ns + i];
+      epi.ustart = (i == 0) ? nullptr : u;
+      epi.ustar = out;
+      epi.extra = e->E;
+      if ((rc = ins_k_momentum_rk_fused(G, visc, cur, rk->ku[i], epi, s))) return rc;
+      if (with_temp) {
+        double coefs[INS_MAX_STAGES];
+        const double* ks[INS_MAX_STAGES];
+        int n = 0;
+        for (int j = 0; j < i; ++j) {
+          coefs[n] = dt * rk->A[i * ns + j];
+          ks[n] = e->ktemp[j];
+          ++n;
+        }
+        bool later = false;
+        for (int i2 = i + 1; i2 < ns; ++i2) later = later || rk->A[i2 * ns + i] != 0.0;
+        if ((rc = ins_k_temp_stage(G, td.a4, td.diss_coef, cur, tin, nullptr, e->tempstart, n, coefs, ks, dt * rk->A[i * ns + i],
+                                   later ? e->ktemp[i] : nullptr, tout, s, nullptr, td.dodissipation ? e->diff : nullptr)))
+          return rc;
+      }
+      if ((rc = ins_k_apply_bc_u(G, out, 0, nullptr, s))) return rc;                                          // :48
+      if ((rc = ins_k_project(G, rk->ps, out, rk->p, s))) return rc;                                            // :49
+      cur = out;
+      tin = tout;
+    }
+    if (ns == 1) {
+      INS_HIP_TRY(hipMemcpyAsync(u, rk->ub[0], vbytes, hipMemcpyDeviceToDevice, s));
+      if (with_temp) INS_HIP_TRY(hipMemcpyAsync(temp, e->tb[0], sbytes, hipMemcpyDeviceToDevice, s));
+    }
+    if ((rc = ins_k_apply_bc_u(G, u, 0, nullptr, s))) return rc;                                               // :55
+    return bc_temp();                                                                                          // :56
   }
 
   // any grid: the reference's kernel sequence
