@@ -262,6 +262,40 @@ def test_fused_extended_stage_loop_matches_oracle(ins, oracle, n, what, gdir, di
         assert rell2(u3, u) < 1e-12 and rell2(temp3, temp) < 1e-12
 
 
+@pytest.mark.parametrize("geom,kind,closure", [("dirichlet3d", "dirichlet", False), ("mixed3d", "symmetric", True), ("dirichlet3d", None, True)])
+def test_tiled_extended_stage_loop_on_wall_bounded_grids(ins, oracle, geom, kind, closure):
+    """Wall-bounded / stretched 3-D grids: the extended loop on the tiled stage kernel (closure force + gravity as one extra field inside it, one
+    temperature kernel per stage, diffusion(u) from the face-flux kernel with zero-weight records; csrc/ins_rk_ext.hip) against the oracle's
+    loop, and against the reference's kernel sequence on the device (INS_DISABLE_EXT_FUSED)."""
+    import ctypes
+
+    from ins_amd import _lib
+
+    o = oracle
+    lib = _lib.load()
+    lib.ins_dbg_ext_tiled_steps.restype = ctypes.c_longlong
+
+    def run(fused):
+        so = GEOMS[geom](o)
+        sp = with_temperature(ins, o, so, kind, gdir=2) if kind else mirror(ins, so, o)
+        if kind:
+            so.Re = sp.Re = 1.0 / so.temperature.a1
+        if closure:
+            so.closure_model = o.smagorinsky_closure(so)
+            sp.closure_model = ins.smagorinsky_closure(sp)
+        temp0 = 0.5 + 0.1 * fx.randn_field(so.grid.N, 4) if kind else None
+        before = lib.ins_dbg_ext_tiled_steps()
+        with _lib.options(INS_DISABLE_EXT_FUSED=0 if fused else 1):
+            st, u, temp = _run_steps(ins, o, so, sp, "RK44", 3, 2e-3, theta=0.17 if closure else None, temp0=temp0)
+        assert lib.ins_dbg_ext_tiled_steps() - before == (3 if fused else 0)
+        return st, u, temp
+
+    st, u, temp = run(True)
+    assert rell2(u, st["u"]) < STEP_TOL and (temp is None or rell2(temp, st["temp"]) < STEP_TOL)
+    _, u2, temp2 = run(False)
+    assert rell2(u2, u) < 1e-12 and (temp is None or rell2(temp2, temp) < 1e-12)
+
+
 @pytest.mark.parametrize("geom", ["periodic2d", "periodic3d", "periodic3d_wide"])
 def test_energy_spectrum_matches_oracle(ins, oracle, geom):
     o = oracle
