@@ -21,6 +21,10 @@ bool ins_flux64_supported(const ins_grid* G);
 bool ins_k_spectral_own3d(const ins_poisson* ps);
 int ins_k_spectral_solve_from_u32(ins_poisson* ps, const float* u32, hipStream_t s);
 const double* ins_k_spectral_pI(const ins_poisson* ps);
+bool ins_k_spectral_own3d_f32(const ins_poisson* ps);
+int ins_k_spectral_solve_f32(ins_poisson* ps, const float* u32, float* pI32, float* phat32, int kxs32, const float* twx, const float* twy,
+                             const float* twz, hipStream_t s);
+int ins_zsolve_twiddles_f32(int nz, float** out);
 int ins_k_flux64_f32(const ins_grid* G, double visc, const float* u, float* F, const RkEpi* epi, const float* pI, int corr_mode, hipStream_t s,
                      int part = 0);
 
@@ -36,6 +40,12 @@ struct ins_poisson32 {
   // float field inside the x pass, five passes instead of hipFFT's 3-D plans + separate kernels; the pressure is MORE accurate than a float
   // solve would give).  512^3 RK44 step: 26.9 ms with hipFFT's float plans -> see DESIGN.md §5.
   ins_poisson* ps64 = nullptr;
+  // sides the three-pass z kernel takes (192, 256, 384, 512 planes): the same five passes on FLOAT2 spectra — half the bytes of every pass; ps64
+  // then only supplies the symbol vectors (INS_F32_FP64_SPECTRA=1 keeps the fp64 passes)
+  bool own32 = false;
+  float* phat32 = nullptr;
+  float* tw32[3] = {nullptr, nullptr, nullptr};
+  int kxs32 = 0;
 };
 
 struct ins_rk32 {
@@ -252,6 +262,9 @@ extern "C" int ins_poisson_destroy_f32(ins_poisson32_t* ps) {
   for (float* a : ps->ahat)
     if (a) (void)hipFree(a);
   if (ps->ps64) (void)ins_poisson_destroy(ps->ps64);
+  if (ps->phat32) (void)hipFree(ps->phat32);
+  for (float* t : ps->tw32)
+    if (t) (void)hipFree(t);
   delete ps;
   return INS_OK;
 }
@@ -314,6 +327,13 @@ extern "C" int ins_poisson_spectral_create_f32(const ins_grid_t* G, ins_poisson3
       else
         (void)ins_poisson_destroy(p64);
     }
+    if (ps->ps64 && ins_k_spectral_own3d_f32(ps->ps64) && !ins_opt(OPT_INS_F32_FP64_SPECTRA)) {
+      ps->kxs32 = (ps->kmax[0] + 15) & ~15;  // rows of the float2 spectrum padded to whole 128-B lines
+      const size_t nb = (size_t)ps->kxs32 * ps->np[1] * ps->np[2] * 2 * sizeof(float);
+      bool ok32 = hipMalloc(&ps->phat32, nb) == hipSuccess && hipMemset(ps->phat32, 0, nb) == hipSuccess;
+      for (int a = 0; ok32 && a < 3; ++a) ok32 = ins_zsolve_twiddles_f32(ps->np[a], &ps->tw32[a]) == INS_OK;
+      ps->own32 = ok32;
+    }
   }
   *out = ps;
   return INS_OK;
@@ -343,6 +363,13 @@ extern "C" int ins_project_f32(const ins_grid_t* G, ins_poisson32_t* ps, float* 
   hipStream_t s = as_stream(stream);
   const Box32 b = box_of(G);
   int rc;
+  if (ps->own32) {
+    if ((rc = ins_k_spectral_solve_f32(ps->ps64, u, ps->pI, ps->phat32, ps->kxs32, ps->tw32[0], ps->tw32[1], ps->tw32[2], s))) return rc;
+    hipLaunchKernelGGL((k32_pad<3, float>), grid_over(b, true), dim3(64, 4), 0, s, b, (const float*)ps->pI, p);
+    hipLaunchKernelGGL(k32_applypressure<3>, grid_over(b, false), dim3(64, 4), 0, s, b, u, p);
+    INS_LAUNCH_CHECK();
+    return bc_periodic(G, u, b.D, s);
+  }
   if (ps->ps64) {
     if ((rc = ins_k_spectral_solve_from_u32(ps->ps64, u, s))) return rc;
     hipLaunchKernelGGL((k32_pad<3, double>), grid_over(b, true), dim3(64, 4), 0, s, b, ins_k_spectral_pI(ps->ps64), p);
@@ -449,7 +476,9 @@ extern "C" int ins_rk_step_f32(ins_rk32_t* rk, float visc, float* u, float dt, v
   const bool incorr = wide && rk->ps->ps64 && ns > 1 && G->uniform_exact && G->g.N[0] >= 8 && G->g.N[1] >= 8 && G->g.N[2] >= 8 &&
                       !ins_opt(OPT_INS_DISABLE_INKERNEL_CORR);
   const long long ncell_in = (long long)(G->g.N[0] - 2) * (G->g.N[1] - 2) * (G->g.N[2] - 2);
-  if (incorr && !rk->pu) INS_HIP_TRY(hipMalloc(&rk->pu, ncell_in * sizeof(float)));
+  const bool own32 = rk->ps->own32;  // float2 spectra: the solver's float pI is what the next stage's stencil kernel reads
+  if (incorr && !own32 && !rk->pu) INS_HIP_TRY(hipMalloc(&rk->pu, ncell_in * sizeof(float)));
+  const float* pcorr = own32 ? rk->ps->pI : rk->pu;
   float* cur = u;
   for (int i = 0; i < ns; ++i) {
     float* outp = (i == ns - 1 && ns > 1) ? u : rk->ub[i & 1];
@@ -468,7 +497,7 @@ extern "C" int ins_rk_step_f32(ins_rk32_t* rk, float visc, float* u, float dt, v
       epi.coef_self = (double)dt * rk->A[i * ns + i];
       epi.ustart = i == 0 ? nullptr : reinterpret_cast<const double*>(u);
       epi.ustar = reinterpret_cast<double*>(outp);
-      if ((rc = ins_k_flux64_f32(G, (double)visc, cur, rk->ku[i], &epi, (incorr && i > 0) ? rk->pu : nullptr, (incorr && i > 0) ? 1 : 0, s))) return rc;   // :21, :35-38
+      if ((rc = ins_k_flux64_f32(G, (double)visc, cur, rk->ku[i], &epi, (incorr && i > 0) ? pcorr : nullptr, (incorr && i > 0) ? 1 : 0, s))) return rc;   // :21, :35-38
     } else {
       if ((rc = ins_momentum_f32(G, visc, cur, rk->ku[i], s))) return rc;       // :21
       Comb32 cb;
@@ -483,7 +512,10 @@ extern "C" int ins_rk_step_f32(ins_rk32_t* rk, float visc, float* u, float dt, v
       hipLaunchKernelGGL(k32_combine, dim3((unsigned)std::min<long long>((nvec + 255) / 256, 8192)), dim3(256), 0, s, nvec, u, outp, cb);  // :35-38
       INS_LAUNCH_CHECK();
     }
-    if (incorr && i < ns - 1) {  // solve only: p (unpadded, float) for the next stage's in-register correction
+    if (incorr && i < ns - 1 && own32) {  // solve only, float2 spectra: p lands in the solver's float pI
+      ins_poisson32* q = rk->ps;
+      if ((rc = ins_k_spectral_solve_f32(q->ps64, outp, q->pI, q->phat32, q->kxs32, q->tw32[0], q->tw32[1], q->tw32[2], s))) return rc;
+    } else if (incorr && i < ns - 1) {  // solve only: p (unpadded, float) for the next stage's in-register correction
       if ((rc = ins_k_spectral_solve_from_u32(rk->ps->ps64, outp, s))) return rc;
       hipLaunchKernelGGL(k32_cvt, dim3((unsigned)std::min<long long>((ncell_in + 255) / 256, 8192)), dim3(256), 0, s, ncell_in,
                          ins_k_spectral_pI(rk->ps->ps64), rk->pu);

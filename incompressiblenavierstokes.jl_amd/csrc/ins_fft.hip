@@ -18,12 +18,38 @@
 
 namespace {
 
-__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ double2 cmulc(double2 a, double2 b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
-__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }
-__device__ __forceinline__ double2 mul_pi(double2 a) { return make_double2(-a.y, a.x); }
+// The passes are templates over the complex element type C (double2, or float2 for the `_f32` family: half the bytes per pass).
+template <typename C>
+struct real_of;
+template <>
+struct real_of<double2> {
+  using t = double;
+};
+template <>
+struct real_of<float2> {
+  using t = float;
+};
+template <typename C>
+using real_t = typename real_of<C>::t;
+template <typename C>
+__device__ __forceinline__ C mkc(real_t<C> x, real_t<C> y) {
+  C c;
+  c.x = x;
+  c.y = y;
+  return c;
+}
+template <typename C>
+__device__ __forceinline__ C cmul(C a, C b) { return mkc<C>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+template <typename C>
+__device__ __forceinline__ C cmulc(C a, C b) { return mkc<C>(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+template <typename C>
+__device__ __forceinline__ C cadd(C a, C b) { return mkc<C>(a.x + b.x, a.y + b.y); }
+template <typename C>
+__device__ __forceinline__ C csub(C a, C b) { return mkc<C>(a.x - b.x, a.y - b.y); }
+template <typename C>
+__device__ __forceinline__ C mul_mi(C a) { return mkc<C>(a.y, -a.x); }
+template <typename C>
+__device__ __forceinline__ C mul_pi(C a) { return mkc<C>(-a.y, a.x); }
 
 // Transform lengths.  The template parameter LOGN of everything below is a SIZE CODE: codes < 32 are log2 N of a power of two; code
 // 32 + m stands for N = 3 * 2^m (a radix-3 stage in front of the power-of-two stages: 192 = 3 * 64, 384 = 3 * 128), so that boxes with
@@ -61,26 +87,27 @@ __host__ __device__ __forceinline__ int pos_of_freq(int k) {
 // RFAST: consecutive work-items take consecutive butterflies of one line (x layout, SR == 1) instead of the
 // same butterfly of consecutive lines (y/z layout, SC == 1) — keeps LDS accesses unit-stride in both layouts.
 // radix-3 butterfly, forward (w = e^{-2πi/3}) / inverse (conjugate)
-template <bool INV>
-__device__ __forceinline__ void bfly3(double2& x0, double2& x1, double2& x2) {
-  constexpr double h = 0.86602540378443864676;  // sqrt(3)/2
-  const double2 t1 = cadd(x1, x2), d = csub(x1, x2);
-  const double2 t2 = make_double2(x0.x - 0.5 * t1.x, x0.y - 0.5 * t1.y);
-  const double2 t3 = INV ? make_double2(-h * d.y, h * d.x) : make_double2(h * d.y, -h * d.x);  // (+-i) sqrt(3)/2 (x1 - x2)
+template <bool INV, typename C>
+__device__ __forceinline__ void bfly3(C& x0, C& x1, C& x2) {
+  using T = real_t<C>;
+  constexpr T h = (T)0.86602540378443864676;  // sqrt(3)/2
+  const C t1 = cadd(x1, x2), d = csub(x1, x2);
+  const C t2 = mkc<C>(x0.x - (T)0.5 * t1.x, x0.y - (T)0.5 * t1.y);
+  const C t3 = INV ? mkc<C>(-h * d.y, h * d.x) : mkc<C>(h * d.y, -h * d.x);  // (+-i) sqrt(3)/2 (x1 - x2)
   x0 = cadd(x0, t1);
   x1 = cadd(t2, t3);
   x2 = csub(t2, t3);
 }
 
-template <int LOGN, int NC, int SR, int SC, bool RFAST>
-__device__ __forceinline__ void fft_dif(double2* __restrict__ buf, const double2* __restrict__ tw, int t) {
+template <int LOGN, int NC, int SR, int SC, bool RFAST, typename C>
+__device__ __forceinline__ void fft_dif(C* __restrict__ buf, const C* __restrict__ tw, int t) {
   constexpr int N = fft_len(LOGN), R3 = fft_r3(LOGN), M = N / R3;  // M: the power-of-two sub-length
   constexpr bool ODD = fft_lg(LOGN) & 1;
   if (R3 == 3) {  // N = 3 M: one radix-3 stage over the whole line, then the three sub-blocks of length M run the stages below side by side
     for (int w = t; w < M * NC; w += 256) {
       const int c = RFAST ? w / M : w % NC, j = RFAST ? w % M : w / NC;
-      double2* x = buf + c * SC;
-      double2 a0 = x[j * SR], a1 = x[(j + M) * SR], a2 = x[(j + 2 * M) * SR];
+      C* x = buf + c * SC;
+      C a0 = x[j * SR], a1 = x[(j + M) * SR], a2 = x[(j + 2 * M) * SR];
       bfly3<false>(a0, a1, a2);
       x[j * SR] = a0;
       x[(j + M) * SR] = cmul(a1, tw[j]);
@@ -93,8 +120,8 @@ __device__ __forceinline__ void fft_dif(double2* __restrict__ buf, const double2
     for (int w = t; w < (N / 2) * NC; w += 256) {
       const int c = RFAST ? w / (N / 2) : w % NC, jj = RFAST ? w % (N / 2) : w / NC;
       const int sub = jj / (M / 2), j = jj - sub * (M / 2);
-      double2* x = buf + c * SC + sub * M * SR;
-      const double2 a0 = x[j * SR], a1 = x[(j + M / 2) * SR];
+      C* x = buf + c * SC + sub * M * SR;
+      const C a0 = x[j * SR], a1 = x[(j + M / 2) * SR];
       x[j * SR] = cadd(a0, a1);
       x[(j + M / 2) * SR] = cmul(csub(a0, a1), tw[j * R3]);  // W_M^j = W_N^(R3 j)
     }
@@ -108,12 +135,12 @@ __device__ __forceinline__ void fft_dif(double2* __restrict__ buf, const double2
       const int c = RFAST ? w / (N / 4) : w % NC, bb = RFAST ? w % (N / 4) : w / NC;
       const int sub = bb / (M / 4), b = bb - sub * (M / 4);
       const int g = b / Q, j = b - g * Q;
-      double2* x = buf + c * SC + (sub * M + g * L + j) * SR;
-      const double2 a0 = x[0], a1 = x[Q * SR], a2 = x[2 * Q * SR], a3 = x[3 * Q * SR];
-      const double2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
-      double2 y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
+      C* x = buf + c * SC + (sub * M + g * L + j) * SR;
+      const C a0 = x[0], a1 = x[Q * SR], a2 = x[2 * Q * SR], a3 = x[3 * Q * SR];
+      const C t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
+      C y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
       if (L > 4) {
-        const double2 w1 = tw[j * step], w2 = cmul(w1, w1), w3 = cmul(w2, w1);  // one table read instead of three (LDS-bound stages)
+        const C w1 = tw[j * step], w2 = cmul(w1, w1), w3 = cmul(w2, w1);  // one table read instead of three (LDS-bound stages)
         y1 = cmul(y1, w1);
         y2 = cmul(y2, w2);
         y3 = cmul(y3, w3);
@@ -127,8 +154,8 @@ __device__ __forceinline__ void fft_dif(double2* __restrict__ buf, const double2
   }
 }
 
-template <int LOGN, int NC, int SR, int SC, bool RFAST>
-__device__ __forceinline__ void fft_dit(double2* __restrict__ buf, const double2* __restrict__ tw, int t) {
+template <int LOGN, int NC, int SR, int SC, bool RFAST, typename C>
+__device__ __forceinline__ void fft_dit(C* __restrict__ buf, const C* __restrict__ tw, int t) {
   constexpr int N = fft_len(LOGN), R3 = fft_r3(LOGN), M = N / R3;
   constexpr bool ODD = fft_lg(LOGN) & 1;
 #pragma unroll 1
@@ -138,15 +165,15 @@ __device__ __forceinline__ void fft_dit(double2* __restrict__ buf, const double2
       const int c = RFAST ? w / (N / 4) : w % NC, bb = RFAST ? w % (N / 4) : w / NC;
       const int sub = bb / (M / 4), b = bb - sub * (M / 4);
       const int g = b / Q, j = b - g * Q;
-      double2* x = buf + c * SC + (sub * M + g * L + j) * SR;
-      double2 x0 = x[0], x1 = x[Q * SR], x2 = x[2 * Q * SR], x3 = x[3 * Q * SR];
+      C* x = buf + c * SC + (sub * M + g * L + j) * SR;
+      C x0 = x[0], x1 = x[Q * SR], x2 = x[2 * Q * SR], x3 = x[3 * Q * SR];
       if (L > 4) {
-        const double2 w1 = tw[j * step], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+        const C w1 = tw[j * step], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
         x1 = cmulc(x1, w1);
         x2 = cmulc(x2, w2);
         x3 = cmulc(x3, w3);
       }
-      const double2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = mul_pi(csub(x1, x3));
+      const C t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = mul_pi(csub(x1, x3));
       x[0] = cadd(t0, t2);
       x[Q * SR] = cadd(t1, t3);
       x[2 * Q * SR] = csub(t0, t2);
@@ -158,8 +185,8 @@ __device__ __forceinline__ void fft_dit(double2* __restrict__ buf, const double2
     for (int w = t; w < (N / 2) * NC; w += 256) {
       const int c = RFAST ? w / (N / 2) : w % NC, jj = RFAST ? w % (N / 2) : w / NC;
       const int sub = jj / (M / 2), j = jj - sub * (M / 2);
-      double2* x = buf + c * SC + sub * M * SR;
-      const double2 x0 = x[j * SR], x1 = cmulc(x[(j + M / 2) * SR], tw[j * R3]);
+      C* x = buf + c * SC + sub * M * SR;
+      const C x0 = x[j * SR], x1 = cmulc(x[(j + M / 2) * SR], tw[j * R3]);
       x[j * SR] = cadd(x0, x1);
       x[(j + M / 2) * SR] = csub(x0, x1);
     }
@@ -168,8 +195,8 @@ __device__ __forceinline__ void fft_dit(double2* __restrict__ buf, const double2
   if (R3 == 3) {
     for (int w = t; w < M * NC; w += 256) {
       const int c = RFAST ? w / M : w % NC, j = RFAST ? w % M : w / NC;
-      double2* x = buf + c * SC;
-      double2 a0 = x[j * SR], a1 = cmulc(x[(j + M) * SR], tw[j]), a2 = cmulc(x[(j + 2 * M) * SR], tw[2 * j]);
+      C* x = buf + c * SC;
+      C a0 = x[j * SR], a1 = cmulc(x[(j + M) * SR], tw[j]), a2 = cmulc(x[(j + 2 * M) * SR], tw[2 * j]);
       bfly3<true>(a0, a1, a2);
       x[j * SR] = a0;
       x[(j + M) * SR] = a1;
@@ -191,17 +218,18 @@ struct PackMap {
   int nyl, nzl, cw;
 };
 
-template <int LOGN, int TK, bool INVERSE, bool PACKED>
-__global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kxn, int kxs, const double2* __restrict__ tw_g, PackMap pm) {
+template <int LOGN, int TK, bool INVERSE, bool PACKED, typename C = double2>
+__global__ __launch_bounds__(256) void k_yfft(C* __restrict__ data, int kxn, int kxs, const C* __restrict__ tw_g, PackMap pm) {
   constexpr int N = fft_len(LOGN);
-  extern __shared__ double2 lds_dyn[];
-  double2* buf = lds_dyn;          // [N][TK]
-  double2* tw = lds_dyn + N * TK;  // [N]
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  C* lds_dyn = reinterpret_cast<C*>(lds_raw);
+  C* buf = lds_dyn;          // [N][TK]
+  C* tw = lds_dyn + N * TK;  // [N]
   const int t = threadIdx.x;
   const int col = t % TK;
   const int kx = blockIdx.x * TK + col;
   const bool live = kx < kxn;
-  double2* base = data + (long long)blockIdx.y * N * kxs + kx;  // kxs = row stride (>= kxn; a multiple of 8 keeps tiles line-aligned)
+  C* base = data + (long long)blockIdx.y * N * kxs + kx;  // kxs = row stride (>= kxn; a multiple of 8 keeps tiles line-aligned)
   // packed address of (row r, this kx, this plane)
   long long pbase = 0, prow = 0, pq = 0;
   if (PACKED) {
@@ -220,12 +248,12 @@ __global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kx
   constexpr int RPT = 256 / TK;
   constexpr int NIT = N / RPT;  // rows per work-item: all its loads are issued before the first LDS write
   {
-    double2 v[NIT];
+    C v[NIT];
 #pragma unroll
     for (int q = 0; q < NIT; ++q) {
       const int r = t / TK + q * RPT;
-      v[q] = make_double2(0.0, 0.0);
-      if (live) v[q] = (PACKED && INVERSE) ? pm.packed[paddr(r)] : base[(long long)r * kxs];
+      v[q] = mkc<C>(0.0, 0.0);
+      if (live) v[q] = (PACKED && INVERSE) ? static_cast<C*>((void*)pm.packed)[paddr(r)] : base[(long long)r * kxs];
     }
 #pragma unroll
     for (int q = 0; q < NIT; ++q) buf[(t / TK + q * RPT) * TK + col] = v[q];
@@ -240,7 +268,7 @@ __global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kx
     for (int q = 0; q < NIT; ++q) {
       const int r = t / TK + q * RPT;
       if (PACKED && !INVERSE)
-        pm.packed[paddr(r)] = buf[r * TK + col];
+        static_cast<C*>((void*)pm.packed)[paddr(r)] = buf[r * TK + col];
       else
         base[(long long)r * kxs] = buf[r * TK + col];
     }
@@ -250,31 +278,33 @@ __global__ __launch_bounds__(256) void k_yfft(double2* __restrict__ data, int kx
 // Pass 1: x forward, NP row pairs per workgroup.  SRC 0: rows come from pI; SRC 1: rows = Ω·div(u) (K2 fused, periodic
 // wrap in all directions); SRC 2: the same on a z-slab (z neighbour from the ghost plane); SRC 3: the 2-D divergence; SRC 4: the divergence on a grid with walls (ghost volumes of u valid).
 // ------------------------------------------------------------------------------------------------------------
-template <int LOGN, int NP, int SRC>
-__global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restrict__ src, double2* __restrict__ out, int n1,
-                                              const double2* __restrict__ tw_g, int kxs, int kz0) {
+template <int LOGN, int NP, int SRC, typename C = double2>
+__global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restrict__ src, C* __restrict__ out, int n1,
+                                              const C* __restrict__ tw_g, int kxs, int kz0) {
+  using T = real_t<C>;  // (C = float2: `src` points to float data — SRC 0: the float pI; SRC 5: the float velocity field)
   constexpr int N = fft_len(LOGN);
   constexpr int KXN = N / 2 + 1;
-  extern __shared__ double2 lds_dyn[];
-  double2* buf = lds_dyn;          // [NP][N]
-  double2* tw = lds_dyn + NP * N;  // [N]
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  C* lds_dyn = reinterpret_cast<C*>(lds_raw);
+  C* buf = lds_dyn;          // [NP][N]
+  C* tw = lds_dyn + NP * N;  // [N]
   const int t = threadIdx.x;
   const int kz = kz0 + blockIdx.y;  // interior plane index (kz0: first plane of this launch)
   const int j0 = blockIdx.x * 2 * NP;
   for (int m = t; m < N; m += 256) tw[m] = tw_g[m];
-  double* bufd = reinterpret_cast<double*>(buf);
+  T* bufd = reinterpret_cast<T*>(buf);
   // every work-item owns NIT (row, column) points; all their loads are issued (clamped rows, no branches) before the first
   // LDS write, so one round trip to HBM covers the whole tile instead of one per row
   constexpr int NIT = (2 * NP * N) / 256;
   {
-    double v[NIT];
+    T v[NIT];
 #pragma unroll
     for (int q = 0; q < NIT; ++q) {
       const int idx = t + 256 * q;
       const int row = idx / N, i = idx - row * N;
       const int j = min(j0 + row, n1 - 1);
       if (SRC == 0) {
-        v[q] = src[i + (long long)N * (j + (long long)n1 * kz)];
+        v[q] = reinterpret_cast<const T*>(src)[i + (long long)N * (j + (long long)n1 * kz)];
       } else if (SRC == 5) {
         // as SRC 1, from a FLOAT velocity field (the `_f32` family solves its pressure equation with these fp64 passes, ins_f32.hip):
         // differences and metrics in double from the float values
@@ -287,7 +317,7 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
         double d = ((double)sf[c] - (double)sf[cx]) * g.rdx[0][I0];
         d += ((double)sf[g.sc + c] - (double)sf[g.sc + cy]) * g.rdx[1][I1];
         d += ((double)sf[2 * g.sc + c] - (double)sf[2 * g.sc + cz]) * g.rdx[2][I2];
-        v[q] = d * (g.dx[0][I0] * g.dx[1][I1] * g.dx[2][I2]);
+        v[q] = (T)(d * (g.dx[0][I0] * g.dx[1][I1] * g.dx[2][I2]));
       } else if (SRC == 4) {
         // Ω · div(u) at the pressure point (i, j, kz) of a grid with walls: the ghost volumes of u are valid (k_div_to_pI<3, false>)
         const int I0 = g.ip_lo[0] + i, I1 = g.ip_lo[1] + j, I2 = g.ip_lo[2] + kz;
@@ -295,7 +325,7 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
         double d = (src[c] - src[c - 1]) * g.rdx[0][I0];
         d += (src[g.sc + c] - src[g.sc + c - g.sx[1]]) * g.rdx[1][I1];
         d += (src[2 * g.sc + c] - src[2 * g.sc + c - g.sx[2]]) * g.rdx[2][I2];
-        v[q] = d * (g.dx[0][I0] * g.dx[1][I1] * g.dx[2][I2]);
+        v[q] = (T)(d * (g.dx[0][I0] * g.dx[1][I1] * g.dx[2][I2]));
       } else if (SRC == 3) {
         // 2-D: Ω · div(u*) at interior cell (i, j) with periodic wrap (k_div_to_pI<2, true>)
         const int I0 = i + 1, I1 = j + 1;
@@ -303,7 +333,7 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
         const long long cx = I0 == 1 ? c + (long long)(g.N[0] - 3) : c - 1;
         const long long cy = I1 == 1 ? c + (long long)(g.N[1] - 3) * g.sx[1] : c - g.sx[1];
         const double d = (src[c] - src[cx]) * g.rdx[0][I0] + (src[g.sc + c] - src[g.sc + cy]) * g.rdx[1][I1];
-        v[q] = d * (g.dx[0][I0] * g.dx[1][I1]);
+        v[q] = (T)(d * (g.dx[0][I0] * g.dx[1][I1]));
       } else {
         // Ω · div(u*) at interior cell (i, j, kz): periodic wrap instead of ghost reads (k_div_to_pI<3, true>)
         const int I0 = i + 1, I1 = j + 1, I2 = kz + 1;
@@ -316,14 +346,14 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
         d += (src[g.sc + c] - src[g.sc + cy]) * g.rdx[1][I1];
         d += (src[2 * g.sc + c] - src[2 * g.sc + cz]) * g.rdx[2][I2];
         const double om = g.dx[0][I0] * g.dx[1][I1] * g.dx[2][I2];
-        v[q] = d * om;
+        v[q] = (T)(d * om);
       }
     }
 #pragma unroll
     for (int q = 0; q < NIT; ++q) {
       const int idx = t + 256 * q;
       const int row = idx / N, i = idx - row * N;
-      bufd[2 * ((row >> 1) * N + i) + (row & 1)] = (j0 + row < n1) ? v[q] : 0.0;
+      bufd[2 * ((row >> 1) * N + i) + (row & 1)] = (j0 + row < n1) ? v[q] : (T)0;
     }
   }
   __syncthreads();
@@ -333,10 +363,10 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
     const int p = idx / KXN, s = idx - p * KXN;
     const int j = j0 + 2 * p;
     if (j >= n1) continue;
-    const double2 zk = buf[p * N + pos_of_freq<LOGN>(s)];
-    const double2 zm = buf[p * N + pos_of_freq<LOGN>((N - s) % N)];
-    const double2 a = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
-    const double2 b = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+    const C zk = buf[p * N + pos_of_freq<LOGN>(s)];
+    const C zm = buf[p * N + pos_of_freq<LOGN>((N - s) % N)];
+    const C a = mkc<C>((T)0.5 * (zk.x + zm.x), (T)0.5 * (zk.y - zm.y));
+    const C b = mkc<C>((T)0.5 * (zk.y + zm.y), (T)-0.5 * (zk.x - zm.x));
     const long long o = s + (long long)kxs * (j + (long long)n1 * kz);
     out[o] = a;
     out[o + kxs] = b;  // row j + 1 (n1 is even)
@@ -346,21 +376,23 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
 // ------------------------------------------------------------------------------------------------------------
 // Pass 5: x inverse for NP row pairs: Z[k] = A[k] + i B[k], Z[N-k] = conj A[k] + i conj B[k]  ->  DIT  ->  pI rows.
 // ------------------------------------------------------------------------------------------------------------
-template <int LOGN, int NP>
-__global__ __launch_bounds__(256) void k_xinv(const double2* __restrict__ in, double* __restrict__ pI, int n1,
-                                              const double2* __restrict__ tw_g, int kxs) {
+template <int LOGN, int NP, typename C = double2>
+__global__ __launch_bounds__(256) void k_xinv(const C* __restrict__ in, real_t<C>* __restrict__ pI, int n1,
+                                              const C* __restrict__ tw_g, int kxs) {
+  using T = real_t<C>;
   constexpr int N = fft_len(LOGN);
   constexpr int KXN = N / 2 + 1;
-  extern __shared__ double2 lds_dyn[];
-  double2* buf = lds_dyn;
-  double2* tw = lds_dyn + NP * N;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  C* lds_dyn = reinterpret_cast<C*>(lds_raw);
+  C* buf = lds_dyn;
+  C* tw = lds_dyn + NP * N;
   const int t = threadIdx.x;
   const int kz = blockIdx.y;
   const int j0 = blockIdx.x * 2 * NP;
   for (int m = t; m < N; m += 256) tw[m] = tw_g[m];
   constexpr int NIT = (NP * KXN + 255) / 256;  // all loads first (clamped, branch-free), then the LDS scatter
   {
-    double2 av[NIT], bv[NIT];
+    C av[NIT], bv[NIT];
 #pragma unroll
     for (int q = 0; q < NIT; ++q) {
       const int idx = min(t + 256 * q, NP * KXN - 1);
@@ -375,19 +407,19 @@ __global__ __launch_bounds__(256) void k_xinv(const double2* __restrict__ in, do
       const int idx = t + 256 * q;
       if (idx >= NP * KXN) break;
       const int p = idx / KXN, s = idx - p * KXN;
-      double2 a = av[q], b = bv[q];
-      if (j0 + 2 * p >= n1) a = b = make_double2(0.0, 0.0);
+      C a = av[q], b = bv[q];
+      if (j0 + 2 * p >= n1) a = b = mkc<C>(0, 0);
       if (s == 0 || s == N / 2) {  // C2R semantics: DC and Nyquist bins are real
-        a.y = 0.0;
-        b.y = 0.0;
+        a.y = 0;
+        b.y = 0;
       }
-      buf[p * N + pos_of_freq<LOGN>(s)] = make_double2(a.x - b.y, a.y + b.x);
-      if (s != 0 && s != N / 2) buf[p * N + pos_of_freq<LOGN>(N - s)] = make_double2(a.x + b.y, b.x - a.y);
+      buf[p * N + pos_of_freq<LOGN>(s)] = mkc<C>(a.x - b.y, a.y + b.x);
+      if (s != 0 && s != N / 2) buf[p * N + pos_of_freq<LOGN>(N - s)] = mkc<C>(a.x + b.y, b.x - a.y);
     }
   }
   __syncthreads();
   fft_dit<LOGN, NP, 1, N, true>(buf, tw, t);
-  const double* bufd = reinterpret_cast<const double*>(buf);
+  const T* bufd = reinterpret_cast<const T*>(buf);
   for (int idx = t; idx < 2 * NP * N; idx += 256) {
     const int row = idx / N, i = idx - row * N;
     const int j = j0 + row;
@@ -498,30 +530,34 @@ int set_lds(K kernel, size_t lds) {
   return INS_OK;
 }
 
-template <int LOGN>
-int launch_y(double2* data, int kxn, int kxs, int nplanes, const double2* tw, bool inverse, const PackMap* pm, hipStream_t s) {
+template <int LOGN, typename C = double2>
+int launch_y(C* data, int kxn, int kxs, int nplanes, const C* tw, bool inverse, const PackMap* pm, hipStream_t s) {
   constexpr int N = fft_len(LOGN);
-  constexpr int TK = N <= 256 ? 16 : (N <= 512 ? 8 : 4);  // 256-B segments per row where LDS allows (<= 80 KB tiles)
-  constexpr size_t lds = ((size_t)N * TK + N) * sizeof(double2);
+  // 256-B segments per row where LDS allows (<= 80 KB tiles): 16 / 8 / 4 double2 columns, twice as many float2 ones
+  constexpr int TK = (N <= 256 ? 16 : (N <= 512 ? 8 : 4)) * (int)(sizeof(double2) / sizeof(C));
+  constexpr size_t lds = ((size_t)N * TK + N) * sizeof(C);
   dim3 grid((kxn + TK - 1) / TK, nplanes);
   PackMap none{nullptr, 1, 1, 1};
 #define INS_Y_LAUNCH(INV, PK)                                                                                   \
   do {                                                                                                          \
-    int rc = set_lds(&k_yfft<LOGN, TK, INV, PK>, lds);                                                          \
+    int rc = set_lds(&k_yfft<LOGN, TK, INV, PK, C>, lds);                                                       \
     if (rc) return rc;                                                                                          \
-    hipLaunchKernelGGL((k_yfft<LOGN, TK, INV, PK>), grid, dim3(256), lds, s, data, kxn, kxs, tw, pm ? *pm : none);   \
+    hipLaunchKernelGGL((k_yfft<LOGN, TK, INV, PK, C>), grid, dim3(256), lds, s, data, kxn, kxs, tw, pm ? *pm : none);   \
   } while (0)
-  if (pm) {
-    if (inverse)
-      INS_Y_LAUNCH(true, true);
-    else
-      INS_Y_LAUNCH(false, true);
-  } else {
-    if (inverse)
-      INS_Y_LAUNCH(true, false);
-    else
-      INS_Y_LAUNCH(false, false);
+  if constexpr (sizeof(C) == sizeof(double2)) {
+    if (pm) {
+      if (inverse)
+        INS_Y_LAUNCH(true, true);
+      else
+        INS_Y_LAUNCH(false, true);
+      INS_LAUNCH_CHECK();
+      return INS_OK;
+    }
   }
+  if (inverse)
+    INS_Y_LAUNCH(true, false);
+  else
+    INS_Y_LAUNCH(false, false);
 #undef INS_Y_LAUNCH
   INS_LAUNCH_CHECK();
   return INS_OK;
@@ -548,14 +584,29 @@ int launch_xfwd(const GridDev& g, const double* src, int from_u, double2* out, i
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
-
+// float2 spectrum: from the float pI (from_u = 0) or with Ω·div(u) of the float velocity field formed on the fly (from_u != 0)
 template <int LOGN>
-int launch_xinv(const double2* in, double* pI, int n1, int n2, const double2* tw, int kxs, hipStream_t s) {
+int launch_xfwd32(const GridDev& g, const float* src, int from_u, float2* out, int n1, int n2, const float2* tw, int kxs, hipStream_t s) {
+  constexpr int N = fft_len(LOGN);
+  constexpr int NP = fft_r3(LOGN) == 3 ? 768 / N : (N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N));
+  constexpr size_t lds = ((size_t)NP * N + N) * sizeof(float2);
+  dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
+  const double* srcd = reinterpret_cast<const double*>(src);  // the kernel reads float data behind this pointer (C = float2)
+  if (from_u)
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 5, float2>), grid, dim3(256), lds, s, g, srcd, out, n1, tw, kxs, 0);
+  else
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 0, float2>), grid, dim3(256), lds, s, g, srcd, out, n1, tw, kxs, 0);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
+template <int LOGN, typename C = double2>
+int launch_xinv(const C* in, real_t<C>* pI, int n1, int n2, const C* tw, int kxs, hipStream_t s) {
   constexpr int N = fft_len(LOGN);
   constexpr int NP = fft_r3(LOGN) == 3 ? 768 / N : (N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N));  // 2 NP N a multiple of 256
-  constexpr size_t lds = ((size_t)NP * N + N) * sizeof(double2);
+  constexpr size_t lds = ((size_t)NP * N + N) * sizeof(C);
   dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
-  hipLaunchKernelGGL((k_xinv<LOGN, NP>), grid, dim3(256), lds, s, in, pI, n1, tw, kxs);
+  hipLaunchKernelGGL((k_xinv<LOGN, NP, C>), grid, dim3(256), lds, s, in, pI, n1, tw, kxs);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -645,6 +696,31 @@ int ins_k_ownfft_y(double* phat, int kxn, int n1, int n2, const double* tw, bool
   double2* d = reinterpret_cast<double2*>(phat);
   const double2* w = reinterpret_cast<const double2*>(tw);
 #define CALL(LG) launch_y<LG>(d, kxn, kxs, n2, w, inverse, nullptr, s)
+  INS_POW2_SWITCH(n1, CALL)
+#undef CALL
+}
+
+// ---- float2 spectra (the `_f32` family, ins_f32.hip): same passes, half the bytes; tw = float2 twiddles (ins_zsolve_twiddles_f32)
+int ins_k_ownfft_xfwd_f32(const ins_grid* G, const float* src, int from_u, float* phat, int n0, int n1, int n2, const float* tw, hipStream_t s, int kxs) {
+  static const GridDev no_grid{};
+  const GridDev& g = G ? G->g : no_grid;
+  float2* out = reinterpret_cast<float2*>(phat);
+  const float2* w = reinterpret_cast<const float2*>(tw);
+#define CALL(LG) launch_xfwd32<LG>(g, src, from_u, out, n1, n2, w, kxs, s)
+  INS_POW2_SWITCH(n0, CALL)
+#undef CALL
+}
+int ins_k_ownfft_xinv_f32(const float* phat, float* pI, int n0, int n1, int n2, const float* tw, hipStream_t s, int kxs) {
+  const float2* in = reinterpret_cast<const float2*>(phat);
+  const float2* w = reinterpret_cast<const float2*>(tw);
+#define CALL(LG) launch_xinv<LG, float2>(in, pI, n1, n2, w, kxs, s)
+  INS_POW2_SWITCH(n0, CALL)
+#undef CALL
+}
+int ins_k_ownfft_y_f32(float* phat, int kxn, int n1, int n2, const float* tw, bool inverse, hipStream_t s, int kxs) {
+  float2* d = reinterpret_cast<float2*>(phat);
+  const float2* w = reinterpret_cast<const float2*>(tw);
+#define CALL(LG) launch_y<LG, float2>(d, kxn, kxs, n2, w, inverse, nullptr, s)
   INS_POW2_SWITCH(n1, CALL)
 #undef CALL
 }

@@ -1469,6 +1469,28 @@ int ins_k_spectral_solve_from_u32(ins_poisson* ps, const float* u32, hipStream_t
 }
 const double* ins_k_spectral_pI(const ins_poisson* ps) { return ps->pI; }
 
+// The same five passes on float2 spectra (the `_f32` family, ins_f32.hip): `ps` supplies the symbol vectors (double, ây in the digit-reversed order of
+// the y pass) and the grid; the float work arrays and float2 twiddles belong to the caller.  u32 != nullptr: right-hand side Ω·div(u) from the
+// float velocity field inside the x pass (periodic images); else the right-hand side is in pI32.  Solution in pI32 (unpadded).
+bool ins_zsolve_f32_supported(int nz);
+int ins_k_zsolve_f32(float* data, int nz, long long nl, const double* ax, int kxn, const double* ay, const double* az, const float* tw, double inv_n,
+                     bool zero_mean, hipStream_t s, int kxs);
+int ins_k_ownfft_xfwd_f32(const ins_grid* G, const float* src, int from_u, float* phat, int n0, int n1, int n2, const float* tw, hipStream_t s, int kxs);
+int ins_k_ownfft_xinv_f32(const float* phat, float* pI, int n0, int n1, int n2, const float* tw, hipStream_t s, int kxs);
+int ins_k_ownfft_y_f32(float* phat, int kxn, int n1, int n2, const float* tw, bool inverse, hipStream_t s, int kxs);
+bool ins_k_spectral_own3d_f32(const ins_poisson* ps) { return ins_k_spectral_own3d(ps) && ins_zsolve_f32_supported(ps->np[2]); }
+int ins_k_spectral_solve_f32(ins_poisson* ps, const float* u32, float* pI32, float* phat32, int kxs32, const float* twx, const float* twy,
+                             const float* twz, hipStream_t s) {
+  const int n0 = ps->np[0], n1 = ps->np[1], n2 = ps->np[2], kxn = ps->kmax[0];
+  int rc;
+  if ((rc = ins_k_ownfft_xfwd_f32(ps->grid, u32 ? u32 : pI32, u32 ? 1 : 0, phat32, n0, n1, n2, twx, s, kxs32))) return rc;
+  if ((rc = ins_k_ownfft_y_f32(phat32, kxn, n1, n2, twy, false, s, kxs32))) return rc;
+  const double inv_n = 1.0 / ((double)n0 * n1 * n2);
+  if ((rc = ins_k_zsolve_f32(phat32, n2, (long long)kxs32 * n1, ps->ahat[0], kxn, ps->ahat[1], ps->ahat[2], twz, inv_n, true, s, kxs32))) return rc;
+  if ((rc = ins_k_ownfft_y_f32(phat32, kxn, n1, n2, twy, true, s, kxs32))) return rc;
+  return ins_k_ownfft_xinv_f32(phat32, pI32, n0, n1, n2, twx, s, kxs32);
+}
+
 extern "C" int ins_project_f64(const ins_grid_t* G, ins_poisson_t* ps, double* u, double* p, void* stream) {
   INS_REQUIRE(G && ps && u && p, "null argument");
   INS_REQUIRE(ps->grid == G, "psolver was created for a different grid");

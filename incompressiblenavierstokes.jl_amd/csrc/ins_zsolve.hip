@@ -13,6 +13,7 @@
 // nz must be a power of two in [8, 1024]; other sizes keep the rocFFT path.
 #include <cmath>
 #include <cstdlib>
+#include <vector>
 
 #include "ins_internal.h"
 
@@ -202,31 +203,54 @@ __global__ __launch_bounds__(NT) void k_zsolve(double2* __restrict__ data, long 
 // LDS image: position n of line c at ((n ^ ((n >> 3) & 1)) * TK + c): the XOR keeps every access of the three passes conflict-free
 // for ds_read/write_b128 (pass 3 reads positions 8 g + q: without it the sixteen lanes of a b128 group would share eight slots).
 // ------------------------------------------------------------------------------------------------------------------------------
-template <bool INV>
-__device__ __forceinline__ double2 rot90(double2 a) {  // a * (-i) forward, a * (+i) inverse
-  return INV ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
+// (the three-pass kernel is a template over the complex element type C: double2, or float2 for the `_f32` family)
+template <typename C>
+struct zreal;
+template <>
+struct zreal<double2> {
+  using t = double;
+};
+template <>
+struct zreal<float2> {
+  using t = float;
+};
+template <typename C>
+__device__ __forceinline__ C zmk(typename zreal<C>::t x, typename zreal<C>::t y) {
+  C c;
+  c.x = x;
+  c.y = y;
+  return c;
 }
-template <bool INV>
-__device__ __forceinline__ void dft4(double2& x0, double2& x1, double2& x2, double2& x3) {
-  const double2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = rot90<INV>(csub(x1, x3));
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+template <bool INV, typename C>
+__device__ __forceinline__ C rot90(C a) {  // a * (-i) forward, a * (+i) inverse
+  return INV ? zmk<C>(-a.y, a.x) : zmk<C>(a.y, -a.x);
+}
+template <bool INV, typename C>
+__device__ __forceinline__ void dft4(C& x0, C& x1, C& x2, C& x3) {
+  const C t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = rot90<INV>(csub(x1, x3));
   x0 = cadd(t0, t2);
   x1 = cadd(t1, t3);
   x2 = csub(t0, t2);
   x3 = csub(t1, t3);
 }
 // y[k] = sum_n x[n] w^(nk), w = exp(-+2 pi i / R), in place, natural order in and out
-template <bool INV>
-__device__ __forceinline__ void dft3(double2& x0, double2& x1, double2& x2) {
-  constexpr double h = 0.86602540378443864676;  // sqrt(3)/2
-  const double2 t1 = cadd(x1, x2), d = csub(x1, x2);
-  const double2 t2 = make_double2(x0.x - 0.5 * t1.x, x0.y - 0.5 * t1.y);
-  const double2 t3 = INV ? make_double2(-h * d.y, h * d.x) : make_double2(h * d.y, -h * d.x);  // (-+i) sqrt(3)/2 (x1 - x2)
+template <bool INV, typename C>
+__device__ __forceinline__ void dft3(C& x0, C& x1, C& x2) {
+  using T = typename zreal<C>::t;
+  constexpr T h = (T)0.86602540378443864676;  // sqrt(3)/2
+  const C t1 = cadd(x1, x2), d = csub(x1, x2);
+  const C t2 = zmk<C>(x0.x - (T)0.5 * t1.x, x0.y - (T)0.5 * t1.y);
+  const C t3 = INV ? zmk<C>(-h * d.y, h * d.x) : zmk<C>(h * d.y, -h * d.x);  // (-+i) sqrt(3)/2 (x1 - x2)
   x0 = cadd(x0, t1);
   x1 = cadd(t2, t3);
   x2 = csub(t2, t3);
 }
-template <int R, bool INV>
-__device__ __forceinline__ void dft(double2 (&x)[R]) {
+template <int R, bool INV, typename C>
+__device__ __forceinline__ void dft(C (&x)[R]) {
+  using T = typename zreal<C>::t;
   if constexpr (R == 4) {
     dft4<INV>(x[0], x[1], x[2], x[3]);
   } else if constexpr (R == 3) {
@@ -235,12 +259,12 @@ __device__ __forceinline__ void dft(double2 (&x)[R]) {
     // even / odd thirds (radix 3 each), then the radix-2 combination with W6^k
     dft3<INV>(x[0], x[2], x[4]);
     dft3<INV>(x[1], x[3], x[5]);
-    constexpr double h = 0.86602540378443864676;
-    const double2 o1 = x[3], o2 = x[5];
+    constexpr T h = (T)0.86602540378443864676;
+    const C o1 = x[3], o2 = x[5];
     // W6^1 = (1 -+ i sqrt3)/2, W6^2 = (-1 -+ i sqrt3)/2
-    const double2 w1 = INV ? make_double2(0.5 * o1.x - h * o1.y, 0.5 * o1.y + h * o1.x) : make_double2(0.5 * o1.x + h * o1.y, 0.5 * o1.y - h * o1.x);
-    const double2 w2 = INV ? make_double2(-0.5 * o2.x - h * o2.y, -0.5 * o2.y + h * o2.x) : make_double2(-0.5 * o2.x + h * o2.y, -0.5 * o2.y - h * o2.x);
-    const double2 e0 = x[0], e1 = x[2], e2 = x[4], w0 = x[1];
+    const C w1 = INV ? zmk<C>((T)0.5 * o1.x - h * o1.y, (T)0.5 * o1.y + h * o1.x) : zmk<C>((T)0.5 * o1.x + h * o1.y, (T)0.5 * o1.y - h * o1.x);
+    const C w2 = INV ? zmk<C>((T)-0.5 * o2.x - h * o2.y, (T)-0.5 * o2.y + h * o2.x) : zmk<C>((T)-0.5 * o2.x + h * o2.y, (T)-0.5 * o2.y - h * o2.x);
+    const C e0 = x[0], e1 = x[2], e2 = x[4], w0 = x[1];
     x[0] = cadd(e0, w0);
     x[3] = csub(e0, w0);
     x[1] = cadd(e1, w1);
@@ -252,13 +276,13 @@ __device__ __forceinline__ void dft(double2 (&x)[R]) {
     // even / odd halves (radix 4 each), then the radix-2 combination with W8^k
     dft4<INV>(x[0], x[2], x[4], x[6]);
     dft4<INV>(x[1], x[3], x[5], x[7]);
-    constexpr double h = 0.70710678118654752440;
-    const double2 o1 = x[3], o2 = x[5], o3 = x[7];
+    constexpr T h = (T)0.70710678118654752440;
+    const C o1 = x[3], o2 = x[5], o3 = x[7];
     // W8^1 = (1 -+ i)/sqrt2, W8^2 = -+i, W8^3 = (-1 -+ i)/sqrt2
-    const double2 w1 = INV ? make_double2((o1.x - o1.y) * h, (o1.x + o1.y) * h) : make_double2((o1.x + o1.y) * h, (o1.y - o1.x) * h);
-    const double2 w2 = rot90<INV>(o2);
-    const double2 w3 = INV ? make_double2((-o3.x - o3.y) * h, (o3.x - o3.y) * h) : make_double2((o3.y - o3.x) * h, (-o3.x - o3.y) * h);
-    const double2 e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6], w0 = x[1];
+    const C w1 = INV ? zmk<C>((o1.x - o1.y) * h, (o1.x + o1.y) * h) : zmk<C>((o1.x + o1.y) * h, (o1.y - o1.x) * h);
+    const C w2 = rot90<INV>(o2);
+    const C w3 = INV ? zmk<C>((-o3.x - o3.y) * h, (o3.x - o3.y) * h) : zmk<C>((o3.y - o3.x) * h, (-o3.x - o3.y) * h);
+    const C e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6], w0 = x[1];
     x[0] = cadd(e0, w0);
     x[4] = csub(e0, w0);
     x[1] = cadd(e1, w1);
@@ -270,20 +294,20 @@ __device__ __forceinline__ void dft(double2 (&x)[R]) {
   }
 }
 // x[q] *= w^q (q = 1..R-1), powers by multiplication (one table read per transform); CONJ: conjugated twiddle
-template <int R, bool CONJ>
-__device__ __forceinline__ void twiddle(double2 (&x)[R], double2 w1) {
+template <int R, bool CONJ, typename C>
+__device__ __forceinline__ void twiddle(C (&x)[R], C w1) {
   if (CONJ) w1.y = -w1.y;
-  const double2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+  const C w2 = cmul(w1, w1), w3 = cmul(w2, w1);
   x[1] = cmul(x[1], w1);
   x[2] = cmul(x[2], w2);
   if constexpr (R >= 4) x[3] = cmul(x[3], w3);
   if constexpr (R == 6) {
-    const double2 w4 = cmul(w2, w2), w5 = cmul(w4, w1);
+    const C w4 = cmul(w2, w2), w5 = cmul(w4, w1);
     x[4] = cmul(x[4], w4);
     x[5] = cmul(x[5], w5);
   }
   if constexpr (R == 8) {
-    const double2 w4 = cmul(w2, w2), w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
+    const C w4 = cmul(w2, w2), w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
     x[4] = cmul(x[4], w4);
     x[5] = cmul(x[5], w5);
     x[6] = cmul(x[6], w6);
@@ -291,19 +315,20 @@ __device__ __forceinline__ void twiddle(double2 (&x)[R], double2 w1) {
   }
 }
 
-template <int LOGN, int TK, int NT>
-__global__ __launch_bounds__(NT) void k_zsolve3(double2* __restrict__ data, long long nl, const double* __restrict__ ax, int kxn,
+template <int LOGN, int TK, int NT, typename C = double2>
+__global__ __launch_bounds__(NT) void k_zsolve3(C* __restrict__ data, long long nl, const double* __restrict__ ax, int kxn,
                                                 const double* __restrict__ ay, const double* __restrict__ az,
-                                                const double2* __restrict__ tw_g, double inv_n, int zero_mean, int kxs, int skel, int ntiles) {
+                                                const C* __restrict__ tw_g, double inv_n, int zero_mean, int kxs, int skel, int ntiles) {
+  using T = typename zreal<C>::t;
   constexpr int N = LOGN >= 32 ? 3 << (LOGN & 31) : 1 << LOGN;  // size code as in ins_fft.hip: 32 + m stands for 3 * 2^m
   constexpr int R1 = N / 64, R2 = 8, R3 = 8;  // 256 = 4 x 8 x 8, 512 = 8 x 8 x 8, 192 = 3 x 8 x 8, 384 = 6 x 8 x 8
   static_assert(R1 == 4 || R1 == 8 || R1 == 3 || R1 == 6, "nz = 192, 256, 384 or 512");
   constexpr int L2 = N / R1;                  // block length of pass 2 (64)
-  extern __shared__ double2 lds_dyn[];
-  double2* buf = lds_dyn;          // [N][TK], swizzled
-  double2* tw = lds_dyn + N * TK;  // [N]
+  extern __shared__ __align__(16) unsigned char lds_raw3[];
+  C* buf = reinterpret_cast<C*>(lds_raw3);  // [N][TK], swizzled
+  C* tw = buf + N * TK;                      // [N]
   const int t = threadIdx.x;
-  auto at = [&](int n, int c) -> double2& { return buf[(n ^ ((n >> 3) & 1)) * TK + c]; };
+  auto at = [&](int n, int c) -> C& { return buf[(n ^ ((n >> 3) & 1)) * TK + c]; };
   for (int m = t; m < N; m += NT) tw[m] = tw_g[m];
   constexpr int RPI = NT / TK;  // transforms of one line column started per sweep of the workgroup
   constexpr int B1 = (N / R1 + RPI - 1) / RPI, B2 = (N / R2 + RPI - 1) / RPI, B3 = (N / R3 + RPI - 1) / RPI;  // sweeps per pass
@@ -313,7 +338,7 @@ __global__ __launch_bounds__(NT) void k_zsolve3(double2* __restrict__ data, long
   auto is_live = [&](long long line) { return line < nl && (int)(line % kxs) < kxn; };  // padding columns of a row (kx >= kxn) hold nothing
   // The workgroup is persistent: tiles blockIdx.x, blockIdx.x + gridDim.x, ...; the pass-1 loads of the next tile are issued as soon as the
   // registers are free (right after pass 1 of the current tile), so they fly during the LDS passes and the stores of the current tile.
-  double2 x1[B1][R1];
+  C x1[B1][R1];
   auto prefetch = [&](int tile) {
     const long long line = (long long)tile * TK + c;
     const bool live = is_live(line);
@@ -321,7 +346,7 @@ __global__ __launch_bounds__(NT) void k_zsolve3(double2* __restrict__ data, long
     for (int i = 0; i < B1; ++i) {
       const int j = t / TK + i * (NT / TK);
 #pragma unroll
-      for (int q = 0; q < R1; ++q) x1[i][q] = live ? data[(long long)(j + q * (N / R1)) * nl + line] : make_double2(0.0, 0.0);
+      for (int q = 0; q < R1; ++q) x1[i][q] = live ? data[(long long)(j + q * (N / R1)) * nl + line] : zmk<C>(0, 0);
     }
   };
   int tile = blockIdx.x;
@@ -354,7 +379,7 @@ __global__ __launch_bounds__(NT) void k_zsolve3(double2* __restrict__ data, long
       for (int i = 0; i < B2; ++i) {
         const int b = t / TK + i * (NT / TK), g1 = b / (L2 / R2), j = b % (L2 / R2);
         if (G2 && b >= N / R2) break;
-        double2 x[R2];
+        C x[R2];
 #pragma unroll
         for (int q = 0; q < R2; ++q) x[q] = at(g1 * L2 + j + q * (L2 / R2), c);
         dft<R2, false>(x);
@@ -368,7 +393,7 @@ __global__ __launch_bounds__(NT) void k_zsolve3(double2* __restrict__ data, long
       for (int i = 0; i < B3; ++i) {
         const int g = t / TK + i * (NT / TK);
         if (G2 && g >= N / R3) break;
-        double2 x[R3];
+        C x[R3];
 #pragma unroll
         for (int q = 0; q < R3; ++q) x[q] = at(g * R3 + q, c);
         dft<R3, false>(x);
@@ -377,7 +402,7 @@ __global__ __launch_bounds__(NT) void k_zsolve3(double2* __restrict__ data, long
 #pragma unroll
         for (int q = 0; q < R3; ++q) {
           const int k = kbase + R1 * R2 * q;
-          const double sc = (mean_line && k == 0) ? 0.0 : -inv_n / (axy + az[k]);
+          const T sc = (T)((mean_line && k == 0) ? 0.0 : -inv_n / (axy + az[k]));
           x[q].x *= sc;
           x[q].y *= sc;
         }
@@ -391,7 +416,7 @@ __global__ __launch_bounds__(NT) void k_zsolve3(double2* __restrict__ data, long
       for (int i = 0; i < B2; ++i) {
         const int b = t / TK + i * (NT / TK), g1 = b / (L2 / R2), j = b % (L2 / R2);
         if (G2 && b >= N / R2) break;
-        double2 x[R2];
+        C x[R2];
 #pragma unroll
         for (int q = 0; q < R2; ++q) x[q] = at(g1 * L2 + j + q * (L2 / R2), c);
         twiddle<R2, true>(x, tw[j * R1]);
@@ -405,7 +430,7 @@ __global__ __launch_bounds__(NT) void k_zsolve3(double2* __restrict__ data, long
 #pragma unroll
     for (int i = 0; i < B1; ++i) {
       const int j = t / TK + i * (NT / TK);
-      double2 x[R1];
+      C x[R1];
 #pragma unroll
       for (int q = 0; q < R1; ++q) x[q] = at(j + q * (N / R1), c);
       if (!skel) {
@@ -420,15 +445,15 @@ __global__ __launch_bounds__(NT) void k_zsolve3(double2* __restrict__ data, long
   }
 }
 
-template <int LOGN, int TK, int NT>
-int launch_zsolve3(double2* data, long long nl, const double* ax, int kxn, const double* ay, const double* az, const double2* tw,
+template <int LOGN, int TK, int NT, typename C = double2>
+int launch_zsolve3(C* data, long long nl, const double* ax, int kxn, const double* ay, const double* az, const C* tw,
                    double inv_n, bool zero_mean, hipStream_t s, int kxs) {
   const int ntiles = (int)((nl + TK - 1) / TK);
   constexpr int N = LOGN >= 32 ? 3 << (LOGN & 31) : 1 << LOGN;
-  constexpr size_t lds = ((size_t)N * TK + N) * sizeof(double2);
+  constexpr size_t lds = ((size_t)N * TK + N) * sizeof(C);
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    INS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_zsolve3<LOGN, TK, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    INS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_zsolve3<LOGN, TK, NT, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   // 16-line tiles (136 KB of LDS: one workgroup per CU) run persistent, one workgroup per CU walking its share of the tiles with the next
@@ -437,7 +462,7 @@ int launch_zsolve3(double2* data, long long nl, const double* ax, int kxn, const
   const int fit = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / NT));
   const long long per_cu = ins_opt(OPT_INS_ZSOLVE_WGS) > 0 ? ins_opt(OPT_INS_ZSOLVE_WGS) : (TK >= 16 ? fit : (1LL << 20));
   const unsigned nb = (unsigned)std::min<long long>(ntiles, 256LL * per_cu);
-  hipLaunchKernelGGL((k_zsolve3<LOGN, TK, NT>), dim3(nb), dim3(NT), lds, s, data, nl, ax, kxn, ay, az, tw, inv_n, zero_mean ? 1 : 0, kxs,
+  hipLaunchKernelGGL((k_zsolve3<LOGN, TK, NT, C>), dim3(nb), dim3(NT), lds, s, data, nl, ax, kxn, ay, az, tw, inv_n, zero_mean ? 1 : 0, kxs,
                      ins_opt(OPT_INS_ZSOLVE_SKEL) ? 1 : 0, ntiles);
   INS_LAUNCH_CHECK();
   return INS_OK;
@@ -499,6 +524,46 @@ int ins_zsolve_twiddles(int nz, double** out) {
   }
   *out = d;
   return INS_OK;
+}
+
+// float2 spectra (`_f32` family): the three-pass kernel with twice the lines per tile (same bytes per row segment); symbols stay double
+bool ins_zsolve_f32_supported(int nz) { return !ins_opt(OPT_INS_DISABLE_ZSOLVE) && (nz == 192 || nz == 256 || nz == 384 || nz == 512); }
+int ins_zsolve_twiddles_f32(int nz, float** out) {
+  std::vector<float> h(2 * (size_t)nz);
+  for (int m = 0; m < nz; ++m) {
+    const double a = -2.0 * M_PI * (double)m / (double)nz;
+    h[2 * m] = (float)std::cos(a);
+    h[2 * m + 1] = (float)std::sin(a);
+    if ((4 * m) % nz == 0) {
+      const int q = (4 * m) / nz;
+      const float c[4] = {1, 0, -1, 0}, sn[4] = {0, -1, 0, 1};
+      h[2 * m] = c[q];
+      h[2 * m + 1] = sn[q];
+    }
+  }
+  float* d = nullptr;
+  INS_HIP_TRY(hipMalloc(&d, h.size() * sizeof(float)));
+  if (hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(d);
+    ins_set_error("twiddle upload failed");
+    return INS_ERR_HIP;
+  }
+  *out = d;
+  return INS_OK;
+}
+int ins_k_zsolve_f32(float* data, int nz, long long nl, const double* ax, int kxn, const double* ay, const double* az, const float* tw, double inv_n,
+                     bool zero_mean, hipStream_t s, int kxs) {
+  if (kxs <= 0) kxs = kxn;
+  float2* d = reinterpret_cast<float2*>(data);
+  const float2* w = reinterpret_cast<const float2*>(tw);
+  switch (nz) {
+    case 192: return launch_zsolve3<32 + 6, 16, 256, float2>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+    case 256: return launch_zsolve3<8, 16, 256, float2>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+    case 384: return launch_zsolve3<32 + 7, 16, 256, float2>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+    case 512: return launch_zsolve3<9, 32, 512, float2>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+  }
+  ins_set_error("ins_k_zsolve_f32: unsupported nz = %d", nz);
+  return INS_ERR_UNSUPPORTED;
 }
 
 // data[kz][line] (line = ky*kxs + kx, nl = kxs * nky lines of which kx < kxn are live), in place.  kxs <= 0: kxs = kxn.
