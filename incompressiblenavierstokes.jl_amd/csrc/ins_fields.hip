@@ -416,8 +416,13 @@ __device__ __forceinline__ double lane_prev(double v) {  // lane l receives lane
   return __hiloint2double(hi, lo);
 }
 constexpr int GR_XO = 62;
-template <int OP, int R>
-__global__ __launch_bounds__(256) void k_gradient_rows(GridDev g, BoxMap L, int zc, double par, const double* __restrict__ u, double* __restrict__ out) {
+// CORRP (all-periodic boxes, extended stage loop without a gradient-subtract pass): `u` is the UNCORRECTED stage velocity (interior volumes
+// only) and pI the unpadded pressure of its projection; every volume is read through its periodic image and corrected in registers as its plane
+// arrives, u = u* - ∇p (applypressure!, operators.jl:225-233).  Lane 63's x-component would need p of a 65th column: 61 outputs per wavefront.
+template <int OP, int R, bool CORRP = false>
+__global__ __launch_bounds__(256) void k_gradient_rows(GridDev g, BoxMap L, int zc, double par, const double* __restrict__ u, double* __restrict__ out,
+                                                       const double* __restrict__ pI = nullptr) {
+  constexpr int XO = CORRP ? GR_XO - 1 : GR_XO;
   int seq = (int)(blockIdx.x >> 3);
   const int tx = seq % L.ntx;
   seq /= L.ntx;
@@ -425,22 +430,55 @@ __global__ __launch_bounds__(256) void k_gradient_rows(GridDev g, BoxMap L, int 
   if (ty >= L.nty) return;  // whole workgroup
   const int chunk = seq / L.nty_l;
   const int lane = threadIdx.x, wy = threadIdx.y;
-  const int i = g.ip_lo[0] - 1 + tx * GR_XO + lane;  // lane 0 = left halo column
+  const int i = g.ip_lo[0] - 1 + tx * XO + lane;  // lane 0 = left halo column
   const int ic = min(i, g.N[0] - 1);
   const int jb = g.ip_lo[1] + (ty * 4 + wy) * R;  // first output row of this wavefront
   const int k0 = g.ip_lo[2] + chunk * zc, k1 = min(k0 + zc, g.ip_hi[2]);
   const bool wave_on = i - lane < g.ip_hi[0] && jb < g.ip_hi[1];  // wave-uniform
-  const bool xout = lane >= 1 && lane <= GR_XO && i < g.ip_hi[0];
+  const bool xout = lane >= 1 && lane <= XO && i < g.ip_hi[0];
+  const int n0 = g.ip_hi[0] - g.ip_lo[0], n1 = g.ip_hi[1] - g.ip_lo[1], n2 = g.ip_hi[2] - g.ip_lo[2];
+  auto img = [](int idx, int lo, int n) {  // padded index -> padded index of the periodic image inside [lo, lo + n)
+    int q = idx - lo;
+    q = q < 0 ? q + n : (q >= n ? q - n : q);
+    return lo + q;
+  };
   long long rowoff[R + 2];
+  long long prow[CORRP ? R + 3 : 1];  // element offset of (row, column) inside an unpadded pI plane
 #pragma unroll
-  for (int rr = 0; rr < R + 2; ++rr) rowoff[rr] = (long long)min(jb - 1 + rr, g.N[1] - 1) * g.sx[1] + ic;
+  for (int rr = 0; rr < R + 2; ++rr)
+    rowoff[rr] = CORRP ? (long long)img(min(jb - 1 + rr, g.N[1]), g.ip_lo[1], n1) * g.sx[1] + img(min(i, g.N[0]), g.ip_lo[0], n0)
+                       : (long long)min(jb - 1 + rr, g.N[1] - 1) * g.sx[1] + ic;
+  if (CORRP) {
+#pragma unroll
+    for (int rr = 0; rr < R + 3; ++rr)
+      prow[rr] = (long long)(img(min(jb - 1 + rr, g.N[1] + 1), g.ip_lo[1], n1) - g.ip_lo[1]) * n0 + (img(min(i, g.N[0]), g.ip_lo[0], n0) - g.ip_lo[0]);
+  }
   double P[3][3][R + 2];  // [plane slot][component][row]
+  double pnext[CORRP ? R + 3 : 1];  // p of the plane after the one loaded last
+  auto load_p = [&](double (&q)[CORRP ? R + 3 : 1], int kk) {
+    const double* base = pI + (long long)(img(min(kk, g.N[2] + 1), g.ip_lo[2], n2) - g.ip_lo[2]) * n0 * n1;
+#pragma unroll
+    for (int rr = 0; rr < R + 3; ++rr) q[rr] = base[prow[rr]];
+  };
+  const double gx = g.rdxu[0][g.ip_lo[0]], gy = g.rdxu[1][g.ip_lo[1]], gz = g.rdxu[2][g.ip_lo[2]];  // CORRP: uniform box
   auto load_plane = [&](double (&Q)[3][R + 2], int kk) {
-    const double* base = u + (long long)min(kk, g.N[2] - 1) * g.sx[2];
+    const double* base = u + (long long)(CORRP ? img(min(kk, g.N[2]), g.ip_lo[2], n2) : min(kk, g.N[2] - 1)) * g.sx[2];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int rr = 0; rr < R + 2; ++rr) Q[a][rr] = base[a * g.sc + rowoff[rr]];
+    if constexpr (CORRP) {
+      double pc[R + 3];
+#pragma unroll
+      for (int rr = 0; rr < R + 3; ++rr) pc[rr] = pnext[rr];
+      load_p(pnext, kk + 1);
+#pragma unroll
+      for (int rr = 0; rr < R + 2; ++rr) {
+        Q[0][rr] -= (lane_next(pc[rr]) - pc[rr]) * gx;
+        Q[1][rr] -= (pc[rr + 1] - pc[rr]) * gy;
+        Q[2][rr] -= (pnext[rr] - pc[rr]) * gz;
+      }
+    }
   };
   // per-lane x metrics
   const double rdx_x = g.rdx[0][ic], rux1 = g.rdxu[0][ic], rux0 = g.rdxu[0][max(ic - 1, 0)];
@@ -489,6 +527,7 @@ __global__ __launch_bounds__(256) void k_gradient_rows(GridDev g, BoxMap L, int 
   }
   // three plane slots (a fourth, loading plane k + 2 during plane k, measured slower: 144 more bytes of registers per lane cost more
   // occupancy than the earlier loads gain — strain dissipation 0.207 -> 0.211 ms, smagtensor 0.449 -> 0.456 at 256^3)
+  if constexpr (CORRP) load_p(pnext, k0 - 1);
   load_plane(P[0], k0 - 1);
   load_plane(P[1], k0);
   int k = k0;
@@ -823,8 +862,26 @@ inline Launch3 ip_launch(const GridDev& g) {
 }
 
 template <int OP>
-int launch_gradient_op(const ins_grid* G, double par, const double* u, double* out, hipStream_t s) {
+int launch_gradient_op(const ins_grid* G, double par, const double* u, double* out, hipStream_t s, const double* pI = nullptr) {
   const GridDev& g = G->g;
+  if (pI) {  // uncorrected input + its pressure (all-periodic uniform 3-D boxes, the caller checks): the correcting register-row kernel
+    if constexpr (OP == 2) {
+      constexpr int R = 2;
+      const int nx = g.ip_hi[0] - g.ip_lo[0], ny = g.ip_hi[1] - g.ip_lo[1], nz = g.ip_hi[2] - g.ip_lo[2];
+      const int zc = ins_opt(OPT_INS_FIELDS_ZC) > 0 ? (int)ins_opt(OPT_INS_FIELDS_ZC) : (nz >= 128 ? 32 : (nz >= 32 ? 16 : (nz >= 8 ? 8 : nz)));
+      Launch3 l;
+      l.block = dim3(64, 4, 1);
+      l.ntx = (int)cdiv(nx, GR_XO - 1);
+      l.nty = (int)cdiv(ny, 4 * R);
+      l.nty_l = (l.nty + 7) / 8;
+      l.grid = dim3(8u * l.ntx * l.nty_l * cdiv(nz, zc), 1, 1);
+      hipLaunchKernelGGL((k_gradient_rows<OP, R, true>), l.grid, l.block, 0, s, g, BoxMap{l.ntx, l.nty, l.nty_l}, zc, par, u, out, pI);
+      INS_LAUNCH_CHECK();
+      return INS_OK;
+    }
+    ins_set_error("in-register pressure correction: stress tensor only");
+    return INS_ERR_UNSUPPORTED;
+  }
   const bool march = !ins_opt(OPT_INS_FIELDS_NO_MARCH);  // A/B switch
   if (g.D == 2) {
     if constexpr (OP != 1) {
@@ -998,6 +1055,11 @@ extern "C" int ins_gravity_f64(const ins_grid_t* G, int gdir, double a2, const d
                          g.D == 3 ? g.iu_hi[gdir][2] - g.iu_lo[gdir][2] : 1);
   INS_LAUNCH_D(k_gravity, l, as_stream(stream), gdir, a2, temp, F);
   return INS_OK;
+}
+
+// smagtensor! of u = ustar - ∇p formed in registers (ins_rk_ext.hip; all-periodic uniform 3-D boxes with at least 32 columns)
+int ins_k_smagtensor_corr(const ins_grid* G, double theta, const double* ustar, const double* pI, double* sig, hipStream_t s) {
+  return launch_gradient_op<2>(G, theta, ustar, sig, s, pI);
 }
 
 extern "C" int ins_smagtensor_f64(const ins_grid_t* G, double theta, const double* u, double* sig, void* stream) {

@@ -340,9 +340,10 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
   // One output plane.  C = plane k, Nx = plane k+1 (both complete, corrected).  As soon as a row of C has been consumed its
   // registers are re-loaded with the same row of plane `kload` (= k+2, the next plane this buffer has to hold), so the
   // prefetch of plane k+2 is in flight during the whole of plane k without a third register plane.
-  // temperature stage (EXTRA, a.tm): state carried from plane to plane
-  T Tz[EXTRA ? R : 1];      // T of plane k-1 at the output rows
-  T wwprev[EXTRA ? R : 1];  // w·diffusion(w) of plane k-1 at the output rows (zero below the first plane: operators.jl:793-807 reads a ghost of `diff`)
+  // temperature stage (EXTRA without in-kernel correction, a.tm): state carried from plane to plane
+  constexpr bool TMK = EXTRA && CORR == 0;
+  T Tz[TMK ? R : 1];      // T of plane k-1 at the output rows
+  T wwprev[TMK ? R : 1];  // w·diffusion(w) of plane k-1 at the output rows (zero below the first plane: operators.jl:793-807 reads a ghost of `diff`)
   T PzV0 = 0;               // v at the halo row of plane k-1
   T hU_prev = 0;            // packed halo columns of u, plane k-1
   auto body = [&](Plane<T, R>& C, const Plane<T, R>& Nx, TExt<T, R>& CT, const TExt<T, R>& NT, int k, int kload) {
@@ -351,11 +352,11 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
     const T ch0 = C.h[0], ch1 = C.h[1], ch2 = C.h[2];
     T sacc[3][R];
     if (FUSE) epi_load(C, k, sacc);
-    const bool tm = EXTRA && a.tm;
+    const bool tm = TMK && a.tm;
     const rsrc_t ntr = plane_rsrc(static_cast<const T*>((const void*)a.te.temp) + (long long)uplane(kload) * sz, ubytes);
-    T tacc[EXTRA ? R : 1];
+    T tacc[TMK ? R : 1];
     const T cth = CT.th;
-    if constexpr (EXTRA) {
+    if constexpr (TMK) {
       if (tm) {  // temp_out = tempstart + Σ_j coef_j ktemp_j + c_self ktemp_i: the loads fly during the flux arithmetic
         const long long pk = (long long)k * sz;
         const rsrc_t rs0 = plane_rsrc(static_cast<const T*>((const void*)a.te.tempstart) + pk, ubytes);
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
               stb(plane_rsrc(w + a.sc, ubytes), ocol, orow[rr - 1], wv);
               stb(plane_rsrc(w + 2 * a.sc, ubytes), ocol, orow[rr - 1], ww);
             }
-            if (tm) {
+            if constexpr (TMK) if (tm) {
               // ---- temperature stage at this volume.  Lower-face terms of dissipation!: the left neighbour's w_x by a wave shift — lane 0
               // takes it from the halo column x0-1, whose Laplacian is formed from wave-uniform values (columns x0-2, x0-1 of the packed
               // halo, lane 0's own column, the halo columns of planes k±1) —, the row below from the previous iteration, the plane below
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
       fyu_o = fyu;
       fyv_o = fyv;
       fyw_o = fyw;
-      if constexpr (EXTRA) {
+      if constexpr (TMK) {
         if (tm) {
           if (rr == 0) {  // v·diffusion(v) at the halo row (the row below the first output row; a ghost row of `diff` when it is row -1 of the box)
             const T Vp = prev_h(Vc, rdlane(ch1, 0));
@@ -485,6 +486,8 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
           To = CT.t[rr];
           CT.t[rr] = ldb<T>(ntr, ucol, urow[rr]);
         }
+      }
+      if constexpr (EXTRA) {
         Uo = Uc;
         Vo = Vc;
         Wo = Wc;
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
     C.h[0] = ldb<T>(n0r, uhoff, 0);
     C.h[1] = ldb<T>(n1r, uhoff, 0);
     C.h[2] = ldb<T>(n2r, uhoff, 0);
-    if constexpr (EXTRA) {
+    if constexpr (TMK) {
       if (tm) {
         hU_prev = ch0;
         CT.t[R + 1] = ldb<T>(ntr, ucol, urow[R + 1]);

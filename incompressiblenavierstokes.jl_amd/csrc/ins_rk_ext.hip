@@ -32,6 +32,7 @@ int ins_k_diffusion_overwrite(const ins_grid* G, double visc, const double* u, d
 int ins_k_diffusion_flux3d(const ins_grid* G, double visc, const double* u, double* F, bool zero_shell, hipStream_t s);
 int ins_k_momentum_rk_fused_corr(const ins_grid* G, double visc, const double* ustar_prev, const double* pI, double* k_out, const RkEpi& epi, hipStream_t s);
 int ins_k_project_periodic_solve_only(const ins_grid* G, ins_poisson* ps, const double* u, hipStream_t s);
+int ins_k_smagtensor_corr(const ins_grid* G, double theta, const double* ustar, const double* pI, double* sig, hipStream_t s);
 
 struct ins_rk_ext {
   int closure = 0;  // 0 none, 1 Smagorinsky
@@ -160,14 +161,15 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
     // velocities V_m stay in memory (in the ku arrays) and no k_j is stored or read; INS_RK_KEEP_K=1 restores the k-basis.
     bool vbasis = ns > 1 && !ins_opt(OPT_INS_RK_KEEP_K);
     for (int i = 0; vbasis && i < ns; ++i) vbasis = rk->A[i * ns + i] != 0.0;
-    // Without a closure every consumer of the stage velocity can correct it on the fly (the stage kernel as on the plain path, the temperature
-    // kernel for its two face velocities), so the gradient-subtract pass runs for the last stage only; the closure kernels need the corrected
-    // field with its ghost volumes in memory.
+    // Every consumer of the stage velocity can correct it on the fly (the stage kernel as on the plain path, the split temperature kernel for
+    // its two face velocities, the stress-tensor kernel through periodic images), so the gradient-subtract pass runs for the last stage only —
+    // except when the temperature stage rides inside the stage kernel (it has no correcting variant).
     // The temperature stage itself rides inside the stage kernel (TempEpi: T as a fourth register component, the lower-face dissipation terms
     // from the halo column / halo row / previous plane); INS_EXT_TEMP_SPLIT=1 keeps it as a kernel of its own (then without a closure the
     // gradient-subtract passes between the stages can go, see above).
     const bool tin_kernel = with_temp && !ins_opt(OPT_INS_EXT_TEMP_SPLIT);
-    const bool incorr = vbasis && !closure && !tin_kernel && !ins_opt(OPT_INS_DISABLE_INKERNEL_CORR) && g.N[0] >= 8 && g.N[1] >= 8 && g.N[2] >= 8;
+    // (with a closure and no temperature equation the stress-tensor kernel corrects on the fly as well: ins_k_smagtensor_corr)
+    const bool incorr = vbasis && !tin_kernel && !ins_opt(OPT_INS_DISABLE_INKERNEL_CORR) && g.N[0] >= 34 && g.N[1] >= 8 && g.N[2] >= 8;
     const double* in = u;
     const double* tin = temp;
     for (int i = 0; i < ns; ++i) {
@@ -177,7 +179,8 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
       double* tout = with_temp ? (last ? temp : e->tb[i & 1]) : nullptr;
       const bool corr_in = incorr && i > 0;  // `in` is the uncorrected V_{i-1}, ps->pI its pressure
       if (closure) {
-        if ((rc = ins_smagtensor_f64(G, e->theta, in, e->sigma, stream))) return rc;
+        rc = corr_in ? ins_k_smagtensor_corr(G, e->theta, in, rk->ps->pI, e->sigma, s) : ins_smagtensor_f64(G, e->theta, in, e->sigma, stream);
+        if (rc) return rc;
         if ((rc = ins_k_apply_bc_p_fields(G, e->sigma, D * (D + 1) / 2, s))) return rc;  // apply_bc_p!(σ, 0, setup)   operators.jl:1302
         if ((rc = ins_divoftensor_f64(G, e->sigma, e->E, stream))) return rc;
       }
