@@ -282,10 +282,24 @@ __global__ __launch_bounds__(256, 2) void k_momentum_flux(GridDev g, const Rec* 
       if (xout && j <= N1 - 2) {
         const long long c = i + (long long)j * N0 + (long long)k * sz;
         if constexpr (FUSE && CORR == 0) {
-          if (epi.extra) {  // the stage force is F + E (closure term, gravity: ins_rk_ext.hip); E is zero off the degrees of freedom
+          if (epi.extra) {  // the stage force is F + E (closure term: ins_rk_ext.hip); E is zero off the degrees of freedom
             fu += epi.extra[c];
             fv += epi.extra[c + g.sc];
             fw += epi.extra[c + 2 * g.sc];
+          }
+          if (epi.gtemp) {  // gravity!: F[I, gdir] += α2 avg(temp, Δ, I, gdir) on Iu[gdir] (operators.jl:914-931, avg: :59-62)
+            const int gd = epi.gdir;
+            const int I3[3] = {i, j, k};
+            bool dof = true;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) dof = dof && I3[b] >= g.iu_lo[gd][b] && I3[b] < g.iu_hi[gd][b];
+            if (dof) {
+              const double d0 = g.dx[gd][I3[gd]], d1 = g.dx[gd][I3[gd] + 1];
+              const double gv = epi.ga2 * ((d1 * epi.gtemp[c] + d0 * epi.gtemp[c + g.sx[gd]]) / (d0 + d1));
+              if (gd == 0) fu += gv;
+              if (gd == 1) fv += gv;
+              if (gd == 2) fw += gv;
+            }
           }
         }
         if (FUSE) {
@@ -612,7 +626,7 @@ int ins_k_flux64m(const ins_grid* G, double visc, const double* u, double* k_out
 int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s) {
   if (ins_flux64_supported(G)) return ins_k_flux64(G, visc, u_in, k_out, &epi, nullptr, 0, s);
   // (the non-correcting 64-wide masked kernel is opt-in: INS_FLUX64M_FIRST=1; at 256^3 the 62-wide one with 3 rows per thread is faster, 0.29 vs 0.38 ms)
-  if (ins_opt(OPT_INS_FLUX64M_FIRST) && !epi.extra && ins_flux64m_supported(G)) return ins_k_flux64m(G, visc, u_in, k_out, epi, nullptr, s);
+  if (ins_opt(OPT_INS_FLUX64M_FIRST) && !epi.extra && !epi.gtemp && ins_flux64m_supported(G)) return ins_k_flux64m(G, visc, u_in, k_out, epi, nullptr, s);
   int rc = ins_flux3d_prepare(G, visc, s);
   if (rc) return rc;
   return launch_flux_any<true>(G, u_in, k_out, epi, nullptr, 0, s);

@@ -317,10 +317,7 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
         if ((rc = ins_smagtensor_f64(G, e->theta, cur, e->sigma, stream))) return rc;
         if ((rc = ins_k_apply_bc_p_fields(G, e->sigma, D * (D + 1) / 2, s))) return rc;
         if ((rc = ins_divoftensor_f64(G, e->sigma, e->E, stream))) return rc;
-      } else {
-        INS_HIP_TRY(hipMemsetAsync(e->E + (size_t)td.gdir * G->ncell, 0, sbytes, s));
       }
-      if (with_temp && (rc = ins_gravity_f64(G, td.gdir, td.a2, tin, e->E, stream))) return rc;
       if (with_temp && td.dodissipation && (rc = ins_k_diffusion_flux3d(G, visc, cur, e->diff, false, s))) return rc;  // e->diff: shell zero since its allocation
       RkEpi epi;
       memset(&epi, 0, sizeof(epi));
@@ -343,7 +340,12 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
       epi.coef_self = dt * rk->A[i * ns + i];
       epi.ustart = (i == 0) ? nullptr : u;
       epi.ustar = out;
-      epi.extra = e->E;
+      epi.extra = closure ? e->E : nullptr;
+      if (with_temp) {  // gravity inside the stage kernel (two loads of temp per volume)
+        epi.gtemp = tin;
+        epi.ga2 = td.a2;
+        epi.gdir = td.gdir;
+      }
       if ((rc = ins_k_momentum_rk_fused(G, visc, cur, rk->ku[i], epi, s))) return rc;
       if (with_temp) {
         double coefs[INS_MAX_STAGES];
