@@ -767,6 +767,10 @@ static int flux64_dispatch(const ins_grid* G, double visc, const T* u, T* F, con
   if (!zc) {
     const bool small_plane = (long long)(g.N[0] - 2) * (g.N[1] - 2) <= 256LL * 256;
     zc = n2 >= 256 && small_plane ? 64 : (n2 >= 128 ? 32 : (n2 >= 64 ? 16 : (n2 >= 32 ? 8 : 4)));
+    // boxes below 256 planes: chunks as long as two workgroups per CU allow (128^3: 32-plane chunks are 128 workgroups for 256 CUs —
+    // 0.61 ms/step; 8-plane chunks 0.45)
+    if (n2 < 256)
+      while (zc > 4 && tiles(nw, zc) < 2 * mintiles) zc >>= 1;
   }
   if (rows != 2 && nw == 16) nw = 8;
   if (epi && (epi->extra || epi->gtemp || epi->wout || epi->tstage)) {  // one instantiation serves the extended stage loop
