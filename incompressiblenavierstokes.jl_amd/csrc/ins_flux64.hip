@@ -731,7 +731,9 @@ static int flux64_dispatch(const ins_grid* G, double visc, const T* u, T* F, con
   const int waves_x = cdiv(g.N[0] - 2, 64);
   // wavefronts side by side: 4 for 256-wide rows (2.85 vs 2.90 ms/step with 2), 2 for 512-wide ones (23.7 vs 24.3 ms/step)
   const int xwo = (corr_mode && ins_opt(OPT_INS_FLUX64_XW_CORR)) ? (int)ins_opt(OPT_INS_FLUX64_XW_CORR) : g_xw;
-  const int xw = xwo ? xwo : (waves_x >= 8 ? 2 : (waves_x >= 4 ? 4 : (waves_x >= 2 ? 2 : 1)));
+  int xw = xwo ? xwo : (waves_x >= 8 ? 2 : (waves_x >= 4 ? 4 : (waves_x >= 2 ? 2 : 1)));
+  if (!xwo)  // rows of 3 or 6 wavefronts (192, 384 columns): side-by-side counts that leave no wavefront outside the box
+    while (xw > 1 && cdiv(waves_x, xw) * xw > waves_x) xw >>= 1;
   int rows = corr_mode ? (g_rows_corr ? g_rows_corr : 2) : (g_rows ? g_rows : 4);
   rows = std::min(std::max(rows, 2), corr_mode ? 5 : 6);
   constexpr bool F32 = sizeof(T) == 4;  // the fp32 family is built for the default shapes only (2 rows correcting, 4 otherwise)
