@@ -33,6 +33,8 @@ struct ins_fdm {
   double null_s[3] = {1.0, 1.0, 1.0};   // ... and the constant its eigenvector equals
   // periodic uniform z: Fourier modes instead of the dense Vz (ins_fdm_enable_zfft)
   bool zfft = false;
+  bool zdct = false;        // uniform z between two walls: cosine modes (ins_fdm_enable_zdct), same fused pass in its DCT form
+  double* zwq = nullptr;    // e^{-iπk/2n2}, k = 0..n2/2
   double hz = 0.0;
   double* lzk = nullptr;    // λz(k), k = 0..n2/2
   double* ztw = nullptr;    // twiddles
@@ -206,6 +208,7 @@ int ins_fdm_destroy(ins_fdm* F) {
   if (F->sums) (void)hipFree(F->sums);
   if (F->lzk) (void)hipFree(F->lzk);
   if (F->ztw) (void)hipFree(F->ztw);
+  if (F->zwq) (void)hipFree(F->zwq);
   if (F->zpart) (void)hipFree(F->zpart);
   if (F->lxd) (void)hipFree(F->lxd);
   if (F->oxd) (void)hipFree(F->oxd);
@@ -338,6 +341,41 @@ int ins_fdm_enable_zfft(ins_fdm* F, double hz, const double* lam_z_host) {
   if (rc) return rc;
   F->hz = hz;
   F->zfft = true;
+  F->fold[2] = false;
+  return INS_OK;
+}
+
+// Uniform z between two walls (the pressure problem has Neumann ends there: Dirichlet or Symmetric velocity sides): the eigenvectors of the
+// factor are cos(π(2i+1)k/2n), eigenvalues -(4/hz²) sin²(πk/2n) — taken, as above, only when the host's eigenvalues are that set.  The fused
+// pass (k_fdm_z<.., DCT>) replaces the two z GEMMs and the scaling pass.
+int ins_fdm_enable_zdct(ins_fdm* F, double hz, const double* lam_z_host) {
+  const int n2 = F->n[2];
+  if (ins_opt(OPT_INS_DISABLE_FDM_ZDCT) || F->zfft || F->xfft || F->xyfft || F->D != 3 || (F->n[0] & 1) || n2 < 32 || n2 > 512 || (n2 & (n2 - 1))) return INS_OK;
+  std::vector<double> want(n2), have(lam_z_host, lam_z_host + n2), lzk(n2), wq(2 * (n2 / 2 + 1));
+  for (int k = 0; k < n2; ++k) {
+    const double sn = std::sin(M_PI * (double)k / (2.0 * n2));
+    want[k] = lzk[k] = -4.0 * sn * sn / (hz * hz);
+    if (k <= n2 / 2) {
+      wq[2 * k] = std::cos(M_PI * (double)k / (2.0 * n2));
+      wq[2 * k + 1] = -std::sin(M_PI * (double)k / (2.0 * n2));
+    }
+  }
+  std::sort(want.begin(), want.end());
+  std::sort(have.begin(), have.end());
+  const double scale = 4.0 / (hz * hz);
+  for (int k = 0; k < n2; ++k)
+    if (std::fabs(want[k] - have[k]) > 1e-9 * scale) return INS_OK;
+  const int nblk = (int)(((long long)(F->n[0] / 2) * F->n[1] + 7) / 8);
+  if (hipMalloc(&F->lzk, lzk.size() * 8) != hipSuccess || hipMemcpy(F->lzk, lzk.data(), lzk.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMalloc(&F->zwq, wq.size() * 8) != hipSuccess || hipMemcpy(F->zwq, wq.data(), wq.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMalloc(&F->zpart, (size_t)nblk * 8) != hipSuccess || hipMemset(F->zpart, 0, (size_t)nblk * 8) != hipSuccess) {
+    ins_set_error("ins_fdm_enable_zdct: allocation failed");
+    return INS_ERR_HIP;
+  }
+  int rc = ins_zsolve_twiddles(n2, &F->ztw);
+  if (rc) return rc;
+  F->hz = hz;
+  F->zdct = true;
   F->fold[2] = false;
   return INS_OK;
 }
@@ -554,13 +592,13 @@ int ins_fdm_solve(ins_fdm* F, hipStream_t s, const ins_grid* G, const double* u,
   // forward: q = (Vxᵀ ⊗ Vyᵀ ⊗ Vzᵀ) f
   if ((rc = gemm_x(true, x, y))) return rc;
   if ((rc = gemm_y(true, y, x))) return rc;
-  if (F->zfft) {  // x holds (Vxᵀ ⊗ Vyᵀ) f: the z transform, the scaling and the inverse z transform are one pass
+  if (F->zfft || F->zdct) {  // x holds (Vxᵀ ⊗ Vyᵀ) f: the z transform, the scaling and the inverse z transform are one pass
     const long long idx_xy = F->null_i[0] + (long long)n0 * F->null_i[1];
     if (F->singular)
       hipLaunchKernelGGL(k_fdm_null_z, dim3(1), dim3(64), 0, s, x, idx_xy, n01, n2, 1.0 / (F->null_s[0] * F->null_s[1] * (double)total), F->sums);
     int nb = 0;
     rc = ins_k_fdm_z(x, n0, n1, n2, F->lam[0], F->lam[1], F->lzk, F->ones[0], F->ones[1], F->hz, F->lam_tol, F->singular ? 1 : 0, F->sums + 4096,
-                     F->zpart, F->ztw, &nb, s);
+                     F->zpart, F->ztw, &nb, s, F->zdct ? F->zwq : nullptr);
     if (rc) return rc;
     if (F->singular) hipLaunchKernelGGL(k_fdm_mean_z, dim3(1), dim3(256), 0, s, F->zpart, nb, 1.0 / (double)total, F->sums);
     INS_LAUNCH_CHECK();
@@ -606,6 +644,7 @@ int ins_fdm_fold_mask(const ins_fdm* F) { return (F->fold[0] ? 1 : 0) | (F->fold
 
 // the solve starts with an x pass that can form Ω·div(u) itself (ins_fdm_solve(F, s, G, u))
 bool ins_fdm_takes_u(const ins_fdm* F) { return F->xfft || F->xyfft; }
+int ins_fdm_modes(const ins_fdm* F) { return (F->zfft ? 1 : 0) | (F->xfft ? 2 : 0) | (F->xyfft ? 4 : 0) | (F->zdct ? 8 : 0); }
 
 // device scalar mean(p[Ip]) of the last solve: the consumer of the buffer subtracts it (e'p = 0, pressure.jl:133-140); nullptr when L is regular
 const double* ins_fdm_mean(ins_fdm* F) { return F->singular ? F->sums + 4097 : nullptr; }

@@ -440,7 +440,8 @@ struct FdmZArgs {
   long long nl;
   int n0h;                // n0 / 2
   const double *lx, *ly;  // generalised eigenvalues of the x and y factors
-  const double* lz;       // λz(k), k = 0..N/2: -(4/h²) sin²(πk/N)
+  const double* lz;       // λz(k), k = 0..N/2: -(4/h²) sin²(πk/N);  DCT: k = 0..N-1: -(4/h²) sin²(πk/2N)
+  const double2* wq;      // DCT: e^{-iπk/2N}, k = 0..N/2
   const double *ox, *oy;  // Vxᵀ1, Vyᵀ1
   double h, tol;
   int singular;
@@ -448,7 +449,12 @@ struct FdmZArgs {
   double* partial;        // [gridDim.x] block partials of Σ ox oy R'[k=0] / h
 };
 
-template <int LOGN, int TK>
+// DCT (uniform z between two walls: Neumann pressure on both sides): the z eigenvectors are cos(π(2n+1)k/2N), so the same pass serves with three
+// changes (Makhoul's N-point form of the DCT-II): the line enters the FFT reordered (v[m] = x[2m], v[N-1-m] = x[2m+1]); the spectrum of a real
+// line gives its cosine coefficients as C[k] = Re y, C[N-k] = -Im y with y = e^{-iπk/2N} V[k]; after the scaling the spectrum is rebuilt as
+// V'[k] = e^{+iπk/2N} (C'[k] - i C'[N-k]) and the inverse FFT returns the reordered solution.  k = 0 is the plain sum as in the Fourier case,
+// so the singular-system bookkeeping is unchanged.
+template <int LOGN, int TK, bool DCT = false>
 __global__ __launch_bounds__(256) void k_fdm_z(FdmZArgs a, const double2* __restrict__ tw_g) {
   constexpr int N = fft_len(LOGN);
   extern __shared__ double2 lds_dyn[];
@@ -467,7 +473,11 @@ __global__ __launch_bounds__(256) void k_fdm_z(FdmZArgs a, const double2* __rest
 #pragma unroll
     for (int q = 0; q < NIT; ++q) v[q] = live ? a.data[(long long)(t / TK + q * RPT) * a.nl + line] : make_double2(0.0, 0.0);
 #pragma unroll
-    for (int q = 0; q < NIT; ++q) buf[(t / TK + q * RPT) * TK + col] = v[q];
+    for (int q = 0; q < NIT; ++q) {
+      const int z = t / TK + q * RPT;
+      const int r = DCT ? ((z & 1) ? N - 1 - (z >> 1) : (z >> 1)) : z;  // plane z -> row of the transform
+      buf[r * TK + col] = v[q];
+    }
   }
   __syncthreads();
   fft_dif<LOGN, TK, TK, 1, false>(buf, tw, t);
@@ -486,6 +496,42 @@ __global__ __launch_bounds__(256) void k_fdm_z(FdmZArgs a, const double2* __rest
     const bool self = k == 0 || k == N / 2;
     double2 A = self ? make_double2(zk.x, 0.0) : make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
     double2 B = self ? make_double2(zk.y, 0.0) : make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+    if constexpr (DCT) {
+      // cosine coefficients of the two columns at k and N-k, each with its own eigenvalue
+      const double2 w = a.wq[k];
+      const double2 ya = cmul(A, w), yb = cmul(B, w);
+      double ca[2] = {ya.x, -ya.y}, cb[2] = {yb.x, -yb.y};  // [0]: k, [1]: N - k
+      const int kk[2] = {k, N - k};
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (q == 1 && self) {  // k = 0: C[N] does not exist; k = N/2: the same coefficient
+          ca[1] = k == 0 ? 0.0 : ca[0];
+          cb[1] = k == 0 ? 0.0 : cb[0];
+          break;
+        }
+        const double lyz = a.ly[j] + a.lz[kk[q]];
+        const double la = a.lx[ia] + lyz, lb = a.lx[ib] + lyz;
+        if (a.singular) {
+          const double oa = a.ox[ia] * a.oy[j], ob = a.ox[ib] * a.oy[j];
+          if (kk[q] == 0) {
+            ca[q] -= mf * oa * (double)N;
+            cb[q] -= mf * ob * (double)N;
+          }
+          ca[q] *= fabs(la) <= a.tol ? 0.0 : 1.0 / la;
+          cb[q] *= fabs(lb) <= a.tol ? 0.0 : 1.0 / lb;
+          if (kk[q] == 0) acc += (oa * ca[q] + ob * cb[q]) / a.h;
+        } else {
+          ca[q] /= la;
+          cb[q] /= lb;
+        }
+      }
+      const double2 wc = make_double2(w.x, -w.y);
+      A = cmul(make_double2(ca[0], -ca[1]), wc);  // V'[k] = e^{+iπk/2N} (C'[k] - i C'[N-k])
+      B = cmul(make_double2(cb[0], -cb[1]), wc);
+      buf[pk * TK + c] = make_double2(inv * (A.x - B.y), inv * (A.y + B.x));
+      if (!self) buf[pm * TK + c] = make_double2(inv * (A.x + B.y), inv * (B.x - A.y));
+      continue;
+    }
     const double lyz = a.ly[j] + a.lz[k];
     const double la = a.lx[ia] + lyz, lb = a.lx[ib] + lyz;
     if (a.singular) {
@@ -514,7 +560,11 @@ __global__ __launch_bounds__(256) void k_fdm_z(FdmZArgs a, const double2* __rest
   __syncthreads();
   if (live)
 #pragma unroll
-    for (int q = 0; q < NIT; ++q) a.data[(long long)(t / TK + q * RPT) * a.nl + line] = buf[(t / TK + q * RPT) * TK + col];
+    for (int q = 0; q < NIT; ++q) {
+      const int z = t / TK + q * RPT;
+      const int r = DCT ? ((z & 1) ? N - 1 - (z >> 1) : (z >> 1)) : z;
+      a.data[(long long)z * a.nl + line] = buf[r * TK + col];
+    }
   if (a.singular) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -738,8 +788,9 @@ int ins_k_ownfft_y_packed(double* phat, double* packed, int kxn, int n1, int nzl
 
 // In-place on the real work array of the direct solver (n0 even, nz a power of two in 32..512); see k_fdm_z.  Returns the block count.
 int ins_k_fdm_z(double* data, int n0, int n1, int nz, const double* lx, const double* ly, const double* lz, const double* ox, const double* oy,
-                double h, double tol, int singular, const double* meanf, double* partial, const double* tw, int* nblk, hipStream_t s) {
+                double h, double tol, int singular, const double* meanf, double* partial, const double* tw, int* nblk, hipStream_t s, const double* dct_w) {
   FdmZArgs a;
+  a.wq = reinterpret_cast<const double2*>(dct_w);
   a.data = reinterpret_cast<double2*>(data);
   a.n0h = n0 / 2;
   a.nl = (long long)a.n0h * n1;
@@ -752,9 +803,15 @@ int ins_k_fdm_z(double* data, int n0, int n1, int nz, const double* lx, const do
 #define INS_FDMZ(LOG)                                                                                          \
   {                                                                                                             \
     const size_t lds = ((size_t)(1 << LOG) * TK + (1 << LOG)) * sizeof(double2);                                \
-    int rc = set_lds(&k_fdm_z<LOG, TK>, lds);                                                                   \
-    if (rc) return rc;                                                                                          \
-    hipLaunchKernelGGL((k_fdm_z<LOG, TK>), dim3(nb), dim3(256), lds, s, a, w);                                  \
+    if (dct_w) {                                                                                                \
+      int rc = set_lds(&k_fdm_z<LOG, TK, true>, lds);                                                           \
+      if (rc) return rc;                                                                                        \
+      hipLaunchKernelGGL((k_fdm_z<LOG, TK, true>), dim3(nb), dim3(256), lds, s, a, w);                          \
+    } else {                                                                                                    \
+      int rc = set_lds(&k_fdm_z<LOG, TK>, lds);                                                                 \
+      if (rc) return rc;                                                                                        \
+      hipLaunchKernelGGL((k_fdm_z<LOG, TK>), dim3(nb), dim3(256), lds, s, a, w);                                \
+    }                                                                                                           \
     break;                                                                                                      \
   }
   switch (nz) {

@@ -59,6 +59,7 @@ void ins_set_error(const char* fmt, ...);
   X(INS_FLUX_XW)                 \
   X(INS_FLUX_BAR)                \
   X(INS_FLUX64_62_FROM)          \
+  X(INS_DISABLE_FDM_ZDCT)        \
   X(INS_DISABLE_FDM_ZFFT)        \
   X(INS_DISABLE_FDM_XFFT)        \
   X(INS_DISABLE_FDM_XYFFT)       \
@@ -170,6 +171,7 @@ struct ins_fdm;
 int ins_fdm_create(int D, const int n[3], const double* const V[3], const double* const lam[3], int singular, ins_fdm** out);
 int ins_fdm_destroy(ins_fdm* F);
 int ins_fdm_enable_zfft(ins_fdm* F, double hz, const double* lam_z_host);
+int ins_fdm_enable_zdct(ins_fdm* F, double hz, const double* lam_z_host);
 int ins_fdm_enable_xfft(ins_fdm* F, double hx, const double* lam_x_host);
 int ins_fdm_enable_xyfft(ins_fdm* F, double hx, double hy, const double* lam_x_host, const double* lam_y_host);
 int ins_fdm_solve(ins_fdm* F, hipStream_t s, const ins_grid* G = nullptr, const double* u = nullptr, bool folded_io = false);
@@ -329,7 +331,7 @@ int ins_k_ownfft_y_packed(double* phat, double* packed, int kxn, int n1, int nzl
                           hipStream_t s);
 int ins_zsolve_twiddles(int nz, double** out);
 int ins_k_fdm_z(double* data, int n0, int n1, int nz, const double* lx, const double* ly, const double* lz, const double* ox, const double* oy,
-                double h, double tol, int singular, const double* meanf, double* partial, const double* tw, int* nblk, hipStream_t s);
+                double h, double tol, int singular, const double* meanf, double* partial, const double* tw, int* nblk, hipStream_t s, const double* dct_w = nullptr);
 int ins_k_zsolve(double* data, int nz, long long nl, const double* ax, int kxn, const double* ay, const double* az, const double* tw,
                  double inv_n, bool zero_mean, hipStream_t s, int kxs = 0);
 

@@ -1252,6 +1252,17 @@ extern "C" int ins_poisson_fdm_create(const ins_grid_t* G, const double* const* 
       return rc;
     }
   }
+  if (g.D == 3 && g.bc[2][0] != INS_BC_PERIODIC) {  // uniform z between walls: cosine modes (the enable call checks the eigenvalues it was given)
+    const ins_grid_desc_t& d = G->desc;
+    const double hz = d.dx[2][1];
+    const double ztol = 4.0 * d.N[2] * 2.220446049250313e-16 * hz;
+    bool uni = true;
+    for (int k = 1; k < d.N[2] - 1; ++k) uni = uni && std::fabs(d.dx[2][k] - hz) <= ztol;
+    if (uni && (rc = ins_fdm_enable_zdct(ps->fdm, hz, lam[2]))) {
+      ins_poisson_destroy(ps);
+      return rc;
+    }
+  }
   *out = ps;
   return INS_OK;
 }
@@ -1270,6 +1281,9 @@ extern "C" int ins_poisson_solve_f64(ins_poisson_t* ps, double* p, void* stream)
 }
 
 // experiment / test hook (not in the public header): which directions of a direct solver run as folded half-size GEMMs (bit a = direction a)
+int ins_fdm_modes(const ins_fdm* F);
+// test hook: which directions of the direct solver run in trigonometric modes (1 Fourier z, 2 Fourier x, 4 Fourier x and y, 8 cosine z)
+extern "C" int ins_dbg_fdm_modes(const ins_poisson_t* ps) { return (ps && ps->kind == POISSON_FDM) ? ins_fdm_modes(ps->fdm) : -1; }
 extern "C" int ins_dbg_fdm_fold_mask(const ins_poisson_t* ps) { return (ps && ps->kind == POISSON_FDM) ? ins_fdm_fold_mask(ps->fdm) : -1; }
 
 extern "C" int ins_poisson_last_info(const ins_poisson_t* ps, int64_t* iterations, double* residual) {

@@ -159,6 +159,11 @@ def _zperiodic(o, kind):
     if kind in ("zwall", "zopen"):  # periodic x and y, walls (or an open top) in z: the orientation of the reference's TurbulentChannel.jl
         x = (np.linspace(0.0, 2 * np.pi, 33), np.linspace(0.0, 1.0, 17), o.tanh_grid(0.0, 1.0, 11, 1.4))
         return o.make_setup(x, ((P(), P()), (P(), P()), (D(), D() if kind == "zwall" else W())), Re=100.0)
+    if kind in ("dctwalls", "dctsym", "dctopen"):  # a UNIFORM power-of-two z between walls: the fused z pass in its cosine (DCT) form
+        x = (o.cosine_grid(0.0, 1.0, 12), o.tanh_grid(0.0, 1.0, 10, 1.3), np.linspace(0.0, 0.5, 33))
+        zb = (S(), S()) if kind == "dctsym" else (D(), D((0.1, 0.0, 0.0)))
+        xb = (D(), W()) if kind == "dctopen" else (D(), D())  # dctopen: an open side makes the system regular
+        return o.make_setup(x, (xb, (D(), D((1.0, 0.0, 0.2))), zb), Re=100.0)
     bcs = {"cavity": ((D(), D()), (D(), D((1.0, 0.0, 0.2))), (P(), P())),
            "open": ((D(), W()), (S(), S()), (P(), P())),
            "xyper": ((P(), P()), (D(), D()), (P(), P())),
@@ -170,7 +175,8 @@ def _zperiodic(o, kind):
     return o.make_setup(x, bcs, Re=100.0)
 
 
-@pytest.mark.parametrize("geom", ["dirichlet2d", "dirichlet3d", "mixed3d", "periodic2d", "periodic3d", "channel3d", "z:cavity", "z:open", "z:xyper", "z:channel", "z:zwall", "z:zopen"])
+@pytest.mark.parametrize("geom", ["dirichlet2d", "dirichlet3d", "mixed3d", "periodic2d", "periodic3d", "channel3d", "z:cavity", "z:open", "z:xyper", "z:channel", "z:zwall", "z:zopen",
+                                  "z:dctwalls", "z:dctsym", "z:dctopen"])
 @pytest.mark.parametrize("consistent", [True, False])
 def test_direct_matches_oracle_direct(ins, oracle, geom, consistent):
     """psolver_direct (fast diagonalisation on rocBLAS) against the oracle's sparse-LU factorisation of laplacian_mat,
@@ -187,6 +193,10 @@ def test_direct_matches_oracle_direct(ins, oracle, geom, consistent):
     want = o.poisson(o.psolver_direct(so), f)
     solver = ins.psolver_direct(sp)
     assert solver.kind == "direct"
+    if geom.startswith("z:dct"):  # the cosine form of the fused z pass really runs
+        from ins_amd import _lib
+
+        assert _lib.load().ins_dbg_fdm_modes(solver.handle) & 8
     got = ins.to_numpy(ins.poisson(solver, ins.from_numpy(sp, f)))
     ip = tuple(slice(lo, hi) for lo, hi in g.Ip)
     assert rell2(got[ip], want[ip]) < POISSON_TOL
@@ -710,7 +720,7 @@ def test_nearly_uniform_boxes_take_the_constant_record_kernels(ins, oracle, n, L
     assert ins.max_abs_divergence(u, sp) * (L / n[0]) < 1e-11
 
 
-@pytest.mark.parametrize("kind", ["cavity", "xyper", "channel", "zwall", "zopen"])
+@pytest.mark.parametrize("kind", ["cavity", "xyper", "channel", "zwall", "zopen", "dctwalls", "dctsym", "dctopen"])
 def test_rk44_with_fourier_directions_in_the_direct_solver(ins, oracle, kind):
     """Walls / open sides in one or two directions, the others periodic and uniform: the native stage loop with the direct solver whose
     periodic directions run in Fourier modes (divergence formed inside its x pass where x is periodic) against the oracle."""
