@@ -74,7 +74,7 @@ void ins_set_error(const char* fmt, ...);
   X(INS_FLUX64M_NOBAR)           \
   X(INS_FLUX64M_XW)              \
   X(INS_FLUX64M_ROWS)            \
-  X(INS_FLUX64M_FIRST)           \
+  X(INS_FLUX64M_SKIP_FIRST)      \
   X(INS_DISABLE_FLUX64)          \
   X(INS_FLUX64_ROWS)             \
   X(INS_FLUX64_ROWS_CORR)        \
