@@ -36,6 +36,7 @@ struct FluxMArgs {
   const Rec *rx, *ry, *rz;
   int per[3];  // CORR = 3: direction read through the periodic image
   int lo[3][3], hi[3][3];  // Iu[α] = [lo[α][β], hi[α][β]) (padded indices)
+  const double* gdx;       // WT: Δ of the gravity direction (avg(temp, Δ, I, gdir), operators.jl:59-62)
   RkEpi epi;
 };
 
@@ -51,7 +52,9 @@ struct PlaneM {
   double h[3];  // packed halo columns: lane r = row r of column x0-1, lane 16+r = row r of column x0+64
 };
 
-template <int R, int XW, int CORR>
+// WT (extended stage loop on wall-bounded grids, ins_rk_ext.hip; CORR = 0): gravity from epi.gtemp is added to the stage force, and
+// w_α = u_α · diffusion(u)_α is stored to epi.wout — the diffusive part of every face flux is accumulated a second time on its own.
+template <int R, int XW, int CORR, bool WT = false>
 __global__ __launch_bounds__(256, 2) void k_flux64m(FluxMArgs a) {  // (256, 3) = 168 VGPRs + 284 B scratch measured neutral (cavity 4.27 vs 4.29 ms/step)
   constexpr unsigned EB = 8;
   constexpr int NW = 4;
@@ -186,12 +189,18 @@ __global__ __launch_bounds__(256, 2) void k_flux64m(FluxMArgs a) {  // (256, 3) 
   };
 
   double zprev[3][R];
+  double dzprev[3][WT ? R : 1];  // WT: the diffusive parts of the same fluxes
   auto zflux0 = [&](const PlaneM<R>& C, const PlaneM<R>& Nx, int k) {  // upper-face z-fluxes of the plane below the chunk
     const Rec Z = a.rz[k];
 #pragma unroll
     for (int rr = 1; rr <= R; ++rr) {
       const Rec& Y = Yr[rr];
       const double Wc = C.v[2][rr];
+      if constexpr (WT) {
+        dzprev[0][rr - 1] = (Nx.v[0][rr] - C.v[0][rr]) * Z.vo;
+        dzprev[1][rr - 1] = (Nx.v[1][rr] - C.v[1][rr]) * Z.vo;
+        dzprev[2][rr - 1] = (Nx.v[2][rr] - Wc) * Z.vs;
+      }
       zprev[0][rr - 1] = fluxm(C.v[0][rr], Nx.v[0][rr], Wc, next_h(Wc, rdlane(C.h[2], 16 + rr)), X.a2, X.b2, Z.vo);
       zprev[1][rr - 1] = fluxm(C.v[1][rr], Nx.v[1][rr], Wc, C.v[2][rr + 1], Y.a2, Y.b2, Z.vo);
       zprev[2][rr - 1] = fluxm(Wc, Nx.v[2][rr], Wc, Nx.v[2][rr], Z.a2, Z.b2, Z.vs);
@@ -267,6 +276,7 @@ __global__ __launch_bounds__(256, 2) void k_flux64m(FluxMArgs a) {  // (256, 3) 
     double sacc[3][R];
     epi_load(C, k, sacc);
     double fyu_o = 0, fyv_o = 0, fyw_o = 0;
+    double dyu_o = 0, dyv_o = 0, dyw_o = 0;
 #pragma unroll
     for (int rr = 0; rr <= R; ++rr) {
       const Rec& Y = Yr[rr];  // row rr (nominal padded index jb0 + rr)
@@ -276,6 +286,7 @@ __global__ __launch_bounds__(256, 2) void k_flux64m(FluxMArgs a) {  // (256, 3) 
       const double fyu = fluxm(Uc, C.v[0][rr + 1], Vc, Vn, X.a1, X.b1, Y.vo);
       const double fyv = fluxm(Vc, C.v[1][rr + 1], Vc, C.v[1][rr + 1], Y.a1, Y.b1, Y.vs);
       const double fyw = fluxm(Wc, C.v[2][rr + 1], Vc, Nx.v[1][rr], Z.a1, Z.b1, Y.vo);
+      const double dyu = WT ? (C.v[0][rr + 1] - Uc) * Y.vo : 0.0, dyv = WT ? (C.v[1][rr + 1] - Vc) * Y.vs : 0.0, dyw = WT ? (C.v[2][rr + 1] - Wc) * Y.vo : 0.0;
       if (rr >= 1) {
         const double Un = next_h(Uc, rdlane(ch0, 16 + rr)), Wn = next_h(Wc, rdlane(ch2, 16 + rr));
         const double fxu = fluxm(Uc, Un, Uc, Un, X.a0, X.b0, X.vs);
@@ -303,14 +314,54 @@ __global__ __launch_bounds__(256, 2) void k_flux64m(FluxMArgs a) {  // (256, 3) 
         zprev[1][rr - 1] = zv;
         zprev[2][rr - 1] = zw;
         const int j = jb0 + rr;  // padded row
-        fu = (dofx[0] && kin[0] && j >= a.lo[0][1] && j < a.hi[0][1]) ? fu : 0.0;
-        fv = (dofx[1] && kin[1] && j >= a.lo[1][1] && j < a.hi[1][1]) ? fv : 0.0;
-        fw = (dofx[2] && kin[2] && j >= a.lo[2][1] && j < a.hi[2][1]) ? fw : 0.0;
+        const bool du_ = dofx[0] && kin[0] && j >= a.lo[0][1] && j < a.hi[0][1];
+        const bool dv_ = dofx[1] && kin[1] && j >= a.lo[1][1] && j < a.hi[1][1];
+        const bool dw_ = dofx[2] && kin[2] && j >= a.lo[2][1] && j < a.hi[2][1];
+        fu = du_ ? fu : 0.0;
+        fv = dv_ ? fv : 0.0;
+        fw = dw_ ? fw : 0.0;
+        if constexpr (WT) {
+          // diffusion!(F, u) alone: the diffusive parts (up - uc)·ν/Δb of the same nine faces, differenced with the same reciprocals
+          const double dxu = (Un - Uc) * X.vs, dxv = (Vn - Vc) * X.vo, dxw = (Wn - Wc) * X.vo;
+          const double lu = (Uc - sU) * XL.vs, lv = (Vc - sV) * XL.vo, lw = (Wc - sW) * XL.vo;
+          const double dzu = (Nx.v[0][rr] - Uc) * Z.vo, dzv = (Nx.v[1][rr] - Vc) * Z.vo, dzw = (Nx.v[2][rr] - Wc) * Z.vs;
+          double Du = (dxu - prev_h(dxu, lu)) * X.rs + (dyu - dyu_o) * Y.ro + (dzu - dzprev[0][rr - 1]) * Z.ro;
+          double Dv = (dxv - prev_h(dxv, lv)) * X.ro + (dyv - dyv_o) * Y.rs + (dzv - dzprev[1][rr - 1]) * Z.ro;
+          double Dw = (dxw - prev_h(dxw, lw)) * X.ro + (dyw - dyw_o) * Y.ro + (dzw - dzprev[2][rr - 1]) * Z.rs;
+          dzprev[0][rr - 1] = dzu;
+          dzprev[1][rr - 1] = dzv;
+          dzprev[2][rr - 1] = dzw;
+          const long long pk = (long long)k * sz;
+          if (a.epi.wout && xout && jb0 + rr - 1 < n1) {
+            double* w = a.epi.wout + pk;
+            stb(plane_rsrc(w, ubytes), ocol, orow[rr - 1], du_ ? Uc * Du : 0.0);
+            stb(plane_rsrc(w + a.sc, ubytes), ocol, orow[rr - 1], dv_ ? Vc * Dv : 0.0);
+            stb(plane_rsrc(w + 2 * a.sc, ubytes), ocol, orow[rr - 1], dw_ ? Wc * Dw : 0.0);
+          }
+          if (a.epi.gtemp) {  // gravity!: F[I, gdir] += α2 avg(temp, Δ, I, gdir) on Iu[gdir] (operators.jl:914-931)
+            const int gd = a.epi.gdir;
+            const int idx = gd == 0 ? min(ci, n0 - 1) + 1 : (gd == 1 ? min(j, n1) : k);  // clamped like the store addresses (masked lanes / rows)
+            const bool dof = gd == 0 ? du_ : (gd == 1 ? dv_ : dw_);
+            const rsrc_t r0 = plane_rsrc(a.epi.gtemp + pk, ubytes), r1 = plane_rsrc(gd == 2 ? a.epi.gtemp + pk + sz : a.epi.gtemp + pk, ubytes);
+            const double t0 = ldb<double>(r0, ocol, orow[rr - 1]);
+            const double t1 = ldb<double>(r1, ocol + (gd == 0 ? EB : 0u), orow[rr - 1] + (gd == 1 ? (unsigned)N0 * EB : 0u));
+            const double d0 = a.gdx[idx], d1 = a.gdx[idx + 1];
+            const double gv = dof ? a.epi.ga2 * ((d1 * t0 + d0 * t1) / (d0 + d1)) : 0.0;
+            if (gd == 0) fu += gv;
+            if (gd == 1) fv += gv;
+            if (gd == 2) fw += gv;
+          }
+        }
         emit(rr, k, fu, fv, fw, sacc[0][rr - 1], sacc[1][rr - 1], sacc[2][rr - 1]);
       }
       fyu_o = fyu;
       fyv_o = fyv;
       fyw_o = fyw;
+      if constexpr (WT) {
+        dyu_o = dyu;
+        dyv_o = dyv;
+        dyw_o = dyw;
+      }
       // row rr of plane k is dead: its registers receive plane `kload`
       C.v[0][rr] = ldb<double>(n0r, ucol, urow[rr]);
       C.v[1][rr] = ldb<double>(n1r, ucol, urow[rr]);
@@ -369,13 +420,13 @@ __global__ __launch_bounds__(256, 2) void k_flux64m(FluxMArgs a) {  // (256, 3) 
   }
 }
 
-template <int R, int XW, int CORR>
+template <int R, int XW, int CORR, bool WT = false>
 int launchm(FluxMArgs& a, hipStream_t s) {
   a.ntx = cdiv(a.N0 - 2, 64 * XW);
   a.nty = cdiv(a.N1 - 2, (4 / XW) * R);
   a.ntz = cdiv(a.N2 - 2, a.zc);
   const unsigned nb = (unsigned)(8LL * a.ntx * ((a.nty + 7) / 8) * a.ntz);
-  hipLaunchKernelGGL((k_flux64m<R, XW, CORR>), dim3(nb), dim3(64, 4, 1), 0, s, a);
+  hipLaunchKernelGGL((k_flux64m<R, XW, CORR, WT>), dim3(nb), dim3(64, 4, 1), 0, s, a);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -392,7 +443,8 @@ bool ins_flux64m_supported(const ins_grid* G) {
 // Stage kernel with the RK epilogue; p_padded != nullptr: `u` is the previous stage's uncorrected u* (boundary data applied), corrected in registers.
 int ins_k_flux64m(const ins_grid* G, double visc, const double* u, double* k_out, const RkEpi& epi, const double* p_padded, hipStream_t s) {
   const GridDev& g = G->g;
-  if (epi.self_in != 0.0 || epi.ustart_out || epi.extra || epi.gtemp || epi.wout) {
+  const bool wt = epi.gtemp || epi.wout;  // temperature loop on wall-bounded grids: gravity in, u·diffusion(u) out
+  if (epi.self_in != 0.0 || epi.ustart_out || epi.extra || (wt && p_padded)) {
     ins_set_error("ins_k_flux64m: epilogue term not supported on stretched / masked grids");
     return INS_ERR_UNSUPPORTED;
   }
@@ -417,6 +469,7 @@ int ins_k_flux64m(const ins_grid* G, double visc, const double* u, double* k_out
       a.hi[al][be] = g.iu_hi[al][be];
     }
   a.epi = epi;
+  a.gdx = epi.gtemp ? g.dx[epi.gdir] : nullptr;
   const int n2 = g.N[2] - 2;
   const int zco = (int)ins_opt(OPT_INS_FLUX64M_ZC);
   a.zc = zco > 0 ? zco : (n2 >= 128 ? 32 : (n2 >= 32 ? 8 : 4));
@@ -432,6 +485,11 @@ int ins_k_flux64m(const ins_grid* G, double visc, const double* u, double* k_out
     if (xw == 4) return launchm<RR, 4, CC>(a, s);   \
     if (xw == 2) return launchm<RR, 2, CC>(a, s);   \
     return launchm<RR, 1, CC>(a, s);                \
+  }
+  if (wt) {
+    if (xw == 4) return launchm<2, 4, 0, true>(a, s);
+    if (xw == 2) return launchm<2, 2, 0, true>(a, s);
+    return launchm<2, 1, 0, true>(a, s);
   }
   if (corr) {
     INS_F64M(2, 3)

@@ -29,6 +29,7 @@ int ins_k_temp_stage(const ins_grid* G, double a4, double coef, const double* u,
                      const double* coefs, const double* const* ks, double c_self, double* ktemp_out, double* temp_out, hipStream_t s, const double* pI,
                      const double* diff = nullptr);
 int ins_k_diffusion_overwrite(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s);
+bool ins_flux64m_supported(const ins_grid* G);
 int ins_k_diffusion_flux3d(const ins_grid* G, double visc, const double* u, double* F, bool zero_shell, hipStream_t s);
 int ins_k_momentum_rk_fused_corr(const ins_grid* G, double visc, const double* ustar_prev, const double* pI, double* k_out, const RkEpi& epi, hipStream_t s);
 int ins_k_project_periodic_solve_only(const ins_grid* G, ins_poisson* ps, const double* u, hipStream_t s);
@@ -304,6 +305,10 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
           INS_HIP_TRY(hipMemcpyAsync(e->tb[b], temp, sbytes, hipMemcpyDeviceToDevice, s));
         }
     }
+    // Without a closure the 64-wide masked stage kernel also leaves w = u·diffusion(u) (the dissipation term of the temperature equation) from
+    // the diffusive parts of the fluxes it has in registers: no diffusion pass of its own.
+    const bool w_from_stage = with_temp && td.dodissipation && !closure && ins_flux64m_supported(G);
+    if (w_from_stage && (rc = zalloc(&e->w, vbytes, s))) return rc;  // ghost volumes stay zero (the reference's fill!(diff, 0))
     ++g_tiled_steps;
     double* cur = u;
     double* tin = temp;
@@ -318,7 +323,8 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
         if ((rc = ins_k_apply_bc_p_fields(G, e->sigma, D * (D + 1) / 2, s))) return rc;
         if ((rc = ins_divoftensor_f64(G, e->sigma, e->E, stream))) return rc;
       }
-      if (with_temp && td.dodissipation && (rc = ins_k_diffusion_flux3d(G, visc, cur, e->diff, false, s))) return rc;  // e->diff: shell zero since its allocation
+      if (with_temp && td.dodissipation && !w_from_stage && (rc = ins_k_diffusion_flux3d(G, visc, cur, e->diff, false, s)))
+        return rc;  // e->diff: shell zero since its allocation
       RkEpi epi;
       memset(&epi, 0, sizeof(epi));
       for (int j = 0; j < i; ++j) {
@@ -345,6 +351,7 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
         epi.gtemp = tin;
         epi.ga2 = td.a2;
         epi.gdir = td.gdir;
+        if (w_from_stage) epi.wout = e->w;
       }
       if ((rc = ins_k_momentum_rk_fused(G, visc, cur, rk->ku[i], epi, s))) return rc;
       if (with_temp) {
@@ -358,8 +365,8 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
         }
         bool later = false;
         for (int i2 = i + 1; i2 < ns; ++i2) later = later || rk->A[i2 * ns + i] != 0.0;
-        if ((rc = ins_k_temp_stage(G, td.a4, td.diss_coef, cur, tin, nullptr, e->tempstart, n, coefs, ks, dt * rk->A[i * ns + i],
-                                   later ? e->ktemp[i] : nullptr, tout, s, nullptr, td.dodissipation ? e->diff : nullptr)))
+        if ((rc = ins_k_temp_stage(G, td.a4, td.diss_coef, cur, tin, w_from_stage ? e->w : nullptr, e->tempstart, n, coefs, ks, dt * rk->A[i * ns + i],
+                                   later ? e->ktemp[i] : nullptr, tout, s, nullptr, td.dodissipation && !w_from_stage ? e->diff : nullptr)))
           return rc;
       }
       if ((rc = ins_k_apply_bc_u(G, out, 0, nullptr, s))) return rc;                                          // :48

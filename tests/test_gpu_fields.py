@@ -262,11 +262,29 @@ def test_fused_extended_stage_loop_matches_oracle(ins, oracle, n, what, gdir, di
         assert rell2(u3, u) < 1e-12 and rell2(temp3, temp) < 1e-12
 
 
-@pytest.mark.parametrize("geom,kind,closure", [("dirichlet3d", "dirichlet", False), ("mixed3d", "symmetric", True), ("dirichlet3d", None, True)])
-def test_tiled_extended_stage_loop_on_wall_bounded_grids(ins, oracle, geom, kind, closure):
+def _walls_wide(o):  # stretched, walls everywhere; 72 volumes in x: a full and a partial wavefront of the 64-wide masked stage kernel
+    x = (o.tanh_grid(0.0, 1.0, 72, 1.2), o.cosine_grid(0.0, 1.0, 12), o.tanh_grid(0.0, 0.5, 10, 1.1))
+    bc = (o.DirichletBC(), o.DirichletBC())
+    return o.make_setup(x, (bc, bc, bc), Re=1000.0)
+
+
+def _channel_wide(o):  # periodic x (three wavefronts), walls in y, symmetric / outflow z
+    x = (np.linspace(0.0, 2.0, 137), o.tanh_grid(0.0, 1.0, 10, 1.5), o.cosine_grid(0.0, 0.8, 9))
+    bcs = ((o.PeriodicBC(), o.PeriodicBC()), (o.DirichletBC(), o.DirichletBC()), (o.SymmetricBC(), o.PressureBC()))
+    return o.make_setup(x, bcs, Re=1000.0)
+
+
+WIDE = {"walls_wide": _walls_wide, "channel_wide": _channel_wide}
+
+
+@pytest.mark.parametrize("geom,kind,closure,gdir", [("dirichlet3d", "dirichlet", False, 2), ("mixed3d", "symmetric", True, 2), ("dirichlet3d", None, True, 2),
+                                                    ("walls_wide", "dirichlet", False, 2), ("walls_wide", "symmetric", False, 1),
+                                                    ("channel_wide", "dirichlet", False, 0), ("channel_wide", "symmetric", True, 1)])
+def test_tiled_extended_stage_loop_on_wall_bounded_grids(ins, oracle, geom, kind, closure, gdir):
     """Wall-bounded / stretched 3-D grids: the extended loop on the tiled stage kernel (closure force + gravity as one extra field inside it, one
     temperature kernel per stage, diffusion(u) from the face-flux kernel with zero-weight records; csrc/ins_rk_ext.hip) against the oracle's
-    loop, and against the reference's kernel sequence on the device (INS_DISABLE_EXT_FUSED)."""
+    loop, and against the reference's kernel sequence on the device (INS_DISABLE_EXT_FUSED).  On rows of 66 volumes and more and without a
+    closure the 64-wide masked stage kernel takes gravity and leaves u·diffusion(u) itself (csrc/ins_flux64m.hip, WT), every gravity direction."""
     import ctypes
 
     from ins_amd import _lib
@@ -276,8 +294,8 @@ def test_tiled_extended_stage_loop_on_wall_bounded_grids(ins, oracle, geom, kind
     lib.ins_dbg_ext_tiled_steps.restype = ctypes.c_longlong
 
     def run(fused):
-        so = GEOMS[geom](o)
-        sp = with_temperature(ins, o, so, kind, gdir=2) if kind else mirror(ins, so, o)
+        so = (WIDE[geom] if geom in WIDE else GEOMS[geom])(o)
+        sp = with_temperature(ins, o, so, kind, gdir=gdir) if kind else mirror(ins, so, o)
         if kind:
             so.Re = sp.Re = 1.0 / so.temperature.a1
         if closure:
