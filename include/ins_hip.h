@@ -238,6 +238,10 @@ int ins_gravity_f64(const ins_grid_t* grid, int gdir, double a2, const double* t
 int ins_smagtensor_f64(const ins_grid_t* grid, double theta, const double* u, double* sigma, void* stream);
 /* divoftensor!(s, σ, setup)                operators.jl:1203-1236 (writes Iu[α]) */
 int ins_divoftensor_f64(const ins_grid_t* grid, const double* sigma, double* s, void* stream);
+/* smagorinsky_closure(setup)(u, θ) = divoftensor(apply_bc_p(smagtensor(u, θ)))   operators.jl:1284-1300, the three steps above as one call.
+ * All-periodic uniform 3-D boxes: one kernel, the stress stays in registers (sigma may be NULL); other grids: the three kernels with `sigma`
+ * (D(D+1)/2 scalar fields) as scratch.  Writes the degrees of freedom of s. */
+int ins_smagorinsky_force_f64(const ins_grid_t* grid, double theta, const double* u, double* sigma, double* s, void* stream);
 /* tensorbasis!(B, V, u, setup)            tensorbasis.jl:16-72 (writes Ip): nb, nv = 3, 2 (2-D) or 11, 5 (3-D).  B is nb·D·D scalar fields,
  * element (a, b) of basis tensor ib at field index ib·D·D + a + D·b (the SMatrix' column-major order); V is nv scalar fields. */
 int ins_tensorbasis_f64(const ins_grid_t* grid, const double* u, double* B, double* V, void* stream);

@@ -70,6 +70,9 @@ void ins_set_error(const char* fmt, ...);
   X(INS_FIELDS_ZC)               \
   X(INS_DISABLE_FLUX2D)          \
   X(INS_DISABLE_FLUX64M)         \
+  X(INS_DISABLE_SMAGFORCE)       \
+  X(INS_SMAGFORCE_ZC)            \
+  X(INS_SMAGFORCE_BAR)         \
   X(INS_FLUX64M_ZC)              \
   X(INS_FLUX64M_NOBAR)           \
   X(INS_FLUX64M_XW)              \

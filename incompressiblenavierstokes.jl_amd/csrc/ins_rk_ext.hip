@@ -30,6 +30,8 @@ int ins_k_temp_stage(const ins_grid* G, double a4, double coef, const double* u,
                      const double* diff = nullptr);
 int ins_k_diffusion_overwrite(const ins_grid* G, double visc, const double* u, double* F, hipStream_t s);
 bool ins_flux64m_supported(const ins_grid* G);
+bool ins_smagforce_supported(const ins_grid* G);
+int ins_k_smagforce(const ins_grid* G, double theta, const double* u, const double* pI, double* sout, hipStream_t s);
 int ins_k_diffusion_flux3d(const ins_grid* G, double visc, const double* u, double* F, bool zero_shell, hipStream_t s);
 int ins_k_momentum_rk_fused_corr(const ins_grid* G, double visc, const double* ustar_prev, const double* pI, double* k_out, const RkEpi& epi, hipStream_t s);
 int ins_k_project_periodic_solve_only(const ins_grid* G, ins_poisson* ps, const double* u, hipStream_t s);
@@ -170,6 +172,9 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
     // gradient-subtract passes between the stages can go, see above).
     const bool tin_kernel = with_temp && !ins_opt(OPT_INS_EXT_TEMP_SPLIT);
     // (with a closure and no temperature equation the stress-tensor kernel corrects on the fly as well: ins_k_smagtensor_corr)
+    // The closure force as one kernel (ins_smagforce.hip: the stress never leaves the registers; it corrects on the fly like the stress-tensor
+    // kernel, from the uncorrected stage velocity and its pressure)
+    const bool smag1 = closure && ins_smagforce_supported(G);
     const bool incorr = vbasis && !tin_kernel && !ins_opt(OPT_INS_DISABLE_INKERNEL_CORR) && g.N[0] >= 34 && g.N[1] >= 8 && g.N[2] >= 8;
     const double* in = u;
     const double* tin = temp;
@@ -179,7 +184,9 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
       double* corrected = (last || incorr) ? out : rk->ub[i & 1];          // what the projection leaves (K4 route: with ghost volumes)
       double* tout = with_temp ? (last ? temp : e->tb[i & 1]) : nullptr;
       const bool corr_in = incorr && i > 0;  // `in` is the uncorrected V_{i-1}, ps->pI its pressure
-      if (closure) {
+      if (smag1) {
+        if ((rc = ins_k_smagforce(G, e->theta, in, corr_in ? rk->ps->pI : nullptr, e->E, s))) return rc;
+      } else if (closure) {
         rc = corr_in ? ins_k_smagtensor_corr(G, e->theta, in, rk->ps->pI, e->sigma, s) : ins_smagtensor_f64(G, e->theta, in, e->sigma, stream);
         if (rc) return rc;
         if ((rc = ins_k_apply_bc_p_fields(G, e->sigma, D * (D + 1) / 2, s))) return rc;  // apply_bc_p!(σ, 0, setup)   operators.jl:1302

@@ -385,14 +385,12 @@ def smagorinsky_closure(setup):
     σ = tensorfield(setup)
     s = vectorfield(setup)
     D = setup.grid.dimension
-    ncell = int(np.prod(setup.grid.N))
 
     def closure(u, θ):
-        smagtensor_(σ, u, θ, setup)
-        base = setup.ptr(σ, D * (D + 1) // 2).value
-        for q in range(D * (D + 1) // 2):  # apply_bc_p!(σ, 0, setup): every component is a pressure-point scalar
-            _lib.call("ins_apply_bc_p_f64", setup.handle, C.c_void_p(base + 8 * ncell * q), setup.stream)
-        return divoftensor_(s, σ, setup)
+        # smagtensor! -> apply_bc_p!(σ) -> divoftensor! behind one entry point: a single kernel on all-periodic uniform 3-D boxes
+        # (csrc/ins_smagforce.hip), the three kernels with σ as scratch elsewhere
+        _lib.call("ins_smagorinsky_force_f64", setup.handle, float(θ), setup.ptr(u, True), setup.ptr(σ, D * (D + 1) // 2), setup.ptr(s, True), setup.stream)
+        return s
 
     closure._ins_closure, closure._ins_setup = "smagorinsky", setup  # lets timestep_ run it inside the native stage loop (ins_rk_set_closure)
     return closure

@@ -387,14 +387,10 @@ function smagorinsky_closure(setup::ROCSetup)
 end
 function (m::HipSmagorinsky)(u, θ)
     (; setup, σ, s) = m
-    D = setup.grid.dimension()
-    ns = D * (D + 1) ÷ 2
-    ncell = prod(setup.grid.N)
-    check(ccall((:ins_smagtensor_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), θ, pointer(u), pointer(σ), stream()))
-    for q = 0:ns-1   # apply_bc_p!(σ, 0, setup) component by component (operators.jl:1296)
-        check(ccall((:ins_apply_bc_p_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), pointer(σ) + 8 * ncell * q, stream()))
-    end
-    check(ccall((:ins_divoftensor_f64, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}), handle(setup), pointer(σ), pointer(s), stream()))
+    # smagtensor! -> apply_bc_p!(σ) -> divoftensor! (operators.jl:1284-1300) behind one entry point: one kernel on all-periodic uniform 3-D
+    # boxes (the stress stays in registers), the three kernels with σ as scratch elsewhere
+    check(ccall((:ins_smagorinsky_force_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                handle(setup), θ, pointer(u), pointer(σ), pointer(s), stream()))
     s
 end
 # observespectrum: shells from spectral_stuff (host), everything else on the device

@@ -121,7 +121,30 @@ def test_temperature_operators_match_oracle(ins, oracle, geom, kind):
     assert np.array_equal(ins.to_numpy(ins.temperaturefield(sp, f, 0.3)), o.temperaturefield(so, f, 0.3))
 
 
-@pytest.mark.parametrize("geom", ["periodic2d", "periodic3d", "dirichlet3d", "mixed3d"])
+@pytest.mark.parametrize("n", [(136, 20, 37), (64, 9, 4), (61, 16, 70), (5, 4, 6)])
+def test_one_kernel_closure_force_matches_the_three_kernel_sequence(ins, n):
+    """All-periodic uniform 3-D boxes: smagorinsky_closure as one kernel (csrc/ins_smagforce.hip: stress in registers, periodic images instead of
+    the ghost fill of σ) against smagtensor! -> apply_bc_p! -> divoftensor! on the device (INS_DISABLE_SMAGFORCE), on boxes that reach partial
+    wavefront windows (60 outputs each), partial row groups, several z-chunks and boxes smaller than one window (columns wrap more than once)."""
+    import torch
+
+    from ins_amd import _lib
+
+    x = tuple(np.linspace(0.0, L, ni + 1) for ni, L in zip(n, (1.0, 0.7, 1.3)))
+    sp = ins.Setup(x=x, Re=1000.0)
+    u = ins.apply_bc_u(ins.from_numpy(sp, fx.randn_field(sp.grid.N + (3,), 5)), 0.0, sp)
+    m = ins.smagorinsky_closure(sp)
+    one = ins.to_numpy(m(u, 0.17)).copy()
+    with _lib.options(INS_DISABLE_SMAGFORCE=1):
+        three = ins.to_numpy(m(u, 0.17)).copy()
+    assert np.max(np.abs(three)) > 0 and relmax(one, three) < OP_TOL
+    for zc in (4, 8):  # z-chunks shorter than the default
+        with _lib.options(INS_SMAGFORCE_ZC=zc):
+            assert relmax(ins.to_numpy(m(u, 0.17)), three) < OP_TOL
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("geom", ["periodic2d", "periodic3d", "periodic3d_wide", "dirichlet3d", "mixed3d"])
 def test_smagorinsky_closure_matches_oracle(ins, oracle, geom):
     o = oracle
     so = GEOMS[geom](o)
@@ -260,6 +283,9 @@ def test_fused_extended_stage_loop_matches_oracle(ins, oracle, n, what, gdir, di
     if temp is not None:  # the temperature stage as a kernel of its own (and, without a closure, no gradient-subtract pass between the stages)
         _, u3, temp3 = run(True, INS_EXT_TEMP_SPLIT=1)
         assert rell2(u3, u) < 1e-12 and rell2(temp3, temp) < 1e-12
+    if theta is not None:  # the closure force as the reference's three kernels instead of one (csrc/ins_smagforce.hip; with / without correction on the fly)
+        _, u4, temp4 = run(True, INS_DISABLE_SMAGFORCE=1)
+        assert rell2(u4, u) < 1e-12 and (temp is None or rell2(temp4, temp) < 1e-12)
 
 
 def _walls_wide(o):  # stretched, walls everywhere; 72 volumes in x: a full and a partial wavefront of the 64-wide masked stage kernel
