@@ -161,8 +161,8 @@ __device__ __forceinline__ double strain_norm2(const double (&G)[D][D]) {  // Σ
   return ss;
 }
 
-// middle eigenvalue of S² + R² (operators.jl:1484-1488): closed form for a symmetric 3x3 matrix (trigonometric solution of the
-// characteristic cubic) plus one Newton step
+// middle eigenvalue of S² + R² (operators.jl:1484-1488): the characteristic cubic of a symmetric 3x3 matrix in its depressed form, the middle
+// root by Newton on a well-conditioned substitute equation, plus one Newton step on the determinant
 __device__ __forceinline__ double eig2_of(const double (&G)[3][3]) {
   double S[3][3], R[3][3], M[3][3];
 #pragma unroll
@@ -190,11 +190,21 @@ __device__ __forceinline__ double eig2_of(const double (&G)[3][3]) {
   const double b01 = M[0][1] * ip, b02 = M[0][2] * ip, b12 = M[1][2] * ip;
   double r = (b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02)) / 2;
   r = fmin(1.0, fmax(-1.0, r));
-  const double phi = acos(r) / 3;
-  const double e1 = q + 2 * p * cos(phi);                             // largest
-  const double e3 = q + 2 * p * cos(phi + 2.0943951023931954923084);  // smallest (phi + 2π/3)
-  double e2 = 3 * q - e1 - e3;
-  // one Newton step on det(M - λ) = 0: the arccosine loses digits when two eigenvalues are close to each other
+  // The eigenvalues are q + 2p x over the roots of 4x³ - 3x = r; the middle one is x = ∓(1/2 - δ) for r ≷ 0 with δ in [0, 1/2] the root of
+  // δ²(6 - 4δ) = 1 - |r|.  Newton on that (quadratic also at the double root δ -> 0, where it is the iteration of a square root) from
+  // δ0 = sqrt(c / (6 - 4 sqrt(c/6))) reaches double precision in three steps (reciprocals from v_rcp_f64: their error scales the shrinking
+  // correction) — no arccosine and no cosines: this kernel was bound by them (0.36 ms at 256³, tools/fields_bench.py).
+  const double c = 1.0 - fabs(r);
+  double dl = sqrt(c / (6.0 - 4.0 * sqrt(c * (1.0 / 6.0))));
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const double h = (6.0 - 4.0 * dl) * dl * dl - c;
+    dl -= h * __builtin_amdgcn_rcp(12.0 * dl * (1.0 - dl));
+  }
+  dl = c > 0.0 ? dl : 0.0;
+  const double xm = r >= 0.0 ? dl - 0.5 : 0.5 - dl;
+  double e2 = q + 2 * p * xm;
+  // one Newton step on det(M - λ) = 0: 1 - |r| loses digits when two eigenvalues are close to each other
   const double a00 = M[0][0] - e2, a11 = M[1][1] - e2, a22 = M[2][2] - e2;
   const double m0 = a11 * a22 - M[1][2] * M[1][2], m1 = a00 * a22 - M[0][2] * M[0][2], m2 = a00 * a11 - M[0][1] * M[0][1];
   const double det = a00 * m0 - M[0][1] * (M[0][1] * a22 - M[1][2] * M[0][2]) + M[0][2] * (M[0][1] * M[1][2] - a11 * M[0][2]);
@@ -420,9 +430,11 @@ constexpr int GR_XO = 62;
 // only) and pI the unpadded pressure of its projection; every volume is read through its periodic image and corrected in registers as its plane
 // arrives, u = u* - ∇p (applypressure!, operators.jl:225-233).  Lane 63's x-component would need p of a 65th column: 61 outputs per wavefront.
 template <int OP, int R, bool CORRP = false>
-__global__ __launch_bounds__(256) void k_gradient_rows(GridDev g, BoxMap L, int zc, double par, const double* __restrict__ u, double* __restrict__ out,
+__global__ __launch_bounds__(256) void k_gradient_rows(GridDev g, BoxMap L, int zc_, double par, const double* __restrict__ u, double* __restrict__ out,
                                                        const double* __restrict__ pI = nullptr) {
   constexpr int XO = CORRP ? GR_XO - 1 : GR_XO;
+  const bool bar = zc_ > 0;  // zc_ < 0: no barrier per plane (INS_FIELDS_NOBAR)
+  const int zc = bar ? zc_ : -zc_;
   int seq = (int)(blockIdx.x >> 3);
   const int tx = seq % L.ntx;
   seq /= L.ntx;
@@ -522,7 +534,7 @@ __global__ __launch_bounds__(256) void k_gradient_rows(GridDev g, BoxMap L, int 
     }
   };
   if (!wave_on) {  // keeps the workgroup's barrier count
-    for (int k = k0; k < k1; ++k) __builtin_amdgcn_s_barrier();
+    for (int k = k0; bar && k < k1; ++k) __builtin_amdgcn_s_barrier();
     return;
   }
   // three plane slots (a fourth, loading plane k + 2 during plane k, measured slower: 144 more bytes of registers per lane cost more
@@ -532,15 +544,15 @@ __global__ __launch_bounds__(256) void k_gradient_rows(GridDev g, BoxMap L, int 
   load_plane(P[1], k0);
   int k = k0;
   while (true) {  // rotation unrolled so that every register index is static
-    __builtin_amdgcn_s_barrier();
+    if (bar) __builtin_amdgcn_s_barrier();
     load_plane(P[2], k + 1);
     body(P[0], P[1], P[2], k);
     if (++k >= k1) break;
-    __builtin_amdgcn_s_barrier();
+    if (bar) __builtin_amdgcn_s_barrier();
     load_plane(P[0], k + 1);
     body(P[1], P[2], P[0], k);
     if (++k >= k1) break;
-    __builtin_amdgcn_s_barrier();
+    if (bar) __builtin_amdgcn_s_barrier();
     load_plane(P[1], k + 1);
     body(P[2], P[0], P[1], k);
     if (++k >= k1) break;
@@ -740,7 +752,9 @@ __global__ __launch_bounds__(256) void k_divoftensor(GridDev g, BoxMap L, const 
 // plane for 3 R results (R = 4: 2.4 loads per result; the plain kernel issues 10 per result and ran at the vector-L1 rate: 0.68 ms at 256³).
 // Same expressions in the same order as k_divoftensor.  Needs every DOF inside [1, N - 1) (no PressureBC side: the host checks).
 template <int R>
-__global__ __launch_bounds__(256) void k_divoftensor_rows(GridDev g, BoxMap L, int zc, const double* __restrict__ sig, double* __restrict__ s) {
+__global__ __launch_bounds__(256) void k_divoftensor_rows(GridDev g, BoxMap L, int zc_, const double* __restrict__ sig, double* __restrict__ s) {
+  const bool bar = zc_ > 0;  // zc_ < 0: no barrier per plane (INS_FIELDS_NOBAR)
+  const int zc = bar ? zc_ : -zc_;
   int seq = (int)(blockIdx.x >> 3);
   const int tx = seq % L.ntx;
   seq /= L.ntx;
@@ -755,7 +769,7 @@ __global__ __launch_bounds__(256) void k_divoftensor_rows(GridDev g, BoxMap L, i
   const int k0 = 1 + chunk * zc, k1 = min(k0 + zc, N2 - 1);
   const bool wave_on = i - lane < N0 - 1 && jb < N1 - 1;  // wave-uniform
   if (!wave_on) {  // keeps the workgroup's barrier count
-    for (int k = k0; k < k1; ++k) __builtin_amdgcn_s_barrier();
+    for (int k = k0; bar && k < k1; ++k) __builtin_amdgcn_s_barrier();
     return;
   }
   const bool xout = lane >= 1 && lane <= GR_XO && i < N0 - 1;
@@ -809,7 +823,7 @@ __global__ __launch_bounds__(256) void k_divoftensor_rows(GridDev g, BoxMap L, i
   load_upper(k0);
   rotate();
   for (int k = k0; k < k1; ++k) {
-    __builtin_amdgcn_s_barrier();  // the y-stacked wavefronts stay on one plane: their shared halo rows are cache hits
+    if (bar) __builtin_amdgcn_s_barrier();  // the y-stacked wavefronts stay on one plane: their shared halo rows are cache hits
     load_upper(k + 1);
     load_own(k);
     const double ruz = g.rdxu[2][k], rdx_z = g.rdx[2][k];
@@ -888,20 +902,21 @@ int launch_gradient_op(const ins_grid* G, double par, const double* u, double* o
       Launch3 l = ip_launch(g);
       hipLaunchKernelGGL((k_gradient_op<2, OP>), l.grid, l.block, 0, s, g, BoxMap{l.ntx, l.nty, l.nty_l}, par, u, out);
     }
-  } else if ((OP != 1 || ins_opt(OPT_INS_FIELDS_ROWS) >= 2) && ins_opt(OPT_INS_FIELDS_ROWS) >= 0 && g.ip_hi[0] - g.ip_lo[0] >= 32 && g.N[2] >= 4) {
+  } else if (ins_opt(OPT_INS_FIELDS_ROWS) >= 0 && g.ip_hi[0] - g.ip_lo[0] >= 32 && g.N[2] >= 4) {
     // register rows + DPP (INS_FIELDS_ROWS=-1: the older kernels).  256^3: strain dissipation 0.282 -> 0.207 ms, smagtensor 0.460 -> 0.449;
-    // eig2 (its arithmetic dominates: 0.362 plain, 0.453 here) keeps the plain kernel
+    // eig2 0.362 (plain kernel, arccosine form) -> 0.339 (plain, Newton form of eig2_of) -> 0.313 here
     // rows per work-item: 2 (with 4 rows the stress-tensor kernel needs all 256 VGPRs and runs one wavefront per SIMD); INS_FIELDS_ROWS = 2, 3, 4 overrides
     const int ro = (int)ins_opt(OPT_INS_FIELDS_ROWS);
-    const int R = (ro >= 2 && ro <= 4) ? ro : 2;  // 256^3: strain dissipation 0.202 (4 rows) -> 0.186 ms, smagtensor 0.45 -> 0.33; eig2 (only with INS_FIELDS_ROWS set) is slower here: 0.40-0.47 vs 0.36 plain
+    const int R = (ro >= 2 && ro <= 4) ? ro : 2;  // 256^3: strain dissipation 0.202 (4 rows) -> 0.186 ms, smagtensor 0.45 -> 0.33
     const int nx = g.ip_hi[0] - g.ip_lo[0], ny = g.ip_hi[1] - g.ip_lo[1], nz = g.ip_hi[2] - g.ip_lo[2];
-    const int zc = ins_opt(OPT_INS_FIELDS_ZC) > 0 ? (int)ins_opt(OPT_INS_FIELDS_ZC) : (nz >= 128 ? 32 : (nz >= 32 ? 16 : (nz >= 8 ? 8 : nz)));
+    const int zca = ins_opt(OPT_INS_FIELDS_ZC) > 0 ? (int)ins_opt(OPT_INS_FIELDS_ZC) : (nz >= 128 ? 32 : (nz >= 32 ? 16 : (nz >= 8 ? 8 : nz)));
+    const int zc = ins_opt(OPT_INS_FIELDS_NOBAR) ? -zca : zca;
     Launch3 l;
     l.block = dim3(64, 4, 1);
     l.ntx = (int)cdiv(nx, GR_XO);
     l.nty = (int)cdiv(ny, 4 * R);
     l.nty_l = (l.nty + 7) / 8;
-    l.grid = dim3(8u * l.ntx * l.nty_l * cdiv(nz, zc), 1, 1);
+    l.grid = dim3(8u * l.ntx * l.nty_l * cdiv(nz, zca), 1, 1);
     if (R == 2)
       hipLaunchKernelGGL((k_gradient_rows<OP, 2>), l.grid, l.block, 0, s, g, BoxMap{l.ntx, l.nty, l.nty_l}, zc, par, u, out);
     else if (R == 3)
@@ -1083,7 +1098,7 @@ extern "C" int ins_divoftensor_f64(const ins_grid_t* G, const double* sig, doubl
     l.nty = (int)cdiv(ny, 4 * R);
     l.nty_l = (l.nty + 7) / 8;
     l.grid = dim3(8u * l.ntx * l.nty_l * cdiv(nz, zc), 1, 1);
-    hipLaunchKernelGGL((k_divoftensor_rows<R>), l.grid, l.block, 0, as_stream(stream), g, BoxMap{l.ntx, l.nty, l.nty_l}, zc, sig, s);
+    hipLaunchKernelGGL((k_divoftensor_rows<R>), l.grid, l.block, 0, as_stream(stream), g, BoxMap{l.ntx, l.nty, l.nty_l}, ins_opt(OPT_INS_FIELDS_NOBAR) ? -zc : zc, sig, s);
     INS_LAUNCH_CHECK();
     return INS_OK;
   }

@@ -67,6 +67,7 @@ void ins_set_error(const char* fmt, ...);
   X(INS_OWNFFT_POW2_ONLY)        \
   X(INS_FIELDS_NO_MARCH)         \
   X(INS_FIELDS_ROWS)             \
+  X(INS_FIELDS_NOBAR)            \
   X(INS_FIELDS_ZC)               \
   X(INS_DISABLE_FLUX2D)          \
   X(INS_DISABLE_FLUX64M)         \

@@ -283,7 +283,7 @@ def test_fused_extended_stage_loop_matches_oracle(ins, oracle, n, what, gdir, di
     if temp is not None:  # the temperature stage as a kernel of its own (and, without a closure, no gradient-subtract pass between the stages)
         _, u3, temp3 = run(True, INS_EXT_TEMP_SPLIT=1)
         assert rell2(u3, u) < 1e-12 and rell2(temp3, temp) < 1e-12
-    if theta is not None:  # the closure force as the reference's three kernels instead of one (csrc/ins_smagforce.hip; with / without correction on the fly)
+    if what in ("smag", "both"):  # the closure force as the reference's three kernels instead of one (csrc/ins_smagforce.hip; with / without correction on the fly)
         _, u4, temp4 = run(True, INS_DISABLE_SMAGFORCE=1)
         assert rell2(u4, u) < 1e-12 and (temp is None or rell2(temp4, temp) < 1e-12)
 
