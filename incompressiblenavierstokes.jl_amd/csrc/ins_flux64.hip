@@ -737,7 +737,7 @@ static int flux64_dispatch(const ins_grid* G, double visc, const T* u, T* F, con
   int rows = corr_mode ? (g_rows_corr ? g_rows_corr : 2) : (g_rows ? g_rows : 4);
   rows = std::min(std::max(rows, 2), corr_mode ? 5 : 6);
   constexpr bool F32 = sizeof(T) == 4;  // the fp32 family is built for the default shapes only (2 rows correcting, 4 otherwise)
-  if (F32) rows = corr_mode ? 2 : 4;
+  if (F32) rows = corr_mode ? (ins_opt(OPT_INS_F32_CORR_ROWS) == 4 ? 4 : 2) : 4;
   // Workgroup shape and z-chunk.  The wavefronts of a workgroup share halo rows / columns; a workgroup barrier per plane keeps them on
   // the same plane, so those shared lines are cache hits instead of HBM re-reads (512^3 plain K1, same box: 1.45 -> 1.37 ms with 4
   // wavefronts, 1.28 ms with 8 wavefronts = 128 x 16 cells per plane and workgroup: the flat-copy rate of that box, profiles/r02_k1_lab.txt;

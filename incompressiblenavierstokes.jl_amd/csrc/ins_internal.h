@@ -113,6 +113,7 @@ void ins_set_error(const char* fmt, ...);
   X(INS_ZTRI_SKEL)               \
   X(INS_CG_HOSTSYNC)             \
   X(INS_CG_BATCH)                \
+  X(INS_F32_CORR_ROWS)           \
   X(INS_F32_FP64_SPECTRA)        \
   X(INS_F32_HIPFFT_PROJECT)      \
   X(INS_FFT_ALLOW_RESET)
