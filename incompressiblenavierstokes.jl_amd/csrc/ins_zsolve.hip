@@ -560,7 +560,13 @@ int ins_k_zsolve_f32(float* data, int nz, long long nl, const double* ax, int kx
     case 192: return launch_zsolve3<32 + 6, 16, 256, float2>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
     case 256: return launch_zsolve3<8, 16, 256, float2>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
     case 384: return launch_zsolve3<32 + 7, 16, 256, float2>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
-    case 512: return launch_zsolve3<9, 32, 512, float2>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+    case 512: {
+      const int tk = (int)ins_opt(OPT_INS_ZSOLVE_TK), nt = (int)ins_opt(OPT_INS_ZSOLVE_NT);
+      // 16 lines (70 KB of LDS: two workgroups per CU) against 32 (135 KB, one): 512^3 fp32 step 15.7 -> 14.65 ms, the pass 0.63 -> 0.37 ms
+      if (tk == 32) return launch_zsolve3<9, 32, 512, float2>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+      if (tk == 16 && nt == 256) return launch_zsolve3<9, 16, 256, float2>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+      return launch_zsolve3<9, 16, 512, float2>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+    }
   }
   ins_set_error("ins_k_zsolve_f32: unsupported nz = %d", nz);
   return INS_ERR_UNSUPPORTED;

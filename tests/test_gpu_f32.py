@@ -54,7 +54,8 @@ def test_momentum_f32_matches_oracle(ins, oracle, n):
     assert np.max(np.abs(got[ip] - F64[ip])) / np.max(np.abs(F64[ip])) < 2e-5
 
 
-@pytest.mark.parametrize("n", [(128, 16, 12), (32, 16, 64), (24, 18), (66, 12, 10)])  # last: rocFFT non-power-of-two sizes
+@pytest.mark.parametrize("n", [(128, 16, 12), (32, 16, 64), (24, 18), (66, 12, 10),  # last: rocFFT non-power-of-two sizes
+                               (32, 16, 512), (64, 16, 256), (32, 32, 192), (32, 16, 384)])  # the float2 z pass (three-pass kernel: every length it has)
 def test_project_and_poisson_f32_match_oracle(ins, oracle, n):
     o = oracle
     f32 = ins.f32
@@ -73,7 +74,7 @@ def test_project_and_poisson_f32_match_oracle(ins, oracle, n):
     got = u.cpu().numpy().astype(np.float64)
     assert rell2(got, want) < 2e-5  # ghosts included
     # divergence-free at float32 level: max|div u| h / max|u| ~ eps32 * few
-    h = 1.0 / n[0]
+    h = 1.0 / max(n)  # the finest spacing sets the rounding level of a difference quotient
     assert f32.max_abs_divergence32(u, sp, ps) * h < 2e-5 * float(u.abs().max())
     # psolver(p) alone
     f = fx.randn_field(so.grid.N, 23)
