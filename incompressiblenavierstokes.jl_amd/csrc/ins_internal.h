@@ -116,6 +116,7 @@ void ins_set_error(const char* fmt, ...);
   X(INS_F32_CORR_ROWS)           \
   X(INS_F32_FP64_SPECTRA)        \
   X(INS_F32_HIPFFT_PROJECT)      \
+  X(INS_F32_SPLIT_GRADIENT)      \
   X(INS_FFT_ALLOW_RESET)
 #define INS_OPT_ENUM(id) OPT_##id,
 enum InsOptId { INS_OPT_LIST(INS_OPT_ENUM) INS_OPT_COUNT };
