@@ -121,7 +121,7 @@ def test_temperature_operators_match_oracle(ins, oracle, geom, kind):
     assert np.array_equal(ins.to_numpy(ins.temperaturefield(sp, f, 0.3)), o.temperaturefield(so, f, 0.3))
 
 
-@pytest.mark.parametrize("n", [(136, 20, 37), (64, 9, 4), (61, 16, 70), (5, 4, 6)])
+@pytest.mark.parametrize("n", [(136, 20, 37), (64, 9, 4), (61, 16, 70), (5, 4, 6), (256, 140, 70)])
 def test_one_kernel_closure_force_matches_the_three_kernel_sequence(ins, n):
     """All-periodic uniform 3-D boxes: smagorinsky_closure as one kernel (csrc/ins_smagforce.hip: stress in registers, periodic images instead of
     the ghost fill of σ) against smagtensor! -> apply_bc_p! -> divoftensor! on the device (INS_DISABLE_SMAGFORCE), on boxes that reach partial
@@ -286,6 +286,51 @@ def test_fused_extended_stage_loop_matches_oracle(ins, oracle, n, what, gdir, di
     if what in ("smag", "both"):  # the closure force as the reference's three kernels instead of one (csrc/ins_smagforce.hip; with / without correction on the fly)
         _, u4, temp4 = run(True, INS_DISABLE_SMAGFORCE=1)
         assert rell2(u4, u) < 1e-12 and (temp is None or rell2(temp4, temp) < 1e-12)
+
+
+@pytest.mark.parametrize("n,what", [((256, 24, 136), "temp"), ((256, 24, 136), "smag"), ((256, 72, 40), "both"), ((512, 16, 72), "temp")])
+def test_extended_loop_at_bench_tile_shapes(ins, n, what):
+    """The launch geometry of the 256³ / 512³ runs of the extended loop (four wavefronts side by side on 256-wide rows, two on 512-wide ones,
+    nty_local > 1, 32-plane z-chunks; the one-kernel closure force with several windows, row groups and chunks), which the oracle-backed boxes
+    above do not reach: two RK44 steps of the fused loop against the reference's kernel sequence on the device (INS_DISABLE_EXT_FUSED; that
+    sequence is the one the oracle pins on the small boxes) and against the split / three-kernel forms."""
+    from ins_amd import _lib
+
+    x = tuple(np.linspace(0.0, L, ni + 1) for ni, L in zip(n, (1.0, 0.5, 0.8)))
+    kw = {}
+    if what in ("temp", "both"):
+        per = (ins.PeriodicBC(), ins.PeriodicBC())
+        kw["temperature"] = ins.temperature_equation(Pr=0.71, Ra=1e6, Ge=0.1, boundary_conditions=(per, per, per), gdir=2, dodissipation=True)
+    sp = ins.Setup(x=x, **({} if kw else {"Re": 1000.0}), **kw)
+    if what in ("smag", "both"):
+        sp.closure_model = ins.smagorinsky_closure(sp)
+    ps = ins.psolver_spectral(sp)
+    u0 = ins.apply_bc_u(ins.project(ins.apply_bc_u(ins.from_numpy(sp, 0.1 * fx.randn_field(sp.grid.N + (3,), 11)), 0.0, sp), sp, ps), 0.0, sp)
+    t0 = ins.apply_bc_temp(ins.from_numpy(sp, 0.5 + 0.1 * fx.randn_field(sp.grid.N, 4)), 0.0, sp) if kw else None
+    theta = 0.17 if what in ("smag", "both") else None
+
+    def run(**opts):
+        with _lib.options(**opts):
+            (u, t, _), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 4e-3), ustart=u0.clone(), tempstart=None if t0 is None else t0.clone(),
+                                              method=ins.RKMethods.RK44(), psolver=ps, Δt=2e-3, θ=theta)
+        return ins.to_numpy(u), None if t is None else ins.to_numpy(t)
+
+    import ctypes
+
+    lib = _lib.load()
+    lib.ins_dbg_ext_fused_steps.restype = ctypes.c_longlong
+    before = lib.ins_dbg_ext_fused_steps()
+    u, t = run()
+    assert lib.ins_dbg_ext_fused_steps() - before == 2
+    variants = [dict(INS_DISABLE_EXT_FUSED=1)]
+    if t is not None:
+        variants.append(dict(INS_EXT_TEMP_SPLIT=1))
+    if theta is not None:
+        variants.append(dict(INS_DISABLE_SMAGFORCE=1))
+    for opts in variants:
+        u2, t2 = run(**opts)
+        assert rell2(u2, u) < 1e-12, opts
+        assert t is None or rell2(t2, t) < 1e-12, opts
 
 
 def _walls_wide(o):  # stretched, walls everywhere; 72 volumes in x: a full and a partial wavefront of the 64-wide masked stage kernel
