@@ -626,7 +626,7 @@ int ins_k_flux64m(const ins_grid* G, double visc, const double* u, double* k_out
 int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s) {
   if (ins_flux64_supported(G)) return ins_k_flux64(G, visc, u_in, k_out, &epi, nullptr, 0, s);
   // (INS_FLUX64M_SKIP_FIRST=1 keeps the 62-wide kernel for the non-correcting first stage: cavity 256^3 4.15 vs 4.11 ms/step)
-  if ((!ins_opt(OPT_INS_FLUX64M_SKIP_FIRST) || epi.wout) && !epi.extra && ins_flux64m_supported(G)) return ins_k_flux64m(G, visc, u_in, k_out, epi, nullptr, s);
+  if ((!ins_opt(OPT_INS_FLUX64M_SKIP_FIRST) || epi.wout) && ins_flux64m_supported(G)) return ins_k_flux64m(G, visc, u_in, k_out, epi, nullptr, s);
   int rc = ins_flux3d_prepare(G, visc, s);
   if (rc) return rc;
   return launch_flux_any<true>(G, u_in, k_out, epi, nullptr, 0, s);

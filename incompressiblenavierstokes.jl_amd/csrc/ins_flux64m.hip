@@ -52,7 +52,8 @@ struct PlaneM {
   double h[3];  // packed halo columns: lane r = row r of column x0-1, lane 16+r = row r of column x0+64
 };
 
-// WT (extended stage loop on wall-bounded grids, ins_rk_ext.hip; CORR = 0): gravity from epi.gtemp is added to the stage force, and
+// WT (extended stage loop on wall-bounded grids, ins_rk_ext.hip; CORR = 0): gravity from epi.gtemp and the closure force epi.extra are added to the
+// stage force, and
 // w_α = u_α · diffusion(u)_α is stored to epi.wout — the diffusive part of every face flux is accumulated a second time on its own.
 template <int R, int XW, int CORR, bool WT = false>
 __global__ __launch_bounds__(256, 2) void k_flux64m(FluxMArgs a) {  // (256, 3) = 168 VGPRs + 284 B scratch measured neutral (cavity 4.27 vs 4.29 ms/step)
@@ -338,6 +339,12 @@ __global__ __launch_bounds__(256, 2) void k_flux64m(FluxMArgs a) {  // (256, 3) 
             stb(plane_rsrc(w + a.sc, ubytes), ocol, orow[rr - 1], dv_ ? Vc * Dv : 0.0);
             stb(plane_rsrc(w + 2 * a.sc, ubytes), ocol, orow[rr - 1], dw_ ? Wc * Dw : 0.0);
           }
+          if (a.epi.extra) {  // the stage force is F + E (closure term: ins_rk_ext.hip); E is zero off the degrees of freedom
+            const double* e = a.epi.extra + pk;
+            fu += ldb<double>(plane_rsrc(e, ubytes), ocol, orow[rr - 1]);
+            fv += ldb<double>(plane_rsrc(e + a.sc, ubytes), ocol, orow[rr - 1]);
+            fw += ldb<double>(plane_rsrc(e + 2 * a.sc, ubytes), ocol, orow[rr - 1]);
+          }
           if (a.epi.gtemp) {  // gravity!: F[I, gdir] += α2 avg(temp, Δ, I, gdir) on Iu[gdir] (operators.jl:914-931)
             const int gd = a.epi.gdir;
             const int idx = gd == 0 ? min(ci, n0 - 1) + 1 : (gd == 1 ? min(j, n1) : k);  // clamped like the store addresses (masked lanes / rows)
@@ -443,8 +450,8 @@ bool ins_flux64m_supported(const ins_grid* G) {
 // Stage kernel with the RK epilogue; p_padded != nullptr: `u` is the previous stage's uncorrected u* (boundary data applied), corrected in registers.
 int ins_k_flux64m(const ins_grid* G, double visc, const double* u, double* k_out, const RkEpi& epi, const double* p_padded, hipStream_t s) {
   const GridDev& g = G->g;
-  const bool wt = epi.gtemp || epi.wout;  // temperature loop on wall-bounded grids: gravity in, u·diffusion(u) out
-  if (epi.self_in != 0.0 || epi.ustart_out || epi.extra || (wt && p_padded)) {
+  const bool wt = epi.gtemp || epi.wout || epi.extra;  // extended loop on wall-bounded grids: gravity and the closure force in, u·diffusion(u) out
+  if (epi.self_in != 0.0 || epi.ustart_out || (wt && p_padded)) {
     ins_set_error("ins_k_flux64m: epilogue term not supported on stretched / masked grids");
     return INS_ERR_UNSUPPORTED;
   }

@@ -312,9 +312,9 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
           INS_HIP_TRY(hipMemcpyAsync(e->tb[b], temp, sbytes, hipMemcpyDeviceToDevice, s));
         }
     }
-    // Without a closure the 64-wide masked stage kernel also leaves w = u·diffusion(u) (the dissipation term of the temperature equation) from
+    // The 64-wide masked stage kernel also leaves w = u·diffusion(u) (the dissipation term of the temperature equation) from
     // the diffusive parts of the fluxes it has in registers: no diffusion pass of its own.
-    const bool w_from_stage = with_temp && td.dodissipation && !closure && ins_flux64m_supported(G);
+    const bool w_from_stage = with_temp && td.dodissipation && ins_flux64m_supported(G);
     if (w_from_stage && (rc = zalloc(&e->w, vbytes, s))) return rc;  // ghost volumes stay zero (the reference's fill!(diff, 0))
     ++g_tiled_steps;
     double* cur = u;

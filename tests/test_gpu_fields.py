@@ -350,12 +350,12 @@ WIDE = {"walls_wide": _walls_wide, "channel_wide": _channel_wide}
 
 @pytest.mark.parametrize("geom,kind,closure,gdir", [("dirichlet3d", "dirichlet", False, 2), ("mixed3d", "symmetric", True, 2), ("dirichlet3d", None, True, 2),
                                                     ("walls_wide", "dirichlet", False, 2), ("walls_wide", "symmetric", False, 1),
-                                                    ("channel_wide", "dirichlet", False, 0), ("channel_wide", "symmetric", True, 1)])
+                                                    ("channel_wide", "dirichlet", False, 0), ("channel_wide", "symmetric", True, 1), ("walls_wide", None, True, 2)])
 def test_tiled_extended_stage_loop_on_wall_bounded_grids(ins, oracle, geom, kind, closure, gdir):
     """Wall-bounded / stretched 3-D grids: the extended loop on the tiled stage kernel (closure force + gravity as one extra field inside it, one
     temperature kernel per stage, diffusion(u) from the face-flux kernel with zero-weight records; csrc/ins_rk_ext.hip) against the oracle's
-    loop, and against the reference's kernel sequence on the device (INS_DISABLE_EXT_FUSED).  On rows of 66 volumes and more and without a
-    closure the 64-wide masked stage kernel takes gravity and leaves u·diffusion(u) itself (csrc/ins_flux64m.hip, WT), every gravity direction."""
+    loop, and against the reference's kernel sequence on the device (INS_DISABLE_EXT_FUSED).  On rows of 66 volumes and more the 64-wide masked
+    stage kernel takes gravity and the closure force and leaves u·diffusion(u) itself (csrc/ins_flux64m.hip, WT), every gravity direction."""
     import ctypes
 
     from ins_amd import _lib
