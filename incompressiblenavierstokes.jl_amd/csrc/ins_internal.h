@@ -72,6 +72,8 @@ void ins_set_error(const char* fmt, ...);
   X(INS_DISABLE_FLUX2D)          \
   X(INS_DISABLE_FLUX64M)         \
   X(INS_DISABLE_SMAGFORCE)       \
+  X(INS_DISABLE_SMAGFORCE_GEN)   \
+  X(INS_SMAGFORCE_FORCE_GEN)     \
   X(INS_SMAGFORCE_ZC)            \
   X(INS_SMAGFORCE_BAR)         \
   X(INS_FLUX64M_ZC)              \

@@ -325,7 +325,9 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
       double* tout = with_temp ? (last ? temp : e->tb[i & 1]) : nullptr;
       if ((rc = ins_k_apply_bc_u(G, cur, 0, nullptr, s))) return rc;                                         // :19
       if (with_temp && (rc = ins_apply_bc_temp_f64(G, td.bc, td.val, nullptr, tin, stream))) return rc;      // :20
-      if (closure) {
+      if (closure && ins_smagforce_supported(G)) {  // one kernel, also with walls and on stretched grids (ins_smagforce.hip, GEN)
+        if ((rc = ins_k_smagforce(G, e->theta, cur, nullptr, e->E, s))) return rc;
+      } else if (closure) {
         if ((rc = ins_smagtensor_f64(G, e->theta, cur, e->sigma, stream))) return rc;
         if ((rc = ins_k_apply_bc_p_fields(G, e->sigma, D * (D + 1) / 2, s))) return rc;
         if ((rc = ins_divoftensor_f64(G, e->sigma, e->E, stream))) return rc;

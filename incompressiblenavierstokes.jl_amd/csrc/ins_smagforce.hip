@@ -27,6 +27,11 @@ struct SmagArgs {
   double rh[3];          // 1/Δ
   double theta, d2;      // Σ Δα²
   int ntx, nty, nty_l, zc, bar;
+  // GEN (non-periodic sides and / or stretched grids): metric tables (padded index), periodicity and the DOF boxes of the three components
+  int per[3];
+  int gz[3][2];  // what a ghost volume of σ holds at side [d][lo / hi]: 0 its periodic image, 1 the adjacent interior volume (Symmetric), 2 zero (Dirichlet)
+  const double *dx[3], *rdx[3], *rdxu[3];
+  int lo[3][3], hi[3][3];
 };
 
 __device__ __forceinline__ double lnext(double v) { return next_h(v, v); }  // lane l <- l+1
@@ -34,7 +39,14 @@ __device__ __forceinline__ double lprev(double v) { return prev_h(v, v); }  // l
 
 constexpr int SF_XO = 60;
 
-template <int R, bool CORRP>
+// GEN: any mix of Periodic / Dirichlet / Symmetric sides on a stretched grid.  apply_bc_p!(σ) gives a ghost volume the stress of its periodic image
+// (boundary_conditions.jl:306-318), of the adjacent interior volume at a Symmetric side (:445-453), and leaves it as allocated — zero — at a Dirichlet
+// side (:388), direction by direction.  A wrapped index is a wrapped address as before; a copy comes from the neighbour lane (x), the neighbour row (y)
+// or, in z, by spending the first / last plane's stress a second time in the role of the ghost plane below / above; zero is zero.
+// STR (stretched grid): gradient and divergence with the metric tables
+// (four one-sided differences per off-diagonal entry, as the reference; the row metrics are read once per wavefront: stores to s may alias the
+// tables as far as the compiler knows, so it would re-read them every plane); stores masked to the degrees of freedom.
+template <int R, bool CORRP, bool GEN = false, bool STR = false>
 __global__ __launch_bounds__(256, 2) void k_smagforce(SmagArgs a) {
   int seq = (int)(blockIdx.x >> 3);
   const int tx = seq % a.ntx;
@@ -59,12 +71,16 @@ __global__ __launch_bounds__(256, 2) void k_smagforce(SmagArgs a) {
   // buffer addressing (ins_wave64.h): descriptor = one plane of one component, soffset = row start (scalar), voffset = the lane's column
   constexpr unsigned EB = 8;
   const unsigned pbytes = (unsigned)(a.sz * EB), ppbytes = (unsigned)((long long)n0 * n1 * EB);
-  const int col = mod(xi, n0);
+  auto mapi = [&](int q, int n, int d) {  // interior index -> the index whose data stands for it (wrap, or clamp into the ghost layer)
+    if (!GEN || a.per[d]) return mod(q, n);
+    return min(max(q, -1), n);
+  };
+  const int col = mapi(xi, n0, 0);
   const unsigned colb = (unsigned)(col + 1) * EB, pcol = (unsigned)col * EB;
   unsigned rowb[R + 4];              // velocity row rr = interior row jb - 2 + rr
   unsigned prow[CORRP ? R + 5 : 1];  // pressure rows jb - 2 .. jb + R + 2 (unpadded array)
 #pragma unroll
-  for (int rr = 0; rr < R + 4; ++rr) rowb[rr] = (unsigned)((mod(jb - 2 + rr, n1) + 1) * a.sy) * EB;
+  for (int rr = 0; rr < R + 4; ++rr) rowb[rr] = (unsigned)((mapi(jb - 2 + rr, n1, 1) + 1) * a.sy) * EB;
   if constexpr (CORRP) {
 #pragma unroll
     for (int rr = 0; rr < R + 5; ++rr) prow[rr] = (unsigned)(mod(jb - 2 + rr, n1) * n0) * EB;
@@ -79,8 +95,8 @@ __global__ __launch_bounds__(256, 2) void k_smagforce(SmagArgs a) {
   }
   // x, y of plane kk into (QX, QY); z of plane kk - 1 into QZ (the slot of plane kk - 1)
   auto load_plane = [&](double (&QX)[R + 4], double (&QY)[R + 4], double (&QZ)[R + 4], int kk) {
-    const double* bxy = a.u + (long long)(mod(kk, n2) + 1) * a.sz;
-    const double* bz = a.u + 2 * a.sc + (long long)(mod(kk - 1, n2) + 1) * a.sz;
+    const double* bxy = a.u + (long long)(mapi(kk, n2, 2) + 1) * a.sz;
+    const double* bz = a.u + 2 * a.sc + (long long)(mapi(kk - 1, n2, 2) + 1) * a.sz;
     const rsrc_t rx = plane_rsrc(bxy, pbytes), ry = plane_rsrc(bxy + a.sc, pbytes), rz = plane_rsrc(bz, pbytes);
 #pragma unroll
     for (int rr = 0; rr < R + 4; ++rr) {
@@ -110,12 +126,40 @@ __global__ __launch_bounds__(256, 2) void k_smagforce(SmagArgs a) {
   }
   const double rq[3] = {a.rh[0] / 4, a.rh[1] / 4, a.rh[2] / 4};
   const double nu0 = a.theta * a.theta * a.d2;
+  // GEN: per-lane x metrics at the lane's (mapped) column, kept inside the interior index range (ghost lanes never use theirs)
+  const int Ix = STR ? min(max(col + 1, 1), n0) : 1;
+  const double gx_d = STR ? a.rdx[0][Ix] : 0.0, gx_u1 = STR ? a.rdxu[0][Ix] : 0.0, gx_u0 = STR ? a.rdxu[0][Ix - 1] : 0.0, gx_w = STR ? a.dx[0][Ix] : 0.0;
+  // STR: y metrics of the R + 2 stress rows and the R output rows (wave-uniform)
+  double gy_d[STR ? R + 2 : 1], gy_u1[STR ? R + 2 : 1], gy_u0[STR ? R + 2 : 1], gy_w[STR ? R + 2 : 1], oy_q[STR ? R : 1], oy_u[STR ? R : 1];
+  if constexpr (STR) {
+#pragma unroll
+    for (int q = 0; q < R + 2; ++q) {
+      const int Jy = min(max(mapi(jb - 1 + q, n1, 1) + 1, 1), n1);
+      gy_d[q] = a.rdx[1][Jy];
+      gy_u1[q] = a.rdxu[1][Jy];
+      gy_u0[q] = a.rdxu[1][Jy - 1];
+      gy_w[q] = a.dx[1][Jy];
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int Jo = min(jb + q + 1, n1);  // padded output row
+      oy_q[q] = a.rdx[1][Jo] / 4;
+      oy_u[q] = a.rdxu[1][Jo];
+    }
+  }
+  const bool ghl = GEN && !a.per[0] && xi == -1, ghr = GEN && !a.per[0] && xi == n0;  // this lane holds a ghost column at a non-periodic side
+  const bool xz0 = GEN && ((ghl && a.gz[0][0] == 2) || (ghr && a.gz[0][1] == 2));   // ... whose stress is zero
+  bool dofx[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) dofx[c] = !GEN || (xi + 1 >= a.lo[c][0] && xi + 1 < a.hi[c][0]);
   struct Sig {
     double xx, yy, zz, xy, xz, yz;
   };
   // planes: M = m - 1, C = m, N = m + 1 (no z component)
   auto process = [&](const double (&MX)[R + 4], const double (&MY)[R + 4], const double (&MZ)[R + 4], const double (&CX)[R + 4],
                      const double (&CY)[R + 4], const double (&CZ)[R + 4], const double (&NX)[R + 4], const double (&NY)[R + 4], int m) {
+    const int Kz = STR ? min(max(mapi(m, n2, 2) + 1, 1), n2) : 1;
+    const double gz_d = STR ? a.rdx[2][Kz] : 0.0, gz_u1 = STR ? a.rdxu[2][Kz] : 0.0, gz_u0 = STR ? a.rdxu[2][Kz - 1] : 0.0, gz_w = STR ? a.dx[2][Kz] : 0.0;
     auto sigma = [&](int q) {  // stress row q = interior row jb - 1 + q = velocity row q + 1
       const int uc = q + 1;
       auto U = [&](int c, int ox, int oy, int oz) {
@@ -134,18 +178,36 @@ __global__ __launch_bounds__(256, 2) void k_smagforce(SmagArgs a) {
       // ∇(u, I, Δ, Δu)   operators.jl:1023-1034, 1069-1085.  On a uniform box the four one-sided differences of an off-diagonal entry share
       // their metric, so the middle values cancel: two central differences (the kernel is bound by its instruction count, not by HBM).
       double G[3][3];
+      double d2 = a.d2;
+      if constexpr (STR) {
+        const double gd[3] = {gx_d, gy_d[q], gz_d}, g1[3] = {gx_u1, gy_u1[q], gz_u1}, g0[3] = {gx_u0, gy_u0[q], gz_u0};
+        const double wy_ = gy_w[q];
+        d2 = gx_w * gx_w + wy_ * wy_ + gz_w * gz_w;  // gridsize² = Σ Δα²
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          if (c == b)
-            G[c][b] = (at(c, c, 0, b, 0) - at(c, c, 0, b, -1)) * a.rh[b];
-          else
-            G[c][b] = ((at(c, c, 0, b, 1) - at(c, c, 0, b, -1)) + (at(c, c, -1, b, 1) - at(c, c, -1, b, -1))) * rq[b];
-        }
+          for (int b = 0; b < 3; ++b) {
+            if (c == b)
+              G[c][b] = (at(c, c, 0, b, 0) - at(c, c, 0, b, -1)) * gd[b];
+            else
+              G[c][b] = ((at(c, c, 0, b, 1) - at(c, c, 0, b, 0)) * g1[b] + (at(c, c, -1, b, 1) - at(c, c, -1, b, 0)) * g1[b] +
+                         (at(c, c, 0, b, 0) - at(c, c, 0, b, -1)) * g0[b] + (at(c, c, -1, b, 0) - at(c, c, -1, b, -1)) * g0[b]) /
+                        4;
+          }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            if (c == b)
+              G[c][b] = (at(c, c, 0, b, 0) - at(c, c, 0, b, -1)) * a.rh[b];
+            else
+              G[c][b] = ((at(c, c, 0, b, 1) - at(c, c, 0, b, -1)) + (at(c, c, -1, b, 1) - at(c, c, -1, b, -1))) * rq[b];
+          }
+      }
       const double sxy = (G[0][1] + G[1][0]) / 2, sxz = (G[0][2] + G[2][0]) / 2, syz = (G[1][2] + G[2][1]) / 2;
       const double ss = G[0][0] * G[0][0] + G[1][1] * G[1][1] + G[2][2] * G[2][2] + 2 * (sxy * sxy + sxz * sxz + syz * syz);  // Σ S_ab S_ab
-      const double eddy = nu0 * sqrt(2 * ss);  // smagtensor!: νt = θ² Δ² sqrt(2 S:S)
+      const double eddy = (STR ? a.theta * a.theta * d2 : nu0) * sqrt(2 * ss);  // smagtensor!: νt = θ² Δ² sqrt(2 S:S)
       Sig o;
       o.xx = 2 * eddy * G[0][0];
       o.yy = 2 * eddy * G[1][1];
@@ -153,34 +215,80 @@ __global__ __launch_bounds__(256, 2) void k_smagforce(SmagArgs a) {
       o.xy = 2 * eddy * sxy;
       o.xz = 2 * eddy * sxz;
       o.yz = 2 * eddy * syz;
+      if constexpr (GEN) {
+        if (!a.per[0]) {  // a ghost column carries the stress of the adjacent interior column (Symmetric) or none (Dirichlet)
+          auto fix = [&](double v) {  // (the wave shifts run in every lane: a DPP read of a lane masked off by a branch returns nothing)
+            const double vn = lnext(v), vp = lprev(v);
+            return xz0 ? 0.0 : (ghl ? vn : (ghr ? vp : v));
+          };
+          // only σxy and σxz are read from a ghost column by a degree of freedom (the y / z force of the first and last column); σxx of a
+          // ghost column would enter the x force of the wall face, which is no degree of freedom
+          o.xy = fix(o.xy);
+          o.xz = fix(o.xz);
+        }
+      }
       return o;
     };
+    if constexpr (GEN) {
+      if (!a.per[2] && (m < 0 || m >= n2)) return;  // ghost planes at walls: their stress is the first / last plane's, spent below
+    }
+    const bool zfirst = GEN && !a.per[2] && m == 0, zlast = GEN && !a.per[2] && m == n2 - 1;
+    const double zf_c = (GEN && a.gz[2][0] == 2) ? 0.0 : 1.0, zl_c = (GEN && a.gz[2][1] == 2) ? 0.0 : 1.0;  // Dirichlet: the ghost plane's stress is zero
+    // z metrics by role (padded indices): plane m - 1 is output plane index m, plane m is m + 1, plane m + 1 is m + 2
+    const int Km = min(max(m, 0), n2 + 1), Kc = min(max(m + 1, 0), n2 + 1), Kp = min(max(m + 2, 0), n2 + 1);
+    const double rzm = STR ? a.rdx[2][Km] / 4 : rq[2], rzc = STR ? a.rdx[2][Kc] / 4 : rq[2], rzp = STR ? a.rdx[2][Kp] / 4 : rq[2];
+    const double zum = STR ? a.rdxu[2][Km] : a.rh[2], zuc = STR ? a.rdxu[2][Kc] : a.rh[2];
+    bool dofzm[3], dofzc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      dofzm[c] = !GEN || (m >= a.lo[c][2] && m < a.hi[c][2]);
+      dofzc[c] = !GEN || (m + 1 >= a.lo[c][2] && m + 1 < a.hi[c][2]);
+    }
     const bool store = m - 1 >= k0;  // plane m - 1 is complete now
     const double* spl = a.s + (long long)m * a.sz;  // padded plane index of interior plane m - 1
     const rsrc_t o0 = plane_rsrc(spl, pbytes), o1 = plane_rsrc(spl + a.sc, pbytes), o2 = plane_rsrc(spl + 2 * a.sc, pbytes);
+    const double* spc = a.s + (long long)(m + 1) * a.sz;  // padded plane index of interior plane m (stored here only at a wall above)
+    const rsrc_t c0 = plane_rsrc(spc, pbytes), c1 = plane_rsrc(spc + a.sc, pbytes), c2 = plane_rsrc(spc + 2 * a.sc, pbytes);
     // rows in rolling order: output row q is emitted when stress row q + 1 exists
+    const Sig zero{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     Sig lo = sigma(0), mid = sigma(1);
+    if constexpr (GEN) {
+      if (!a.per[1] && jb == 0) lo = a.gz[1][0] == 2 ? zero : mid;  // ghost row below the first row
+    }
 #pragma unroll
     for (int q = 1; q <= R; ++q) {
-      const Sig hi = sigma(q + 1);
-      const double xz_n = lnext(mid.xz), xz_p = lprev(mid.xz);
-      const double up_x = (mid.xz + xz_n) * rq[2];
-      const double up_y = (mid.yz + hi.yz) * rq[2];
-      const double cz = (xz_n - xz_p) * rq[0] + (hi.yz - lo.yz) * rq[1];
-      const double zt = mid.zz * a.rh[2];
-      const double own_x = (lnext(mid.xx) - mid.xx) * a.rh[0] + ((hi.xy + lnext(hi.xy)) - (lo.xy + lnext(lo.xy))) * rq[1];
-      const double own_y = ((lnext(mid.xy) + lnext(hi.xy)) - (lprev(mid.xy) + lprev(hi.xy))) * rq[0] + (hi.yy - mid.yy) * a.rh[1];
+      Sig hi = sigma(q + 1);
       const int row = jb + q - 1;
-      if (store && xout && row < n1) {
-        stb(o0, colb, rowb[q + 1], Ep[0][q - 1] + up_x);
-        stb(o1, colb, rowb[q + 1], Ep[1][q - 1] + up_y);
-        stb(o2, colb, rowb[q + 1], Ep[2][q - 1] + (cz + zt));
+      if constexpr (GEN) {
+        if (!a.per[1] && row + 1 == n1) hi = a.gz[1][1] == 2 ? zero : mid;  // ghost row above the last row
       }
-      Ep[0][q - 1] = En[0][q - 1] + own_x;
-      Ep[1][q - 1] = En[1][q - 1] + own_y;
-      Ep[2][q - 1] = cz - zt;
-      En[0][q - 1] = -up_x;
-      En[1][q - 1] = -up_y;
+      const double ryq = STR ? oy_q[q - 1] : rq[1], ryu = STR ? oy_u[q - 1] : a.rh[1];
+      const double rxq = STR ? gx_d / 4 : rq[0], rxu = STR ? gx_u1 : a.rh[0];
+      const double xz_n = lnext(mid.xz), xz_p = lprev(mid.xz);
+      const double upr_x = mid.xz + xz_n, upr_y = mid.yz + hi.yz;  // (times a z metric by role)
+      const double cz = (xz_n - xz_p) * rxq + (hi.yz - lo.yz) * ryq;
+      const double own_x = (lnext(mid.xx) - mid.xx) * rxu + ((hi.xy + lnext(hi.xy)) - (lo.xy + lnext(lo.xy))) * ryq;
+      const double own_y = ((lnext(mid.xy) + lnext(hi.xy)) - (lprev(mid.xy) + lprev(hi.xy))) * rxq + (hi.yy - mid.yy) * ryu;
+      bool dofy[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dofy[c] = !GEN || (row + 1 >= a.lo[c][1] && row + 1 < a.hi[c][1]);
+      if (store && xout && row < n1) {
+        if (dofx[0] && dofy[0] && dofzm[0]) stb(o0, colb, rowb[q + 1], Ep[0][q - 1] + upr_x * rzm);
+        if (dofx[1] && dofy[1] && dofzm[1]) stb(o1, colb, rowb[q + 1], Ep[1][q - 1] + upr_y * rzm);
+        if (dofx[2] && dofy[2] && dofzm[2]) stb(o2, colb, rowb[q + 1], Ep[2][q - 1] + (cz + mid.zz * zum));
+      }
+      Ep[0][q - 1] = (zfirst ? -(upr_x * rzc) * zf_c : En[0][q - 1]) + own_x;  // zfirst: the ghost plane below carries this plane's stress, or none
+      Ep[1][q - 1] = (zfirst ? -(upr_y * rzc) * zf_c : En[1][q - 1]) + own_y;
+      Ep[2][q - 1] = cz - mid.zz * zuc;
+      En[0][q - 1] = -(upr_x * rzp);
+      En[1][q - 1] = -(upr_y * rzp);
+      if constexpr (GEN) {
+        if (zlast && xout && row < n1) {  // the ghost plane above carries this plane's stress, or none: plane m is complete as well
+          if (dofx[0] && dofy[0] && dofzc[0]) stb(c0, colb, rowb[q + 1], Ep[0][q - 1] + upr_x * rzc * zl_c);
+          if (dofx[1] && dofy[1] && dofzc[1]) stb(c1, colb, rowb[q + 1], Ep[1][q - 1] + upr_y * rzc * zl_c);
+          if (dofx[2] && dofy[2] && dofzc[2]) stb(c2, colb, rowb[q + 1], Ep[2][q - 1] + (cz + mid.zz * zuc) * zl_c);
+        }
+      }
       lo = mid;
       mid = hi;
     }
@@ -207,17 +315,31 @@ __global__ __launch_bounds__(256, 2) void k_smagforce(SmagArgs a) {
 
 }  // namespace
 
+// all-periodic uniform boxes: the specialised form (central differences, no masks, on-the-fly correction available)
+static bool smagforce_uniform(const ins_grid* G) { return G->all_dof && G->uniform_exact; }
+
 bool ins_smagforce_supported(const ins_grid* G) {
   const GridDev& g = G->g;
-  return !ins_opt(OPT_INS_DISABLE_SMAGFORCE) && g.D == 3 && G->all_dof && G->uniform_exact && g.N[0] - 2 >= 4 && g.N[1] - 2 >= 4 && g.N[2] - 2 >= 4;
+  if (ins_opt(OPT_INS_DISABLE_SMAGFORCE) || g.D != 3 || g.N[0] - 2 < 4 || g.N[1] - 2 < 4 || g.N[2] - 2 < 4) return false;
+  if (smagforce_uniform(G)) return true;
+  if (ins_opt(OPT_INS_DISABLE_SMAGFORCE_GEN)) return false;
+  for (int d = 0; d < 3; ++d)
+    for (int side = 0; side < 2; ++side)
+      if (g.bc[d][side] == INS_BC_PRESSURE) return false;  // (its ghost rule for σ and its DOF range are not covered: the three kernels)
+  return true;
 }
+// the correcting form (uncorrected input + pressure) exists for all-periodic uniform boxes only
+bool ins_smagforce_corr_supported(const ins_grid* G) { return ins_smagforce_supported(G) && smagforce_uniform(G); }
 
-// s (interior volumes of the three components; ghost volumes untouched) = closure force of u.  pI == nullptr: u is a velocity field (its ghost
-// volumes are not read); else u is an uncorrected stage velocity and pI the (unpadded) pressure of its projection.
+// s (degrees of freedom of the three components; everything else untouched) = closure force of u.  pI == nullptr: u is a velocity field with its
+// boundary data applied (periodic directions: ghost volumes not read); else (all-periodic uniform boxes) u is an uncorrected stage velocity and
+// pI the (unpadded) pressure of its projection.
 int ins_k_smagforce(const ins_grid* G, double theta, const double* u, const double* pI, double* sout, hipStream_t s) {
   const GridDev& g = G->g;
-  if (!ins_smagforce_supported(G)) {
-    ins_set_error("ins_k_smagforce: all-periodic uniform 3-D boxes only");
+  const int force = (int)ins_opt(OPT_INS_SMAGFORCE_FORCE_GEN);  // experiment: the generalised forms on a periodic uniform box (1: uniform, 2: stretched)
+  const bool gen = !smagforce_uniform(G) || (force && !pI);
+  if (!ins_smagforce_supported(G) || (gen && pI)) {
+    ins_set_error("ins_k_smagforce: grid not supported");
     return INS_ERR_UNSUPPORTED;
   }
   constexpr int R = 2;  // 3 rows: 76 bytes of scratch per lane, 0.40 ms against 0.27 at 256^3
@@ -231,6 +353,15 @@ int ins_k_smagforce(const ins_grid* G, double theta, const double* u, const doub
     a.n[b] = g.N[b] - 2;
     a.rh[b] = 1.0 / G->h[b];
     a.d2 += G->h[b] * G->h[b];
+    a.per[b] = g.bc[b][0] == INS_BC_PERIODIC;
+    for (int side = 0; side < 2; ++side) a.gz[b][side] = a.per[b] ? 0 : (g.bc[b][side] == INS_BC_SYMMETRIC ? 1 : 2);
+    a.dx[b] = g.dx[b];
+    a.rdx[b] = g.rdx[b];
+    a.rdxu[b] = g.rdxu[b];
+    for (int d = 0; d < 3; ++d) {
+      a.lo[b][d] = g.iu_lo[b][d];
+      a.hi[b][d] = g.iu_hi[b][d];
+    }
   }
   a.sy = g.sx[1];
   a.sz = g.sx[2];
@@ -244,10 +375,14 @@ int ins_k_smagforce(const ins_grid* G, double theta, const double* u, const doub
   while (zc > 4 && (long long)a.ntx * a.nty * cdiv(a.n[2], zc) < 1024) zc >>= 1;
   a.zc = zc;
   const unsigned nb = 8u * a.ntx * a.nty_l * (unsigned)cdiv(a.n[2], zc);
-  if (pI)
-    hipLaunchKernelGGL((k_smagforce<2, true>), dim3(nb), dim3(64, 4, 1), 0, s, a);
+  if (gen && (!G->uniform_exact || force == 2))  // (uniform_exact: every width and every centre distance incl. the ghost layers equal to 2.5e-13)
+    hipLaunchKernelGGL((k_smagforce<R, false, true, true>), dim3(nb), dim3(64, 4, 1), 0, s, a);
+  else if (gen)  // uniform spacing with walls: the central-difference form, ghost rules and masks only
+    hipLaunchKernelGGL((k_smagforce<R, false, true, false>), dim3(nb), dim3(64, 4, 1), 0, s, a);
+  else if (pI)
+    hipLaunchKernelGGL((k_smagforce<R, true>), dim3(nb), dim3(64, 4, 1), 0, s, a);
   else
-    hipLaunchKernelGGL((k_smagforce<2, false>), dim3(nb), dim3(64, 4, 1), 0, s, a);
+    hipLaunchKernelGGL((k_smagforce<R, false>), dim3(nb), dim3(64, 4, 1), 0, s, a);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }

@@ -144,10 +144,49 @@ def test_one_kernel_closure_force_matches_the_three_kernel_sequence(ins, n):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("geom", ["periodic2d", "periodic3d", "periodic3d_wide", "dirichlet3d", "mixed3d"])
+@pytest.mark.parametrize("case", ["walls", "channel", "mixed", "tiny"])
+def test_one_kernel_closure_force_on_wall_bounded_and_stretched_grids(ins, case):
+    """The generalised form of the one-kernel closure force (csrc/ins_smagforce.hip, GEN: metric tables, the ghost rule of apply_bc_p!(σ) as wrapped
+    addresses / copies from the neighbour lane, row or plane, stores masked to the degrees of freedom) against the three-kernel sequence on the
+    device (INS_DISABLE_SMAGFORCE_GEN): Dirichlet, Symmetric and Periodic sides in every direction, stretched grids, several windows / row groups /
+    z-chunks (the chunk length forced to 4, 8 and 32 planes).  The oracle pins the same entry point on the small boxes of the test below."""
+    from ins_amd import _lib
+
+    Dr, Sy, Pe = ins.DirichletBC, ins.SymmetricBC, ins.PeriodicBC
+    if case == "walls":
+        x = (ins.tanh_grid(0.0, 1.0, 72, 1.2), ins.cosine_grid(0.0, 1.0, 12), ins.tanh_grid(0.0, 0.5, 10, 1.1))
+        bc = ((Dr(), Dr((0.3, 0.0, 0.1))), (Dr(), Dr((1.0, 0.2, 0.0))), (Dr(), Dr()))
+    elif case == "channel":
+        x = (np.linspace(0.0, 2.0, 138), ins.tanh_grid(0.0, 1.0, 10, 1.5), ins.cosine_grid(0.0, 0.8, 9))
+        bc = ((Pe(), Pe()), (Dr(), Dr()), (Sy(), Sy()))
+    elif case == "mixed":
+        x = (ins.cosine_grid(0.0, 1.0, 61), np.linspace(0.0, 0.7, 17), ins.tanh_grid(0.0, 1.3, 70, 1.3))
+        bc = ((Sy(), Dr()), (Pe(), Pe()), (Dr(), Sy()))
+    else:
+        x = (np.linspace(0.0, 1.0, 6), np.linspace(0.0, 1.0, 5), np.linspace(0.0, 1.0, 7))
+        bc = ((Dr(), Dr()), (Dr(), Sy()), (Sy(), Dr()))
+    sp = ins.Setup(x=x, Re=1000.0, boundary_conditions=bc)
+    u = ins.apply_bc_u(ins.from_numpy(sp, fx.randn_field(sp.grid.N + (3,), 5)), 0.0, sp)
+    m = ins.smagorinsky_closure(sp)
+    with _lib.options(INS_DISABLE_SMAGFORCE_GEN=1):
+        three = ins.to_numpy(m(u, 0.17)).copy()
+    assert np.max(np.abs(three)) > 0
+    for zc in (0, 4, 8, 32):
+        with _lib.options(INS_SMAGFORCE_ZC=zc):
+            one = ins.to_numpy(m(u, 0.17)).copy()
+        assert relmax(one, three) < OP_TOL, zc
+
+
+def _symmetric3d(o):  # Symmetric / Dirichlet sides in every direction on a stretched grid (σ ghosts: copies of the neighbour / zero)
+    x = (o.tanh_grid(0.0, 1.0, 14, 1.2), o.cosine_grid(0.0, 1.0, 9), o.tanh_grid(0.0, 0.5, 10, 1.1))
+    S, Dr = o.SymmetricBC, o.DirichletBC
+    return o.make_setup(x, ((S(), S()), (S(), Dr()), (Dr(), S())), Re=1000.0)
+
+
+@pytest.mark.parametrize("geom", ["periodic2d", "periodic3d", "periodic3d_wide", "dirichlet3d", "mixed3d", "symmetric3d"])
 def test_smagorinsky_closure_matches_oracle(ins, oracle, geom):
     o = oracle
-    so = GEOMS[geom](o)
+    so = _symmetric3d(o) if geom == "symmetric3d" else GEOMS[geom](o)
     sp = mirror(ins, so, o)
     g = so.grid
     u_h = o.apply_bc_u(fx.randn_field(g.N + (g.D,), 1), 0.0, so)

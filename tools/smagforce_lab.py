@@ -24,3 +24,5 @@ t("three kernels", INS_DISABLE_SMAGFORCE=1)
 for zc in (16, 32, 64):
     t(f"one kernel zc={zc}", INS_SMAGFORCE_ZC=zc)
 t("one kernel, barrier per plane", INS_SMAGFORCE_BAR=1)
+t("generalised form, uniform", INS_SMAGFORCE_FORCE_GEN=1)
+t("generalised form, metric tables", INS_SMAGFORCE_FORCE_GEN=2)
