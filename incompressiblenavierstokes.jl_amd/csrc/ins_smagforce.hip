@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256, 2) void k_smagforce(SmagArgs a) {
     for (int q = 0; q < R + 2; ++q) {
       const int Jy = min(max(mapi(jb - 1 + q, n1, 1) + 1, 1), n1);
       gy_d[q] = a.rdx[1][Jy];
-      gy_u1[q] = a.rdxu[1][Jy];
-      gy_u0[q] = a.rdxu[1][Jy - 1];
+      gy_u1[q] = a.rdxu[1][Jy] / 4;
+      gy_u0[q] = a.rdxu[1][Jy - 1] / 4;
       gy_w[q] = a.dx[1][Jy];
     }
 #pragma unroll
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void k_smagforce(SmagArgs a) {
       double G[3][3];
       double d2 = a.d2;
       if constexpr (STR) {
-        const double gd[3] = {gx_d, gy_d[q], gz_d}, g1[3] = {gx_u1, gy_u1[q], gz_u1}, g0[3] = {gx_u0, gy_u0[q], gz_u0};
+        const double gd[3] = {gx_d, gy_d[q], gz_d}, g1[3] = {gx_u1 / 4, gy_u1[q], gz_u1 / 4}, g0[3] = {gx_u0 / 4, gy_u0[q], gz_u0 / 4};  // (gy_u*: quarters already)
         const double wy_ = gy_w[q];
         d2 = gx_w * gx_w + wy_ * wy_ + gz_w * gz_w;  // gridsize² = Σ Δα²
 #pragma unroll
@@ -189,10 +189,11 @@ __global__ __launch_bounds__(256, 2) void k_smagforce(SmagArgs a) {
           for (int b = 0; b < 3; ++b) {
             if (c == b)
               G[c][b] = (at(c, c, 0, b, 0) - at(c, c, 0, b, -1)) * gd[b];
-            else
-              G[c][b] = ((at(c, c, 0, b, 1) - at(c, c, 0, b, 0)) * g1[b] + (at(c, c, -1, b, 1) - at(c, c, -1, b, 0)) * g1[b] +
-                         (at(c, c, 0, b, 0) - at(c, c, 0, b, -1)) * g0[b] + (at(c, c, -1, b, 0) - at(c, c, -1, b, -1)) * g0[b]) /
-                        4;
+            else {  // the reference's four one-sided differences, the two that share a metric taken together: ((s+ - s0) r1 + (s0 - s-) r0) / 4
+              const double s0 = at(c, c, 0, b, 0) + at(c, c, -1, b, 0);
+              const double sp = at(c, c, 0, b, 1) + at(c, c, -1, b, 1), sm = at(c, c, 0, b, -1) + at(c, c, -1, b, -1);
+              G[c][b] = (sp - s0) * g1[b] + (s0 - sm) * g0[b];
+            }
           }
       } else {
 #pragma unroll
