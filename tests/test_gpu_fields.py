@@ -384,12 +384,19 @@ def _channel_wide(o):  # periodic x (three wavefronts), walls in y, symmetric / 
     return o.make_setup(x, bcs, Re=1000.0)
 
 
-WIDE = {"walls_wide": _walls_wide, "channel_wide": _channel_wide}
+def _channel_pd(o):  # periodic x and z, walls in y
+    x = (np.linspace(0.0, 2.0, 73), o.tanh_grid(0.0, 1.0, 10, 1.5), np.linspace(0.0, 0.8, 9))
+    bcs = ((o.PeriodicBC(), o.PeriodicBC()), (o.DirichletBC(), o.DirichletBC()), (o.PeriodicBC(), o.PeriodicBC()))
+    return o.make_setup(x, bcs, Re=1000.0)
+
+
+WIDE = {"walls_wide": _walls_wide, "channel_wide": _channel_wide, "channel_pd": _channel_pd}
 
 
 @pytest.mark.parametrize("geom,kind,closure,gdir", [("dirichlet3d", "dirichlet", False, 2), ("mixed3d", "symmetric", True, 2), ("dirichlet3d", None, True, 2),
                                                     ("walls_wide", "dirichlet", False, 2), ("walls_wide", "symmetric", False, 1),
-                                                    ("channel_wide", "dirichlet", False, 0), ("channel_wide", "symmetric", True, 1), ("walls_wide", None, True, 2)])
+                                                    ("channel_wide", "dirichlet", False, 0), ("channel_wide", "symmetric", True, 1), ("walls_wide", None, True, 2),
+                                                    ("channel_pd", "dirichlet", False, 1), ("channel_pd", None, True, 0)])
 def test_tiled_extended_stage_loop_on_wall_bounded_grids(ins, oracle, geom, kind, closure, gdir):
     """Wall-bounded / stretched 3-D grids: the extended loop on the tiled stage kernel (closure force + gravity as one extra field inside it, one
     temperature kernel per stage, diffusion(u) from the face-flux kernel with zero-weight records; csrc/ins_rk_ext.hip) against the oracle's
