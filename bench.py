@@ -238,7 +238,7 @@ def main():
         k1_512["frac"] = k1_512["achieved"] / HBM_PEAK_GBS
         del u5, F5, s5
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r02e_pmc_traffic.json")
+    tfile = os.path.join(ROOT, "profiles", "r02h_pmc_traffic.json")
     if n == 256 and os.path.exists(tfile):  # PMC counters cannot be read in-process: committed rocprofv3 --pmc result
         try:
             traffic = json.load(open(tfile))["per_kernel"]["stage kernel, RK44 step average"]["hbm_total_GB"] * 1e9
@@ -274,7 +274,7 @@ def main():
             "unit": "GB/s",
             "frac": k1_gbs / HBM_PEAK_GBS,
             "traffic": traffic,
-            "traffic_note": "B per launch, HBM FETCH(x2 gfx950)+WRITE from rocprofv3 --pmc (two passes of this command), profiles/r02e_pmc_traffic.json; PMC counters cannot be read inside the timed run",
+            "traffic_note": "B per launch, HBM FETCH(x2 gfx950)+WRITE from rocprofv3 --pmc (two passes of this command), profiles/r02h_pmc_traffic.json; PMC counters cannot be read inside the timed run",
             "bytes_per_cell": fused_bytes_per_cell,
             "bytes_per_cell_by_stage": stage_bytes,
             "avg_launch_ms": k1_avg_ms,
