@@ -109,8 +109,9 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
   const int ns = rk->nstage, D = g.D;
   const size_t sbytes = (size_t)G->ncell * sizeof(double), vbytes = sbytes * D;
   int rc;
-  if (closure && (rc = zalloc(&e->sigma, sbytes * (D * (D + 1) / 2), s))) return rc;
-  if ((rc = zalloc(&e->E, vbytes, s))) return rc;
+  // the stress scratch (D(D+1)/2 scalar fields: 6.5 GB at 512^3) exists only where the three-kernel closure runs (the one-kernel form keeps σ in registers)
+  auto need_sigma = [&]() { return zalloc(&e->sigma, sbytes * (D * (D + 1) / 2), s); };
+  if (closure && (rc = zalloc(&e->E, vbytes, s))) return rc;
   if (with_temp) {
     if ((rc = zalloc(&e->tempstart, sbytes, s))) return rc;
     if (e->td.dodissipation && (rc = zalloc(&e->diff, vbytes, s))) return rc;
@@ -187,6 +188,7 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
       if (smag1) {
         if ((rc = ins_k_smagforce(G, e->theta, in, corr_in ? rk->ps->pI : nullptr, e->E, s))) return rc;
       } else if (closure) {
+        if ((rc = need_sigma())) return rc;
         rc = corr_in ? ins_k_smagtensor_corr(G, e->theta, in, rk->ps->pI, e->sigma, s) : ins_smagtensor_f64(G, e->theta, in, e->sigma, stream);
         if (rc) return rc;
         if ((rc = ins_k_apply_bc_p_fields(G, e->sigma, D * (D + 1) / 2, s))) return rc;  // apply_bc_p!(σ, 0, setup)   operators.jl:1302
@@ -328,6 +330,7 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
       if (closure && ins_smagforce_supported(G)) {  // one kernel, also with walls and on stretched grids (ins_smagforce.hip, GEN)
         if ((rc = ins_k_smagforce(G, e->theta, cur, nullptr, e->E, s))) return rc;
       } else if (closure) {
+        if ((rc = need_sigma())) return rc;
         if ((rc = ins_smagtensor_f64(G, e->theta, cur, e->sigma, stream))) return rc;
         if ((rc = ins_k_apply_bc_p_fields(G, e->sigma, D * (D + 1) / 2, s))) return rc;
         if ((rc = ins_divoftensor_f64(G, e->sigma, e->E, stream))) return rc;
@@ -401,6 +404,7 @@ extern "C" int ins_rk_step_ext_f64(ins_rk_t* rk, double visc, double* u, double*
     if (with_temp && (rc = ins_gravity_f64(G, td.gdir, td.a2, temp, rk->ku[i], stream))) return rc;
     if ((rc = temp_rhs(u, i))) return rc;
     if (closure) {
+      if ((rc = need_sigma())) return rc;
       if ((rc = ins_smagtensor_f64(G, e->theta, u, e->sigma, stream))) return rc;
       if ((rc = ins_k_apply_bc_p_fields(G, e->sigma, D * (D + 1) / 2, s))) return rc;
       if ((rc = ins_divoftensor_f64(G, e->sigma, e->E, stream))) return rc;
