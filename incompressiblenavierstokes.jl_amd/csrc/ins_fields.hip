@@ -413,16 +413,16 @@ __global__ __launch_bounds__(256) void k_gradient_march(GridDev g, BoxMap L, int
 // a work-item issues 3 (R + 2) loads for R cells (R = 4: 4.6 per cell with the halo lanes) against ~40 for the plain kernel — the plain and
 // the LDS-ring kernels were bound by the vector-L1 / texture-addresser rate (250 M accesses per launch at 256³), not by HBM.
 // One barrier per plane keeps the four y-stacked wavefronts of a workgroup on one plane (shared halo rows are cache hits).
+// (no `old` operand: the lane without a source lane reads zero — lanes 0 / 63 are halo columns whose shifted values are never used; update_dpp(old = v, v)
+// costs a register copy per 32-bit half on top of the DPP move)
 __device__ __forceinline__ double lane_next(double v) {  // lane l receives lane l+1
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x130, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x130, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double lane_prev(double v) {  // lane l receives lane l-1
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x138, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x138, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 constexpr int GR_XO = 62;

@@ -34,8 +34,16 @@ struct SmagArgs {
   int lo[3][3], hi[3][3];
 };
 
-__device__ __forceinline__ double lnext(double v) { return next_h(v, v); }  // lane l <- l+1
-__device__ __forceinline__ double lprev(double v) { return prev_h(v, v); }  // lane l <- l-1
+// Wave shifts without an `old` operand (the lane with no source lane reads zero: lanes 0 / 63 are halo lanes here, their shifted values are
+// never used) — update_dpp(old = v, v) costs a register copy per 32-bit half before the DPP move, and this kernel is bound by instruction issue.
+template <int CTRL>
+__device__ __forceinline__ double shift_dpp(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lnext(double v) { return shift_dpp<0x130>(v); }  // lane l <- l+1
+__device__ __forceinline__ double lprev(double v) { return shift_dpp<0x138>(v); }  // lane l <- l-1
 
 constexpr int SF_XO = 60;
 
