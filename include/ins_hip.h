@@ -242,6 +242,9 @@ int ins_divoftensor_f64(const ins_grid_t* grid, const double* sigma, double* s, 
  * All-periodic uniform 3-D boxes: one kernel, the stress stays in registers (sigma may be NULL); other grids: the three kernels with `sigma`
  * (D(D+1)/2 scalar fields) as scratch.  Writes the degrees of freedom of s. */
 int ins_smagorinsky_force_f64(const ins_grid_t* grid, double theta, const double* u, double* sigma, double* s, void* stream);
+/* 1 if ins_smagorinsky_force_f64 needs the `sigma` scratch on this grid (three-kernel route), 0 if it may be NULL (a host then need not
+ * allocate the D(D+1)/2 fields the reference's closure keeps: 6.5 GB at 512³). */
+int ins_smagorinsky_force_needs_sigma(const ins_grid_t* grid);
 /* tensorbasis!(B, V, u, setup)            tensorbasis.jl:16-72 (writes Ip): nb, nv = 3, 2 (2-D) or 11, 5 (3-D).  B is nb·D·D scalar fields,
  * element (a, b) of basis tensor ib at field index ib·D·D + a + D·b (the SMatrix' column-major order); V is nv scalar fields. */
 int ins_tensorbasis_f64(const ins_grid_t* grid, const double* u, double* B, double* V, void* stream);

@@ -76,6 +76,7 @@ SIGNATURES = {
     "ins_smagtensor_f64": (C.c_int, [vp, C.c_double, vp, vp, vp]),
     "ins_divoftensor_f64": (C.c_int, [vp, vp, vp, vp]),
     "ins_smagorinsky_force_f64": (C.c_int, [vp, C.c_double, vp, vp, vp, vp]),
+    "ins_smagorinsky_force_needs_sigma": (C.c_int, [vp]),
     "ins_tensorbasis_f64": (C.c_int, [vp, vp, vp, vp, vp]),
     "ins_combine_scalar_f64": (C.c_int, [vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), vp]),
     "ins_spectrum_create": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(vp)]),

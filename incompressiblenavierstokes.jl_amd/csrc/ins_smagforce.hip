@@ -399,6 +399,7 @@ int ins_k_smagforce(const ins_grid* G, double theta, const double* u, const doub
 // smagorinsky_closure(setup)(u, θ)   operators.jl:1284-1300 as one kernel where the box allows it, else the reference's three steps
 // (sigma: scratch of D(D+1)/2 scalar fields, used by the three-step route only)
 int ins_k_apply_bc_p_fields(const ins_grid* G, double* p, int nf, hipStream_t s);
+extern "C" int ins_smagorinsky_force_needs_sigma(const ins_grid_t* G) { return (G && ins_smagforce_supported(G)) ? 0 : 1; }
 extern "C" int ins_smagorinsky_force_f64(const ins_grid_t* G, double theta, const double* u, double* sigma, double* s, void* stream) {
   INS_REQUIRE(G && u && s, "null argument");
   if (ins_smagforce_supported(G)) return ins_k_smagforce(G, theta, u, nullptr, s, as_stream(stream));

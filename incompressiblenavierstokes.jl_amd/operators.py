@@ -382,14 +382,20 @@ def divoftensor_(s, σ, setup):
 
 def smagorinsky_closure(setup):
     """Create Smagorinsky closure model `m(u, θ)` (operators.jl:1284-1300)."""
-    σ = tensorfield(setup)
     s = vectorfield(setup)
     D = setup.grid.dimension
+    scratch = {}
 
     def closure(u, θ):
-        # smagtensor! -> apply_bc_p!(σ) -> divoftensor! behind one entry point: a single kernel on all-periodic uniform 3-D boxes
-        # (csrc/ins_smagforce.hip), the three kernels with σ as scratch elsewhere
-        _lib.call("ins_smagorinsky_force_f64", setup.handle, float(θ), setup.ptr(u, True), setup.ptr(σ, D * (D + 1) // 2), setup.ptr(s, True), setup.stream)
+        # smagtensor! -> apply_bc_p!(σ) -> divoftensor! behind one entry point: a single kernel wherever the grid allows it (csrc/ins_smagforce.hip:
+        # the stress stays in registers, no σ field is allocated), the three kernels with σ as scratch elsewhere — asked per call, an option may
+        # switch the route
+        σp = None
+        if _lib.load().ins_smagorinsky_force_needs_sigma(setup.handle):
+            if "σ" not in scratch:
+                scratch["σ"] = tensorfield(setup)
+            σp = setup.ptr(scratch["σ"], D * (D + 1) // 2)
+        _lib.call("ins_smagorinsky_force_f64", setup.handle, float(θ), setup.ptr(u, True), σp, setup.ptr(s, True), setup.stream)
         return s
 
     closure._ins_closure, closure._ins_setup = "smagorinsky", setup  # lets timestep_ run it inside the native stage loop (ins_rk_set_closure)

@@ -374,23 +374,26 @@ function apply_bc_temp!(temp::RA, t, setup; kwargs...)
 end
 # smagorinsky_closure(setup): σ as D(D+1)/2 scalar fields [xx, yy, (zz), xy, (xz, yz)].  A callable struct, so that `timestep!` can tell this
 # closure from a user function and carry it inside the native stage loop (ins_rk_set_closure).
-struct HipSmagorinsky{S,A,B}
+mutable struct HipSmagorinsky{S,B}
     setup::S
-    σ::A
+    σ::Any     # stress scratch of the three-kernel route, allocated when a call first needs it (the one-kernel route keeps σ in registers)
     s::B
 end
-function smagorinsky_closure(setup::ROCSetup)
-    D = setup.grid.dimension()
-    ns = D * (D + 1) ÷ 2
-    σ = similar(setup.grid.x[1], Float64, (setup.grid.N..., ns)); fill!(σ, 0)
-    HipSmagorinsky(setup, σ, IncompressibleNavierStokes.vectorfield(setup))
-end
+smagorinsky_closure(setup::ROCSetup) = HipSmagorinsky(setup, nothing, IncompressibleNavierStokes.vectorfield(setup))
 function (m::HipSmagorinsky)(u, θ)
-    (; setup, σ, s) = m
-    # smagtensor! -> apply_bc_p!(σ) -> divoftensor! (operators.jl:1284-1300) behind one entry point: one kernel on all-periodic uniform 3-D
-    # boxes (the stress stays in registers), the three kernels with σ as scratch elsewhere
+    (; setup, s) = m
+    # smagtensor! -> apply_bc_p!(σ) -> divoftensor! (operators.jl:1284-1300) behind one entry point: one kernel wherever the grid allows it (the
+    # stress stays in registers), the three kernels with σ as scratch elsewhere
+    σp = Ptr{Float64}(C_NULL)
+    if ccall((:ins_smagorinsky_force_needs_sigma, lib), Cint, (Ptr{Cvoid},), handle(setup)) != 0
+        if isnothing(m.σ)
+            D = setup.grid.dimension()
+            m.σ = similar(setup.grid.x[1], Float64, (setup.grid.N..., D * (D + 1) ÷ 2)); fill!(m.σ, 0)
+        end
+        σp = pointer(m.σ)
+    end
     check(ccall((:ins_smagorinsky_force_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
-                handle(setup), θ, pointer(u), pointer(σ), pointer(s), stream()))
+                handle(setup), θ, pointer(u), σp, pointer(s), stream()))
     s
 end
 # observespectrum: shells from spectral_stuff (host), everything else on the device
