@@ -3,7 +3,8 @@
 3-D Taylor-Green vortex, fp64 (BASELINE.json `metric`).
 
   python bench.py --gpus 1 --steps K --warmup W          (N = 1: TGV3D 256^3 = BASELINE configs[1])
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (z-slab decomposition)
+  python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N rank processes — `self_launch` — before anything touches the GPU)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (the same ranks started by the caller; z-slab decomposition)
 
 Prints ONE JSON line on rank 0.  `roofline` is the dominant kernel of the step — the momentum-RHS stencil with the
 RK stage combination fused behind it (K1+K6) — timed live with HIP events recorded on the step's own
@@ -82,12 +83,11 @@ def cpu_baseline(n=256, budget_s=20.0):
     }
 
 
-def strong_512_single_gpu(ins, dev, steps=10, warmup=2):
+def strong_single_gpu(ins, dev, n=512, steps=10, warmup=2):
     """The strong-scaling workload of BASELINE configs[3] (TGV3D 512^3, RK44 + spectral Poisson, dt = 2.5e-4) on ONE GPU: the N = 1 point of the
     1/2/4/8-GPU curve (`bench.py --gpus N` runs the same box on z-slabs of 512/N planes and reports the same object)."""
     import torch
 
-    n = 512
     setup = ins.Setup(x=(np.linspace(0.0, 1.0, n + 1),) * 3, Re=1000.0, device=dev)
     ps = ins.psolver_spectral(setup)
     u = ins.velocityfield(setup, tgv3d, 0.0, psolver=ps)
@@ -95,17 +95,67 @@ def strong_512_single_gpu(ins, dev, steps=10, warmup=2):
     cache = ins.ode_method_cache(method, setup, ps)
     st = ins.create_stepper(method, setup=setup, psolver=ps, u=u, t=0.0)
     dt = 2.5e-4
-    st = ins.timesteps_(method, st, dt, warmup, cache=cache)
+    if warmup:
+        st = ins.timesteps_(method, st, dt, warmup, cache=cache)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     st = ins.timesteps_(method, st, dt, steps, cache=cache)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / steps
     div = ins.max_abs_divergence(st.u, setup)
-    assert div / n < 1e-10, f"512^3 state is not divergence-free: {div}"
-    return {"workload": "TaylorGreenVortex3D 512^3 periodic fp64, RK44 + spectral Poisson, dt=2.5e-4 (BASELINE configs[3]), total work fixed over N",
+    assert div / n < 1e-10, f"{n}^3 state is not divergence-free: {div}"
+    return {"workload": f"TaylorGreenVortex3D {n}^3 periodic fp64, RK44 + spectral Poisson, dt=2.5e-4 (BASELINE configs[3]), total work fixed over N",
             "scaling": "strong", "n_gpus": 1, "grid": [n, n, n], "steps": steps, "warmup": warmup, "ms_per_step": ms,
-            "value": float(n) ** 3 / (ms * 1e-3) / 1e6, "unit": "M cell-updates/s", "max_abs_div_times_dx": div / n}
+            "value": float(n) ** 3 / (ms * 1e-3) / 1e6, "unit": "M cell-updates/s", "max_abs_div_times_dx": div / n,
+            "speedup_vs_n1_hint": {"n1_ms_per_step": ms, "speedup": 1.0, "source": "this run (N = 1)"}}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as CHILD processes (torch.distributed.run, rendezvous on 127.0.0.1, a free
+    port) — this parent never imports torch and never touches the GPU, so nothing is exec'ed from a GPU-initialised process —, relay rank 0's single JSON line and
+    exit non-zero if any rank failed, no line came back or the run exceeded INS_BENCH_LAUNCH_TIMEOUT seconds (default 1500; the whole process group is killed)."""
+    import signal
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__),
+           # spelled out (not sys.argv): torch.distributed.run's parser claims abbreviations such as `--n` even behind the script name
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--cells", str(args.n)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL across processes)
+    env["INS_BENCH_SELF_LAUNCHED"] = "1"
+    limit = float(os.environ.get("INS_BENCH_LAUNCH_TIMEOUT", "1500"))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        stdout, _ = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        print(f"bench.py: the {args.gpus} ranks did not finish within {limit:.0f} s; killed", file=sys.stderr)
+        sys.exit(124)
+    line = None
+    for ln in stdout.splitlines():
+        if ln.startswith("{"):
+            try:
+                if "metric" in json.loads(ln):
+                    line = ln
+            except ValueError:
+                pass
+    if proc.returncode != 0 or line is None:
+        sys.stderr.write(stdout)
+        print(f"bench.py: rank launcher exited with {proc.returncode}" + ("" if line else "; no result line from rank 0"), file=sys.stderr)
+        sys.exit(proc.returncode or 1)
+    print(line)
+    sys.exit(0)
 
 
 def main():
@@ -113,9 +163,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=256, help="cells per direction on one GPU")
+    ap.add_argument("--n", "--cells", dest="n", type=int, default=256, help="cells per direction on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)  # before torch / the library are imported: the parent stays off the GPU
 
     import torch
 
@@ -125,8 +177,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU")
     if world > 1:
         from bench_dist import run_distributed  # z-slab path
 
@@ -258,7 +309,7 @@ def main():
         "ms_per_step": ms_per_step,
         "ms_per_step_single_calls": single_ms,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "single",  # one GPU: the N = 1 point of both curves (weak: 256^3 per GPU = this line's value; strong: `strong_512`)
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -298,7 +349,7 @@ def main():
     del stepper, cache, u, ps, setup
     torch.cuda.empty_cache()
     if not os.environ.get("INS_BENCH_SKIP_STRONG_512"):
-        out["strong_512"] = strong_512_single_gpu(ins, dev)
+        out["strong_512"] = strong_single_gpu(ins, dev)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n)
     print(json.dumps(out))

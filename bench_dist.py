@@ -4,6 +4,7 @@ Headline line (`value`): weak scaling, every rank holds 256^3 cells — the glob
 (nx, ny, nz) = (256, 256, 512) at N=2, (256, 512, 512) at N=4 and 512^3 at N=8 (= BASELINE configs[3]).
 `strong_512`: the strong-scaling leg the north star asks for — the SAME 512^3 box at every N (z-slabs of 512/N planes);
 bench.py's N = 1 line carries the single-GPU point of that curve."""
+import importlib
 import json
 import os
 import time
@@ -35,12 +36,30 @@ def tgv_local(lay, L=(1.0, 1.0, 1.0)):
     return out
 
 
+def _rehearsal_kernels():
+    """INS_BENCH_REHEARSAL_KERNELS="module:Class" (honoured with INS_BENCH_BACKEND=gloo only): rank-local kernels injected by a TEST so that the launch path,
+    the rank bookkeeping and the JSON line can be exercised on a machine without a GPU (tests/test_bench_launch.py injects the oracle-backed CPU kernels of
+    tests/slab_cpu_kernels.py).  The line then says `"rehearsal"` and its numbers mean nothing; no measured run ever takes this branch."""
+    spec = os.environ.get("INS_BENCH_REHEARSAL_KERNELS")
+    if not spec or os.environ.get("INS_BENCH_BACKEND") != "gloo":
+        return None
+    mod, cls = spec.split(":")
+    return getattr(importlib.import_module(mod), cls)
+
+
+def _sync(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+
+
 def run_slab(ins, n, dt, steps, warmup, dev, backend, profile=True):
     """Warm-up + timed `steps` chained RK44 steps of the TGV on the global box `n`, this rank's z-slab.  Returns (max-over-ranks seconds,
     diagnostics).  Barrier + device synchronisation on both sides of the timed region."""
     world, rank = dist.get_world_size(), dist.get_rank()
     lay = ins.SlabLayout(n, world, rank)
-    K = ins.HipSlabKernels(lay, Re=1000.0, device=dev)
+    reh = _rehearsal_kernels()
+    K = reh(lay, Re=1000.0, own=True) if reh else ins.HipSlabKernels(lay, Re=1000.0, device=dev)
+    profile = profile and reh is None
     # zsolve (INS_SLAB_ZSOLVE): "tridiag" (default for > 1 rank) needs no transposes; "fft" pipelines them over kx-chunks on a second
     # communicator so that back-transposes of finished chunks run beside forward ones (full-duplex xGMI links)
     zs = os.environ.get("INS_SLAB_ZSOLVE") or ("tridiag" if world > 1 else "fft")
@@ -63,21 +82,22 @@ def run_slab(ins, n, dt, steps, warmup, dev, backend, profile=True):
     if warmup:
         st.steps_(u, dt, warmup)
     dist.barrier()
-    torch.cuda.synchronize()
+    _sync(dev)
     t0 = time.perf_counter()
     st.steps_(u, dt, steps)
-    torch.cuda.synchronize()
+    _sync(dev)
     dist.barrier()
     t1 = time.perf_counter()
     el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    info = {"zsolve": st.zsolve, "kx_chunks": len(st.chunks), "nzl": lay.nzl}
+    info = {"zsolve": st.zsolve, "kx_chunks": len(st.chunks), "nzl": lay.nzl, "stage_ms": 0.0, "nstage": 0, "stage_bytes": 0.0,
+            "cells_rank": float(n[0]) * n[1] * lay.nzl}
     if profile:
         # roofline of the dominant kernel (the correcting stage kernel, K1 + K6 + the previous projection's gradient-subtract): two more
         # steps with HIP events around its launches on the stream it runs on; outside the timed region
         K.prof = []
         st.steps_(u, dt, 2)
-        torch.cuda.synchronize()
+        _sync(dev)
         prof, K.prof = K.prof, None
         info["stage_ms"] = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
         info["nstage"] = sum(1 for _, _, b in prof if b)
@@ -86,7 +106,8 @@ def run_slab(ins, n, dt, steps, warmup, dev, backend, profile=True):
     info["div"] = st.max_abs_divergence(u)
     info["finite"] = bool(torch.isfinite(u).all())
     del st, K, u
-    torch.cuda.empty_cache()
+    if dev.type == "cuda":
+        torch.cuda.empty_cache()
     return float(el), info
 
 
@@ -96,15 +117,29 @@ def run_distributed(args, ins):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("INS_BENCH_BACKEND", "nccl")  # "gloo": rehearsal with several ranks on one GPU
     ndev = torch.cuda.device_count()
-    dev = torch.device("cuda", local_rank if backend == "nccl" else local_rank % ndev)
-    torch.cuda.set_device(dev)
+    rehearsal = _rehearsal_kernels() is not None
+    if rehearsal:
+        dev = torch.device("cpu")
+    else:
+        if backend == "nccl" and local_rank >= ndev:
+            raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({ndev} visible); one rank per GPU")
+        dev = torch.device("cuda", local_rank if backend == "nccl" else local_rank % ndev)
+        torch.cuda.set_device(dev)
     if backend == "nccl":
         dist.init_process_group("nccl", device_id=dev)
+        # the communicator's size as RCCL itself reports it: a sum of ones over the ranks, reduced on the devices
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == world, f"RCCL communicator spans {rccl_ranks} ranks, expected {world}"
     else:
         dist.init_process_group(backend)
+        rccl_ranks = None  # gloo rehearsal: no RCCL communicator exists
     n = GLOBAL_GRIDS.get(world)
     if n is None:
         n = (args.n, args.n, args.n * world)
+    elif args.n != 256:  # --n: cells per direction and GPU (default 256); the weak-scaling boxes keep their aspect
+        n = tuple(v * args.n // 256 for v in n)
     el, info = run_slab(ins, n, 1e-3, args.steps, args.warmup, dev, backend)
     stage_ms, nstage, cells_rank, stage_bytes, div, finite = (info[k] for k in ("stage_ms", "nstage", "cells_rank", "stage_bytes", "div", "finite"))
     # strong-scaling leg (north star / BASELINE configs[3]): the SAME 512^3 box on every N, z-slabs of 512/N planes
@@ -114,10 +149,20 @@ def run_distributed(args, ins):
         ssteps, swarm = max(2, min(args.steps, 10)), min(args.warmup, 2)
         el5, info5 = run_slab(ins, n5, 2.5e-4, ssteps, swarm, dev, backend, profile=False)
         ms5 = el5 * 1e3 / ssteps
+        # the N = 1 point of the same curve on the same node: rank 0 runs the single-GPU path on the same box while the other ranks wait at the barrier below
+        n1 = None
+        if rank == 0 and not rehearsal and not os.environ.get("INS_BENCH_SKIP_N1_REF") and n5[0] == n5[1] == n5[2]:
+            from bench import strong_single_gpu
+
+            n1 = strong_single_gpu(ins, dev, n=n5[0], steps=ssteps, warmup=swarm)["ms_per_step"]
+        dist.barrier()
         strong = {"workload": f"TaylorGreenVortex3D {n5[0]}x{n5[1]}x{n5[2]} periodic fp64, RK44 + distributed spectral Poisson, dt=2.5e-4 (BASELINE configs[3]), "
                               "total work fixed over N", "scaling": "strong", "n_gpus": world, "grid": list(n5), "planes_per_rank": info5["nzl"],
                   "steps": ssteps, "warmup": swarm, "ms_per_step": ms5, "value": float(n5[0]) * n5[1] * n5[2] / (ms5 * 1e-3) / 1e6, "unit": "M cell-updates/s",
-                  "max_abs_div_times_dx": info5["div"] / n5[0], "finite": info5["finite"], "zsolve": info5["zsolve"]}
+                  "max_abs_div_times_dx": info5["div"] / n5[0], "finite": info5["finite"], "zsolve": info5["zsolve"],
+                  "speedup_vs_n1_hint": {"n1_ms_per_step": n1, "speedup": (n1 / ms5) if n1 else None,
+                                         "source": "single-GPU path on the same box, timed by rank 0 on its GPU right after the slab run (same steps / warm-up); "
+                                                   "the driver's own N = 1 run is the figure to divide by" if n1 else "not measured in this run: divide by the N = 1 line's strong_512.ms_per_step"}}
     if rank == 0:
         ms = el * 1e3 / args.steps
         cells = float(n[0]) * n[1] * n[2]
@@ -135,7 +180,7 @@ def run_distributed(args, ins):
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"TaylorGreenVortex3D {n[0]}x{n[1]}x{n[2]} periodic fp64, RK44 + distributed spectral Poisson, dt=1e-3, Re=1e3",
-                       "grid": list(n), "decomposition": f"z-slabs x{world} (256^3 cells per GPU), RCCL halo planes + "
+                       "grid": list(n), "decomposition": f"z-slabs x{world} ({args.n}^3 cells per GPU), RCCL halo planes + "
                                         + ("one all-gather of interface values per solve (distributed tridiagonal z solve)" if info["zsolve"] == "tridiag"
                                            else "all-to-all transposes around the z-FFT")},
             "roofline": {"kernel": "k_flux64 CORR (slab): momentum-RHS stencil + RK stage combination + in-register pressure correction, per rank (rank 0)",
@@ -145,6 +190,8 @@ def run_distributed(args, ins):
                          "note": "algorithmic bytes of the stages measured (2 chained RK44 steps after the timed region) / HIP-event time of their launches "
                                  "(interior + boundary plane ranges summed per stage); N = 1 has the PMC traffic figure"},
             "strong_512": strong,
+            "rccl_ranks": rccl_ranks,
+            "rehearsal": ("CPU stand-in kernels injected by a test (INS_BENCH_REHEARSAL_KERNELS): launch-path check only, the numbers mean nothing" if rehearsal else None),
             "check": {"max_abs_div_times_dx": div * (1.0 / n[0]), "finite": finite, "backend": backend, "zsolve": info["zsolve"], "kx_chunks": info["kx_chunks"]},
         }
         print(json.dumps(out))
