@@ -384,6 +384,11 @@ int ins_comm_unique_id(void* id128);
 int ins_comm_create(int nranks, int rank, const void* id128, ins_comm_t** out);
 /* One process driving ngpu devices (devices == NULL: 0..ngpu-1): out[i] is the communicator of devices[i] (ncclCommInitAll). */
 int ins_comm_create_local(int ngpu, const int* devices, ins_comm_t** out);
+/* ngpu > 1 driven by ONE host thread: bracket every round of exchange calls over the communicators (comm 0, comm 1, ...) with group_begin / group_end
+ * (ncclGroupStart / ncclGroupEnd; RCCL's single-thread multi-device rule — the groups the entry points open themselves nest inside); with one host thread
+ * per device, or one process per GPU, they are not needed.  The ngpu > 1 local mode has never run on hardware (no multi-GPU box): unpinned. */
+int ins_comm_group_begin(void);
+int ins_comm_group_end(void);
 int ins_comm_destroy(ins_comm_t* comm);
 int ins_comm_rank(const ins_comm_t* comm, int* rank, int* nranks);
 /* Generic grouped exchange; messages between one pair of ranks match in posting order. */

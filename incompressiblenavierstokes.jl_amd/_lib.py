@@ -149,6 +149,8 @@ SIGNATURES = {
     "ins_comm_unique_id": (C.c_int, [vp]),
     "ins_comm_create": (C.c_int, [C.c_int, C.c_int, vp, C.POINTER(vp)]),
     "ins_comm_create_local": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]),
+    "ins_comm_group_begin": (C.c_int, []),
+    "ins_comm_group_end": (C.c_int, []),
     "ins_comm_destroy": (C.c_int, [vp]),
     "ins_comm_rank": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ins_comm_sendrecv_f64": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int, C.POINTER(vp),

@@ -77,6 +77,17 @@ int load_rccl() {
     }                                                                                                   \
   } while (0)
 
+// inside an open group: close it before returning, or the thread's group stays open and later calls are silently queued
+#define INS_NCCL_TRY_G(expr)                                                                            \
+  do {                                                                                                  \
+    ncclResult_t _r = (expr);                                                                           \
+    if (_r != ncclSuccess) {                                                                            \
+      ins_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, g_rccl.GetErrorString(_r));           \
+      g_rccl.GroupEnd();                                                                                \
+      return INS_ERR_COMM;                                                                              \
+    }                                                                                                   \
+  } while (0)
+
 }  // namespace
 
 struct ins_comm {
@@ -112,6 +123,21 @@ extern "C" int ins_comm_create(int nranks, int rank, const void* id128, ins_comm
     return INS_ERR_COMM;
   }
   *out = c;
+  return INS_OK;
+}
+
+// One host thread driving several communicators (ins_comm_create_local with ngpu > 1): RCCL wants the calls of ALL its devices inside one group, so the host
+// brackets each round of per-communicator exchange calls with these two (the groups the entry points open themselves nest inside).
+extern "C" int ins_comm_group_begin(void) {
+  int rc = load_rccl();
+  if (rc) return rc;
+  INS_NCCL_TRY(g_rccl.GroupStart());
+  return INS_OK;
+}
+extern "C" int ins_comm_group_end(void) {
+  int rc = load_rccl();
+  if (rc) return rc;
+  INS_NCCL_TRY(g_rccl.GroupEnd());
   return INS_OK;
 }
 
@@ -158,8 +184,8 @@ extern "C" int ins_comm_sendrecv_f64(ins_comm_t* c, int nsend, const double* con
   for (int i = 0; i < nrecv; ++i) INS_REQUIRE(recvbufs[i] && recvcounts[i] >= 0 && srcs[i] >= 0 && srcs[i] < c->nranks, "bad receive");
   hipStream_t s = as_stream(stream);
   INS_NCCL_TRY(g_rccl.GroupStart());
-  for (int i = 0; i < nsend; ++i) INS_NCCL_TRY(g_rccl.Send(sendbufs[i], (size_t)sendcounts[i], ncclDouble, dsts[i], c->comm, s));
-  for (int i = 0; i < nrecv; ++i) INS_NCCL_TRY(g_rccl.Recv(recvbufs[i], (size_t)recvcounts[i], ncclDouble, srcs[i], c->comm, s));
+  for (int i = 0; i < nsend; ++i) INS_NCCL_TRY_G(g_rccl.Send(sendbufs[i], (size_t)sendcounts[i], ncclDouble, dsts[i], c->comm, s));
+  for (int i = 0; i < nrecv; ++i) INS_NCCL_TRY_G(g_rccl.Recv(recvbufs[i], (size_t)recvcounts[i], ncclDouble, srcs[i], c->comm, s));
   INS_NCCL_TRY(g_rccl.GroupEnd());
   return INS_OK;
 }
@@ -178,15 +204,15 @@ extern "C" int ins_halo_exchange_f64(ins_comm_t* c, const ins_grid_t* G, double*
   INS_NCCL_TRY(g_rccl.GroupStart());
   // posting order: everything for `next`, then everything for `prev`; receives: from `prev`, then from `next` (pairs up when prev == next)
   for (int a = 0; a < 3; ++a)
-    if (comp_mask & (1 << a)) INS_NCCL_TRY(g_rccl.Send(u + a * g.sc + (long long)nzl * plane, (size_t)plane, ncclDouble, next, c->comm, s));
+    if (comp_mask & (1 << a)) INS_NCCL_TRY_G(g_rccl.Send(u + a * g.sc + (long long)nzl * plane, (size_t)plane, ncclDouble, next, c->comm, s));
   if (!down_only)
     for (int a = 0; a < 3; ++a)
-      if (comp_mask & (1 << a)) INS_NCCL_TRY(g_rccl.Send(u + a * g.sc + plane, (size_t)plane, ncclDouble, prev, c->comm, s));
+      if (comp_mask & (1 << a)) INS_NCCL_TRY_G(g_rccl.Send(u + a * g.sc + plane, (size_t)plane, ncclDouble, prev, c->comm, s));
   for (int a = 0; a < 3; ++a)
-    if (comp_mask & (1 << a)) INS_NCCL_TRY(g_rccl.Recv(u + a * g.sc, (size_t)plane, ncclDouble, prev, c->comm, s));
+    if (comp_mask & (1 << a)) INS_NCCL_TRY_G(g_rccl.Recv(u + a * g.sc, (size_t)plane, ncclDouble, prev, c->comm, s));
   if (!down_only)
     for (int a = 0; a < 3; ++a)
-      if (comp_mask & (1 << a)) INS_NCCL_TRY(g_rccl.Recv(u + a * g.sc + (long long)(nzl + 1) * plane, (size_t)plane, ncclDouble, next, c->comm, s));
+      if (comp_mask & (1 << a)) INS_NCCL_TRY_G(g_rccl.Recv(u + a * g.sc + (long long)(nzl + 1) * plane, (size_t)plane, ncclDouble, next, c->comm, s));
   INS_NCCL_TRY(g_rccl.GroupEnd());
   return INS_OK;
 }
@@ -199,10 +225,10 @@ extern "C" int ins_halo_exchange_p_f64(ins_comm_t* c, double* p_ext, int64_t pla
   hipStream_t s = as_stream(stream);
   const size_t pl = (size_t)plane_elems;
   INS_NCCL_TRY(g_rccl.GroupStart());
-  INS_NCCL_TRY(g_rccl.Send(p_ext + pl * nzl, pl, ncclDouble, next, c->comm, s));
-  INS_NCCL_TRY(g_rccl.Send(p_ext + pl, 2 * pl, ncclDouble, prev, c->comm, s));
-  INS_NCCL_TRY(g_rccl.Recv(p_ext, pl, ncclDouble, prev, c->comm, s));
-  INS_NCCL_TRY(g_rccl.Recv(p_ext + pl * (nzl + 1), 2 * pl, ncclDouble, next, c->comm, s));
+  INS_NCCL_TRY_G(g_rccl.Send(p_ext + pl * nzl, pl, ncclDouble, next, c->comm, s));
+  INS_NCCL_TRY_G(g_rccl.Send(p_ext + pl, 2 * pl, ncclDouble, prev, c->comm, s));
+  INS_NCCL_TRY_G(g_rccl.Recv(p_ext, pl, ncclDouble, prev, c->comm, s));
+  INS_NCCL_TRY_G(g_rccl.Recv(p_ext + pl * (nzl + 1), 2 * pl, ncclDouble, next, c->comm, s));
   INS_NCCL_TRY(g_rccl.GroupEnd());
   return INS_OK;
 }
@@ -220,10 +246,10 @@ extern "C" int ins_ztri_allgather_f64(ins_comm_t* c, const double* edge, double*
   INS_HIP_TRY(hipMemcpyAsync(edges_all + (long long)c->rank * count, edge, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, s));
   if (c->nranks == 1) return INS_OK;
   INS_NCCL_TRY(g_rccl.GroupStart());
-  for (int d = 1; d < c->nranks; ++d) INS_NCCL_TRY(g_rccl.Send(edge, (size_t)count, ncclDouble, (c->rank + d) % c->nranks, c->comm, s));
+  for (int d = 1; d < c->nranks; ++d) INS_NCCL_TRY_G(g_rccl.Send(edge, (size_t)count, ncclDouble, (c->rank + d) % c->nranks, c->comm, s));
   for (int d = c->nranks - 1; d >= 1; --d) {
     const int q = (c->rank + d) % c->nranks;
-    INS_NCCL_TRY(g_rccl.Recv(edges_all + (long long)q * count, (size_t)count, ncclDouble, q, c->comm, s));
+    INS_NCCL_TRY_G(g_rccl.Recv(edges_all + (long long)q * count, (size_t)count, ncclDouble, q, c->comm, s));
   }
   INS_NCCL_TRY(g_rccl.GroupEnd());
   return INS_OK;
@@ -252,10 +278,10 @@ extern "C" int ins_halo_exchange_scalar_f64(ins_comm_t* c, const ins_grid_t* G, 
   const int prev = (c->rank + c->nranks - 1) % c->nranks, next = (c->rank + 1) % c->nranks;
   hipStream_t s = as_stream(stream);
   INS_NCCL_TRY(g_rccl.GroupStart());
-  INS_NCCL_TRY(g_rccl.Send(p + plane * nzl, plane, ncclDouble, next, c->comm, s));
-  INS_NCCL_TRY(g_rccl.Send(p + plane, plane, ncclDouble, prev, c->comm, s));
-  INS_NCCL_TRY(g_rccl.Recv(p, plane, ncclDouble, prev, c->comm, s));
-  INS_NCCL_TRY(g_rccl.Recv(p + plane * (nzl + 1), plane, ncclDouble, next, c->comm, s));
+  INS_NCCL_TRY_G(g_rccl.Send(p + plane * nzl, plane, ncclDouble, next, c->comm, s));
+  INS_NCCL_TRY_G(g_rccl.Send(p + plane, plane, ncclDouble, prev, c->comm, s));
+  INS_NCCL_TRY_G(g_rccl.Recv(p, plane, ncclDouble, prev, c->comm, s));
+  INS_NCCL_TRY_G(g_rccl.Recv(p + plane * (nzl + 1), plane, ncclDouble, next, c->comm, s));
   INS_NCCL_TRY(g_rccl.GroupEnd());
   return INS_OK;
 }
@@ -267,8 +293,8 @@ extern "C" int ins_comm_alltoall_f64(ins_comm_t* c, const double* send, double* 
   hipStream_t s = as_stream(stream);
   INS_NCCL_TRY(g_rccl.GroupStart());
   for (int r = 0; r < c->nranks; ++r) {
-    INS_NCCL_TRY(g_rccl.Send(send + (long long)r * count, (size_t)count, ncclDouble, r, c->comm, s));
-    INS_NCCL_TRY(g_rccl.Recv(recv + (long long)r * count, (size_t)count, ncclDouble, r, c->comm, s));
+    INS_NCCL_TRY_G(g_rccl.Send(send + (long long)r * count, (size_t)count, ncclDouble, r, c->comm, s));
+    INS_NCCL_TRY_G(g_rccl.Recv(recv + (long long)r * count, (size_t)count, ncclDouble, r, c->comm, s));
   }
   INS_NCCL_TRY(g_rccl.GroupEnd());
   return INS_OK;

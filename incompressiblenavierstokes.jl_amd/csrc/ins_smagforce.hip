@@ -325,7 +325,14 @@ __global__ __launch_bounds__(256, 2) void k_smagforce(SmagArgs a) {
 }  // namespace
 
 // all-periodic uniform boxes: the specialised form (central differences, no masks, on-the-fly correction available)
-static bool smagforce_uniform(const ins_grid* G) { return G->all_dof && G->uniform_exact; }
+// (z-slab grids — INS_BC_HALO sides — are all_dof and uniform_exact too, but their z neighbours are exchanged ghost planes, not images inside the slab)
+static bool smagforce_uniform(const ins_grid* G) { return G->all_periodic && G->all_dof && G->uniform_exact; }
+static bool has_halo_side(const ins_grid* G) {
+  for (int d = 0; d < G->g.D; ++d)
+    for (int side = 0; side < 2; ++side)
+      if (G->g.bc[d][side] == INS_BC_HALO) return true;
+  return false;
+}
 
 bool ins_smagforce_supported(const ins_grid* G) {
   const GridDev& g = G->g;
@@ -334,7 +341,8 @@ bool ins_smagforce_supported(const ins_grid* G) {
   if (ins_opt(OPT_INS_DISABLE_SMAGFORCE_GEN)) return false;
   for (int d = 0; d < 3; ++d)
     for (int side = 0; side < 2; ++side)
-      if (g.bc[d][side] == INS_BC_PRESSURE) return false;  // (its ghost rule for σ and its DOF range are not covered: the three kernels)
+      if (g.bc[d][side] == INS_BC_PRESSURE || g.bc[d][side] == INS_BC_HALO) return false;  // (ghost rule for σ / DOF range not covered: the three kernels;
+                                                                                           //  slab grids: refused by the entry points)
   return true;
 }
 // the correcting form (uncorrected input + pressure) exists for all-periodic uniform boxes only
@@ -402,6 +410,10 @@ int ins_k_apply_bc_p_fields(const ins_grid* G, double* p, int nf, hipStream_t s)
 extern "C" int ins_smagorinsky_force_needs_sigma(const ins_grid_t* G) { return (G && ins_smagforce_supported(G)) ? 0 : 1; }
 extern "C" int ins_smagorinsky_force_f64(const ins_grid_t* G, double theta, const double* u, double* sigma, double* s, void* stream) {
   INS_REQUIRE(G && u && s, "null argument");
+  if (has_halo_side(G)) {  // the stress tensor's ghost planes would have to travel between the ranks inside this call
+    ins_set_error("ins_smagorinsky_force_f64: z-slab grids (INS_BC_HALO sides) are not supported");
+    return INS_ERR_UNSUPPORTED;
+  }
   if (ins_smagforce_supported(G)) return ins_k_smagforce(G, theta, u, nullptr, s, as_stream(stream));
   INS_REQUIRE(sigma, "sigma scratch needed on this grid");
   const int D = G->g.D;

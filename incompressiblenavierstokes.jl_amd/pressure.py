@@ -114,10 +114,28 @@ def _laplacian_1d(setup, a):
     return T
 
 
+def _sym_slack(S):
+    """How far a decomposition may be from the given matrix and still count as 'at rounding level': 64 x the backward-error bound n·eps·max|S| of the
+    symmetric eigensolver itself (cosine grids are mirror-symmetric only up to the rounding of their coordinates: 1.5e-12 relative in the wall cells at
+    n = 256, 5e-12 at n = 1024 — inside this slack; a grid that is merely close to symmetric is not)."""
+    return 64.0 * S.shape[0] * np.finfo(float).eps * np.abs(S).max()
+
+
 def _centrosymmetric(S):
     """A symmetric grid (cosine, tanh, uniform walls) gives a factor that commutes with the reflection i -> n-1-i."""
     n = S.shape[0]
-    return n % 2 == 0 and n >= 8 and np.allclose(S, S[::-1, ::-1], rtol=1e-12, atol=1e-12 * np.abs(S).max())
+    return n % 2 == 0 and n >= 8 and np.abs(S - S[::-1, ::-1]).max() <= _sym_slack(S)
+
+
+def _eigh_1d(S):
+    """Eigenpairs of the symmetric 1-D factor: through the even / odd blocks when the grid is mirror-symmetric, and only if those pairs satisfy the GIVEN
+    matrix to rounding level (the even / odd route diagonalises the symmetrised matrix: on a grid that is only approximately symmetric its pairs belong to
+    a perturbed operator and the projection residual grows to that perturbation times the condition number — advisor finding, round 2); else LAPACK's."""
+    if _centrosymmetric(S):
+        lam, W = _eigh_even_odd(S)
+        if np.abs(S @ W - W * lam[None, :]).max() <= _sym_slack(S):
+            return lam, W
+    return np.linalg.eigh(S)
 
 
 def _eigh_even_odd(S):
@@ -161,7 +179,7 @@ class psolver_direct(_PSolver):
                 raise ValueError("psolver_direct: the 1-D Laplacian factor is not symmetric")
             dm = 1.0 / np.sqrt(g.Δ[a][lo:hi])
             S = dm[:, None] * T * dm[None, :]  # D^-1/2 T D^-1/2 = W Λ Wᵀ
-            lam, W = _eigh_even_odd(S) if _centrosymmetric(S) else np.linalg.eigh(S)
+            lam, W = _eigh_1d(S)
             self._V.append(np.asfortranarray(dm[:, None] * W))  # Vα = D^-1/2 W,  VαᵀDαVα = I
             self._lam.append(np.ascontiguousarray(lam))
         dp = C.POINTER(C.c_double)

@@ -83,3 +83,31 @@ def test_fdm_solve_matches_sparse_direct(name):
     if singular:
         q = q - q.mean()
     assert np.abs(q - pref).max() <= 1e-10 * np.abs(pref).max()
+
+
+def _factor_1d(x):
+    so = o.make_setup((x, np.linspace(0.0, 1.0, 5)), ((o.DirichletBC(), o.DirichletBC()), (o.PeriodicBC(), o.PeriodicBC())), Re=100.0)
+    hs = host_setup(so)
+    lo, hi = so.grid.Ip[0]
+    dm = 1.0 / np.sqrt(so.grid.dx[0][lo:hi])
+    return dm[:, None] * _laplacian_1d(hs, 0) * dm[None, :]
+
+
+@pytest.mark.parametrize("n", [64, 256, 1024])
+def test_even_odd_eigenpairs_only_when_they_satisfy_the_given_matrix(n):
+    """The half-size (even / odd) eigen-decomposition is taken for mirror-symmetric grids — the reference's cosine grid is one up to the rounding of its
+    coordinates — and its pairs must satisfy the GIVEN 1-D factor at the eigensolver's own rounding level; a grid that is only approximately symmetric
+    (wall cells 1e-9 apart) gets LAPACK's pairs of the given matrix instead of pairs of a perturbed one (advisor finding, round 2)."""
+    from ins_amd.pressure import _eigh_1d, _sym_slack
+
+    S = _factor_1d(o.cosine_grid(0.0, 1.0, n))
+    lam, W = _eigh_1d(S)
+    h = n // 2
+    assert np.array_equal(W[:h, :h], W[h:, :h][::-1]) and np.array_equal(W[:h, h:], -W[h:, h:][::-1])  # exactly even / odd: the fold applies
+    assert np.abs(S @ W - W * lam[None, :]).max() <= _sym_slack(S)
+    x = o.cosine_grid(0.0, 1.0, n).copy()
+    x[1] *= 1.0 + 1e-9  # first cell 1e-9 (relative) wider than the last
+    S2 = _factor_1d(x)
+    lam2, W2 = _eigh_1d(S2)
+    assert not np.array_equal(W2[:h, :h], W2[h:, :h][::-1])
+    assert np.abs(S2 @ W2 - W2 * lam2[None, :]).max() <= _sym_slack(S2)

@@ -67,7 +67,9 @@ def test_comm_handles_and_raw_exchanges(ins):
     _lib.call("ins_comm_create_local", 1, None, hs)
     _lib.call("ins_comm_rank", hs[0], C.byref(r), C.byref(n))
     assert (r.value, n.value) == (0, 1)
+    _lib.call("ins_comm_group_begin")  # the bracket a single host thread puts around a round of per-communicator calls (nests with the calls' own groups)
     _lib.call("ins_comm_allreduce_f64", hs[0], C.c_void_p(t.data_ptr()), 2, 0, None)
+    _lib.call("ins_comm_group_end")
     torch.cuda.synchronize()
     assert lib.ins_comm_destroy(hs[0]) == 0 and lib.ins_comm_destroy(None) == 0
 

@@ -144,7 +144,37 @@ def test_one_kernel_closure_force_matches_the_three_kernel_sequence(ins, n):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("case", ["walls", "channel", "mixed", "tiny"])
+def test_closure_force_refuses_slab_grids(ins):
+    """A z-slab grid (INS_BC_HALO sides) is all_dof and uniform_exact like a periodic box, but its z neighbours are exchanged ghost planes: the closure-force
+    entry point must refuse it (INS_ERR_UNSUPPORTED) instead of wrapping z inside the slab (advisor finding, round 2)."""
+    from ins_amd import _lib
+
+    x = tuple(np.linspace(0.0, 1.0, n + 1) for n in (72, 12, 10))
+    per = (ins.PeriodicBC(), ins.PeriodicBC())
+    sp = ins.Setup(x=x, Re=1000.0, boundary_conditions=(per, per, (ins.HaloBC(), ins.HaloBC())))
+    u = ins.from_numpy(sp, fx.randn_field(sp.grid.N + (3,), 5))
+    with pytest.raises(_lib.INSHipError, match="slab"):
+        ins.smagorinsky_closure(sp)(u, 0.17)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("force", [1, 2])
+def test_generalised_closure_force_forms_on_a_periodic_box(ins, force):
+    """INS_SMAGFORCE_FORCE_GEN = 1 / 2 run the generalised forms (ghost rules + masks with central differences / with metric tables) on a periodic uniform
+    box, where the specialised form is the default: all three must agree."""
+    from ins_amd import _lib
+
+    x = tuple(np.linspace(0.0, 1.0, n + 1) for n in (136, 12, 10))
+    sp = ins.Setup(x=x, Re=1000.0)
+    u = ins.apply_bc_u(ins.from_numpy(sp, fx.randn_field(sp.grid.N + (3,), 6)), 0.0, sp)
+    m = ins.smagorinsky_closure(sp)
+    want = ins.to_numpy(m(u, 0.17)).copy()
+    with _lib.options(INS_SMAGFORCE_FORCE_GEN=force):
+        got = ins.to_numpy(m(u, 0.17)).copy()
+    assert np.max(np.abs(want)) > 0 and relmax(got, want) < OP_TOL
+
+
+@pytest.mark.parametrize("case", ["walls", "channel", "mixed", "tiny", "symuniform"])
 def test_one_kernel_closure_force_on_wall_bounded_and_stretched_grids(ins, case):
     """The generalised form of the one-kernel closure force (csrc/ins_smagforce.hip, GEN: metric tables, the ghost rule of apply_bc_p!(σ) as wrapped
     addresses / copies from the neighbour lane, row or plane, stores masked to the degrees of freedom) against the three-kernel sequence on the
@@ -162,6 +192,9 @@ def test_one_kernel_closure_force_on_wall_bounded_and_stretched_grids(ins, case)
     elif case == "mixed":
         x = (ins.cosine_grid(0.0, 1.0, 61), np.linspace(0.0, 0.7, 17), ins.tanh_grid(0.0, 1.3, 70, 1.3))
         bc = ((Sy(), Dr()), (Pe(), Pe()), (Dr(), Sy()))
+    elif case == "symuniform":  # uniform spacing, Symmetric / Periodic sides only: uniform_exact but not all_dof -> k_smagforce<R, false, true, false>
+        x = (np.linspace(0.0, 1.0, 71), np.linspace(0.0, 0.5, 13), np.linspace(0.0, 0.25, 11))
+        bc = ((Sy(), Sy()), (Pe(), Pe()), (Sy(), Sy()))
     else:
         x = (np.linspace(0.0, 1.0, 6), np.linspace(0.0, 1.0, 5), np.linspace(0.0, 1.0, 7))
         bc = ((Dr(), Dr()), (Dr(), Sy()), (Sy(), Dr()))
@@ -177,16 +210,22 @@ def test_one_kernel_closure_force_on_wall_bounded_and_stretched_grids(ins, case)
         assert relmax(one, three) < OP_TOL, zc
 
 
+def _symuniform3d(o):  # uniform spacing with Symmetric / Periodic sides only: the central-difference generalised form of the one-kernel closure force
+    x = (np.linspace(0.0, 1.0, 67), np.linspace(0.0, 0.5, 9), np.linspace(0.0, 0.25, 8))
+    S, P = o.SymmetricBC, o.PeriodicBC
+    return o.make_setup(x, ((S(), S()), (P(), P()), (S(), S())), Re=1000.0)
+
+
 def _symmetric3d(o):  # Symmetric / Dirichlet sides in every direction on a stretched grid (σ ghosts: copies of the neighbour / zero)
     x = (o.tanh_grid(0.0, 1.0, 14, 1.2), o.cosine_grid(0.0, 1.0, 9), o.tanh_grid(0.0, 0.5, 10, 1.1))
     S, Dr = o.SymmetricBC, o.DirichletBC
     return o.make_setup(x, ((S(), S()), (S(), Dr()), (Dr(), S())), Re=1000.0)
 
 
-@pytest.mark.parametrize("geom", ["periodic2d", "periodic3d", "periodic3d_wide", "dirichlet3d", "mixed3d", "symmetric3d"])
+@pytest.mark.parametrize("geom", ["periodic2d", "periodic3d", "periodic3d_wide", "dirichlet3d", "mixed3d", "symmetric3d", "symuniform3d"])
 def test_smagorinsky_closure_matches_oracle(ins, oracle, geom):
     o = oracle
-    so = _symmetric3d(o) if geom == "symmetric3d" else GEOMS[geom](o)
+    so = _symmetric3d(o) if geom == "symmetric3d" else _symuniform3d(o) if geom == "symuniform3d" else GEOMS[geom](o)
     sp = mirror(ins, so, o)
     g = so.grid
     u_h = o.apply_bc_u(fx.randn_field(g.N + (g.D,), 1), 0.0, so)
