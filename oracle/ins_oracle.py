@@ -10,8 +10,10 @@ the reference ships no golden vectors.  This restatement i
 the reference's OWN known-answer tests and invariants, re-run against it in `tests/test_oracle_*.py`:
   test/psolvers.jl:1-32 (analytic Poisson solution, direct/cg/spectral), test/operators.jl:58-160
   (G = -D', laplacian! == laplacian_mat, skew-symmetric convection, dissipative diffusion,
-  fused == unfused), test/matrices.jl:19-51 (mixed BCs), test/timesteppers.jl:1-43,
-  examples/TaylorGreenVortex2D.jl:29-74 (analytic decay, n^-2 convergence).
+  fused == unfused), test/matrices.jl:19-51 (BC / divergence / gradient / diffusion matrices on the mixed-BC
+  fixture: the matrices are restated by INDEX ASSEMBLY in oracle/ins_matrices.py — src/matrices.jl:1-555, the
+  reference's second implementation, which never calls the stencil code below — tests/test_oracle_matrices.py),
+  test/timesteppers.jl:1-43, examples/TaylorGreenVortex2D.jl:29-74 (analytic decay, n^-2 convergence).
 
 Conventions.  All indices here are 0-based; the reference is 1-based.  Fields are Fortran-ordered
 numpy arrays of shape `N + (D,)` (vector) / `N` (scalar) so that `u[i, j, k, a]` addresses the same
@@ -593,8 +595,16 @@ def laplacian_mat_apply(pdof, setup):
 
 
 def laplacian_mat(setup, dense=False):
-    """Assemble `laplacian_mat` (matrices.jl:484-492) by coloured probing of its matrix-free
-    definition above: the operator couples a DOF only with its 2·D face neighbours, so DOFs whose
+    """`laplacian_mat` (matrices.jl:483-492) = P' Ω M Bu G Bp P from the index-assembled sparse factors of oracle/ins_matrices.py (the
+    reference's own construction; independent of the stencil code in this file).  `laplacian_mat_probed` below is the third cross-check."""
+    from . import ins_matrices
+
+    L = ins_matrices.laplacian_mat(setup)
+    return L.toarray() if dense else L
+
+
+def laplacian_mat_probed(setup, dense=False):
+    """`laplacian_mat` by coloured probing of the matrix-free definition above (this file's stencil operators): the operator couples a DOF only with its 2·D face neighbours, so DOFs whose
     indices differ by a multiple of `c >= 3` in every direction (with `c | Np` when periodic) can be
     probed together.  Returns scipy CSR (or a dense array)."""
     import itertools

@@ -155,7 +155,6 @@ def test_closure_force_refuses_slab_grids(ins):
     u = ins.from_numpy(sp, fx.randn_field(sp.grid.N + (3,), 5))
     with pytest.raises(_lib.INSHipError, match="slab"):
         ins.smagorinsky_closure(sp)(u, 0.17)
-    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("force", [1, 2])
