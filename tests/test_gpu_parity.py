@@ -767,7 +767,9 @@ def test_direct_solver_keeps_physical_modes_on_strongly_stretched_grid(ins, orac
     w, q = want[ip] - want[ip].mean(), got[ip] - got[ip].mean()
     assert rell2(q, w) < 1e-6
     # and the projection really removes the divergence of the large scales
-    assert _flux_imbalance_ratio(ins, sp, solver, u_h, ip) < 1e-4  # cond(L) ~ 7e11 (observed 1.2e-6); dropped low modes: O(1)
+    ratio = _flux_imbalance_ratio(ins, sp, solver, u_h, ip)
+    print(f"strongly stretched tanh grid: flux imbalance after / before project! = {ratio:.3e}")
+    assert ratio < 1.2e-5  # 10 x the observed 1.2e-6 (cond(L) ~ 7e11); a partial regression of the null-mode rule (dropped low modes: O(1)) cannot pass
 
 
 def _flux_imbalance_ratio(ins, sp, solver, u_h, ip):
@@ -798,8 +800,11 @@ def test_direct_solver_cosine_grid_1024_projection(ins, oracle):
     solver = ins.psolver_direct(sp)
     p = ins.to_numpy(ins.poisson(solver, ins.from_numpy(sp, f)))
     res = o.laplacian(o.apply_bc_p(p, 0.0, so), so)[ip] - (f[ip] - f[ip].mean())
-    assert np.abs(res).sum() < 1e-5 * np.abs(f[ip]).sum()  # cond(L) ~ 1e10..1e11 (observed 1.3e-7); dropped low modes: O(1)
-    assert _flux_imbalance_ratio(ins, sp, solver, u_h, ip) < 1e-5
+    r1 = np.abs(res).sum() / np.abs(f[ip]).sum()
+    r2 = _flux_imbalance_ratio(ins, sp, solver, u_h, ip)
+    print(f"cosine grid 1024^2: |L p - f|_1 / |f|_1 = {r1:.3e}, flux imbalance after / before project! = {r2:.3e}")
+    assert r1 < 1.3e-6  # 10 x the observed 1.3e-7 (cond(L) ~ 1e10..1e11); dropped low modes: O(1)
+    assert r2 < 1.3e-6
     assert np.abs(p[ip]).max() > 1e-2  # the pressure of this smooth field lives in the first cosine modes (0.29 at N = 256)
 
 
