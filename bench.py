@@ -83,6 +83,43 @@ def cpu_baseline(n=256, budget_s=20.0):
     }
 
 
+def stage_bytes_per_cell(method, steps, chained):
+    """Compulsory bytes per cell of the fused stage kernel, stage by stage           step_explicit_runge_kutta.jl:35-38
+         k-basis:              R u_in + (R ustart, not for stage 1) + R k_j (non-zero a_ij) + W u* + (W k_i when a later stage needs it)
+         stage-velocity basis: R u_in + (R ustart) + R V_m (non-zero β_im) + W u*       (csrc/ins_rk.hip; no stage force is stored)
+    Returns (list per stage, K4 bytes per cell and step)."""
+    A = np.asarray(method.A, dtype=float)
+    ns = len(method.b)
+    inkernel = ns > 1 and not os.environ.get("INS_DISABLE_INKERNEL_CORR")
+    vbasis = inkernel and not os.environ.get("INS_RK_KEEP_K") and all(A[i, i] != 0.0 for i in range(ns))
+    stage_bytes = []
+    for i in range(ns):
+        inkernel_p = 8 if (i > 0 and inkernel) else 0  # stages >= 2 also read p
+        if vbasis:
+            beta = np.linalg.solve(A[:i, :i].T, A[i, :i]) if i else np.zeros(0)
+            nk, wk = int(np.count_nonzero(beta[: max(i - 1, 0)])), False  # β[i-1] multiplies the stencil input itself: taken from registers
+        else:
+            nk = sum(1 for j in range(i) if A[i, j] != 0.0)
+            wk = any(A[i2, i] != 0.0 for i2 in range(i + 1, ns))
+        stage_bytes.append(24 * (1 + (1 if i > 0 else 0) + nk + 1 + (1 if wk else 0)) + inkernel_p)
+    k4_bytes = 64.0  # final gradient-subtract + ghost images + padded p: once per step, or once per call when the steps are chained
+    if chained and vbasis and steps > 1:
+        # chained steps: the first stage of steps 2..K also reads p and stores the corrected start field (+8 + 24 B), and K4 runs once
+        stage_bytes[0] += 32.0 * (steps - 1) / steps
+        k4_bytes /= steps
+    return stage_bytes, k4_bytes
+
+
+def committed_traffic(name):
+    """HBM bytes per launch of the stage kernel (RK44 step average) from a committed `rocprofv3 --pmc` result under profiles/ (FETCH_SIZE and WRITE_SIZE in
+    separate passes, FETCH doubled: gfx950 rule; tools/run_r03_profiles.sh) — PMC counters cannot be read inside the timed run."""
+    tfile = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(tfile))["per_kernel"]["stage kernel, RK44 step average"]["hbm_total_GB"] * 1e9
+    except Exception:
+        return None
+
+
 def strong_single_gpu(ins, dev, n=512, steps=10, warmup=2):
     """The strong-scaling workload of BASELINE configs[3] (TGV3D 512^3, RK44 + spectral Poisson, dt = 2.5e-4) on ONE GPU: the N = 1 point of the
     1/2/4/8-GPU curve (`bench.py --gpus N` runs the same box on z-slabs of 512/N planes and reports the same object)."""
@@ -97,14 +134,27 @@ def strong_single_gpu(ins, dev, n=512, steps=10, warmup=2):
     dt = 2.5e-4
     if warmup:
         st = ins.timesteps_(method, st, dt, warmup, cache=cache)
+    import ctypes as C
+
+    ins._lib.call("ins_rk_profile_enable", cache.handle, 1)  # HIP events around the stage-kernel launches, on their stream
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     st = ins.timesteps_(method, st, dt, steps, cache=cache)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / steps
+    k_ms, k_n = C.c_double(), C.c_int64()
+    ins._lib.call("ins_rk_profile_read", cache.handle, C.byref(k_ms), C.byref(k_n))
+    ins._lib.call("ins_rk_profile_enable", cache.handle, 0)
+    sb, _ = stage_bytes_per_cell(method, steps, True)
+    avg_ms = k_ms.value / max(k_n.value, 1)
+    gbs = float(np.mean(sb)) * float(n) ** 3 / (avg_ms * 1e-3) / 1e9
+    roof = {"kernel": "k_flux64 FUSE[/CORR] (stage kernel: K1 + K6 + the previous projection's gradient-subtract in registers)", "bound": "hbm", "achieved": gbs,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": committed_traffic("r03_pmc_traffic_512.json") if n == 512 else None,
+            "traffic_note": "B per launch from profiles/r03_pmc_traffic_512.json (rocprofv3 --pmc of `bench.py --n 512`, two passes)",
+            "bytes_per_cell": float(np.mean(sb)), "bytes_per_cell_by_stage": sb, "avg_launch_ms": avg_ms, "launches": k_n.value}
     div = ins.max_abs_divergence(st.u, setup)
     assert div / n < 1e-10, f"{n}^3 state is not divergence-free: {div}"
-    return {"workload": f"TaylorGreenVortex3D {n}^3 periodic fp64, RK44 + spectral Poisson, dt=2.5e-4 (BASELINE configs[3]), total work fixed over N",
+    return {"roofline": roof, "workload": f"TaylorGreenVortex3D {n}^3 periodic fp64, RK44 + spectral Poisson, dt=2.5e-4 (BASELINE configs[3]), total work fixed over N",
             "scaling": "strong", "n_gpus": 1, "grid": [n, n, n], "steps": steps, "warmup": warmup, "ms_per_step": ms,
             "value": float(n) ** 3 / (ms * 1e-3) / 1e6, "unit": "M cell-updates/s", "max_abs_div_times_dx": div / n,
             "speedup_vs_n1_hint": {"n1_ms_per_step": ms, "speedup": 1.0, "source": "this run (N = 1)"}}
@@ -193,7 +243,7 @@ def main():
     method = ins.RKMethods.RK44()
     cache = ins.ode_method_cache(method, setup, ps)
     stepper = ins.create_stepper(method, setup=setup, psolver=ps, u=u, t=0.0)
-    dt = 1e-3
+    dt = 1e-3 if n <= 256 else 2.5e-4  # (--n 512: the strong-scaling box of BASELINE configs[3] as the headline workload, for profiling)
     # The timed region is the fixed-Δt loop of solve_unsteady (solver.jl:74-83, no processors) = `timesteps_`: K steps in one native call,
     # u valid before and after; INS_BENCH_SINGLE_STEPS=1 times K calls of `timestep_` instead (u materialised after every step).
     chained = not os.environ.get("INS_BENCH_SINGLE_STEPS")
@@ -232,28 +282,7 @@ def main():
     cells = float(n) ** 3
     value = cells / (ms_per_step * 1e-3) / 1e6
     k1_avg_ms = k1_ms.value / max(k1_n.value, 1)
-    # compulsory bytes per cell of the fused stage kernel                  step_explicit_runge_kutta.jl:35-38
-    #   k-basis:              R u_in + (R ustart, not for stage 1) + R k_j (non-zero a_ij) + W u* + (W k_i when a later stage needs it)
-    #   stage-velocity basis: R u_in + (R ustart) + R V_m (non-zero β_im) + W u*       (csrc/ins_rk.hip; no stage force is stored)
-    A = np.asarray(method.A, dtype=float)
-    ns = len(method.b)
-    inkernel = ns > 1 and not os.environ.get("INS_DISABLE_INKERNEL_CORR")
-    vbasis = inkernel and not os.environ.get("INS_RK_KEEP_K") and all(A[i, i] != 0.0 for i in range(ns))
-    stage_bytes = []
-    for i in range(ns):
-        inkernel_p = 8 if (i > 0 and inkernel) else 0  # stages >= 2 also read p
-        if vbasis:
-            beta = np.linalg.solve(A[:i, :i].T, A[i, :i]) if i else np.zeros(0)
-            nk, wk = int(np.count_nonzero(beta[: max(i - 1, 0)])), False  # β[i-1] multiplies the stencil input itself: taken from registers
-        else:
-            nk = sum(1 for j in range(i) if A[i, j] != 0.0)
-            wk = any(A[i2, i] != 0.0 for i2 in range(i + 1, ns))
-        stage_bytes.append(24 * (1 + (1 if i > 0 else 0) + nk + 1 + (1 if wk else 0)) + inkernel_p)
-    k4_bytes = 64.0  # final gradient-subtract + ghost images + padded p: once per step, or once per call when the steps are chained
-    if chained and vbasis and args.steps > 1:
-        # chained steps: the first stage of steps 2..K also reads p and stores the corrected start field (+8 + 24 B), and K4 runs once
-        stage_bytes[0] += 32.0 * (args.steps - 1) / args.steps
-        k4_bytes /= args.steps
+    stage_bytes, k4_bytes = stage_bytes_per_cell(method, args.steps, chained)
     fused_bytes_per_cell = float(np.mean(stage_bytes))
     k1_gbs = fused_bytes_per_cell * cells / (k1_avg_ms * 1e-3) / 1e9
     # plain K1 (momentum! only), 48 B/cell, on the final state
@@ -288,13 +317,7 @@ def main():
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_cell": K1_BYTES_PER_CELL, "avg_launch_ms": ms5}
         k1_512["frac"] = k1_512["achieved"] / HBM_PEAK_GBS
         del u5, F5, s5
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r02h_pmc_traffic.json")
-    if n == 256 and os.path.exists(tfile):  # PMC counters cannot be read in-process: committed rocprofv3 --pmc result
-        try:
-            traffic = json.load(open(tfile))["per_kernel"]["stage kernel, RK44 step average"]["hbm_total_GB"] * 1e9
-        except Exception:
-            traffic = None
+    traffic = committed_traffic("r03_pmc_traffic.json") if n == 256 else (committed_traffic("r03_pmc_traffic_512.json") if n == 512 else None)
     div = ins.max_abs_divergence(stepper.u, setup)
     energy = ins.total_kinetic_energy(stepper.u, setup)
     assert np.isfinite(energy) and div / n < 1e-10, f"bench state is not a valid flow: div={div}, E={energy}"
@@ -313,7 +336,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"TaylorGreenVortex3D {n}^3 periodic fp64, RK44 + spectral Poisson, dt=1e-3, Re=1e3",
+        "config": {"workload": f"TaylorGreenVortex3D {n}^3 periodic fp64, RK44 + spectral Poisson, dt={dt:g}, Re=1e3",
                    "grid": [n, n, n], "decomposition": "single GPU",
                    "loop": "timesteps_ (K steps, one native call)" if chained else "timestep_ x K"},
         "roofline": {
@@ -325,7 +348,7 @@ def main():
             "unit": "GB/s",
             "frac": k1_gbs / HBM_PEAK_GBS,
             "traffic": traffic,
-            "traffic_note": "B per launch, HBM FETCH(x2 gfx950)+WRITE from rocprofv3 --pmc (two passes of this command), profiles/r02h_pmc_traffic.json; PMC counters cannot be read inside the timed run",
+            "traffic_note": "B per launch, HBM FETCH(x2 gfx950)+WRITE from rocprofv3 --pmc (two passes of this command with the same --steps/--warmup), profiles/r03_pmc_traffic[_512].json; PMC counters cannot be read inside the timed run",
             "bytes_per_cell": fused_bytes_per_cell,
             "bytes_per_cell_by_stage": stage_bytes,
             "avg_launch_ms": k1_avg_ms,

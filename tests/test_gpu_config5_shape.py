@@ -17,7 +17,7 @@ shapes.  Until now these kernels were oracle-checked at nx in {64, 72, 136} x 48
 import numpy as np
 import pytest
 
-from tests.test_gpu_parity import STEP_TOL, _numpy_fast_diagonalisation, rell2
+from tests.test_gpu_parity import STEP_TOL, _numpy_fast_diagonalisation, ins, rell2  # noqa: F401  (ins: the module-scoped fixture)
 
 pytestmark = pytest.mark.gpu
 
@@ -98,8 +98,8 @@ def test_config5_full_size_fused_vs_reference_order(ins, name, n):
     assert scale > 0.05
     assert float((a - b)[mask].abs().max()) < 1e-12 * scale
     assert float((b - u0)[mask].abs().max()) > 1e-6 * scale  # the step did something
-    # both leave a field the solver's own divergence operator sees as solenoidal
-    assert float(ins.max_abs_divergence(a, sp)) * float(np.min(sp.grid.Δ[0][1:-1])) < 1e-9
+    if name == "channel":  # (the lid (1, 0.2, 0) has a normal component: the bordered system then has no divergence-free solution, pressure.jl:133-140)
+        assert float(ins.max_abs_divergence(a, sp)) * float(np.min(sp.grid.Δ[1][1:-1])) < 1e-9
     del b
     # the same sequence with a solver that takes no structured shortcut (dense eigenvector GEMMs in every direction): a different
     # factorisation of the same matrix, so the two agree at the solver's conditioning (observed: see DESIGN §4), not at rounding level
