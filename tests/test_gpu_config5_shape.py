@@ -109,7 +109,7 @@ def test_config5_full_size_fused_vs_reference_order(ins, name, n):
         c = _one_step(ins, sp, ps2, u0, dt).u
     err = float((a - c)[mask].abs().max()) / scale
     print(f"config5 {name} {n}: fused vs dense-solver reference order: {err:.3e}")
-    assert err < 1e-8
+    assert err < 1e-10  # observed 4.9e-12 (cavity: cond ~ 3e8), 1.2e-14 (all-walls), 1.2e-15 (channel)
     torch.cuda.synchronize()
     del a, c, ps, ps2, sp
     torch.cuda.empty_cache()
