@@ -22,49 +22,9 @@
 
 #include "ins_internal.h"
 #include "ins_wave64.h"
+#include "ins_flux_common.h"
 
 namespace {
-
-// The constant metric record of one direction.  The uniform half weights ¼ = ½·½ of the convective flux are folded into the
-// constants (4× the diffusion coefficients, ¼× the width reciprocals): power-of-two scalings, so every result is bitwise
-// what the unscaled expression gives, and twelve multiplications per cell disappear.
-struct Dir {
-  double vs, vo;  // 4ν/Δ (α == β), 4ν/Δu (α != β)
-  double rs, ro;  // ¼/Δu, ¼/Δ
-  double gs;      // 1/Δu (pressure gradient, CORR)
-};
-// the same record in the arithmetic type T of the kernel (double, or float for the `_f32` entry points: the host computes the
-// constants in double and rounds once)
-template <typename T>
-struct DirT {
-  T vs, vo, rs, ro, gs;
-  __device__ DirT(const Dir& d) : vs((T)d.vs), vo((T)d.vo), rs((T)d.rs), ro((T)d.ro), gs((T)d.gs) {}
-};
-
-struct FluxArgs {  // field pointers are T* of the kernel instantiation (RkEpi's pointers likewise)
-  const void* u;
-  const void* pI;
-  void* F;
-  long long sc;  // component stride (elements)
-  int N0, N1, N2;
-  int zc, ntx, nty, ntz;
-  // plane range of this launch: chunk t covers [k_lo + t zc, min(.. + zc, k_hi)); kB > 0: two chunks, [k_lo, k_lo + zc) and [kB, kB + zc)
-  // (the host runs the planes that read no ghost plane beside the halo exchange, then the two thin boundary ranges)
-  int k_lo, k_hi, kB;
-  int nt;   // cache-policy experiment on the result stores (INS_FLUX64_NT)
-  int bar;  // one workgroup barrier per plane: the y-stacked wavefronts of a workgroup stay on the same plane (their shared halo rows are then cache hits)
-  Dir X, Y, Z;
-  RkEpi epi;
-  int tm;      // temperature stage inside the kernel (EXTRA instantiation, CORR = 0)
-  TempEpi te;
-};
-
-// 4 × face flux:  4ν(up - uc)/Δb - (uc + up)(ub0 + ub1)        [ν(up - uc)/Δb - ½(uc + up)·½(ub0 + ub1), times 4]
-template <typename T>
-__device__ __forceinline__ T flux(T uc, T up, T ub0, T ub1, T vd4) {
-  return (up - uc) * vd4 - (uc + up) * (ub0 + ub1);
-}
-
 
 template <typename T, int R>
 struct Plane {
@@ -599,18 +559,6 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
 #define g_lds ((int)ins_opt(OPT_INS_FLUX64_LDS))    // experiment: dynamic LDS bytes per workgroup (caps workgroups per CU)
 #define g_skel ((int)ins_opt(OPT_INS_FLUX64_SKEL))  // timing experiment only: wrong results by design
 
-Dir make_dir(const ins_grid* G, int d, double visc) {
-  // the constant record ins_fast3d_flux.hip's UNIFORM kernels read (index 1): same fp64 operations, on the host
-  const double dxu = G->desc.dxu[d][1], dx1 = G->desc.dx[d][1], dx2 = G->desc.dx[d][2];
-  Dir r;
-  r.vs = 4.0 * (visc * (dx2 > 2 * INS_EPS ? 1.0 / dx2 : 0.0));
-  r.vo = 4.0 * (visc * (dxu > 2 * INS_EPS ? 1.0 / dxu : 0.0));
-  r.gs = 1.0 / dxu;
-  r.rs = 0.25 * r.gs;
-  r.ro = 0.25 * (1.0 / dx1);
-  return r;
-}
-
 template <typename T, int R, int XW, bool FUSE, int NW>
 int launch_range(const ins_grid* G, FluxArgs& a, int corr_mode, hipStream_t s) {
   const unsigned nb = (unsigned)(8LL * a.ntx * ((a.nty + 7) / 8) * a.ntz);
@@ -820,12 +768,19 @@ static int flux64_dispatch(const ins_grid* G, double visc, const T* u, T* F, con
   return INS_ERR_INVALID;
 }
 
+// two x-columns per lane (16 B per lane and memory instruction) wherever the box allows it: ins_flux128.hip
+bool ins_flux128_supported(const ins_grid* G, const RkEpi* epi, int corr_mode);
+int ins_k_flux128(const ins_grid* G, double visc, const double* u, double* F, const RkEpi* epi, const double* pI, int corr_mode, hipStream_t s, int part);
+int ins_k_flux128_f32(const ins_grid* G, double visc, const float* u, float* F, const RkEpi* epi, const float* pI, int corr_mode, hipStream_t s, int part);
+
 int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, const RkEpi* epi, const double* pI, int corr_mode, hipStream_t s,
                  int part) {
+  if (ins_flux128_supported(G, epi, corr_mode)) return ins_k_flux128(G, visc, u, F, epi, pI, corr_mode, s, part);
   return flux64_dispatch<double>(G, visc, u, F, epi, pI, corr_mode, s, part);
 }
 // fp32 family (`_f32` entry points): same kernels instantiated for float; RkEpi's pointers are float arrays then
 int ins_k_flux64_f32(const ins_grid* G, double visc, const float* u, float* F, const RkEpi* epi, const float* pI, int corr_mode, hipStream_t s,
                      int part) {
+  if (ins_flux128_supported(G, epi, corr_mode) && !ins_opt(OPT_INS_F32_ONE_COLUMN)) return ins_k_flux128_f32(G, visc, u, F, epi, pI, corr_mode, s, part);
   return flux64_dispatch<float>(G, visc, u, F, epi, pI, corr_mode, s, part);
 }

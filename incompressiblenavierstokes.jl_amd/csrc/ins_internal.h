@@ -59,6 +59,14 @@ void ins_set_error(const char* fmt, ...);
   X(INS_FLUX_XW)                 \
   X(INS_FLUX_BAR)                \
   X(INS_FLUX64_62_FROM)          \
+  X(INS_DISABLE_FLUX128)         \
+  X(INS_F32_ONE_COLUMN)          \
+  X(INS_FLUX128_CORR)            \
+  X(INS_FLUX128_XW)              \
+  X(INS_FLUX128_ROWS)            \
+  X(INS_FLUX128_ROWS_CORR)       \
+  X(INS_FLUX128_NW)              \
+  X(INS_FLUX128_ZC)              \
   X(INS_DISABLE_FDM_ZDCT)        \
   X(INS_DISABLE_FDM_ZFFT)        \
   X(INS_DISABLE_FDM_XFFT)        \

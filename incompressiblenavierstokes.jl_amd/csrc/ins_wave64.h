@@ -29,6 +29,7 @@ __device__ __forceinline__ T prev_h(T v, T h) { return dpp_old<0x138>(h, v); }  
 // Buffer addressing: descriptor (4 SGPRs) = one plane of one array, soffset (SGPR) = row start, voffset (VGPR) = column.
 // All plane / row arithmetic runs on the scalar unit; a lane holds one 32-bit offset for every load and store it issues.
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 template <typename T>
 __device__ __forceinline__ rsrc_t plane_rsrc(const T* base, unsigned bytes) {

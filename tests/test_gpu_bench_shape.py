@@ -32,6 +32,19 @@ def ins():
     return ins_amd
 
 
+@pytest.fixture(scope="module", params=["default", "two-columns", "two-columns-2rows", "one-column"], autouse=True)
+def lane_columns(request, ins):
+    """Every test of this module runs on: the default routing (two x-columns per lane — csrc/ins_flux128.hip, 16 B per lane — for the plain and the
+    first-stage kernel wherever a row holds an even number >= 130 of volumes, one column per lane — csrc/ins_flux64.hip — for the correcting stage
+    kernels); two columns everywhere (INS_FLUX128_CORR, correcting form with one and with two rows of pairs); one column everywhere."""
+    from ins_amd import _lib
+
+    opts = {"default": {}, "two-columns": {"INS_FLUX128_CORR": 1}, "two-columns-2rows": {"INS_FLUX128_CORR": 1, "INS_FLUX128_ROWS_CORR": 2},
+            "one-column": {"INS_DISABLE_FLUX128": 1}}[request.param]
+    with _lib.options(**opts):
+        yield request.param
+
+
 @pytest.fixture(scope="module")
 def cport():
     import os

@@ -50,6 +50,8 @@ def run(n, variants, once):
             apply(opts)
             ins.momentum_(F, u, None, 0.0, setup)
             torch.cuda.synchronize()
+        F.copy_(u)  # the flat copy of the same arrays, for the counter passes
+        torch.cuda.synchronize()
         return
     # reference result for a correctness check of every variant
     apply({"INS_DISABLE_FLUX64": 1})
