@@ -475,7 +475,12 @@ int flux128_dispatch(const ins_grid* G, double visc, const T* u, T* F, const RkE
     while (xw > 1 && cdiv(waves_x, xw) * xw > waves_x) xw >>= 1;
   // rows per lane: 2 (x 2 columns: the register budget of four single-column rows); the correcting kernel runs 1 unless INS_FLUX128_ROWS_CORR=2
   int rows = 2;
-  if (corr_mode && ins_opt(OPT_INS_FLUX128_ROWS_CORR) != 2) rows = 1;
+  if (corr_mode && ins_opt(OPT_INS_FLUX128_ROWS_CORR) != 2) {
+    // fp32: two rows of pairs where 8-wavefront workgroups with 64-plane chunks still give every CU a tile (512^3: RK44 step 14.2 -> 13.6 ms), one row on
+    // smaller boxes (256^3: 1.95 -> 1.91 ms with one row, 2.00 with two)
+    const bool big = (long long)cdiv(n0, 128 * xw) * cdiv(n1, (8 / xw) * 2) * cdiv(n2, 64) >= 256;
+    if (!(sizeof(T) == 4 && ins_opt(OPT_INS_FLUX128_ROWS_CORR) == 0 && big)) rows = 1;
+  }
   if (!corr_mode && ins_opt(OPT_INS_FLUX128_ROWS) == 1) rows = 1;
   // workgroup size and z-chunk: 8 wavefronts and 64-plane chunks when that gives every CU a workgroup, else 4 wavefronts and shorter chunks
   // (the rule of ins_flux64.hip: every chunk re-reads two planes, the wavefronts of a workgroup share halo rows under the per-plane barrier)
@@ -534,10 +539,11 @@ int flux128_dispatch(const ins_grid* G, double visc, const T* u, T* F, const RkE
 // The correcting forms (corr_mode != 0) are built and parity-tested but not the default: measured same-box they equal the one-column kernel with one row of
 // pairs (256^3 step 2.596 vs 2.610 ms, 512^3 21.84 vs 21.81) and lose with two (2.68 ms at one wavefront per SIMD, 3.99 ms with scratch spills) — the stage
 // kernels are bound below L2, not by vector-memory issue (profiles/r03_k1_pmc_512.txt).  INS_FLUX128_CORR=1 selects them.
-bool ins_flux128_supported(const ins_grid* G, const RkEpi* epi, int corr_mode) {
+// In fp32 the correcting form with two rows of pairs fits (218 VGPRs, two wavefronts per SIMD) and is the default: 8 B per lane instead of 4.
+bool ins_flux128_supported(const ins_grid* G, const RkEpi* epi, int corr_mode, bool f32) {
   const GridDev& g = G->g;
   if (ins_opt(OPT_INS_DISABLE_FLUX128) || ins_opt(OPT_INS_DISABLE_FLUX64) || ins_opt(OPT_INS_FLUX64_SKEL)) return false;
-  if (corr_mode && !ins_opt(OPT_INS_FLUX128_CORR)) return false;
+  if (corr_mode && !f32 && !ins_opt(OPT_INS_FLUX128_CORR)) return false;
   if (epi && (epi->extra || epi->gtemp || epi->wout || epi->tstage)) return false;
   const int n0 = g.N[0] - 2;
   return g.D == 3 && G->all_dof && G->uniform_exact && n0 >= 130 && n0 % 2 == 0 && g.N[1] - 2 >= 8 && g.N[2] - 2 >= 4;

@@ -769,18 +769,18 @@ static int flux64_dispatch(const ins_grid* G, double visc, const T* u, T* F, con
 }
 
 // two x-columns per lane (16 B per lane and memory instruction) wherever the box allows it: ins_flux128.hip
-bool ins_flux128_supported(const ins_grid* G, const RkEpi* epi, int corr_mode);
+bool ins_flux128_supported(const ins_grid* G, const RkEpi* epi, int corr_mode, bool f32);
 int ins_k_flux128(const ins_grid* G, double visc, const double* u, double* F, const RkEpi* epi, const double* pI, int corr_mode, hipStream_t s, int part);
 int ins_k_flux128_f32(const ins_grid* G, double visc, const float* u, float* F, const RkEpi* epi, const float* pI, int corr_mode, hipStream_t s, int part);
 
 int ins_k_flux64(const ins_grid* G, double visc, const double* u, double* F, const RkEpi* epi, const double* pI, int corr_mode, hipStream_t s,
                  int part) {
-  if (ins_flux128_supported(G, epi, corr_mode)) return ins_k_flux128(G, visc, u, F, epi, pI, corr_mode, s, part);
+  if (ins_flux128_supported(G, epi, corr_mode, false)) return ins_k_flux128(G, visc, u, F, epi, pI, corr_mode, s, part);
   return flux64_dispatch<double>(G, visc, u, F, epi, pI, corr_mode, s, part);
 }
 // fp32 family (`_f32` entry points): same kernels instantiated for float; RkEpi's pointers are float arrays then
 int ins_k_flux64_f32(const ins_grid* G, double visc, const float* u, float* F, const RkEpi* epi, const float* pI, int corr_mode, hipStream_t s,
                      int part) {
-  if (ins_flux128_supported(G, epi, corr_mode) && !ins_opt(OPT_INS_F32_ONE_COLUMN)) return ins_k_flux128_f32(G, visc, u, F, epi, pI, corr_mode, s, part);
+  if (ins_flux128_supported(G, epi, corr_mode, true) && !ins_opt(OPT_INS_F32_ONE_COLUMN)) return ins_k_flux128_f32(G, visc, u, F, epi, pI, corr_mode, s, part);
   return flux64_dispatch<float>(G, visc, u, F, epi, pI, corr_mode, s, part);
 }
