@@ -162,6 +162,11 @@ int ins_poisson_destroy(ins_poisson_t* ps);
  * (power-of-two sides and 192 / 384 = 3 * 2^m, csrc/ins_fft.hip), 2 when rocFFT 2-D plans feed the own fused z pass, 0 when every transform
  * is a rocFFT plan (pressure.jl:316 leaves the choice to the FFT library).  Other solver kinds: *engine = -1. */
 int ins_poisson_fft_engine(const ins_poisson_t* ps, int32_t* engine);
+/* *partitions > 0: the solver runs FOUR passes per solve — the z direction of pressure.jl:326-341 as periodic tridiagonal systems (the circulant with the
+ * eigenvalues âz) solved by the partition method inside the two y passes, `*partitions` z-partitions (csrc/ins_fft.hip k_yz_*) — instead of five with a
+ * z-FFT pass; 0: five passes (the default: the four-pass route is opt-in, INS_YZ_FUSED=1 / INS_YZ_PARTITIONS=P read at creation — it moves fewer bytes
+ * but measured slower).  Same linear system, results equal to rounding. */
+int ins_poisson_yz_partitions(const ins_poisson_t* ps, int32_t* partitions);
 /* poisson!(psolver, p) = psolver(p)        pressure.jl:22: solves L p = f in place on the padded array.
  * Spectral: asynchronous.  CG: blocking (the reference reads residuals on the host, pressure.jl:244,275). */
 int ins_poisson_solve_f64(ins_poisson_t* ps, double* p, void* stream);

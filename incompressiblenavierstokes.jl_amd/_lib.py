@@ -90,6 +90,7 @@ SIGNATURES = {
     "ins_poisson_fdm_create": (C.c_int, [vp, C.POINTER(c_double_p), C.POINTER(c_double_p), C.POINTER(vp)]),
     "ins_poisson_destroy": (C.c_int, [vp]),
     "ins_poisson_fft_engine": (C.c_int, [vp, C.POINTER(C.c_int32)]),
+    "ins_poisson_yz_partitions": (C.c_int, [vp, C.POINTER(C.c_int32)]),
     "ins_poisson_solve_f64": (C.c_int, [vp, vp, vp]),
     "ins_poisson_last_info": (C.c_int, [vp, C.POINTER(C.c_int64), c_double_p]),
     "ins_project_f64": (C.c_int, [vp, vp, vp, vp, vp]),

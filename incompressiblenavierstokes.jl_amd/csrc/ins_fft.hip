@@ -99,12 +99,12 @@ __device__ __forceinline__ void bfly3(C& x0, C& x1, C& x2) {
   x2 = csub(t2, t3);
 }
 
-template <int LOGN, int NC, int SR, int SC, bool RFAST, typename C>
+template <int LOGN, int NC, int SR, int SC, bool RFAST, int NT = 256, typename C>
 __device__ __forceinline__ void fft_dif(C* __restrict__ buf, const C* __restrict__ tw, int t) {
   constexpr int N = fft_len(LOGN), R3 = fft_r3(LOGN), M = N / R3;  // M: the power-of-two sub-length
   constexpr bool ODD = fft_lg(LOGN) & 1;
   if (R3 == 3) {  // N = 3 M: one radix-3 stage over the whole line, then the three sub-blocks of length M run the stages below side by side
-    for (int w = t; w < M * NC; w += 256) {
+    for (int w = t; w < M * NC; w += NT) {
       const int c = RFAST ? w / M : w % NC, j = RFAST ? w % M : w / NC;
       C* x = buf + c * SC;
       C a0 = x[j * SR], a1 = x[(j + M) * SR], a2 = x[(j + 2 * M) * SR];
@@ -117,7 +117,7 @@ __device__ __forceinline__ void fft_dif(C* __restrict__ buf, const C* __restrict
   }
   int L = M;
   if (ODD) {
-    for (int w = t; w < (N / 2) * NC; w += 256) {
+    for (int w = t; w < (N / 2) * NC; w += NT) {
       const int c = RFAST ? w / (N / 2) : w % NC, jj = RFAST ? w % (N / 2) : w / NC;
       const int sub = jj / (M / 2), j = jj - sub * (M / 2);
       C* x = buf + c * SC + sub * M * SR;
@@ -131,7 +131,7 @@ __device__ __forceinline__ void fft_dif(C* __restrict__ buf, const C* __restrict
 #pragma unroll 1
   for (; L >= 4; L >>= 2) {
     const int Q = L / 4, step = N / L;
-    for (int w = t; w < (N / 4) * NC; w += 256) {
+    for (int w = t; w < (N / 4) * NC; w += NT) {
       const int c = RFAST ? w / (N / 4) : w % NC, bb = RFAST ? w % (N / 4) : w / NC;
       const int sub = bb / (M / 4), b = bb - sub * (M / 4);
       const int g = b / Q, j = b - g * Q;
@@ -154,14 +154,14 @@ __device__ __forceinline__ void fft_dif(C* __restrict__ buf, const C* __restrict
   }
 }
 
-template <int LOGN, int NC, int SR, int SC, bool RFAST, typename C>
+template <int LOGN, int NC, int SR, int SC, bool RFAST, int NT = 256, typename C>
 __device__ __forceinline__ void fft_dit(C* __restrict__ buf, const C* __restrict__ tw, int t) {
   constexpr int N = fft_len(LOGN), R3 = fft_r3(LOGN), M = N / R3;
   constexpr bool ODD = fft_lg(LOGN) & 1;
 #pragma unroll 1
   for (int L = 4; L <= (ODD ? M / 2 : M); L <<= 2) {
     const int Q = L / 4, step = N / L;
-    for (int w = t; w < (N / 4) * NC; w += 256) {
+    for (int w = t; w < (N / 4) * NC; w += NT) {
       const int c = RFAST ? w / (N / 4) : w % NC, bb = RFAST ? w % (N / 4) : w / NC;
       const int sub = bb / (M / 4), b = bb - sub * (M / 4);
       const int g = b / Q, j = b - g * Q;
@@ -182,7 +182,7 @@ __device__ __forceinline__ void fft_dit(C* __restrict__ buf, const C* __restrict
     __syncthreads();
   }
   if (ODD) {
-    for (int w = t; w < (N / 2) * NC; w += 256) {
+    for (int w = t; w < (N / 2) * NC; w += NT) {
       const int c = RFAST ? w / (N / 2) : w % NC, jj = RFAST ? w % (N / 2) : w / NC;
       const int sub = jj / (M / 2), j = jj - sub * (M / 2);
       C* x = buf + c * SC + sub * M * SR;
@@ -193,7 +193,7 @@ __device__ __forceinline__ void fft_dit(C* __restrict__ buf, const C* __restrict
     __syncthreads();
   }
   if (R3 == 3) {
-    for (int w = t; w < M * NC; w += 256) {
+    for (int w = t; w < M * NC; w += NT) {
       const int c = RFAST ? w / M : w % NC, j = RFAST ? w % M : w / NC;
       C* x = buf + c * SC;
       C a0 = x[j * SR], a1 = cmulc(x[(j + M) * SR], tw[j]), a2 = cmulc(x[(j + 2 * M) * SR], tw[2 * j]);
@@ -661,6 +661,440 @@ int launch_xinv(const C* in, real_t<C>* pI, int n1, int n2, const C* tw, int kxs
   return INS_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Four passes instead of five: the z direction of the solve rides on the two y passes.
+//
+// After the x and y transforms the problem is one periodic tridiagonal system per (kx, ky) line,
+//     (âx + ây) p_k + c (2 p_k - p_{k+1} - p_{k-1}) = -f̂_k / (nx ny),      c = Ω/Δz²,
+// whose circulant matrix has exactly the eigenvalues âx + ây + âz the reference divides by (pressure.jl:326-341): the same linear system as the
+// z-FFT · symbol · inverse z-FFT pass (ins_zsolve.hip), solved by the partition (SPIKE) method of ins_ztri.hip with the partitions INSIDE one GPU:
+//   k_yz_fwd   : a workgroup owns TK consecutive kx and ONE z-partition of m planes; plane after plane it loads the tile, runs the y-FFT in LDS and
+//                applies the forward elimination of its block to the spectrum it has just produced (the recurrence is elementwise in (kx, ky): every
+//                work-item carries the state of its own elements from plane to plane), and leaves the two interface numbers of every line;
+//   k_yz_iface : the block-circulant 2P x 2P interface system per line (a P-point DFT over partitions + 2x2 systems), and the singular line;
+//   k_yz_bwd   : back substitution, plane after plane from the top of the partition, each plane followed by the inverse y-FFT in LDS.
+// Closed forms of pivots and spikes in the decaying root r of r + 1/r = (âx + ây)/c + 2 as in ins_ztri.hip (nothing is stored but the field).
+// Per solve this moves 16 B per cell less (one of the five read+write passes over the spectrum) plus 4 complex numbers per line and partition.
+// ------------------------------------------------------------------------------------------------------------
+struct YzArgs {
+  double2* data;      // [n2][N][kxs]
+  int kxn, kxs, n2, m, P;
+  const double* ax;   // [kxn]
+  const double* ay;   // [N], storage (digit-reversed) order of ky
+  double c, scale;    // Ω/Δz², -1/(nx ny)
+  double2* edges;     // [P][stride]: yF[lines] | yL[lines] | the singular line's m right-hand sides;  lines = N kxn, line = pos(ky) kxn + kx
+  long long stride;
+  double2* bc;        // [P][2][lines]: p_last of the partition below, p_first of the partition above
+  double2* sol0;      // [n2]: the singular line's solution
+};
+
+__device__ __forceinline__ double yz_rcp(double x) {  // hardware estimate + one Newton step (as ins_ztri.hip)
+  const double y = __builtin_amdgcn_rcp(x);
+  return y * (2.0 - x * y);
+}
+
+// B planes per round (their y-FFTs run side by side in LDS: a 256 x 8 tile alone gives a 1024-work-item workgroup half a butterfly per work-item and
+// stage); the loads of rounds r + 1 and r + 2 are in flight while round r is transformed (one workgroup per CU: nobody else hides the HBM latency).
+template <int LOGN, int TK, int NT, int B>
+__global__ __launch_bounds__(NT) void k_yz_fwd(YzArgs a, const double2* __restrict__ tw_g) {
+  constexpr int N = fft_len(LOGN);
+  constexpr int RPT = NT / TK, NIT = N / RPT;  // rows per sweep of the workgroup, (row, kx) elements per work-item
+  constexpr int NC = TK * B;                   // LDS columns: plane b of the round, kx column c -> b * TK + c
+  static_assert(N % RPT == 0 && NIT >= 1, "tile shape");
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  double2* buf = reinterpret_cast<double2*>(lds_raw);  // [N][NC]
+  double2* tw = buf + N * NC;                          // [N]
+  const int t = threadIdx.x, col = t % TK, r0 = t / TK;
+  const int kx = blockIdx.x * TK + col;
+  const bool live = kx < a.kxn;
+  const int part = blockIdx.y, z0 = part * a.m;
+  const long long ps = (long long)N * a.kxs;  // plane stride
+  double2* base = a.data + (long long)z0 * ps + kx;
+  for (int i = t; i < N; i += NT) tw[i] = tw_g[i];
+  const long long lines = (long long)N * a.kxn;
+  // per-element constants and state
+  double r_[NIT], pa[NIT], idc_[NIT], rm1_[NIT];
+  double2 gp[NIT], SA[NIT];
+  bool sing[NIT];
+#pragma unroll
+  for (int q = 0; q < NIT; ++q) {
+    const int row = r0 + q * RPT;
+    const double sxy = live ? a.ax[kx] + a.ay[row] : 1.0;
+    sing[q] = sxy == 0.0;
+    const double sc = sing[q] ? 1.0 : sxy / a.c;
+    const double sq = sqrt(sc * (4.0 + sc));
+    const double lnr = -log1p(0.5 * (sc + sq));  // r = 2 / (s + 2 + sq): the decaying root, without cancellation
+    r_[q] = exp(lnr);
+    pa[q] = r_[q];
+    idc_[q] = 1.0 / (-expm1((2.0 * a.m + 2.0) * lnr) * a.c);
+    rm1_[q] = exp((a.m + 1.0) * lnr);
+    gp[q] = make_double2(0.0, 0.0);
+    SA[q] = gp[q];
+  }
+  const int R = a.m / B;  // rounds (even: the host checks)
+  auto load_round = [&](double2 (&v)[B][NIT], int r) {
+    const int rc = min(r, R - 1);  // (past the partition: re-read the last round instead of branching)
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int q = 0; q < NIT; ++q)
+        if (live) v[b][q] = base[(long long)(rc * B + b) * ps + (long long)(r0 + q * RPT) * a.kxs];
+  };
+  auto round = [&](double2 (&v)[B][NIT], int r) {
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int q = 0; q < NIT; ++q) buf[(r0 + q * RPT) * NC + b * TK + col] = v[b][q];
+    __syncthreads();
+    load_round(v, r + 2);  // two rounds ahead
+    fft_dif<LOGN, NC, NC, 1, false, NT>(buf, tw, t);
+    if (live) {
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int k = r * B + b;
+#pragma unroll
+        for (int q = 0; q < NIT; ++q) {
+          const int row = r0 + q * RPT;
+          double2 g = buf[row * NC + b * TK + col];
+          g.x *= a.scale;
+          g.y *= a.scale;
+          double2 out = g;
+          if (sing[q]) {
+            a.edges[(long long)part * a.stride + 2 * lines + k] = g;  // the singular line: its right-hand side goes to k_yz_iface
+          } else {
+            const double rr = r_[q], E = pa[q] * pa[q];
+            const double inv = (rr / a.c) * (1.0 - E) * yz_rcp(1.0 - E * rr * rr);  // 1/den_k = (r/c)(1 - E_k)/(1 - E_k r²), E_k = r^(2k+2)
+            gp[q].x = inv * (g.x + a.c * gp[q].x);
+            gp[q].y = inv * (g.y + a.c * gp[q].y);
+            SA[q].x += pa[q] * g.x;  // Σ r^(k+1) g_k
+            SA[q].y += pa[q] * g.y;
+            pa[q] *= rr;
+            out = gp[q];
+          }
+          base[(long long)k * ps + (long long)row * a.kxs] = out;
+        }
+      }
+    }
+    __syncthreads();  // every read of this round's spectra is done before the next round overwrites the tiles
+  };
+  double2 va[B][NIT], vb[B][NIT];
+#pragma unroll
+  for (int b = 0; b < B; ++b)
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) va[b][q] = vb[b][q] = make_double2(0.0, 0.0);
+  load_round(va, 0);
+  load_round(vb, 1);
+  for (int r = 0; r < R; r += 2) {
+    round(va, r);
+    round(vb, r + 1);
+  }
+  if (live) {
+    // (A⁻¹ g)_last = gp_{m-1};  (A⁻¹ g)_first = (SA - r^(m+1) SB)/(c D) with SB = Σ r^(m-k) g_k = c D gp_{m-1} + r^(m+1) SA
+    double2* e = a.edges + (long long)part * a.stride;
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) {
+      const long long l = (long long)(r0 + q * RPT) * a.kxn + kx;
+      if (sing[q]) {
+        e[l] = e[lines + l] = make_double2(0.0, 0.0);
+      } else {
+        const double f = idc_[q] * (1.0 - rm1_[q] * rm1_[q]);
+        e[l] = make_double2(f * SA[q].x - rm1_[q] * gp[q].x, f * SA[q].y - rm1_[q] * gp[q].y);
+        e[lines + l] = gp[q];
+      }
+    }
+  }
+}
+
+// interface system of every line for all P partitions (ins_ztri.hip k_ztri_iface solves it for one rank):
+//   F_q - α L_{q-1} - β F_{q+1} = yF_q,   L_q - β L_{q-1} - α F_{q+1} = yL_q,   α = v_0, β = v_{m-1};   bc[q] = (L_{q-1}, F_{q+1})
+template <int PT>
+__global__ __launch_bounds__(64) void k_yz_iface(YzArgs a) {
+  __shared__ double2 tw[PT];
+  constexpr int P = PT;
+  const long long lines = (long long)(a.stride - a.m) / 2;
+  if (blockIdx.x == gridDim.x - 1) {
+    // extra workgroup: the singular line.  -c (p_{k+1} - 2 p_k + p_{k-1}) = g_k - mean(g), periodic, mean(p) = 0 (pressure.jl:336-341 gauge):
+    // q_k = p_{k+1} - p_k = q_0 - S_k, S_k = Σ_{j=1..k} h_j, h = (g - ḡ)/c; p_k = p_0 + k q_0 - T_k, T_k = Σ_{j<k} S_j; q_0 = T_N/N.  One wavefront, serial chunks.
+    const int lane = threadIdx.x, Nz = a.n2;
+    const int C = (Nz + 63) / 64, s0 = min(lane * C, Nz), e0 = min(s0 + C, Nz);
+    auto g_at = [&](int k) { return a.edges[(long long)(k / a.m) * a.stride + 2 * lines + (k % a.m)]; };
+    auto wsum = [&](double2 v) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        v.x += __shfl_xor(v.x, off, 64);
+        v.y += __shfl_xor(v.y, off, 64);
+      }
+      return v;
+    };
+    auto wscan = [&](double2 v) {  // exclusive prefix sum over lanes
+      double2 inc = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const double tx = __shfl_up(inc.x, off, 64), ty = __shfl_up(inc.y, off, 64);
+        if (lane >= off) {
+          inc.x += tx;
+          inc.y += ty;
+        }
+      }
+      return make_double2(inc.x - v.x, inc.y - v.y);
+    };
+    const double ic = 1.0 / a.c, iN = 1.0 / Nz;
+    double2 sum = make_double2(0.0, 0.0);
+    for (int k = s0; k < e0; ++k) {
+      const double2 g = g_at(k);
+      sum.x += g.x;
+      sum.y += g.y;
+    }
+    sum = wsum(sum);
+    const double2 gbar = make_double2(iN * sum.x, iN * sum.y);
+    auto h_at = [&](int k) {
+      const double2 g = g_at(k);
+      return make_double2((g.x - gbar.x) * ic, (g.y - gbar.y) * ic);
+    };
+    const double2 h0 = h_at(0);
+    double2 A = make_double2(0.0, 0.0);
+    for (int k = s0; k < e0; ++k) {
+      const double2 h = h_at(k);
+      A.x += h.x;
+      A.y += h.y;
+    }
+    const double2 Hbase = wscan(A);
+    double2 B = make_double2(0.0, 0.0), H = Hbase;
+    for (int k = s0; k < e0; ++k) {
+      const double2 h = h_at(k);
+      H.x += h.x;
+      H.y += h.y;
+      B.x += H.x - h0.x;
+      B.y += H.y - h0.y;
+    }
+    const double2 Tbase = wscan(B);
+    const double2 Bs = wsum(B);
+    const double2 q0 = make_double2(iN * Bs.x, iN * Bs.y);
+    double2 Cs = make_double2(0.0, 0.0), T = Tbase;
+    H = Hbase;
+    for (int k = s0; k < e0; ++k) {
+      Cs.x += k * q0.x - T.x;
+      Cs.y += k * q0.y - T.y;
+      const double2 h = h_at(k);
+      H.x += h.x;
+      H.y += h.y;
+      T.x += H.x - h0.x;
+      T.y += H.y - h0.y;
+    }
+    Cs = wsum(Cs);
+    const double2 p0 = make_double2(-iN * Cs.x, -iN * Cs.y);
+    T = Tbase;
+    H = Hbase;
+    for (int k = s0; k < e0; ++k) {
+      a.sol0[k] = make_double2(p0.x + k * q0.x - T.x, p0.y + k * q0.y - T.y);
+      const double2 h = h_at(k);
+      H.x += h.x;
+      H.y += h.y;
+      T.x += H.x - h0.x;
+      T.y += H.y - h0.y;
+    }
+    return;
+  }
+  if ((int)threadIdx.x < P) {
+    double sn, cs;
+    sincospi(-2.0 * (double)threadIdx.x / P, &sn, &cs);
+    tw[threadIdx.x] = make_double2(cs, sn);
+  }
+  __syncthreads();
+  const long long l = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (l >= lines) return;
+  const int ky = (int)(l / a.kxn), kx = (int)(l - (long long)ky * a.kxn);
+  const double sxy = a.ax[kx] + a.ay[ky];
+  if (sxy == 0.0) {
+#pragma unroll
+    for (int q = 0; q < P; ++q) a.bc[((long long)q * 2) * lines + l] = a.bc[((long long)q * 2 + 1) * lines + l] = make_double2(0.0, 0.0);
+    return;
+  }
+  const double sc = sxy / a.c, sq = sqrt(sc * (4.0 + sc)), lnr = -log1p(0.5 * (sc + sq));
+  const double r = exp(lnr), D = -expm1((2.0 * a.m + 2.0) * lnr);
+  const double alpha = r * (-expm1(2.0 * a.m * lnr)) / D;
+  const double beta = exp(a.m * lnr) * (1.0 - r * r) / D;
+  auto cm = [](double2 x, double2 y) { return make_double2(x.x * y.x - x.y * y.y, x.x * y.y + x.y * y.x); };
+  double2 hF[PT], hL[PT];
+#pragma unroll
+  for (int j = 0; j < P; ++j) hF[j] = hL[j] = make_double2(0.0, 0.0);
+#pragma unroll
+  for (int q = 0; q < P; ++q) {  // forward DFT over partitions: e^{-iθ_j q}
+    const double2 yF = a.edges[(long long)q * a.stride + l], yL = a.edges[(long long)q * a.stride + lines + l];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const double2 w = tw[(j * q) % P];
+      const double2 x = cm(w, yF), y = cm(w, yL);
+      hF[j].x += x.x;
+      hF[j].y += x.y;
+      hL[j].x += y.x;
+      hL[j].y += y.y;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    const double2 em = tw[j], ep = make_double2(em.x, -em.y);  // e^{-iθ}, e^{+iθ}
+    // [ 1 - β e^{+iθ}    -α e^{-iθ} ] [F̂]   [ŷF]
+    // [   -α e^{+iθ}   1 - β e^{-iθ} ] [L̂] = [ŷL]
+    const double2 a11 = make_double2(1.0 - beta * ep.x, -beta * ep.y), a22 = make_double2(1.0 - beta * em.x, -beta * em.y);
+    const double2 a12 = make_double2(-alpha * em.x, -alpha * em.y), a21 = make_double2(-alpha * ep.x, -alpha * ep.y);
+    const double idet = 1.0 / (1.0 - 2.0 * beta * em.x + beta * beta - alpha * alpha);
+    const double2 x1 = cm(a22, hF[j]), x2 = cm(a12, hL[j]), y1 = cm(a11, hL[j]), y2 = cm(a21, hF[j]);
+    hF[j] = make_double2(idet * (x1.x - x2.x), idet * (x1.y - x2.y));
+    hL[j] = make_double2(idet * (y1.x - y2.x), idet * (y1.y - y2.y));
+  }
+  const double iP = 1.0 / P;
+#pragma unroll
+  for (int q = 0; q < P; ++q) {  // inverse DFT at partitions q-1 (its last value) and q+1 (its first value): e^{+iθ_j q'}
+    const int qp = (q + P - 1) % P, qn = (q + 1) % P;
+    double2 Lp = make_double2(0.0, 0.0), Fn = Lp;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const double2 wp = tw[(j * qp) % P], wn = tw[(j * qn) % P];
+      const double2 x = cm(make_double2(wp.x, -wp.y), hL[j]), y = cm(make_double2(wn.x, -wn.y), hF[j]);
+      Lp.x += x.x;
+      Lp.y += x.y;
+      Fn.x += y.x;
+      Fn.y += y.y;
+    }
+    a.bc[((long long)q * 2) * lines + l] = make_double2(iP * Lp.x, iP * Lp.y);
+    a.bc[((long long)q * 2 + 1) * lines + l] = make_double2(iP * Fn.x, iP * Fn.y);
+  }
+}
+
+// back substitution with the interface values folded in (ins_ztri.hip k_ztri_bwd), plane after plane from the top of the partition, each plane
+// followed by the inverse y-FFT:   g̃ = g + c L e_0 + c F e_{m-1}  =>  gp̃_k = gp_k + c L φ_k (+ c F/den_{m-1} at k = m-1),  φ_k = r^(k+1)(1-r²)/(c(1-E_k r²));
+//   p_{m-1} = gp̃_{m-1},  p_k = gp̃_k + (c/den_k) p_{k+1}
+template <int LOGN, int TK, int NT, int B>
+__global__ __launch_bounds__(NT) void k_yz_bwd(YzArgs a, const double2* __restrict__ tw_g) {
+  constexpr int N = fft_len(LOGN);
+  constexpr int RPT = NT / TK, NIT = N / RPT;
+  constexpr int NC = TK * B;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  double2* buf = reinterpret_cast<double2*>(lds_raw);
+  double2* tw = buf + N * NC;
+  const int t = threadIdx.x, col = t % TK, r0 = t / TK;
+  const int kx = blockIdx.x * TK + col;
+  const bool live = kx < a.kxn;
+  const int part = blockIdx.y, z0 = part * a.m;
+  const long long ps = (long long)N * a.kxs;
+  double2* base = a.data + (long long)z0 * ps + kx;
+  for (int i = t; i < N; i += NT) tw[i] = tw_g[i];
+  // the singular line's solution on this partition's planes (selecting it per element inside the recurrence — `sing ? sol : p` — crashes ROCm 7.2's
+  // backend in the 1024-work-item instantiation, MachineCopyPropagation; it is patched into the tile instead)
+  double2* sol = tw + N;  // [m]
+  for (int i = t; i < a.m; i += NT) sol[i] = a.sol0[z0 + i];
+  const long long lines = (long long)N * a.kxn;
+  const int R = a.m / B;  // rounds; round r holds planes m-1-rB ... m-rB-B (b = 0 is the upper one)
+  auto load_round = [&](double2 (&v)[B][NIT], int r) {
+    const int rc = min(r, R - 1);
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int q = 0; q < NIT; ++q)
+        if (live) v[b][q] = base[(long long)(a.m - 1 - rc * B - b) * ps + (long long)(r0 + q * RPT) * a.kxs];
+  };
+  double2 va[B][NIT], vb[B][NIT];
+#pragma unroll
+  for (int b = 0; b < B; ++b)
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) va[b][q] = vb[b][q] = make_double2(0.0, 0.0);
+  load_round(va, 0);
+  load_round(vb, 1);
+  double r_[NIT], pa[NIT];
+  double2 p[NIT], Lp[NIT];
+#pragma unroll
+  for (int q = 0; q < NIT; ++q) {
+    const int row = r0 + q * RPT;
+    const double sxy = live ? a.ax[kx] + a.ay[row] : 1.0;
+    const double sc = sxy == 0.0 ? 1.0 : sxy / a.c;  // (the singular line runs on a placeholder and is patched below)
+    const double sq = sqrt(sc * (4.0 + sc));
+    const double lnr = -log1p(0.5 * (sc + sq));
+    const double r = exp(lnr);
+    r_[q] = r;
+    pa[q] = exp((double)a.m * lnr);  // r^(k+1) at k = m - 1
+    const long long l = (long long)row * a.kxn + kx;
+    Lp[q] = live ? a.bc[((long long)part * 2) * lines + l] : make_double2(0.0, 0.0);
+    const double2 Fn = live ? a.bc[((long long)part * 2 + 1) * lines + l] : make_double2(0.0, 0.0);
+    // the upper interface value enters at the last plane of the partition only: fold c/den_{m-1} F into that plane's right-hand side here
+    const double E = pa[q] * pa[q];
+    const double cinv = r * (1.0 - E) * yz_rcp(1.0 - E * r * r);
+    va[0][q].x += cinv * Fn.x;
+    va[0][q].y += cinv * Fn.y;
+    p[q] = make_double2(0.0, 0.0);
+  }
+  auto round = [&](double2 (&v)[B][NIT], int r) {
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const int k = a.m - 1 - r * B - b;
+      // r^(k+1): a running product re-seeded from exp() every 16 planes (a seed that underflows cannot become significant within 16 steps: r >= ~0.1
+      // on these grids; ins_ztri.hip)
+      if ((k & 15) == 15 && k != a.m - 1) {
+#pragma unroll
+        for (int q = 0; q < NIT; ++q) pa[q] = exp((k + 1.0) * log(r_[q]));
+      }
+#pragma unroll
+      for (int q = 0; q < NIT; ++q) {
+        const double rr = r_[q];
+        const double E = pa[q] * pa[q], qq = yz_rcp(1.0 - E * rr * rr);
+        const double cinv = rr * (1.0 - E) * qq;          // c / den_k
+        const double phi = pa[q] * (1.0 - rr * rr) * qq;  // c φ_k
+        p[q].x = (v[b][q].x + phi * Lp[q].x) + cinv * p[q].x;
+        p[q].y = (v[b][q].y + phi * Lp[q].y) + cinv * p[q].y;
+        pa[q] *= yz_rcp(rr);
+        buf[(r0 + q * RPT) * NC + b * TK + col] = p[q];
+      }
+      // the singular line (kx = 0, ky = 0: storage row 0 of the first tile, owned by work-item 0, whose own recurrence ran on a placeholder)
+      if (t == 0 && blockIdx.x == 0) buf[b * TK] = sol[k];
+    }
+    __syncthreads();
+    load_round(v, r + 2);
+    fft_dit<LOGN, NC, NC, 1, false, NT>(buf, tw, t);
+    if (live) {
+#pragma unroll
+      for (int b = 0; b < B; ++b)
+#pragma unroll
+        for (int q = 0; q < NIT; ++q)
+          base[(long long)(a.m - 1 - r * B - b) * ps + (long long)(r0 + q * RPT) * a.kxs] = buf[(r0 + q * RPT) * NC + b * TK + col];
+    }
+    __syncthreads();
+  };
+  for (int r = 0; r < R; r += 2) {
+    round(va, r);
+    round(vb, r + 1);
+  }
+}
+
+template <int LOGN>
+int launch_yz(YzArgs& a, const double2* tw, hipStream_t s) {
+  constexpr int N = fft_len(LOGN);
+  constexpr int TK = 8, NT = 1024;
+  constexpr int B = N <= 256 ? 2 : 1;  // planes per round: 64 KB of tiles either way
+  if (a.m % (2 * B)) {
+    ins_set_error("fused y/z passes: %d planes per partition, need a multiple of %d", a.m, 2 * B);
+    return INS_ERR_UNSUPPORTED;
+  }
+  const size_t lds = ((size_t)N * TK * B + N + a.m) * sizeof(double2);
+  const dim3 grid((a.kxn + TK - 1) / TK, a.P);
+  int rc = set_lds(&k_yz_fwd<LOGN, TK, NT, B>, lds);
+  if (rc) return rc;
+  if ((rc = set_lds(&k_yz_bwd<LOGN, TK, NT, B>, lds))) return rc;
+  hipLaunchKernelGGL((k_yz_fwd<LOGN, TK, NT, B>), grid, dim3(NT), lds, s, a, tw);
+  const long long lines = (long long)N * a.kxn;
+  const dim3 gi((unsigned)((lines + 63) / 64) + 1);
+  switch (a.P) {
+    case 2: hipLaunchKernelGGL(k_yz_iface<2>, gi, dim3(64), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(k_yz_iface<4>, gi, dim3(64), 0, s, a); break;
+    case 8: hipLaunchKernelGGL(k_yz_iface<8>, gi, dim3(64), 0, s, a); break;
+    case 16: hipLaunchKernelGGL(k_yz_iface<16>, gi, dim3(64), 0, s, a); break;
+    default: ins_set_error("fused y/z passes: %d partitions not built", a.P); return INS_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL((k_yz_bwd<LOGN, TK, NT, B>), grid, dim3(NT), lds, s, a, tw);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
 }  // namespace
 
 #define INS_POW2_SWITCH(n, CALL)            \
@@ -739,6 +1173,55 @@ int ins_k_ownfft_xinv(const double* phat, double* pI, int n0, int n1, int n2, co
 #define CALL(LG) launch_xinv<LG>(in, pI, n1, n2, w, kxs, s)
   INS_POW2_SWITCH(n0, CALL)
 #undef CALL
+}
+
+// The fused y + z passes (k_yz_*): partition count for a box, scratch size (complex numbers), and the solve itself on the spectrum after the x pass.
+// P: the smallest power of two that gives every CU a workgroup (tiles of 8 kx) with partitions of at least 8 planes; 0 = not for this box.
+// NOT the default (INS_YZ_FUSED=1 or a forced partition count select it): measured same-box the four-pass solve is slower than the five-pass one — 256^3 step
+// 2.89 against 2.61 ms, 512^3 25.2 against 21.6 (k_yz_fwd + k_yz_iface + k_yz_bwd 104 + 30 + 94 us against 53 + 53 + 53 for y, z, y at 256^3;
+// profiles/r03_yz_fused_lab.txt).  One 1024-work-item workgroup per CU marches its planes alone: 6.5 us (256^3) / 19 us (512^3) per plane against
+// ~3.5 / 6.7 us of HBM time — five barriers and five LDS round trips per plane with nobody to overlap them.  DESIGN.md §8 has what would have to change.
+int ins_ownfft_yz_partitions(int kxn, int n1, int n2) {
+  if (ins_opt(OPT_INS_DISABLE_YZ_FUSED)) return 0;
+  if (!ins_opt(OPT_INS_YZ_FUSED) && !ins_opt(OPT_INS_YZ_PARTITIONS)) return 0;
+  if (!(n1 == 128 || n1 == 256 || n1 == 512) || n2 < 64 || (n2 & (n2 - 1))) return 0;
+  const int forced = (int)ins_opt(OPT_INS_YZ_PARTITIONS);
+  if (forced == 2 || forced == 4 || forced == 8 || forced == 16) return (n2 % forced == 0 && (n2 / forced) % 4 == 0) ? forced : 0;
+  const int tiles = (kxn + 7) / 8;
+  int P = 2;
+  while (P < 16 && tiles * P < 240 && n2 / (2 * P) >= 8) P *= 2;
+  return tiles * P >= 128 ? P : 0;
+}
+long long ins_ownfft_yz_scratch(int kxn, int n1, int n2, int P) {
+  const long long lines = (long long)n1 * kxn;
+  return (long long)P * (2 * lines + n2 / P) + (long long)P * 2 * lines + n2;
+}
+int ins_k_ownfft_yz_solve(double* phat, int kxn, int n1, int n2, int kxs, int P, const double* ax, const double* ay, double c, double scale, const double* tw_y,
+                          double* scratch, hipStream_t s) {
+  YzArgs a;
+  a.data = reinterpret_cast<double2*>(phat);
+  a.kxn = kxn;
+  a.kxs = kxs;
+  a.n2 = n2;
+  a.m = n2 / P;
+  a.P = P;
+  a.ax = ax;
+  a.ay = ay;
+  a.c = c;
+  a.scale = scale;
+  const long long lines = (long long)n1 * kxn;
+  a.stride = 2 * lines + a.m;
+  a.edges = reinterpret_cast<double2*>(scratch);
+  a.bc = a.edges + (long long)P * a.stride;
+  a.sol0 = a.bc + (long long)P * 2 * lines;
+  const double2* w = reinterpret_cast<const double2*>(tw_y);
+  switch (n1) {
+    case 128: return launch_yz<7>(a, w, s);
+    case 256: return launch_yz<8>(a, w, s);
+    case 512: return launch_yz<9>(a, w, s);
+  }
+  ins_set_error("fused y/z passes: unsupported length %d", n1);
+  return INS_ERR_UNSUPPORTED;
 }
 
 int ins_k_ownfft_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s, int kxs) {

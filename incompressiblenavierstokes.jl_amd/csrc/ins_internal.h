@@ -60,6 +60,9 @@ void ins_set_error(const char* fmt, ...);
   X(INS_FLUX_BAR)                \
   X(INS_FLUX64_62_FROM)          \
   X(INS_DISABLE_FLUX128)         \
+  X(INS_DISABLE_YZ_FUSED)        \
+  X(INS_YZ_FUSED)                \
+  X(INS_YZ_PARTITIONS)           \
   X(INS_F32_ONE_COLUMN)          \
   X(INS_FLUX128_CORR)            \
   X(INS_FLUX128_XW)              \
@@ -216,6 +219,8 @@ struct ins_poisson {
   double* tw = nullptr;     // z twiddles
   double* tw_x = nullptr;   // x / y twiddles (ownfft)
   double* tw_y = nullptr;
+  int yz_P = 0;             // > 0: the z direction rides on the y passes (ins_fft.hip k_yz_*: four passes per solve), yz_P partitions
+  double* yz_scratch = nullptr;
   // cg
   double abstol = 0, reltol = 0;
   long long maxiter = 0;
@@ -343,6 +348,10 @@ int ins_k_ownfft_xfwd(const ins_grid* G, const double* src, int from_u, double* 
                       int kxs = 0, int kz0 = 0);
 int ins_k_ownfft_xinv(const double* phat, double* pI, int n0, int n1, int n2, const double* tw, hipStream_t s, int kxs = 0);
 int ins_k_ownfft_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s, int kxs = 0);
+int ins_ownfft_yz_partitions(int kxn, int n1, int n2);
+long long ins_ownfft_yz_scratch(int kxn, int n1, int n2, int P);
+int ins_k_ownfft_yz_solve(double* phat, int kxn, int n1, int n2, int kxs, int P, const double* ax, const double* ay, double c, double scale, const double* tw_y,
+                          double* scratch, hipStream_t s);
 int ins_k_ownfft_y_packed(double* phat, double* packed, int kxn, int n1, int nzl, int nyl, int cw, const double* tw, bool inverse,
                           hipStream_t s);
 int ins_zsolve_twiddles(int nz, double** out);

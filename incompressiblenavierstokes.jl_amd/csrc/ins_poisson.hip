@@ -858,6 +858,15 @@ extern "C" int ins_poisson_spectral_create(const ins_grid_t* G, ins_poisson_t** 
     if ((rc = ins_zsolve_twiddles(ps->np[1], &ps->tw_y))) return fail(rc);
     if ((rc = ins_zsolve_twiddles(ps->np[2], &ps->tw))) return fail(rc);
     ps->zfused = true;
+    // four passes instead of five where the box allows it: the z direction as tridiagonal systems carried by the two y passes (ins_fft.hip, k_yz_*)
+    ps->yz_P = ins_ownfft_yz_partitions(ps->kmax[0], ps->np[1], ps->np[2]);
+    if (ps->yz_P) {
+      const long long nc = ins_ownfft_yz_scratch(ps->kmax[0], ps->np[1], ps->np[2], ps->yz_P);
+      if (hipMalloc(&ps->yz_scratch, nc * 2 * sizeof(double)) != hipSuccess) {
+        ins_set_error("hipMalloc(yz scratch) failed");
+        return fail(INS_ERR_HIP);
+      }
+    }
   } else {
     int nfull[3] = {ps->np[2], ps->np[1], ps->np[0]};
     ps->zfused = D == 3 && ins_zsolve_supported(ps->np[2]);
@@ -882,6 +891,12 @@ static int ownfft_transform(ins_poisson* ps, const double* from_u, hipStream_t s
     return ins_k_ownfft_xinv(ph, ps->pI, n0, n1, 1, ps->tw_x, s, kxs);
   }
   if ((rc = ins_k_ownfft_xfwd(ps->grid, from_u ? from_u : ps->pI, from_u ? src_code : 0, ph, n0, n1, n2, ps->tw_x, s, kxs))) return rc;
+  if (ps->yz_P && !ins_opt(OPT_INS_DISABLE_YZ_FUSED)) {
+    const ins_grid* G = ps->grid;
+    const double c = G->h[0] * G->h[1] / G->h[2];  // Ω/Δz²
+    if ((rc = ins_k_ownfft_yz_solve(ph, kxn, n1, n2, kxs, ps->yz_P, ps->ahat[0], ps->ahat[1], c, -1.0 / ((double)n0 * n1), ps->tw_y, ps->yz_scratch, s))) return rc;
+    return ins_k_ownfft_xinv(ph, ps->pI, n0, n1, n2, ps->tw_x, s, kxs);
+  }
   if ((rc = ins_k_ownfft_y(ph, kxn, n1, n2, ps->tw_y, false, s, kxs))) return rc;
   const double inv_n = 1.0 / ((double)n0 * n1 * n2);
   if ((rc = ins_k_zsolve(ph, n2, (long long)kxs * n1, ps->ahat[0], kxn, ps->ahat[1], ps->ahat[2], ps->tw, inv_n, true, s, kxs))) return rc;
@@ -1146,6 +1161,15 @@ extern "C" int ins_poisson_fft_engine(const ins_poisson_t* ps, int32_t* engine) 
   return INS_OK;
 }
 
+extern "C" int ins_poisson_yz_partitions(const ins_poisson_t* ps, int32_t* partitions) {
+  if (!ps || !partitions) {
+    ins_set_error("ins_poisson_yz_partitions: null argument");
+    return INS_ERR_INVALID;
+  }
+  *partitions = ps->kind == POISSON_SPECTRAL ? ps->yz_P : 0;
+  return INS_OK;
+}
+
 extern "C" int ins_poisson_destroy(ins_poisson_t* ps) {
   if (!ps) return INS_OK;
   if (ps->plans) {
@@ -1156,6 +1180,7 @@ extern "C" int ins_poisson_destroy(ins_poisson_t* ps) {
   if (ps->tw) (void)hipFree(ps->tw);
   if (ps->tw_x) (void)hipFree(ps->tw_x);
   if (ps->tw_y) (void)hipFree(ps->tw_y);
+  if (ps->yz_scratch) (void)hipFree(ps->yz_scratch);
   if (ps->pI) (void)hipFree(ps->pI);
   if (ps->phat) (void)hipFree(ps->phat);
   for (int a = 0; a < 3; ++a)

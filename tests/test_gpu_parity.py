@@ -523,6 +523,48 @@ def test_own_fft_passes_match_oracle(ins, oracle, n):
     assert rell2(ins.to_numpy(u), want_u) < POISSON_TOL
 
 
+@pytest.mark.parametrize("n,P", [((256, 128, 64), 0), ((32, 128, 64), 2), ((32, 128, 64), 8), ((64, 256, 64), 4), ((16, 256, 128), 16), ((32, 256, 128), 4),
+                                 ((16, 512, 64), 2), ((32, 512, 128), 8), ((128, 128, 128), 0), ((64, 256, 256), 16)])
+def test_four_pass_solve_matches_oracle(ins, oracle, n, P):
+    """The z direction of the spectral solve as periodic tridiagonal systems riding on the two y passes (csrc/ins_fft.hip k_yz_fwd / k_yz_iface / k_yz_bwd:
+    four passes per solve instead of five): the same linear system as the reference's division by âx + ây + âz (pressure.jl:326-341), here against the
+    oracle's FFT solve — every built y length (128, 256, 512), partition counts 2 .. 16 (forced: INS_YZ_PARTITIONS; 0: the library's choice), anisotropic
+    spacings (the decaying root of a line ranges from ~1 to ~1e-3), both the psolver(p) entry and the fused projection; and against the five-pass route."""
+    import ctypes
+    from ins_amd import _lib
+
+    o = oracle
+    L = (1.0, 2.0, 0.25) if n[0] != n[2] else (1.0, 1.0, 1.0)
+    x = tuple(np.linspace(0.0, L[a], n[a] + 1) for a in range(3))
+    so = o.make_setup(x, Re=1000.0)
+    sp = ins.Setup(x=x, Re=1000.0)
+    pso = o.psolver_spectral(so)
+    with _lib.options(INS_YZ_FUSED=1, INS_YZ_PARTITIONS=P):
+        psp = ins.psolver_spectral(sp)
+    ps5 = ins.psolver_spectral(sp)  # the default: five passes
+    parts = ctypes.c_int32(-1)
+    _lib.call("ins_poisson_yz_partitions", psp.handle, ctypes.byref(parts))
+    assert parts.value == (P if P else parts.value) and parts.value >= 2
+    _lib.call("ins_poisson_yz_partitions", ps5.handle, ctypes.byref(parts))
+    assert parts.value == 0
+    f = fx.randn_field(so.grid.N, 23)
+    ip = tuple(slice(lo, hi) for lo, hi in so.grid.Ip)
+    f[ip] -= f[ip].mean()
+    want = o.poisson(pso, f)
+    got = ins.to_numpy(ins.poisson(psp, ins.from_numpy(sp, f)))
+    got5 = ins.to_numpy(ins.poisson(ps5, ins.from_numpy(sp, f)))
+    assert rell2(got[ip], want[ip]) < POISSON_TOL
+    assert rell2(got[ip], got5[ip]) < POISSON_TOL
+    assert abs(got[ip].mean()) < 1e-12 * np.abs(got[ip]).max()  # the reference's gauge: zero mean (pressure.jl:336-341)
+    u_h = o.apply_bc_u(fx.randn_field(so.grid.N + (3,), 24), 0.0, so)
+    want_u = o.project_(u_h.copy(order="F"), so, pso, o.scalarfield(so))
+    u = ins.from_numpy(sp, u_h)
+    ins.project_(u, sp, psp, ins.scalarfield(sp))
+    assert rell2(ins.to_numpy(u), want_u) < POISSON_TOL
+    ins.apply_bc_u_(u, 0.0, sp)
+    assert ins.max_abs_divergence(u, sp) * min(L[a] / n[a] for a in range(3)) < 1e-11
+
+
 def test_full_size_512_decaying_turbulence_properties(ins):
     """BASELINE config 3 (DecayingTurbulence3D 512^3, Re = 4000, kp = 10, Δt = 2.5e-4) at full size through
     size-independent properties: solenoidal seeded initial field, divergence-free after stepping (max|div u|·Δx
