@@ -687,6 +687,7 @@ struct YzArgs {
   long long stride;
   double2* bc;        // [P][2][lines]: p_last of the partition below, p_first of the partition above
   double2* sol0;      // [n2]: the singular line's solution
+  int skel;           // measurement only (INS_YZ_SKEL): 1 = no y-FFT, 2 = no recurrence arithmetic — wrong results by design
 };
 
 __device__ __forceinline__ double yz_rcp(double x) {  // hardware estimate + one Newton step (as ins_ztri.hip)
@@ -696,7 +697,8 @@ __device__ __forceinline__ double yz_rcp(double x) {  // hardware estimate + one
 
 // B planes per round (their y-FFTs run side by side in LDS: a 256 x 8 tile alone gives a 1024-work-item workgroup half a butterfly per work-item and
 // stage); the loads of rounds r + 1 and r + 2 are in flight while round r is transformed (one workgroup per CU: nobody else hides the HBM latency).
-template <int LOGN, int TK, int NT, int B>
+// PF: rounds of loads in flight behind the one being transformed (2 where the registers allow it; 1 for N = 512: a round there is long enough to cover the latency)
+template <int LOGN, int TK, int NT, int B, int PF>
 __global__ __launch_bounds__(NT) void k_yz_fwd(YzArgs a, const double2* __restrict__ tw_g) {
   constexpr int N = fft_len(LOGN);
   constexpr int RPT = NT / TK, NIT = N / RPT;  // rows per sweep of the workgroup, (row, kx) elements per work-item
@@ -714,7 +716,7 @@ __global__ __launch_bounds__(NT) void k_yz_fwd(YzArgs a, const double2* __restri
   for (int i = t; i < N; i += NT) tw[i] = tw_g[i];
   const long long lines = (long long)N * a.kxn;
   // per-element constants and state
-  double r_[NIT], pa[NIT], idc_[NIT], rm1_[NIT];
+  double r_[NIT], pa[NIT];
   double2 gp[NIT], SA[NIT];
   bool sing[NIT];
 #pragma unroll
@@ -727,8 +729,6 @@ __global__ __launch_bounds__(NT) void k_yz_fwd(YzArgs a, const double2* __restri
     const double lnr = -log1p(0.5 * (sc + sq));  // r = 2 / (s + 2 + sq): the decaying root, without cancellation
     r_[q] = exp(lnr);
     pa[q] = r_[q];
-    idc_[q] = 1.0 / (-expm1((2.0 * a.m + 2.0) * lnr) * a.c);
-    rm1_[q] = exp((a.m + 1.0) * lnr);
     gp[q] = make_double2(0.0, 0.0);
     SA[q] = gp[q];
   }
@@ -741,14 +741,24 @@ __global__ __launch_bounds__(NT) void k_yz_fwd(YzArgs a, const double2* __restri
       for (int q = 0; q < NIT; ++q)
         if (live) v[b][q] = base[(long long)(rc * B + b) * ps + (long long)(r0 + q * RPT) * a.kxs];
   };
-  auto round = [&](double2 (&v)[B][NIT], int r) {
+  // gfx9 counts loads and stores in ONE counter and only loads return in order: once a store is outstanding, waiting for an older load means waiting for
+  // everything (vmcnt(0)) — this round's stores AND the loads issued two rounds ahead.  So the next round's loads (issued a round ago) are waited for
+  // here, BEFORE this round's stores are issued, while only loads are outstanding (`pin`: an empty asm that reads the registers).
+  auto pin = [&](double2 (&v)[B][NIT]) {
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int q = 0; q < NIT; ++q) asm volatile("" ::"v"(v[b][q].x), "v"(v[b][q].y));
+  };
+  auto round = [&](double2 (&v)[B][NIT], double2 (&vnext)[B][NIT], int r) {
 #pragma unroll
     for (int b = 0; b < B; ++b)
 #pragma unroll
       for (int q = 0; q < NIT; ++q) buf[(r0 + q * RPT) * NC + b * TK + col] = v[b][q];
     __syncthreads();
-    load_round(v, r + 2);  // two rounds ahead
-    fft_dif<LOGN, NC, NC, 1, false, NT>(buf, tw, t);
+    load_round(v, r + PF);  // PF rounds ahead
+    if (a.skel != 1) fft_dif<LOGN, NC, NC, 1, false, NT>(buf, tw, t);
+    pin(vnext);
     if (live) {
 #pragma unroll
       for (int b = 0; b < B; ++b) {
@@ -762,7 +772,7 @@ __global__ __launch_bounds__(NT) void k_yz_fwd(YzArgs a, const double2* __restri
           double2 out = g;
           if (sing[q]) {
             a.edges[(long long)part * a.stride + 2 * lines + k] = g;  // the singular line: its right-hand side goes to k_yz_iface
-          } else {
+          } else if (a.skel != 2) {
             const double rr = r_[q], E = pa[q] * pa[q];
             const double inv = (rr / a.c) * (1.0 - E) * yz_rcp(1.0 - E * rr * rr);  // 1/den_k = (r/c)(1 - E_k)/(1 - E_k r²), E_k = r^(2k+2)
             gp[q].x = inv * (g.x + a.c * gp[q].x);
@@ -784,10 +794,14 @@ __global__ __launch_bounds__(NT) void k_yz_fwd(YzArgs a, const double2* __restri
 #pragma unroll
     for (int q = 0; q < NIT; ++q) va[b][q] = vb[b][q] = make_double2(0.0, 0.0);
   load_round(va, 0);
-  load_round(vb, 1);
-  for (int r = 0; r < R; r += 2) {
-    round(va, r);
-    round(vb, r + 1);
+  if constexpr (PF == 2) {
+    load_round(vb, 1);
+    for (int r = 0; r < R; r += 2) {
+      round(va, vb, r);
+      round(vb, va, r + 1);
+    }
+  } else {
+    for (int r = 0; r < R; ++r) round(va, va, r);
   }
   if (live) {
     // (A⁻¹ g)_last = gp_{m-1};  (A⁻¹ g)_first = (SA - r^(m+1) SB)/(c D) with SB = Σ r^(m-k) g_k = c D gp_{m-1} + r^(m+1) SA
@@ -798,8 +812,11 @@ __global__ __launch_bounds__(NT) void k_yz_fwd(YzArgs a, const double2* __restri
       if (sing[q]) {
         e[l] = e[lines + l] = make_double2(0.0, 0.0);
       } else {
-        const double f = idc_[q] * (1.0 - rm1_[q] * rm1_[q]);
-        e[l] = make_double2(f * SA[q].x - rm1_[q] * gp[q].x, f * SA[q].y - rm1_[q] * gp[q].y);
+        const double lnr = log(r_[q]);
+        const double rm1 = exp((a.m + 1.0) * lnr);                      // r^(m+1)
+        const double idc = 1.0 / (-expm1((2.0 * a.m + 2.0) * lnr) * a.c);  // 1/(c D), D = 1 - r^(2m+2)
+        const double f = idc * (1.0 - rm1 * rm1);
+        e[l] = make_double2(f * SA[q].x - rm1 * gp[q].x, f * SA[q].y - rm1 * gp[q].y);
         e[lines + l] = gp[q];
       }
     }
@@ -966,7 +983,7 @@ __global__ __launch_bounds__(64) void k_yz_iface(YzArgs a) {
 // back substitution with the interface values folded in (ins_ztri.hip k_ztri_bwd), plane after plane from the top of the partition, each plane
 // followed by the inverse y-FFT:   g̃ = g + c L e_0 + c F e_{m-1}  =>  gp̃_k = gp_k + c L φ_k (+ c F/den_{m-1} at k = m-1),  φ_k = r^(k+1)(1-r²)/(c(1-E_k r²));
 //   p_{m-1} = gp̃_{m-1},  p_k = gp̃_k + (c/den_k) p_{k+1}
-template <int LOGN, int TK, int NT, int B>
+template <int LOGN, int TK, int NT, int B, int PF>
 __global__ __launch_bounds__(NT) void k_yz_bwd(YzArgs a, const double2* __restrict__ tw_g) {
   constexpr int N = fft_len(LOGN);
   constexpr int RPT = NT / TK, NIT = N / RPT;
@@ -1001,7 +1018,7 @@ __global__ __launch_bounds__(NT) void k_yz_bwd(YzArgs a, const double2* __restri
 #pragma unroll
     for (int q = 0; q < NIT; ++q) va[b][q] = vb[b][q] = make_double2(0.0, 0.0);
   load_round(va, 0);
-  load_round(vb, 1);
+  if constexpr (PF == 2) load_round(vb, 1);
   double r_[NIT], pa[NIT];
   double2 p[NIT], Lp[NIT];
 #pragma unroll
@@ -1024,7 +1041,13 @@ __global__ __launch_bounds__(NT) void k_yz_bwd(YzArgs a, const double2* __restri
     va[0][q].y += cinv * Fn.y;
     p[q] = make_double2(0.0, 0.0);
   }
-  auto round = [&](double2 (&v)[B][NIT], int r) {
+  auto pin = [&](double2 (&v)[B][NIT]) {  // see k_yz_fwd
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int q = 0; q < NIT; ++q) asm volatile("" ::"v"(v[b][q].x), "v"(v[b][q].y));
+  };
+  auto round = [&](double2 (&v)[B][NIT], double2 (&vnext)[B][NIT], int r) {
 #pragma unroll
     for (int b = 0; b < B; ++b) {
       const int k = a.m - 1 - r * B - b;
@@ -1049,8 +1072,9 @@ __global__ __launch_bounds__(NT) void k_yz_bwd(YzArgs a, const double2* __restri
       if (t == 0 && blockIdx.x == 0) buf[b * TK] = sol[k];
     }
     __syncthreads();
-    load_round(v, r + 2);
-    fft_dit<LOGN, NC, NC, 1, false, NT>(buf, tw, t);
+    load_round(v, r + PF);
+    if (a.skel != 1) fft_dit<LOGN, NC, NC, 1, false, NT>(buf, tw, t);
+    pin(vnext);
     if (live) {
 #pragma unroll
       for (int b = 0; b < B; ++b)
@@ -1060,9 +1084,13 @@ __global__ __launch_bounds__(NT) void k_yz_bwd(YzArgs a, const double2* __restri
     }
     __syncthreads();
   };
-  for (int r = 0; r < R; r += 2) {
-    round(va, r);
-    round(vb, r + 1);
+  if constexpr (PF == 2) {
+    for (int r = 0; r < R; r += 2) {
+      round(va, vb, r);
+      round(vb, va, r + 1);
+    }
+  } else {
+    for (int r = 0; r < R; ++r) round(va, va, r);
   }
 }
 
@@ -1071,16 +1099,17 @@ int launch_yz(YzArgs& a, const double2* tw, hipStream_t s) {
   constexpr int N = fft_len(LOGN);
   constexpr int TK = 8, NT = 1024;
   constexpr int B = N <= 256 ? 2 : 1;  // planes per round: 64 KB of tiles either way
-  if (a.m % (2 * B)) {
-    ins_set_error("fused y/z passes: %d planes per partition, need a multiple of %d", a.m, 2 * B);
+  constexpr int PF = N <= 256 ? 2 : 1;
+  if (a.m % (PF * B)) {
+    ins_set_error("fused y/z passes: %d planes per partition, need a multiple of %d", a.m, PF * B);
     return INS_ERR_UNSUPPORTED;
   }
   const size_t lds = ((size_t)N * TK * B + N + a.m) * sizeof(double2);
   const dim3 grid((a.kxn + TK - 1) / TK, a.P);
-  int rc = set_lds(&k_yz_fwd<LOGN, TK, NT, B>, lds);
+  int rc = set_lds(&k_yz_fwd<LOGN, TK, NT, B, PF>, lds);
   if (rc) return rc;
-  if ((rc = set_lds(&k_yz_bwd<LOGN, TK, NT, B>, lds))) return rc;
-  hipLaunchKernelGGL((k_yz_fwd<LOGN, TK, NT, B>), grid, dim3(NT), lds, s, a, tw);
+  if ((rc = set_lds(&k_yz_bwd<LOGN, TK, NT, B, PF>, lds))) return rc;
+  hipLaunchKernelGGL((k_yz_fwd<LOGN, TK, NT, B, PF>), grid, dim3(NT), lds, s, a, tw);
   const long long lines = (long long)N * a.kxn;
   const dim3 gi((unsigned)((lines + 63) / 64) + 1);
   switch (a.P) {
@@ -1090,7 +1119,7 @@ int launch_yz(YzArgs& a, const double2* tw, hipStream_t s) {
     case 16: hipLaunchKernelGGL(k_yz_iface<16>, gi, dim3(64), 0, s, a); break;
     default: ins_set_error("fused y/z passes: %d partitions not built", a.P); return INS_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL((k_yz_bwd<LOGN, TK, NT, B>), grid, dim3(NT), lds, s, a, tw);
+  hipLaunchKernelGGL((k_yz_bwd<LOGN, TK, NT, B, PF>), grid, dim3(NT), lds, s, a, tw);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -1177,10 +1206,15 @@ int ins_k_ownfft_xinv(const double* phat, double* pI, int n0, int n1, int n2, co
 
 // The fused y + z passes (k_yz_*): partition count for a box, scratch size (complex numbers), and the solve itself on the spectrum after the x pass.
 // P: the smallest power of two that gives every CU a workgroup (tiles of 8 kx) with partitions of at least 8 planes; 0 = not for this box.
-// NOT the default (INS_YZ_FUSED=1 or a forced partition count select it): measured same-box the four-pass solve is slower than the five-pass one — 256^3 step
-// 2.89 against 2.61 ms, 512^3 25.2 against 21.6 (k_yz_fwd + k_yz_iface + k_yz_bwd 104 + 30 + 94 us against 53 + 53 + 53 for y, z, y at 256^3;
-// profiles/r03_yz_fused_lab.txt).  One 1024-work-item workgroup per CU marches its planes alone: 6.5 us (256^3) / 19 us (512^3) per plane against
-// ~3.5 / 6.7 us of HBM time — five barriers and five LDS round trips per plane with nobody to overlap them.  DESIGN.md §8 has what would have to change.
+// NOT the default (INS_YZ_FUSED=1 or a forced partition count select it): measured same-box the four-pass solve does not beat the five-pass one
+// (profiles/r03_yz_fused_lab.txt; one solve through psolver(p): 256^3 428 against 363 us, 512^3 3391 against 3187 us).  What was found on the way:
+//   * gfx9 counts loads and stores in one counter and only loads return in order, so a wait for a prefetched load behind an outstanding store is a wait
+//     for everything: the next round's loads are now waited for before this round's stores are issued (512^3: 3982 -> 3391 us per solve);
+//   * a spill reload inside the plane loop is a scratch load and drains the prefetch the same way (N = 512: one round of loads in flight instead of two);
+//   * with the y-FFT left out (INS_YZ_SKEL=1) the marching passes run at 71 us (256^3) / 670 us (512^3) against 57 / 432 us of HBM time, and the
+//     interface kernel costs 30 us at 256^3 (16 partitions): at 256^3 even a free FFT would lose (384 against 363 us).  The FFT phases (1.1-1.4 us per
+//     radix-4 stage, VALU-bound on index arithmetic) do not overlap the memory phases: ONE 1024-work-item workgroup per CU marches in lock step, and a
+//     box of this size has only tiles x partitions = 272 / 264 independent marches — more partitions cost 4 complex numbers per line each.
 int ins_ownfft_yz_partitions(int kxn, int n1, int n2) {
   if (ins_opt(OPT_INS_DISABLE_YZ_FUSED)) return 0;
   if (!ins_opt(OPT_INS_YZ_FUSED) && !ins_opt(OPT_INS_YZ_PARTITIONS)) return 0;
@@ -1214,6 +1248,7 @@ int ins_k_ownfft_yz_solve(double* phat, int kxn, int n1, int n2, int kxs, int P,
   a.edges = reinterpret_cast<double2*>(scratch);
   a.bc = a.edges + (long long)P * a.stride;
   a.sol0 = a.bc + (long long)P * 2 * lines;
+  a.skel = (int)ins_opt(OPT_INS_YZ_SKEL);
   const double2* w = reinterpret_cast<const double2*>(tw_y);
   switch (n1) {
     case 128: return launch_yz<7>(a, w, s);

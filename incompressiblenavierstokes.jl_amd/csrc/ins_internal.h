@@ -62,6 +62,7 @@ void ins_set_error(const char* fmt, ...);
   X(INS_DISABLE_FLUX128)         \
   X(INS_DISABLE_YZ_FUSED)        \
   X(INS_YZ_FUSED)                \
+  X(INS_YZ_SKEL)                 \
   X(INS_YZ_PARTITIONS)           \
   X(INS_F32_ONE_COLUMN)          \
   X(INS_FLUX128_CORR)            \
