@@ -431,6 +431,9 @@ int ins_project_f32(const ins_grid_t* grid, ins_poisson32_t* ps, float* u, float
 int ins_rk_create_f32(const ins_grid_t* grid, ins_poisson32_t* ps, int nstage, const double* A, const double* c, ins_rk32_t** out);
 int ins_rk_destroy_f32(ins_rk32_t* rk);
 int ins_rk_step_f32(ins_rk32_t* rk, float visc, float* u, float dt, void* stream);                       /* step_explicit_runge_kutta.jl:4-59 */
+/* nsteps steps of size dt as one call (the fixed-Δt loop of solve_unsteady, solver.jl:74-83, T = Float32), chained like ins_rk_steps_f64 where the
+ * in-register correction runs on float2 spectra; u is valid before and after the call. */
+int ins_rk_steps_f32(ins_rk32_t* rk, float visc, float* u, float dt, int nsteps, void* stream);
 /* maximum(abs, divergence(u)) over Ip; blocking.  operators.jl:106-125 */
 int ins_max_abs_divergence_f32(const ins_grid_t* grid, ins_poisson32_t* ps, const float* u, float* out, void* stream);
 

@@ -146,6 +146,7 @@ SIGNATURES = {
     "ins_rk_create_f32": (C.c_int, [vp, vp, C.c_int, c_double_p, c_double_p, C.POINTER(vp)]),
     "ins_rk_destroy_f32": (C.c_int, [vp]),
     "ins_rk_step_f32": (C.c_int, [vp, C.c_float, vp, C.c_float, vp]),
+    "ins_rk_steps_f32": (C.c_int, [vp, C.c_float, vp, C.c_float, C.c_int, vp]),
     "ins_max_abs_divergence_f32": (C.c_int, [vp, vp, vp, C.POINTER(C.c_float), vp]),
     "ins_comm_unique_id": (C.c_int, [vp]),
     "ins_comm_create": (C.c_int, [C.c_int, C.c_int, vp, C.POINTER(vp)]),

@@ -57,6 +57,7 @@ struct ins_rk32 {
   float* ub[2] = {nullptr, nullptr};
   float* p = nullptr;
   float* pu = nullptr;  // unpadded float copy of the stage pressure (in-register correction of the next stage's stencil kernel)
+  float* ustart = nullptr;  // chained steps: the corrected start field of steps 2..K (the caller's array holds the uncorrected last stage velocity then)
 };
 
 namespace {
@@ -473,6 +474,7 @@ extern "C" int ins_poisson_solve_f32(ins_poisson32_t* ps, float* p, void* stream
 
 // ---------------------------------------------------------------------------------------------- explicit Runge-Kutta, T = Float32
 extern "C" int ins_rk_destroy_f32(ins_rk32_t* rk) {
+  if (rk && rk->ustart) (void)hipFree(rk->ustart);
   if (!rk) return INS_OK;
   for (float* k : rk->ku)
     if (k) (void)hipFree(k);
@@ -509,19 +511,21 @@ extern "C" int ins_rk_create_f32(const ins_grid_t* G, ins_poisson32_t* ps, int n
 }
 
 // timestep!(method, stepper, Δt; cache) for closure_model = temp = bodyforce = nothing, T = Float32       step_explicit_runge_kutta.jl:4-59
-// The caller's u is ustart for the whole step; stage velocities ping-pong in two library buffers; on wide 3-D boxes the stage combination
-// is the stencil kernel's epilogue.
-extern "C" int ins_rk_step_f32(ins_rk32_t* rk, float visc, float* u, float dt, void* stream) {
-  INS_REQUIRE(rk && u, "null argument");
+// The caller's u is ustart for the whole step; on wide 3-D boxes the stage combination is the stencil kernel's epilogue.  As on the fp64 path (csrc/ins_rk.hip):
+//   * stage-velocity basis: with in-register correction the uncorrected stage velocities stay in memory anyway, so the combination is written in terms of them
+//     (V_i = (1 - Σβ) ustart + Σ β_im V_m + Δt A[i,i] k_i) and no stage force is stored or read — the `ku` arrays hold the stage velocities;
+//   * chain bit 1: `u` holds the previous step's UNCORRECTED last stage velocity and the solver's pI its pressure: the first stage corrects in registers and
+//     stores the corrected field as this step's ustart; bit 2: the last stage only solves (the next step of the chain corrects).
+static int rk32_step(ins_rk32* rk, float visc, float* u, float dt, hipStream_t s, int chain) {
   const ins_grid* G = rk->grid;
-  hipStream_t s = as_stream(stream);
   const int ns = rk->nstage, D = G->g.D;
   const long long nvec = G->ncell * D;
   const bool wide = ins_flux64_supported(G);
+  const bool raw_in = chain & 1, raw_out = chain & 2;
   int rc;
-  if ((rc = bc_periodic(G, u, D, s))) return rc;                                // :19
-  // Wide power-of-two boxes: the fp64 path's stage structure (csrc/ins_rk.hip) in float — stages >= 2 read the previous stage's UNCORRECTED u* and
-  // its pressure and apply u = u* - ∇p in registers (flux64<float, CORR = 1>), the solve forms Ω·div(u*) from the float field inside its x
+  if (!raw_in && (rc = bc_periodic(G, u, D, s))) return rc;                     // :19
+  // Wide power-of-two boxes: the fp64 path's stage structure in float — stages >= 2 read the previous stage's UNCORRECTED u* and
+  // its pressure and apply u = u* - ∇p in registers (CORR = 1), the solve forms Ω·div(u*) from the float field inside its x
   // pass; only the last stage materialises u (padded p, gradient-subtract, ghosts).
   const bool incorr = wide && rk->ps->ps64 && ns > 1 && G->uniform_exact && G->g.N[0] >= 8 && G->g.N[1] >= 8 && G->g.N[2] >= 8 &&
                       !ins_opt(OPT_INS_DISABLE_INKERNEL_CORR);
@@ -529,25 +533,53 @@ extern "C" int ins_rk_step_f32(ins_rk32_t* rk, float visc, float* u, float dt, v
   const bool own32 = rk->ps->own32;  // float2 spectra: the solver's float pI is what the next stage's stencil kernel reads
   if (incorr && !own32 && !rk->pu) INS_HIP_TRY(hipMalloc(&rk->pu, ncell_in * sizeof(float)));
   const float* pcorr = own32 ? rk->ps->pI : rk->pu;
-  float* cur = u;
+  bool vbasis = incorr && !ins_opt(OPT_INS_RK_KEEP_K);
+  for (int i = 0; vbasis && i < ns; ++i) vbasis = rk->A[i * ns + i] != 0.0;
+  if (chain && !(incorr && own32)) {
+    ins_set_error("ins_rk_steps_f32: chained steps need the in-register correction on float2 spectra");
+    return INS_ERR_UNSUPPORTED;
+  }
+  const float* cur = u;
   for (int i = 0; i < ns; ++i) {
-    float* outp = (i == ns - 1 && ns > 1) ? u : rk->ub[i & 1];
+    float* outp = (i == ns - 1 && ns > 1) ? u : (vbasis ? rk->ku[i] : rk->ub[i & 1]);
     if (wide) {
       RkEpi epi;
       memset(&epi, 0, sizeof(epi));
-      for (int j = 0; j < i; ++j) {
-        const double coef = (double)dt * rk->A[i * ns + j];
-        if (coef == 0.0) continue;
-        epi.coef[epi.n] = coef;
-        epi.k[epi.n] = reinterpret_cast<const double*>(rk->ku[j]);  // float arrays behind RkEpi's untyped pointers (ins_flux64.hip casts back)
-        ++epi.n;
+      if (vbasis) {
+        double beta[INS_MAX_STAGES];
+        for (int m = i - 1; m >= 0; --m) {  // β_i · A[0:i,0:i] = A[i,0:i], A lower triangular
+          double v = rk->A[i * ns + m];
+          for (int j = m + 1; j < i; ++j) v -= beta[j] * rk->A[j * ns + m];
+          beta[m] = v / rk->A[m * ns + m];
+        }
+        for (int m = 0; m < i; ++m) {
+          if (beta[m] == 0.0) continue;
+          epi.c0m1 -= beta[m];
+          if (m == i - 1) {  // V_{i-1} is this stage's stencil input
+            epi.self_in = beta[m];
+            continue;
+          }
+          epi.coef[epi.n] = beta[m];
+          epi.k[epi.n] = reinterpret_cast<const double*>(rk->ku[m]);  // float arrays behind RkEpi's untyped pointers (the kernels cast back)
+          ++epi.n;
+        }
+      } else {
+        for (int j = 0; j < i; ++j) {
+          const double coef = (double)dt * rk->A[i * ns + j];
+          if (coef == 0.0) continue;
+          epi.coef[epi.n] = coef;
+          epi.k[epi.n] = reinterpret_cast<const double*>(rk->ku[j]);
+          ++epi.n;
+        }
+        for (int i2 = i + 1; i2 < ns; ++i2)
+          if (rk->A[i2 * ns + i] != 0.0) epi.write_k = 1;
       }
-      for (int i2 = i + 1; i2 < ns; ++i2)
-        if (rk->A[i2 * ns + i] != 0.0) epi.write_k = 1;
       epi.coef_self = (double)dt * rk->A[i * ns + i];
-      epi.ustart = i == 0 ? nullptr : reinterpret_cast<const double*>(u);
+      epi.ustart = i == 0 ? nullptr : reinterpret_cast<const double*>(raw_in ? rk->ustart : u);
       epi.ustar = reinterpret_cast<double*>(outp);
-      if ((rc = ins_k_flux64_f32(G, (double)visc, cur, rk->ku[i], &epi, (incorr && i > 0) ? pcorr : nullptr, (incorr && i > 0) ? 1 : 0, s))) return rc;   // :21, :35-38
+      if (i == 0 && raw_in) epi.ustart_out = reinterpret_cast<double*>(rk->ustart);
+      const bool corr = incorr && (i > 0 || raw_in);
+      if ((rc = ins_k_flux64_f32(G, (double)visc, cur, vbasis ? rk->ub[0] : rk->ku[i], &epi, corr ? pcorr : nullptr, corr ? 1 : 0, s))) return rc;   // :21, :35-38
     } else {
       if ((rc = ins_momentum_f32(G, visc, cur, rk->ku[i], s))) return rc;       // :21
       Comb32 cb;
@@ -562,7 +594,7 @@ extern "C" int ins_rk_step_f32(ins_rk32_t* rk, float visc, float* u, float dt, v
       hipLaunchKernelGGL(k32_combine, dim3((unsigned)std::min<long long>((nvec + 255) / 256, 8192)), dim3(256), 0, s, nvec, u, outp, cb);  // :35-38
       INS_LAUNCH_CHECK();
     }
-    if (incorr && i < ns - 1 && own32) {  // solve only, float2 spectra: p lands in the solver's float pI
+    if (incorr && (i < ns - 1 || raw_out) && own32) {  // solve only, float2 spectra: p lands in the solver's float pI
       ins_poisson32* q = rk->ps;
       if ((rc = ins_k_spectral_solve_f32(q->ps64, outp, q->pI, q->phat32, q->kxs32, q->tw32[0], q->tw32[1], q->tw32[2], s))) return rc;
     } else if (incorr && i < ns - 1) {  // solve only: p (unpadded, float) for the next stage's in-register correction
@@ -576,6 +608,36 @@ extern "C" int ins_rk_step_f32(ins_rk32_t* rk, float visc, float* u, float dt, v
     cur = outp;
   }
   if (ns == 1) INS_HIP_TRY(hipMemcpyAsync(u, rk->ub[0], nvec * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return INS_OK;
+}
+
+extern "C" int ins_rk_step_f32(ins_rk32_t* rk, float visc, float* u, float dt, void* stream) {
+  INS_REQUIRE(rk && u, "null argument");
+  return rk32_step(rk, visc, u, dt, as_stream(stream), 0);
+}
+
+// nsteps steps of size dt (the fixed-Δt loop of solve_unsteady, solver.jl:74-83) with the final correction of every step but the last folded into the next
+// step's first stage kernel, as ins_rk_steps_f64; u is valid before and after the call.  Falls back to single steps where the chain does not apply.
+extern "C" int ins_rk_steps_f32(ins_rk32_t* rk, float visc, float* u, float dt, int nsteps, void* stream) {
+  INS_REQUIRE(rk && u && nsteps >= 0, "bad argument");
+  const ins_grid* G = rk->grid;
+  hipStream_t s = as_stream(stream);
+  const int ns = rk->nstage;
+  bool ok = ins_flux64_supported(G) && rk->ps->ps64 && rk->ps->own32 && ns > 1 && G->uniform_exact && G->g.N[0] >= 8 && G->g.N[1] >= 8 && G->g.N[2] >= 8 &&
+            !ins_opt(OPT_INS_DISABLE_INKERNEL_CORR) && !ins_opt(OPT_INS_DISABLE_STEP_CHAIN) && !ins_opt(OPT_INS_RK_KEEP_K);
+  for (int i = 0; ok && i < ns; ++i) ok = rk->A[i * ns + i] != 0.0;
+  if (!ok || nsteps < 2) {
+    for (int n = 0; n < nsteps; ++n) {
+      int rc = rk32_step(rk, visc, u, dt, s, 0);
+      if (rc) return rc;
+    }
+    return INS_OK;
+  }
+  if (!rk->ustart) INS_HIP_TRY(hipMalloc(&rk->ustart, (size_t)G->ncell * G->g.D * sizeof(float)));
+  for (int n = 0; n < nsteps; ++n) {
+    int rc = rk32_step(rk, visc, u, dt, s, (n > 0 ? 1 : 0) | (n < nsteps - 1 ? 2 : 0));
+    if (rc) return rc;
+  }
   return INS_OK;
 }
 

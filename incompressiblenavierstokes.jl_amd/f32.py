@@ -120,3 +120,10 @@ def timestep32_(cache, u, Δt):
     s = cache.setup
     _lib.call("ins_rk_step_f32", cache._handle, float(1.0 / s.Re), _ptr(s, u, s.grid.dimension), float(Δt), s.stream)
     return u
+
+
+def timesteps32_(cache, u, Δt, nsteps):
+    """`nsteps` explicit RK steps of size Δt of the float32 field `u` in place: the fixed-Δt loop of solve_unsteady (solver.jl:74-83) as one native call."""
+    s = cache.setup
+    _lib.call("ins_rk_steps_f32", cache._handle, float(1.0 / s.Re), _ptr(s, u, s.grid.dimension), float(Δt), int(nsteps), s.stream)
+    return u
