@@ -268,19 +268,48 @@ def _temp_rhs_(ktemp, diff, u, temp, setup):
     return ktemp
 
 
+def _lmwray3_as_erk(method):
+    """The low-storage scheme IS an explicit Runge-Kutta method — its own comment spells the tableau out (step_lmwray3.jl:65-76): stage i forms
+    x = xstart + Δt (Σ_{j<i} b_j k_j + a_i k_i), so in the shifted form of methods.jl:231-236 A = [[a1], [b1, a2], [b1, b2, a3]], c = (c2, c3, 1).  With
+    time-independent boundary data (both of its apply_bc calls of a stage then do the same thing) the native stage loop therefore runs it: same registers
+    (three vector fields: u and two stage buffers), results equal to the reference's axpy order up to rounding."""
+    a, b, c = method.a, method.b, method.c
+    n = len(a)
+    A = np.zeros((n, n))
+    for i in range(n):
+        A[i, :i] = b[:i]
+        A[i, i] = a[i]
+    return ExplicitRungeKuttaMethod(A, A[-1].copy(), np.array(list(c[1:]) + [1.0]))
+
+
 class LMWray3Cache:
-    """`ode_method_cache(::LMWray3, setup)` (time_stepper_caches.jl:51-66): ustart, ONE ku, p."""
+    """`ode_method_cache(::LMWray3, setup)` (time_stepper_caches.jl:51-66): ustart, ONE ku, p — allocated when the host-driven loop runs (callable
+    boundary data, unsteady body force, user closure model); otherwise the scheme runs inside the native stage loop as the explicit RK method it is
+    (`_lmwray3_as_erk`) and `erk` holds that loop's cache."""
 
     def __init__(self, setup, psolver):
         self.setup, self.psolver = setup, psolver
-        self.ustart, self.ku, self.p = vectorfield(setup), vectorfield(setup), scalarfield(setup)
-        if setup.temperature is not None:
-            self.tempstart, self.ktemp, self.diff = scalarfield(setup), scalarfield(setup), vectorfield(setup)
+        self._host, self._erk = None, None
+
+    def _alloc(self):
+        if self._host is None:
+            setup = self.setup
+            self.ustart, self.ku, self.p = vectorfield(setup), vectorfield(setup), scalarfield(setup)
+            if setup.temperature is not None:
+                self.tempstart, self.ktemp, self.diff = scalarfield(setup), scalarfield(setup), vectorfield(setup)
+            self._host = True
+
+    def erk(self, method):
+        if self._erk is None:
+            m = _lmwray3_as_erk(method)
+            self._erk = (m, ERKCache(m, self.setup, self.psolver))
+        return self._erk
 
 
 def _timestep_lmwray3_(method, stepper, Δt, cache, θ=None):
     """step_lmwray3.jl:4-107: operator-level kernels driven from the host (with the temperature equation and the closure term)."""
     setup, psolver, u, temp, n = stepper.setup, stepper.psolver, stepper.u, stepper.temp, stepper.n
+    cache._alloc()
     ustart, ku, p = cache.ustart, cache.ku, cache.p
     m = setup.closure_model
     tstart = stepper.t
@@ -364,6 +393,10 @@ def timesteps_(method, stepper, Δt, nsteps, *, θ=None, cache):
     The stepper's `u` is valid on entry and on return (intermediate steps are not observable, as inside the reference's loop
     without processors)."""
     setup, psolver = stepper.setup, stepper.psolver
+    if nsteps >= 1 and isinstance(method, LMWray3) and not _host_driven(setup, stepper.temp) and not os.environ.get("INS_HOST_STAGE_LOOP"):
+        m_erk, c_erk = cache.erk(method)
+        st = timesteps_(m_erk, stepper, Δt, nsteps, θ=θ, cache=c_erk)
+        return create_stepper(method, setup=setup, psolver=psolver, u=st.u, temp=None, t=stepper.t + nsteps * Δt, n=stepper.n + nsteps)
     if nsteps >= 1 and not isinstance(method, LMWray3) and not _host_driven(setup, stepper.temp):
         if cache.psolver is not psolver:
             raise ValueError("cache was created for a different psolver")
@@ -385,7 +418,12 @@ def timestep_(method, stepper, Δt, *, θ=None, cache):
     if (temp is None) != (setup.temperature is None):
         raise ValueError("a temperature field needs setup.temperature (temperature_equation) and vice versa")
     if isinstance(method, LMWray3):
-        return _timestep_lmwray3_(method, stepper, Δt, cache, θ)
+        # native when nothing has to run on the host between the kernels: the scheme as the explicit RK method it is, inside the native stage loop
+        if os.environ.get("INS_HOST_STAGE_LOOP") or (_host_driven(setup, temp) and _native_ext(setup, temp, θ) is None):
+            return _timestep_lmwray3_(method, stepper, Δt, cache, θ)
+        m_erk, c_erk = cache.erk(method)
+        st = timestep_(m_erk, stepper, Δt, θ=θ, cache=c_erk)
+        return create_stepper(method, setup=setup, psolver=psolver, u=st.u, temp=st.temp, t=t + Δt, n=n + 1)
     if cache.psolver is not psolver:
         raise ValueError("cache was created for a different psolver")
     if not _host_driven(setup, temp):

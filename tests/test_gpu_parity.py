@@ -493,6 +493,48 @@ def test_lmwray3_and_right_hand_side_match_oracle(ins, oracle, geom):
     assert rell2(ins.to_numpy(u), st["u"]) < tol
 
 
+@pytest.mark.parametrize("geom", ["periodic3d", "periodic3d_wide", "dirichlet3d", "periodic2d"])
+def test_lmwray3_native_loop_equals_host_driven_loop(ins, oracle, geom, monkeypatch):
+    """LMWray3 runs inside the native stage loop as the explicit RK method its own tableau comment describes (step_lmwray3.jl:65-76; time_steppers.py
+    `_lmwray3_as_erk`): single steps and the chained `timesteps_` against the host-driven loop that issues the reference's own axpy sequence
+    (INS_HOST_STAGE_LOOP=1) and against the oracle's restatement of that sequence."""
+    o = oracle
+    so = GEOMS[geom](o)
+    sp = mirror(ins, so, o)
+    g = so.grid
+    periodic = geom.startswith("periodic")
+    pso = o.psolver_spectral(so) if periodic else o.psolver_direct(so)
+    psp = ins.psolver_spectral(sp) if periodic else ins.default_psolver(sp)
+    u0 = o.project(o.apply_bc_u(0.1 * fx.randn_field(g.N + (g.D,), 33), 0.0, so), so, pso)
+    o.apply_bc_u_(u0, 0.0, so)
+    tol = STEP_TOL if periodic else 1e-7
+    st = dict(setup=so, psolver=pso, u=u0.copy(order="F"), t=0.0, n=0)
+    oc = o.ode_method_cache(o.Wray3(), so)
+    for _ in range(3):
+        st = o.timestep_lmwray3_(st, 0.004, oc)
+    m = ins.LMWray3()
+
+    def run(chained):
+        cache = ins.ode_method_cache(m, sp, psp)
+        s = ins.create_stepper(m, setup=sp, psolver=psp, u=ins.from_numpy(sp, u0), t=0.0)
+        if chained:
+            s = ins.timesteps_(m, s, 0.004, 3, cache=cache)
+        else:
+            for _ in range(3):
+                s = ins.timestep_(m, s, 0.004, cache=cache)
+        assert s.t == pytest.approx(0.012) and s.n == 3
+        return ins.to_numpy(s.u), cache
+
+    native, cache = run(False)
+    assert cache._erk is not None and cache._host is None  # the native loop ran; the low-storage registers were never allocated
+    chained, _ = run(True)
+    monkeypatch.setenv("INS_HOST_STAGE_LOOP", "1")
+    host, hcache = run(False)
+    assert hcache._erk is None and hcache._host
+    assert rell2(native, host) < 1e-12 and rell2(chained, host) < 1e-12
+    assert rell2(native, st["u"]) < tol
+
+
 @pytest.mark.parametrize("n", [(16, 16, 16), (32, 16, 64), (128, 32, 16), (64, 128, 32), (256, 16, 16), (16, 256, 32),
                                (512, 16, 16), (16, 512, 16), (1024, 16, 16), (16, 1024, 16),
                                (192, 16, 16), (16, 192, 32), (16, 16, 192), (384, 16, 16), (16, 384, 16), (32, 16, 384), (192, 384, 192)])
