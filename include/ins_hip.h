@@ -186,6 +186,11 @@ int ins_rk_destroy(ins_rk_t* rk);
  * `planes` as in ins_apply_bc_u_f64 (time-independent Dirichlet data only; otherwise drive the stage loop
  * from the host with the operator-level calls). */
 int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, double dt, const double* const* planes, void* stream);
+/* The same with time-dependent Dirichlet data `bc.u(α, x..., t)` (boundary_conditions.jl:351-357): the ghost fills of the stage loop happen at tstart and at
+ * tstart + c[i] Δt (step_explicit_runge_kutta.jl:19, 32, 48, 55), so the host evaluates its closures for those nstage + 1 times before the step and the whole
+ * stage loop runs natively.  planes_by_time: (nstage + 1) sets of 18 device pointers each, laid out per set as `planes` of ins_apply_bc_u_f64;
+ * set 0: t, set q: t + c[q-1] Δt (c as given to ins_rk_create, i.e. shifted: c[nstage-1] = 1).  Blocking at the end (the pointer table is freed). */
+int ins_rk_step_bc_f64(ins_rk_t* rk, double visc, double* u, double t, double dt, const double* const* planes_by_time, void* stream);
 /* The fixed-Δt loop of solve_unsteady (solver.jl:74-83 without processors): nsteps calls of timestep! with time-independent
  * boundary data.  `u` is valid on entry and on return.  On the fused periodic path the projection's gradient-subtract of every step
  * but the last is applied in registers by the next step's first stage kernel (same arithmetic per cell; the uncorrected intermediate

@@ -97,6 +97,7 @@ SIGNATURES = {
     "ins_rk_create": (C.c_int, [vp, vp, C.c_int, c_double_p, c_double_p, C.POINTER(vp)]),
     "ins_rk_destroy": (C.c_int, [vp]),
     "ins_rk_step_f64": (C.c_int, [vp, C.c_double, vp, C.c_double, C.c_double, C.POINTER(vp), vp]),
+    "ins_rk_step_bc_f64": (C.c_int, [vp, C.c_double, vp, C.c_double, C.c_double, C.POINTER(vp), vp]),
     "ins_rk_steps_f64": (C.c_int, [vp, C.c_double, vp, C.c_double, C.c_double, C.c_int, vp]),
     "ins_combine_f64": (C.c_int, [vp, vp, vp, C.c_int, c_double_p, C.POINTER(vp), vp]),
     "ins_rk_profile_enable": (C.c_int, [vp, C.c_int]),

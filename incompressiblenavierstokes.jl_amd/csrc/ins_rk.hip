@@ -363,9 +363,11 @@ extern "C" int ins_rk_steps_f64(ins_rk_t* rk, double visc, double* u, double t, 
   return INS_OK;
 }
 
-extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, double dt, const double* const* planes, void* stream) {
+// planes: nsets x 18 device pointers.  nsets == 1: the same boundary data for every ghost fill of the step; nsets == nstage + 1: set q holds the data at
+// time tstart (q = 0) / tstart + c[q-1] Δt — the fill before stage i's momentum! reads set i (the OLD stage time, step_explicit_runge_kutta.jl:19), the fill
+// before its projection and the final one read set i + 1 (:32, :48, :55).
+static int rk_step_any(ins_rk_t* rk, double visc, double* u, double dt, const double* const* planes, int nsets, void* stream) {
   INS_REQUIRE(rk && u, "null argument");
-  (void)t;  // boundary data is time-independent on this entry point (see header)
   const ins_grid* G = rk->grid;
   hipStream_t s = as_stream(stream);
   {
@@ -385,10 +387,11 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
     }
   } guard{nullptr};
   if (planes) {
-    INS_HIP_TRY(hipMalloc(&dplanes, 18 * sizeof(double*)));
+    INS_HIP_TRY(hipMalloc(&dplanes, (size_t)nsets * 18 * sizeof(double*)));
     guard.p = dplanes;
-    INS_HIP_TRY(hipMemcpy(dplanes, planes, 18 * sizeof(double*), hipMemcpyHostToDevice));
+    INS_HIP_TRY(hipMemcpy(dplanes, planes, (size_t)nsets * 18 * sizeof(double*), hipMemcpyHostToDevice));
   }
+  auto pset = [&](int q) -> const double** { return dplanes ? dplanes + 18 * (nsets > 1 ? q : 0) : nullptr; };
   int rc;
   const int ns = rk->nstage;
   // Time-independent boundary data: K6 runs as K1's epilogue (no k_combine pass, no
@@ -488,7 +491,7 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
   // copyto!(ustart, u)                                                   step_explicit_runge_kutta.jl:14
   INS_HIP_TRY(hipMemcpyAsync(rk->ustart, u, nvec * sizeof(double), hipMemcpyDeviceToDevice, s));
   for (int i = 0; i < ns; ++i) {
-    if ((rc = ins_k_apply_bc_u(G, u, 0, dplanes, s))) return rc;             // :19
+    if ((rc = ins_k_apply_bc_u(G, u, 0, pset(i), s))) return rc;             // :19
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (rk->profiling) {
       INS_HIP_TRY(hipEventCreate(&e0));
@@ -523,10 +526,25 @@ extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, d
     const unsigned nblk = (unsigned)std::min<long long>((nvec / 2 + 255) / 256, 8192);
     hipLaunchKernelGGL(k_combine, dim3(nblk), dim3(256), 0, s, nvec, rk->ustart, u, cb);
     INS_LAUNCH_CHECK();
-    if ((rc = ins_k_apply_bc_u(G, u, 0, dplanes, s))) return rc;             // :48
+    if ((rc = ins_k_apply_bc_u(G, u, 0, pset(i + 1), s))) return rc;         // :48
     if ((rc = ins_k_project(G, rk->ps, u, rk->p, s))) return rc;              // :49
   }
-  if ((rc = ins_k_apply_bc_u(G, u, 0, dplanes, s))) return rc;               // :55
+  if ((rc = ins_k_apply_bc_u(G, u, 0, pset(ns), s))) return rc;              // :55
   if (planes) INS_HIP_TRY(hipStreamSynchronize(s));                           // dplanes is freed on return
   return INS_OK;
+}
+
+extern "C" int ins_rk_step_f64(ins_rk_t* rk, double visc, double* u, double t, double dt, const double* const* planes, void* stream) {
+  (void)t;  // boundary data is time-independent on this entry point (see header)
+  return rk_step_any(rk, visc, u, dt, planes, 1, stream);
+}
+
+// timestep! with time-dependent Dirichlet data (boundary_conditions.jl:351-357: bc.u(α, x..., t)): closures cannot cross the ABI, but the times at which
+// the stage loop fills the ghost volumes are known before the step — tstart and tstart + c[i] Δt —, so the host evaluates its closures on the boundary
+// planes for those nstage + 1 times and the whole stage loop runs here (the reference's kernel sequence: apply_bc_u!, momentum!, the combination,
+// apply_bc_u!, project!).  planes_by_time: (nstage + 1) x 18 device pointers, entry (q·18 + (β·2 + side)·3 + α) as in ins_apply_bc_u_f64 (NULL: constant data).
+extern "C" int ins_rk_step_bc_f64(ins_rk_t* rk, double visc, double* u, double t, double dt, const double* const* planes_by_time, void* stream) {
+  INS_REQUIRE(rk && u && planes_by_time, "null argument");
+  (void)t;
+  return rk_step_any(rk, visc, u, dt, planes_by_time, rk->nstage + 1, stream);
 }

@@ -430,6 +430,23 @@ def timestep_(method, stepper, Δt, *, θ=None, cache):
         _native_force(cache, setup)
         _lib.call("ins_rk_step_f64", cache.handle, 1.0 / setup.Re, setup.ptr(u, True), float(t), float(Δt), None, setup.stream)
         return create_stepper(method, setup=setup, psolver=psolver, u=u, temp=None, t=stepper.t + method.c[-1] * Δt, n=n + 1)
+    if (setup.needs_bc_planes and temp is None and setup.closure_model is None and (setup.bodyforce is None or setup.issteadybodyforce)
+            and not os.environ.get("INS_HOST_STAGE_LOOP")):
+        # callable Dirichlet data is the only thing that needs the host: the ghost fills of the stage loop happen at times known before the step
+        # (tstart and tstart + c[i] Δt), so the closures are evaluated for those now and the whole stage loop runs natively (ins_rk_step_bc_f64)
+        from .operators import _bc_planes
+
+        ns = len(method.b)
+        sets = (C.c_void_p * (18 * (ns + 1)))()
+        keep = []
+        for q in range(ns + 1):
+            arr, k = _bc_planes(setup, t if q == 0 else t + method.c[q - 1] * Δt, False)
+            keep.append(k)
+            for j in range(18):
+                sets[18 * q + j] = arr[j]
+        _native_force(cache, setup)
+        _lib.call("ins_rk_step_bc_f64", cache.handle, 1.0 / setup.Re, setup.ptr(u, True), float(t), float(Δt), sets, setup.stream)
+        return create_stepper(method, setup=setup, psolver=psolver, u=u, temp=None, t=stepper.t + method.c[-1] * Δt, n=n + 1)
     ext = None if os.environ.get("INS_HOST_STAGE_LOOP") else _native_ext(setup, temp, θ)
     if ext is not None:  # temperature equation / Smagorinsky closure inside the native loop
         kind, th, desc = ext

@@ -477,6 +477,24 @@ function timestep!(method::ExplicitRungeKuttaMethod, stepper::HipStepper, Î”t; Î
                     h, 1 / setup.Re, pointer(u), isnothing(temp) ? Ptr{Float64}(C_NULL) : pointer(temp), t, Î”t, stream()))
         return IncompressibleNavierStokes.create_stepper(method; setup, psolver, u, temp, t = t + method.c[end] * Î”t, n = n + 1)
     end
+    # Callable Dirichlet data alone (boundary_conditions.jl:351-357): the ghost fills of the stage loop happen at t and t + c[i] Î”t, so the closures are
+    # evaluated for those nstage + 1 times now and the whole stage loop runs natively (ins_rk_step_bc_f64)
+    if !native && isnothing(setup.closure_model) && isnothing(temp) && (isnothing(setup.bodyforce) || setup.issteadybodyforce)
+        h = native!(cache, method, setup, psolver)
+        check(ccall((:ins_rk_set_bodyforce, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), h,
+                    isnothing(setup.bodyforce) ? Ptr{Float64}(C_NULL) : pointer(setup.bodyforce)))
+        ns = length(method.b)
+        sets = fill(Ptr{Float64}(C_NULL), 18 * (ns + 1))
+        keeps = Any[]
+        for q = 0:ns
+            planes, keep = bc_planes(u, q == 0 ? t : t + method.c[q] * Î”t, setup, false)
+            push!(keeps, keep)
+            isnothing(planes) || (sets[18q+1:18q+18] .= planes)
+        end
+        GC.@preserve keeps check(ccall((:ins_rk_step_bc_f64, lib), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Cdouble, Cdouble, Ptr{Ptr{Float64}}, Ptr{Cvoid}),
+                                       h, 1 / setup.Re, pointer(u), t, Î”t, sets, stream()))
+        return IncompressibleNavierStokes.create_stepper(method; setup, psolver, u, temp, t = t + method.c[end] * Î”t, n = n + 1)
+    end
     if !native
         isnothing(cache.ref) && (cache.ref = invoke(ode_method_cache, Tuple{ExplicitRungeKuttaMethod,Any}, method, setup))
         return invoke(timestep!, Tuple{ExplicitRungeKuttaMethod,Any,Any}, method, stepper, Î”t; Î¸, cache = cache.ref)
