@@ -1147,6 +1147,17 @@ bool ins_ownfft_supported(const int np[3]) {  // power-of-two boxes (slab and 2-
     if (np[a] < 16 || np[a] > 1024 || (np[a] & (np[a] - 1))) return false;
   return ins_zsolve_supported(np[2]);
 }
+// z-slab path: own x / y passes for power-of-two and 3 * 2^m sides (the z direction is either the distributed tridiagonal solve — any plane count — or the
+// transposes around the fused z kernel / a rocFFT z plan)
+bool ins_ownfft_supported_slab(const int np[3]) {
+  if (ins_opt(OPT_INS_DISABLE_OWNFFT)) return false;
+  for (int a = 0; a < 2; ++a) {
+    const bool pow2 = np[a] >= 16 && np[a] <= 1024 && !(np[a] & (np[a] - 1));
+    const bool r3 = (np[a] == 192 || np[a] == 384) && !ins_opt(OPT_INS_OWNFFT_POW2_ONLY);
+    if (!pow2 && !r3) return false;
+  }
+  return np[2] >= 2;
+}
 // single-GPU 3-D solver: sides of 3 * 2^m (192, 384) run on the own passes too (a radix-3 stage in front; INS_OWNFFT_POW2_ONLY keeps rocFFT for them)
 bool ins_ownfft_supported_mixed(const int np[3]) {
   if (ins_opt(OPT_INS_DISABLE_OWNFFT)) return false;

@@ -341,6 +341,7 @@ int ins_fft_make_real_plans(hipfftHandle* fwd, hipfftHandle* inv, int rank, int*
 void ins_fft_solver_released();
 bool ins_zsolve_supported(int nz);
 bool ins_ownfft_supported(const int np[3]);
+bool ins_ownfft_supported_slab(const int np[3]);
 bool ins_ownfft_supported_mixed(const int np[3]);
 void ins_ownfft_permute_symbol(int n, const double* ay, double* out);
 // kxs: row stride of phat in complex elements (0 = dense, n0/2+1); a multiple of 8 keeps the y/z tiles 128-B aligned

@@ -156,7 +156,7 @@ extern "C" int ins_slab_fft_create(const int32_t np[3], const double h[3], int r
   };
   std::vector<double> ax(S->kxn), ay(S->nyl), az(np[2]), ayf(np[1]);
   for (int k = 0; k < S->kxn; ++k) ax[k] = symbol(0, k);
-  S->ownfft = ins_ownfft_supported(np);
+  S->ownfft = ins_ownfft_supported_slab(np);  // x and y: 2^m or 3 * 2^m; z: any even plane count (tridiagonal route), fused z kernel / rocFFT plan (transposes)
   S->cz = om / (h[2] * h[2]);
   S->kxs = S->ownfft ? ((S->kxn + 7) & ~7) : S->kxn;
   if (S->ownfft) {  // the own y pass leaves ky in digit-reversed storage order: slice the permuted symbol vector
@@ -342,7 +342,7 @@ extern "C" int ins_slab_fft_xy_inverse_only(ins_slab_fft_t* S, double* work, dou
 extern "C" int ins_slab_fft_forward_packed(ins_slab_fft_t* S, const ins_grid_t* G, const double* src, int from_u, double* work, double* sendbuf,
                                            int cw, void* stream) {
   INS_REQUIRE(S && src && work && sendbuf, "null argument");
-  INS_REQUIRE(S->ownfft, "packed passes need a power-of-two box");
+  INS_REQUIRE(S->ownfft, "packed passes need x and y sides of 2^m or 3 * 2^m");
   INS_REQUIRE(cw >= 1 && cw <= S->kxn, "bad chunk width");
   if (from_u) {
     INS_REQUIRE(G && G->g.D == 3 && G->g.N[0] == S->np[0] + 2 && G->g.N[1] == S->np[1] + 2 && G->g.N[2] == S->nzl + 2, "grid does not match the slab");
@@ -355,7 +355,7 @@ extern "C" int ins_slab_fft_forward_packed(ins_slab_fft_t* S, const ins_grid_t* 
 
 extern "C" int ins_slab_fft_inverse_packed(ins_slab_fft_t* S, double* recvbuf, double* work, double* pI, int cw, void* stream) {
   INS_REQUIRE(S && recvbuf && work && pI, "null argument");
-  INS_REQUIRE(S->ownfft, "packed passes need a power-of-two box");
+  INS_REQUIRE(S->ownfft, "packed passes need x and y sides of 2^m or 3 * 2^m");
   INS_REQUIRE(cw >= 1 && cw <= S->kxn, "bad chunk width");
   hipStream_t s = as_stream(stream);
   int rc = ins_k_ownfft_y_packed(work, recvbuf, S->kxn, S->np[1], S->nzl, S->nyl, cw, S->tw_y, true, s);
@@ -399,11 +399,11 @@ extern "C" int ins_slab_ztri_transform(ins_slab_fft_t* S, const ins_grid_t* G, c
   hipStream_t s = as_stream(stream);
   int rc;
   if (from_u == 2) {  // x pass already done plane range by plane range (ins_slab_xfwd_planes)
-    INS_REQUIRE(S->ownfft, "forming the right-hand side inside the x pass needs a power-of-two box");
+    INS_REQUIRE(S->ownfft, "forming the right-hand side inside the x pass needs x and y sides of 2^m or 3 * 2^m");
     return ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s, S->kxs);
   }
   if (from_u) {
-    INS_REQUIRE(S->ownfft, "forming the right-hand side inside the x pass needs a power-of-two box");
+    INS_REQUIRE(S->ownfft, "forming the right-hand side inside the x pass needs x and y sides of 2^m or 3 * 2^m");
     INS_REQUIRE(G && G->g.D == 3 && G->g.N[0] == S->np[0] + 2 && G->g.N[1] == S->np[1] + 2 && G->g.N[2] == S->nzl + 2, "grid does not match the slab");
     if ((rc = ins_k_ownfft_xfwd(G, src, 2, work, S->np[0], S->np[1], S->nzl, S->tw_x, s, S->kxs))) return rc;
     return ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s, S->kxs);
@@ -461,7 +461,7 @@ extern "C" int ins_slab_ztri_finish(ins_slab_fft_t* S, double* work, const doubl
 // can be transformed while the w plane below the slab is still travelling; call ins_slab_ztri_forward with from_u = 2 afterwards.
 extern "C" int ins_slab_xfwd_planes(ins_slab_fft_t* S, const ins_grid_t* G, const double* u, double* work, int kz0, int nkz, void* stream) {
   INS_REQUIRE(S && G && u && work, "null argument");
-  INS_REQUIRE(S->ownfft, "forming the right-hand side inside the x pass needs a power-of-two box");
+  INS_REQUIRE(S->ownfft, "forming the right-hand side inside the x pass needs x and y sides of 2^m or 3 * 2^m");
   INS_REQUIRE(G->g.D == 3 && G->g.N[0] == S->np[0] + 2 && G->g.N[1] == S->np[1] + 2 && G->g.N[2] == S->nzl + 2, "grid does not match the slab");
   INS_REQUIRE(kz0 >= 0 && nkz >= 0 && kz0 + nkz <= S->nzl, "bad plane range");
   if (nkz == 0) return INS_OK;
