@@ -110,12 +110,18 @@ def stage_bytes_per_cell(method, steps, chained):
     return stage_bytes, k4_bytes
 
 
-def committed_traffic(name):
-    """HBM bytes per launch of the stage kernel (RK44 step average) from a committed `rocprofv3 --pmc` result under profiles/ (FETCH_SIZE and WRITE_SIZE in
-    separate passes, FETCH doubled: gfx950 rule; tools/run_r03_profiles.sh) — PMC counters cannot be read inside the timed run."""
+def committed_traffic(name, launches=None, chained=True):
+    """HBM bytes per launch of the stage kernel from a committed `rocprofv3 --pmc` result under profiles/ (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH
+    doubled: gfx950 rule; tools/run_r03_profiles.sh) — PMC counters cannot be read inside the timed run.  The file holds the per-launch averages of the
+    correcting form and of the first-stage form; they are weighted with the launch mix of THIS run's timed region (chained: one first-stage launch per call,
+    every other launch corrects; single steps: one first-stage launch per step)."""
     tfile = os.path.join(ROOT, "profiles", name)
     try:
-        return json.load(open(tfile))["per_kernel"]["stage kernel, RK44 step average"]["hbm_total_GB"] * 1e9
+        pk = json.load(open(tfile))["per_kernel"]
+        if launches and "stage kernel, corr" in pk and "stage kernel, first" in pk:
+            nfirst = 1 if chained else max(launches // 4, 1)
+            return (pk["stage kernel, corr"]["hbm_total_GB"] * (launches - nfirst) + pk["stage kernel, first"]["hbm_total_GB"] * nfirst) / launches * 1e9
+        return pk["stage kernel, RK44 step average"]["hbm_total_GB"] * 1e9
     except Exception:
         return None
 
@@ -149,7 +155,7 @@ def strong_single_gpu(ins, dev, n=512, steps=10, warmup=2):
     avg_ms = k_ms.value / max(k_n.value, 1)
     gbs = float(np.mean(sb)) * float(n) ** 3 / (avg_ms * 1e-3) / 1e9
     roof = {"kernel": "k_flux64 FUSE[/CORR] (stage kernel: K1 + K6 + the previous projection's gradient-subtract in registers)", "bound": "hbm", "achieved": gbs,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": committed_traffic("r03_pmc_traffic_512.json") if n == 512 else None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": committed_traffic("r03_pmc_traffic_512.json", k_n.value) if n == 512 else None,
             "traffic_note": "B per launch from profiles/r03_pmc_traffic_512.json (rocprofv3 --pmc of `bench.py --n 512`, two passes)",
             "bytes_per_cell": float(np.mean(sb)), "bytes_per_cell_by_stage": sb, "avg_launch_ms": avg_ms, "launches": k_n.value}
     div = ins.max_abs_divergence(st.u, setup)
@@ -317,7 +323,8 @@ def main():
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_cell": K1_BYTES_PER_CELL, "avg_launch_ms": ms5}
         k1_512["frac"] = k1_512["achieved"] / HBM_PEAK_GBS
         del u5, F5, s5
-    traffic = committed_traffic("r03_pmc_traffic.json") if n == 256 else (committed_traffic("r03_pmc_traffic_512.json") if n == 512 else None)
+    traffic = (committed_traffic("r03_pmc_traffic.json", k1_n.value, chained) if n == 256
+               else (committed_traffic("r03_pmc_traffic_512.json", k1_n.value, chained) if n == 512 else None))
     div = ins.max_abs_divergence(stepper.u, setup)
     energy = ins.total_kinetic_energy(stepper.u, setup)
     assert np.isfinite(energy) and div / n < 1e-10, f"bench state is not a valid flow: div={div}, E={energy}"

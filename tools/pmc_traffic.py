@@ -26,10 +26,21 @@ for k in sorted(set(fe) | set(wr)):
     if rd + wt < 1e-3:
         continue
     out["per_kernel"][k] = {"launches": len(f), "hbm_read_GB": rd, "hbm_write_GB": wt, "hbm_total_GB": rd + wt}
-stage = [v for k, v in out["per_kernel"].items() if re.match(r"k_flux64<(double,)?\d+,\d+,true,", k)]  # <T, R, XW, FUSE, CORR, SKEL, NW>
+# stage kernels of the RK loop: FUSE = true instantiations of k_flux64<T, R, XW, FUSE, CORR, SKEL, NW, EXTRA> / k_flux128<T, R, XW, FUSE, CORR, NW>;
+# CORR != 0: the correcting form (every stage of a chained run but the very first), CORR == 0: the first stage of a call
+def stage_kind(k):
+    m = re.match(r"k_flux(?:64|128)<(?:double,)?\d+,\d+,true,(\d)", k)
+    return None if not m else ("corr" if m.group(1) != "0" else "first")
+for kind in ("corr", "first"):
+    sel = [v for k, v in out["per_kernel"].items() if stage_kind(k) == kind]
+    if sel:
+        n = sum(v["launches"] for v in sel)
+        out["per_kernel"][f"stage kernel, {kind}"] = {"hbm_total_GB": sum(v["hbm_total_GB"] * v["launches"] for v in sel) / n, "launches": n}
+stage = [v for k, v in out["per_kernel"].items() if stage_kind(k)]
 if stage:
     n = sum(v["launches"] for v in stage)
-    out["per_kernel"]["stage kernel, RK44 step average"] = {"hbm_total_GB": sum(v["hbm_total_GB"] * v["launches"] for v in stage) / n, "launches": n}
+    out["per_kernel"]["stage kernel, RK44 step average"] = {"hbm_total_GB": sum(v["hbm_total_GB"] * v["launches"] for v in stage) / n, "launches": n,
+                                                            "note": "launch-weighted over THIS command's launches; bench.py re-weights 'corr' / 'first' for its timed region"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k, v in out["per_kernel"].items():
     print(f"{k:50s} {json.dumps(v)}")
