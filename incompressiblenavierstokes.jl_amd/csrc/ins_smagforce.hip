@@ -341,8 +341,10 @@ bool ins_smagforce_supported(const ins_grid* G) {
   if (ins_opt(OPT_INS_DISABLE_SMAGFORCE_GEN)) return false;
   for (int d = 0; d < 3; ++d)
     for (int side = 0; side < 2; ++side)
-      if (g.bc[d][side] == INS_BC_PRESSURE || g.bc[d][side] == INS_BC_HALO) return false;  // (ghost rule for σ / DOF range not covered: the three kernels;
-                                                                                           //  slab grids: refused by the entry points)
+      // a PressureBC on the RIGHT side is a zero ghost stress (apply_bc_p!: p[I] .= 0, boundary_conditions.jl:497-501) with one more degree of freedom of the
+      // normal component (the masks come from the grid's Iu); on the LEFT side it adds a second ghost layer (N = n + 3), which this kernel's indexing does
+      // not cover: the three kernels.  Slab grids: refused by the entry points.
+      if ((g.bc[d][side] == INS_BC_PRESSURE && side == 0) || g.bc[d][side] == INS_BC_HALO) return false;
   return true;
 }
 // the correcting form (uncorrected input + pressure) exists for all-periodic uniform boxes only

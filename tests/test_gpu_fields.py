@@ -173,7 +173,7 @@ def test_generalised_closure_force_forms_on_a_periodic_box(ins, force):
     assert np.max(np.abs(want)) > 0 and relmax(got, want) < OP_TOL
 
 
-@pytest.mark.parametrize("case", ["walls", "channel", "mixed", "tiny", "symuniform"])
+@pytest.mark.parametrize("case", ["walls", "channel", "mixed", "tiny", "symuniform", "outflow"])
 def test_one_kernel_closure_force_on_wall_bounded_and_stretched_grids(ins, case):
     """The generalised form of the one-kernel closure force (csrc/ins_smagforce.hip, GEN: metric tables, the ghost rule of apply_bc_p!(σ) as wrapped
     addresses / copies from the neighbour lane, row or plane, stores masked to the degrees of freedom) against the three-kernel sequence on the
@@ -191,6 +191,10 @@ def test_one_kernel_closure_force_on_wall_bounded_and_stretched_grids(ins, case)
     elif case == "mixed":
         x = (ins.cosine_grid(0.0, 1.0, 61), np.linspace(0.0, 0.7, 17), ins.tanh_grid(0.0, 1.3, 70, 1.3))
         bc = ((Sy(), Dr()), (Pe(), Pe()), (Dr(), Sy()))
+    elif case == "outflow":  # PressureBC on right sides (zero ghost stress, one more degree of freedom of the normal component): stretched x, uniform z
+        Pr = ins.PressureBC
+        x = (ins.tanh_grid(0.0, 2.0, 72, 1.2), ins.cosine_grid(0.0, 1.0, 12), np.linspace(0.0, 0.5, 11))
+        bc = ((Dr((1.0, 0.0, 0.0)), Pr()), (Sy(), Sy()), (Dr(), Pr()))
     elif case == "symuniform":  # uniform spacing, Symmetric / Periodic sides only: uniform_exact but not all_dof -> k_smagforce<R, false, true, false>
         x = (np.linspace(0.0, 1.0, 71), np.linspace(0.0, 0.5, 13), np.linspace(0.0, 0.25, 11))
         bc = ((Sy(), Sy()), (Pe(), Pe()), (Sy(), Sy()))
