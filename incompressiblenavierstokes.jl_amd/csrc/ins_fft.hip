@@ -54,7 +54,8 @@ __device__ __forceinline__ C mul_pi(C a) { return mkc<C>(-a.y, a.x); }
 // Transform lengths.  The template parameter LOGN of everything below is a SIZE CODE: codes < 32 are log2 N of a power of two; code
 // 32 + m stands for N = 3 * 2^m (a radix-3 stage in front of the power-of-two stages: 192 = 3 * 64, 384 = 3 * 128), so that boxes with
 // such sides run on these passes too instead of rocFFT (pressure.jl:316 plans any even n).
-constexpr int fft_r3(int code) { return code >= 32 ? 3 : 1; }
+// (round 3: code 64 + m stands for N = 5 * 2^m — 320 = 5 * 64, 640 = 5 * 128 — with a radix-5 stage in front.)
+constexpr int fft_r3(int code) { return code >= 64 ? 5 : (code >= 32 ? 3 : 1); }  // the odd leading radix (1: none)
 constexpr int fft_lg(int code) { return code & 31; }                           // log2 of the power-of-two part
 constexpr int fft_len(int code) { return fft_r3(code) << fft_lg(code); }
 
@@ -65,9 +66,9 @@ __host__ __device__ __forceinline__ int pos_of_freq(int k) {
   constexpr int LG = fft_lg(LOGN), R3 = fft_r3(LOGN);
   constexpr bool ODD = LG & 1;
   int p = 0, L = 1 << LG;
-  if (R3 == 3) {
-    p = (k % 3) * L;
-    k /= 3;
+  if (R3 != 1) {
+    p = (k % R3) * L;
+    k /= R3;
   }
   if (ODD) {
     p += (k & 1) * (L / 2);
@@ -99,6 +100,25 @@ __device__ __forceinline__ void bfly3(C& x0, C& x1, C& x2) {
   x2 = csub(t2, t3);
 }
 
+// radix-5 butterfly, forward (w = e^{-2πi/5}) / inverse (conjugate)
+template <bool INV, typename C>
+__device__ __forceinline__ void bfly5(C& x0, C& x1, C& x2, C& x3, C& x4) {
+  using T = real_t<C>;
+  constexpr T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;  // cos(2π/5), cos(4π/5)
+  constexpr T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;   // sin(2π/5), sin(4π/5)
+  const C a = cadd(x1, x4), b = cadd(x2, x3), d = csub(x1, x4), e = csub(x2, x3);
+  const C m1 = mkc<C>(x0.x + c1 * a.x + c2 * b.x, x0.y + c1 * a.y + c2 * b.y);
+  const C m2 = mkc<C>(x0.x + c2 * a.x + c1 * b.x, x0.y + c2 * a.y + c1 * b.y);
+  // forward: X1 = m1 - i (s1 d + s2 e), X4 = m1 + i (...), X2 = m2 - i (s2 d - s1 e), X3 = m2 + i (...)
+  const C u = mkc<C>(s1 * d.x + s2 * e.x, s1 * d.y + s2 * e.y), v = mkc<C>(s2 * d.x - s1 * e.x, s2 * d.y - s1 * e.y);
+  const C iu = INV ? mkc<C>(-u.y, u.x) : mkc<C>(u.y, -u.x), iv = INV ? mkc<C>(-v.y, v.x) : mkc<C>(v.y, -v.x);  // (-+ i) u, (-+ i) v
+  x0 = mkc<C>(x0.x + a.x + b.x, x0.y + a.y + b.y);
+  x1 = cadd(m1, iu);
+  x4 = csub(m1, iu);
+  x2 = cadd(m2, iv);
+  x3 = csub(m2, iv);
+}
+
 template <int LOGN, int NC, int SR, int SC, bool RFAST, int NT = 256, typename C>
 __device__ __forceinline__ void fft_dif(C* __restrict__ buf, const C* __restrict__ tw, int t) {
   constexpr int N = fft_len(LOGN), R3 = fft_r3(LOGN), M = N / R3;  // M: the power-of-two sub-length
@@ -112,6 +132,20 @@ __device__ __forceinline__ void fft_dif(C* __restrict__ buf, const C* __restrict
       x[j * SR] = a0;
       x[(j + M) * SR] = cmul(a1, tw[j]);
       x[(j + 2 * M) * SR] = cmul(a2, tw[2 * j]);
+    }
+    __syncthreads();
+  }
+  if (R3 == 5) {  // N = 5 M: one radix-5 stage over the whole line, twiddles W_N^(q j)
+    for (int w = t; w < M * NC; w += NT) {
+      const int c = RFAST ? w / M : w % NC, j = RFAST ? w % M : w / NC;
+      C* x = buf + c * SC;
+      C a0 = x[j * SR], a1 = x[(j + M) * SR], a2 = x[(j + 2 * M) * SR], a3 = x[(j + 3 * M) * SR], a4 = x[(j + 4 * M) * SR];
+      bfly5<false>(a0, a1, a2, a3, a4);
+      x[j * SR] = a0;
+      x[(j + M) * SR] = cmul(a1, tw[j]);
+      x[(j + 2 * M) * SR] = cmul(a2, tw[2 * j]);
+      x[(j + 3 * M) * SR] = cmul(a3, tw[3 * j]);
+      x[(j + 4 * M) * SR] = cmul(a4, tw[4 * j]);
     }
     __syncthreads();
   }
@@ -201,6 +235,21 @@ __device__ __forceinline__ void fft_dit(C* __restrict__ buf, const C* __restrict
       x[j * SR] = a0;
       x[(j + M) * SR] = a1;
       x[(j + 2 * M) * SR] = a2;
+    }
+    __syncthreads();
+  }
+  if (R3 == 5) {
+    for (int w = t; w < M * NC; w += NT) {
+      const int c = RFAST ? w / M : w % NC, j = RFAST ? w % M : w / NC;
+      C* x = buf + c * SC;
+      C a0 = x[j * SR], a1 = cmulc(x[(j + M) * SR], tw[j]), a2 = cmulc(x[(j + 2 * M) * SR], tw[2 * j]), a3 = cmulc(x[(j + 3 * M) * SR], tw[3 * j]),
+        a4 = cmulc(x[(j + 4 * M) * SR], tw[4 * j]);
+      bfly5<true>(a0, a1, a2, a3, a4);
+      x[j * SR] = a0;
+      x[(j + M) * SR] = a1;
+      x[(j + 2 * M) * SR] = a2;
+      x[(j + 3 * M) * SR] = a3;
+      x[(j + 4 * M) * SR] = a4;
     }
     __syncthreads();
   }
@@ -616,7 +665,7 @@ int launch_y(C* data, int kxn, int kxs, int nplanes, const C* tw, bool inverse, 
 template <int LOGN>
 int launch_xfwd(const GridDev& g, const double* src, int from_u, double2* out, int n1, int n2, const double2* tw, int kxs, hipStream_t s, int kz0) {
   constexpr int N = fft_len(LOGN);
-  constexpr int NP = fft_r3(LOGN) == 3 ? 768 / N : (N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N));  // 2 NP N a multiple of 256
+  constexpr int NP = fft_r3(LOGN) == 5 ? 640 / N : (fft_r3(LOGN) == 3 ? 768 / N : (N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N)));  // 2 NP N a multiple of 256
   constexpr size_t lds = ((size_t)NP * N + N) * sizeof(double2);
   dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
   if (from_u == 5)
@@ -638,7 +687,7 @@ int launch_xfwd(const GridDev& g, const double* src, int from_u, double2* out, i
 template <int LOGN>
 int launch_xfwd32(const GridDev& g, const float* src, int from_u, float2* out, int n1, int n2, const float2* tw, int kxs, hipStream_t s) {
   constexpr int N = fft_len(LOGN);
-  constexpr int NP = fft_r3(LOGN) == 3 ? 768 / N : (N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N));
+  constexpr int NP = fft_r3(LOGN) == 5 ? 640 / N : (fft_r3(LOGN) == 3 ? 768 / N : (N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N)));
   constexpr size_t lds = ((size_t)NP * N + N) * sizeof(float2);
   dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
   const double* srcd = reinterpret_cast<const double*>(src);  // the kernel reads float data behind this pointer (C = float2)
@@ -653,7 +702,7 @@ int launch_xfwd32(const GridDev& g, const float* src, int from_u, float2* out, i
 template <int LOGN, typename C = double2>
 int launch_xinv(const C* in, real_t<C>* pI, int n1, int n2, const C* tw, int kxs, hipStream_t s) {
   constexpr int N = fft_len(LOGN);
-  constexpr int NP = fft_r3(LOGN) == 3 ? 768 / N : (N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N));  // 2 NP N a multiple of 256
+  constexpr int NP = fft_r3(LOGN) == 5 ? 640 / N : (fft_r3(LOGN) == 3 ? 768 / N : (N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N)));  // 2 NP N a multiple of 256
   constexpr size_t lds = ((size_t)NP * N + N) * sizeof(C);
   dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
   hipLaunchKernelGGL((k_xinv<LOGN, NP, C>), grid, dim3(256), lds, s, in, pI, n1, tw, kxs);
@@ -1137,6 +1186,8 @@ int launch_yz(YzArgs& a, const double2* tw, hipStream_t s) {
     case 1024: return CALL(10);             \
     case 192: return CALL(32 + 6);          \
     case 384: return CALL(32 + 7);          \
+    case 320: return CALL(64 + 6);          \
+    case 640: return CALL(64 + 7);          \
   }                                         \
   ins_set_error("own FFT: unsupported length %d", n); \
   return INS_ERR_UNSUPPORTED;
@@ -1153,7 +1204,7 @@ bool ins_ownfft_supported_slab(const int np[3]) {
   if (ins_opt(OPT_INS_DISABLE_OWNFFT)) return false;
   for (int a = 0; a < 2; ++a) {
     const bool pow2 = np[a] >= 16 && np[a] <= 1024 && !(np[a] & (np[a] - 1));
-    const bool r3 = (np[a] == 192 || np[a] == 384) && !ins_opt(OPT_INS_OWNFFT_POW2_ONLY);
+    const bool r3 = (np[a] == 192 || np[a] == 384 || np[a] == 320 || np[a] == 640) && !ins_opt(OPT_INS_OWNFFT_POW2_ONLY);
     if (!pow2 && !r3) return false;
   }
   return np[2] >= 2;
@@ -1163,7 +1214,7 @@ bool ins_ownfft_supported_mixed(const int np[3]) {
   if (ins_opt(OPT_INS_DISABLE_OWNFFT)) return false;
   for (int a = 0; a < 3; ++a) {
     const bool pow2 = np[a] >= 16 && np[a] <= 1024 && !(np[a] & (np[a] - 1));
-    const bool r3 = (np[a] == 192 || np[a] == 384) && !ins_opt(OPT_INS_OWNFFT_POW2_ONLY);
+    const bool r3 = (np[a] == 192 || np[a] == 384 || np[a] == 320 || np[a] == 640) && !ins_opt(OPT_INS_OWNFFT_POW2_ONLY);  // 3 * 2^m, 5 * 2^m
     if (!pow2 && !r3) return false;
   }
   return ins_zsolve_supported(np[2]);
@@ -1171,14 +1222,14 @@ bool ins_ownfft_supported_mixed(const int np[3]) {
 
 // ây permuted to the digit-reversed storage order that pass 2 leaves behind: out[pos] = ay[freq(pos)].
 void ins_ownfft_permute_symbol(int n, const double* ay, double* out) {
-  const int r3 = (n % 3 == 0) ? 3 : 1, m = n / r3;
+  const int r3 = (n % 5 == 0) ? 5 : ((n % 3 == 0) ? 3 : 1), m = n / r3;
   int logm = 0;
   while ((1 << logm) < m) ++logm;
   for (int k = 0; k < n; ++k) {
     int p = 0, kk = k, L = m;
-    if (r3 == 3) {
-      p = (kk % 3) * m;
-      kk /= 3;
+    if (r3 != 1) {
+      p = (kk % r3) * m;
+      kk /= r3;
     }
     if (logm & 1) {
       p += (kk & 1) * (L / 2);

@@ -248,6 +248,22 @@ __device__ __forceinline__ void dft3(C& x0, C& x1, C& x2) {
   x1 = cadd(t2, t3);
   x2 = csub(t2, t3);
 }
+template <bool INV, typename C>
+__device__ __forceinline__ void dft5(C& x0, C& x1, C& x2, C& x3, C& x4) {
+  using T = typename zreal<C>::t;
+  constexpr T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;  // cos(2 pi / 5), cos(4 pi / 5)
+  constexpr T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;   // sin(2 pi / 5), sin(4 pi / 5)
+  const C a = cadd(x1, x4), b = cadd(x2, x3), d = csub(x1, x4), e = csub(x2, x3);
+  const C m1 = zmk<C>(x0.x + c1 * a.x + c2 * b.x, x0.y + c1 * a.y + c2 * b.y);
+  const C m2 = zmk<C>(x0.x + c2 * a.x + c1 * b.x, x0.y + c2 * a.y + c1 * b.y);
+  const C u = zmk<C>(s1 * d.x + s2 * e.x, s1 * d.y + s2 * e.y), v = zmk<C>(s2 * d.x - s1 * e.x, s2 * d.y - s1 * e.y);
+  const C iu = rot90<INV>(u), iv = rot90<INV>(v);  // (-+i) u, (-+i) v
+  x0 = cadd(x0, cadd(a, b));
+  x1 = cadd(m1, iu);
+  x4 = csub(m1, iu);
+  x2 = cadd(m2, iv);
+  x3 = csub(m2, iv);
+}
 template <int R, bool INV, typename C>
 __device__ __forceinline__ void dft(C (&x)[R]) {
   using T = typename zreal<C>::t;
@@ -255,6 +271,27 @@ __device__ __forceinline__ void dft(C (&x)[R]) {
     dft4<INV>(x[0], x[1], x[2], x[3]);
   } else if constexpr (R == 3) {
     dft3<INV>(x[0], x[1], x[2]);
+  } else if constexpr (R == 5) {
+    dft5<INV>(x[0], x[1], x[2], x[3], x[4]);
+  } else if constexpr (R == 10) {
+    // even / odd halves (radix 5 each), then the radix-2 combination with W10^k = (cos, -+sin)(36 k degrees)
+    dft5<INV>(x[0], x[2], x[4], x[6], x[8]);
+    dft5<INV>(x[1], x[3], x[5], x[7], x[9]);
+    constexpr T wc[5] = {(T)1, (T)0.80901699437494742410, (T)0.30901699437494742410, (T)-0.30901699437494742410, (T)-0.80901699437494742410};
+    constexpr T ws[5] = {(T)0, (T)0.58778525229247312917, (T)0.95105651629515357212, (T)0.95105651629515357212, (T)0.58778525229247312917};
+    C e[5], o[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      e[k] = x[2 * k];
+      const C z = x[2 * k + 1];
+      const T sn = INV ? ws[k] : -ws[k];
+      o[k] = k == 0 ? z : zmk<C>(z.x * wc[k] - z.y * sn, z.x * sn + z.y * wc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      x[k] = cadd(e[k], o[k]);
+      x[k + 5] = csub(e[k], o[k]);
+    }
   } else if constexpr (R == 6) {
     // even / odd thirds (radix 3 each), then the radix-2 combination with W6^k
     dft3<INV>(x[0], x[2], x[4]);
@@ -301,6 +338,18 @@ __device__ __forceinline__ void twiddle(C (&x)[R], C w1) {
   x[1] = cmul(x[1], w1);
   x[2] = cmul(x[2], w2);
   if constexpr (R >= 4) x[3] = cmul(x[3], w3);
+  if constexpr (R == 5 || R == 10) {
+    const C w4 = cmul(w2, w2);
+    x[4] = cmul(x[4], w4);
+    if constexpr (R == 10) {
+      const C w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3), w8 = cmul(w4, w4), w9 = cmul(w8, w1);
+      x[5] = cmul(x[5], w5);
+      x[6] = cmul(x[6], w6);
+      x[7] = cmul(x[7], w7);
+      x[8] = cmul(x[8], w8);
+      x[9] = cmul(x[9], w9);
+    }
+  }
   if constexpr (R == 6) {
     const C w4 = cmul(w2, w2), w5 = cmul(w4, w1);
     x[4] = cmul(x[4], w4);
@@ -320,9 +369,10 @@ __global__ __launch_bounds__(NT) void k_zsolve3(C* __restrict__ data, long long 
                                                 const double* __restrict__ ay, const double* __restrict__ az,
                                                 const C* __restrict__ tw_g, double inv_n, int zero_mean, int kxs, int skel, int ntiles) {
   using T = typename zreal<C>::t;
-  constexpr int N = LOGN >= 32 ? 3 << (LOGN & 31) : 1 << LOGN;  // size code as in ins_fft.hip: 32 + m stands for 3 * 2^m
-  constexpr int R1 = N / 64, R2 = 8, R3 = 8;  // 256 = 4 x 8 x 8, 512 = 8 x 8 x 8, 192 = 3 x 8 x 8, 384 = 6 x 8 x 8
-  static_assert(R1 == 4 || R1 == 8 || R1 == 3 || R1 == 6, "nz = 192, 256, 384 or 512");
+  // size code as in ins_fft.hip: 32 + m stands for 3 * 2^m, 64 + m for 5 * 2^m
+  constexpr int N = LOGN >= 64 ? 5 << (LOGN & 31) : (LOGN >= 32 ? 3 << (LOGN & 31) : 1 << LOGN);
+  constexpr int R1 = N / 64, R2 = 8, R3 = 8;  // 256 = 4 x 8 x 8, 512 = 8 x 8 x 8, 192 = 3 x 8 x 8, 384 = 6 x 8 x 8, 320 = 5 x 8 x 8, 640 = 10 x 8 x 8
+  static_assert(R1 == 4 || R1 == 8 || R1 == 3 || R1 == 6 || R1 == 5 || R1 == 10, "nz = 192, 256, 320, 384, 512 or 640");
   constexpr int L2 = N / R1;                  // block length of pass 2 (64)
   extern __shared__ __align__(16) unsigned char lds_raw3[];
   C* buf = reinterpret_cast<C*>(lds_raw3);  // [N][TK], swizzled
@@ -449,7 +499,7 @@ template <int LOGN, int TK, int NT, typename C = double2>
 int launch_zsolve3(C* data, long long nl, const double* ax, int kxn, const double* ay, const double* az, const C* tw,
                    double inv_n, bool zero_mean, hipStream_t s, int kxs) {
   const int ntiles = (int)((nl + TK - 1) / TK);
-  constexpr int N = LOGN >= 32 ? 3 << (LOGN & 31) : 1 << LOGN;
+  constexpr int N = LOGN >= 64 ? 5 << (LOGN & 31) : (LOGN >= 32 ? 3 << (LOGN & 31) : 1 << LOGN);
   constexpr size_t lds = ((size_t)N * TK + N) * sizeof(C);
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
@@ -493,7 +543,8 @@ int launch_zsolve(double2* data, long long nl, const double* ax, int kxn, const 
 
 bool ins_zsolve_supported(int nz) {
   if (ins_opt(OPT_INS_DISABLE_ZSOLVE)) return false;
-  if ((nz == 192 || nz == 384) && !ins_opt(OPT_INS_OWNFFT_POW2_ONLY)) return true;  // 3 x 8 x 8 and 6 x 8 x 8 in the three-pass kernel
+  // 3 x 8 x 8, 6 x 8 x 8, 5 x 8 x 8 and 10 x 8 x 8 in the three-pass kernel
+  if ((nz == 192 || nz == 384 || nz == 320 || nz == 640) && !ins_opt(OPT_INS_OWNFFT_POW2_ONLY)) return true;
   return nz >= 16 && nz <= 1024 && (nz & (nz - 1)) == 0;
 }
 
@@ -585,6 +636,8 @@ int ins_k_zsolve(double* data, int nz, long long nl, const double* ax, int kxn, 
     case 128: return launch_zsolve<7, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
     case 192: return launch_zsolve3<32 + 6, 8, 256>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
     case 384: return launch_zsolve3<32 + 7, 8, 256>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+    case 320: return launch_zsolve3<64 + 6, 8, 256>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+    case 640: return launch_zsolve3<64 + 7, 8, 512>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);  // 92 KB tile
     case 256:
       if (!ins_opt(OPT_INS_ZSOLVE_RADIX4)) {
         return launch_zsolve3<8, 8, 256>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);

@@ -22,7 +22,7 @@ def rell2(a, b):
 
 
 @pytest.mark.parametrize("zsolve", ["fft", "tridiag", "tridiag-3chunks"])
-@pytest.mark.parametrize("n", [(64, 32, 16), (70, 24, 20), (128, 16, 16), (192, 32, 16), (64, 192, 20), (192, 16, 12)])  # (128, ..): 64-wide K1, CORR = 2; 192 / 384: 3 * 2^m sides on the own passes
+@pytest.mark.parametrize("n", [(64, 32, 16), (70, 24, 20), (128, 16, 16), (192, 32, 16), (64, 192, 20), (192, 16, 12), (64, 320, 20)])  # (128, ..): 64-wide K1, CORR = 2; 192 / 384 / 320: 3 * 2^m and 5 * 2^m sides on the own passes
 def test_one_rank_slab_equals_single_gpu_path(oracle, n, zsolve, monkeypatch):
     """zsolve = tridiag: the distributed tridiagonal z solve (csrc/ins_ztri.hip) with one rank is the whole periodic line —
     it must reproduce the z-FFT solve of the single-GPU path."""
@@ -96,9 +96,9 @@ def _worker(rank, world, port, n, nsteps, out_dir, chunks=1, zsolve="fft", backe
                                                    (4, (64, 32, 32), 1, "fft"), (2, (64, 16, 32), 4, "fft"), (2, (66, 16, 32), 3, "fft"),
                                                    (2, (128, 16, 32), 4, "fft"), (2, (64, 16, 32), 1, "tridiag"), (4, (64, 32, 32), 1, "tridiag"),
                                                    (2, (66, 16, 24), 1, "tridiag"), (3, (128, 18, 24), 1, "tridiag"), (2, (128, 16, 32), 1, "tridiag"), (2, (64, 16, 32), 1, "tridiag-2ranges"),
-                                                   (3, (192, 192, 24), 1, "tridiag"), (2, (64, 192, 48), 1, "fft"), (3, (384, 48 * 4, 18), 1, "tridiag")])
+                                                   (3, (192, 192, 24), 1, "tridiag"), (2, (64, 192, 48), 1, "fft"), (3, (384, 48 * 4, 18), 1, "tridiag"), (2, (64, 320, 16), 1, "tridiag"), (2, (320, 64, 32), 1, "fft")])
 def test_multi_rank_slab_on_one_gpu_matches_oracle(tmp_path, oracle, world, n, chunks, zsolve, monkeypatch):
-    """(66,16,24): rocFFT x/y + rocFFT z; boxes whose x and y sides are 2^m or 3 * 2^m (round 3: 192, 384): own x/y passes with the digit-reversed ky order
+    """(66,16,24): rocFFT x/y + rocFFT z; boxes whose x and y sides are 2^m, 3 * 2^m or 5 * 2^m (round 3: 192, 384, 320, 640): own x/y passes with the digit-reversed ky order
     split across ranks; z: the fused z kernel, a rocFFT z plan (48 planes) or — tridiagonal route — no transform at all."""
     _need_gpu()
     o = oracle
@@ -121,7 +121,7 @@ def test_multi_rank_slab_on_one_gpu_matches_oracle(tmp_path, oracle, world, n, c
         assert rell2(got, st["u"][:, :, ks, :]) < 1e-10
         assert float(np.load(tmp_path / f"div_{r}.npy")[0]) < 1e-10
         packed, inkernel, nch = np.load(tmp_path / f"flags_{r}.npy")
-        own = all((v >= 16 and v & (v - 1) == 0) or v in (192, 384) for v in n[:2])
+        own = all((v >= 16 and v & (v - 1) == 0) or v in (192, 384, 320, 640) for v in n[:2])
         assert bool(packed) == own and bool(inkernel) == own and nch == chunks  # the fast slab pipeline really ran
 
 
