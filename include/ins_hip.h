@@ -422,14 +422,21 @@ int ins_comm_alltoall_f64(ins_comm_t* comm, const double* send, double* recv, in
 
 /* ---------------------------------------------------------------------------------- the `_f32` family (T = Float32)
  * The reference is generic in the element type and recommends single precision on GPUs (docs/src/manual/precision.md:3-16;
- * examples/DecayingTurbulence3D.jl:16 runs T = Float32).  This family covers what that example runs: all-periodic uniform boxes (2-D / 3-D),
- * the spectral pressure solver, explicit Runge-Kutta.  Fields are the reference layout with Float32 elements; the grid handle is the
- * fp64 one (`ins_grid_create`).  Other grids return INS_ERR_UNSUPPORTED — there is no silent fp64 fallback.  K1 on wide 3-D boxes is the
- * 64-outputs-per-wavefront stage kernel instantiated for float (csrc/ins_flux64.hip); the FFTs are hipFFT R2C / C2R plans. */
+ * examples/DecayingTurbulence3D.jl:16 runs T = Float32).  Fields are the reference layout with Float32 elements; the grid handle is the
+ * fp64 one (`ins_grid_create`).
+ *   all-periodic uniform boxes (2-D / 3-D; what that example runs): the spectral pressure solver (ins_poisson_spectral_create_f32), K1 on wide 3-D boxes
+ *     as the 64-outputs-per-wavefront stage kernel instantiated for float (csrc/ins_flux64.hip), own float2 FFT passes or hipFFT R2C / C2R plans;
+ *   every other grid of the fp64 family (Dirichlet / Symmetric / Pressure sides with constant boundary data, stretched spacings): float operator kernels
+ *     (csrc/ins_f32g.hip) and a Float32 solver handle wrapped around an fp64 solver of any kind (ins_poisson_wrap_f32).
+ * Slab (halo) grids and time-dependent boundary data return INS_ERR_UNSUPPORTED — there is no silent fp64 fallback. */
 int ins_apply_bc_u_f32(const ins_grid_t* grid, float* u, void* stream);                                  /* boundary_conditions.jl:276-288 */
 int ins_apply_bc_p_f32(const ins_grid_t* grid, float* p, void* stream);                                  /* boundary_conditions.jl:306-318 */
 int ins_momentum_f32(const ins_grid_t* grid, float visc, const float* u, float* F, void* stream);        /* operators.jl:967-976 */
 int ins_poisson_spectral_create_f32(const ins_grid_t* grid, ins_poisson32_t** out);                      /* pressure.jl:289-351 */
+/* psolver_direct / psolver_cg / psolver_spectral with T = Float32 on any grid (pressure.jl:85-154, 209-351): a Float32 solver handle around the fp64
+ * solver `ps64` of the same grid.  project! forms Ω·div(u) from the float field in double, `ps64` solves, the pressure is rounded to float once
+ * (at least as accurate as the reference's Float32 factorisation).  `ps64` stays the caller's and must outlive the returned handle. */
+int ins_poisson_wrap_f32(const ins_grid_t* grid, ins_poisson_t* ps64, ins_poisson32_t** out);
 int ins_poisson_destroy_f32(ins_poisson32_t* ps);
 int ins_poisson_solve_f32(ins_poisson32_t* ps, float* p, void* stream);                                  /* pressure.jl:318-350 */
 int ins_project_f32(const ins_grid_t* grid, ins_poisson32_t* ps, float* u, float* p, void* stream);      /* pressure.jl:69-82 */

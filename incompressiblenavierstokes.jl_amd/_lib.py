@@ -141,6 +141,7 @@ SIGNATURES = {
     "ins_apply_bc_p_f32": (C.c_int, [vp, vp, vp]),
     "ins_momentum_f32": (C.c_int, [vp, C.c_float, vp, vp, vp]),
     "ins_poisson_spectral_create_f32": (C.c_int, [vp, C.POINTER(vp)]),
+    "ins_poisson_wrap_f32": (C.c_int, [vp, vp, C.POINTER(vp)]),
     "ins_poisson_destroy_f32": (C.c_int, [vp]),
     "ins_poisson_solve_f32": (C.c_int, [vp, vp, vp]),
     "ins_project_f32": (C.c_int, [vp, vp, vp, vp, vp]),

@@ -27,6 +27,13 @@ int ins_k_spectral_solve_f32(ins_poisson* ps, const float* u32, float* pI32, flo
 int ins_zsolve_twiddles_f32(int nz, float** out);
 int ins_k_flux64_f32(const ins_grid* G, double visc, const float* u, float* F, const RkEpi* epi, const float* pI, int corr_mode, hipStream_t s,
                      int part = 0);
+// any other grid (walls, stretched spacings, 2-D or 3-D): csrc/ins_f32g.hip
+int ins_k32g_apply_bc_u(const ins_grid* G, float* u, hipStream_t s);
+int ins_k32g_apply_bc_p(const ins_grid* G, float* p, hipStream_t s);
+int ins_k32g_momentum(const ins_grid* G, float visc, const float* u, float* F, hipStream_t s);
+int ins_k32g_divergence(const ins_grid* G, const float* u, float* div, hipStream_t s);
+int ins_k32g_solve(const ins_grid* G, ins_poisson* ps64, double* p64, float* p, hipStream_t s);
+int ins_k32g_project(const ins_grid* G, ins_poisson* ps64, double* p64, float* u, float* p, hipStream_t s);
 
 struct ins_poisson32 {
   const ins_grid* grid = nullptr;
@@ -46,6 +53,10 @@ struct ins_poisson32 {
   float* phat32 = nullptr;
   float* tw32[3] = {nullptr, nullptr, nullptr};
   int kxs32 = 0;
+  // ins_poisson_wrap_f32: a Float32 solver around a caller-owned fp64 solver of any kind (walls / stretched grids: psolver_direct, psolver_cg)
+  ins_poisson* wrap64 = nullptr;
+  double* p64 = nullptr;  // padded fp64 right-hand side / solution
+  float* div32 = nullptr; // padded scratch of the divergence diagnostic
 };
 
 struct ins_rk32 {
@@ -88,11 +99,12 @@ Box32 box_of(const ins_grid* G) {
 
 int require_periodic_uniform(const ins_grid* G, const char* what) {
   if (!(G->all_periodic && G->uniform)) {
-    ins_set_error("%s: the fp32 family covers all-periodic uniform boxes only (use the _f64 entry points elsewhere)", what);
+    ins_set_error("%s: all-periodic uniform boxes only (other grids: ins_poisson_wrap_f32 around psolver_direct / psolver_cg)", what);
     return INS_ERR_UNSUPPORTED;
   }
   return INS_OK;
 }
+inline bool periodic_uniform(const ins_grid* G) { return G->all_periodic && G->uniform; }
 
 // ghost volumes of `ncomp` components: cell 0 <- cell N-2, cell N-1 <- cell 1, direction after direction (corners consistent),
 // boundary_conditions.jl:276-288 / 306-318
@@ -265,23 +277,20 @@ dim3 grid_over(const Box32& b, bool padded) {
 
 extern "C" int ins_apply_bc_u_f32(const ins_grid_t* G, float* u, void* stream) {
   INS_REQUIRE(G && u, "null argument");
-  int rc = require_periodic_uniform(G, "ins_apply_bc_u_f32");
-  if (rc) return rc;
+  if (!periodic_uniform(G)) return ins_k32g_apply_bc_u(G, u, as_stream(stream));
   return bc_periodic(G, u, G->g.D, as_stream(stream));
 }
 
 extern "C" int ins_apply_bc_p_f32(const ins_grid_t* G, float* p, void* stream) {
   INS_REQUIRE(G && p, "null argument");
-  int rc = require_periodic_uniform(G, "ins_apply_bc_p_f32");
-  if (rc) return rc;
+  if (!periodic_uniform(G)) return ins_k32g_apply_bc_p(G, p, as_stream(stream));
   return bc_periodic(G, p, 1, as_stream(stream));
 }
 
 extern "C" int ins_momentum_f32(const ins_grid_t* G, float visc, const float* u, float* F, void* stream) {
   INS_REQUIRE(G && u && F, "null argument");
-  int rc = require_periodic_uniform(G, "ins_momentum_f32");
-  if (rc) return rc;
   hipStream_t s = as_stream(stream);
+  if (!periodic_uniform(G)) return ins_k32g_momentum(G, visc, u, F, s);
   if (ins_flux64_supported(G)) return ins_k_flux64_f32(G, (double)visc, u, F, nullptr, nullptr, 0, s);
   const Box32 b = box_of(G);
   if (b.D == 2)
@@ -306,7 +315,36 @@ extern "C" int ins_poisson_destroy_f32(ins_poisson32_t* ps) {
   if (ps->phat32) (void)hipFree(ps->phat32);
   for (float* t : ps->tw32)
     if (t) (void)hipFree(t);
-  delete ps;
+  if (ps->p64) (void)hipFree(ps->p64);
+  if (ps->div32) (void)hipFree(ps->div32);
+  delete ps;  // wrap64 is the caller's
+  return INS_OK;
+}
+
+// A Float32 pressure solver around ANY fp64 solver of the same grid (psolver_direct, psolver_cg, psolver_spectral; pressure.jl:85-154, 209-351): the
+// right-hand side is formed / widened in double, the fp64 solver runs unchanged, the pressure is rounded to float once.  `ps64` stays the caller's and must
+// outlive the returned handle.  This is what carries the `_f32` family to wall-bounded and stretched grids (csrc/ins_f32g.hip).
+extern "C" int ins_poisson_wrap_f32(const ins_grid_t* G, ins_poisson_t* ps64, ins_poisson32_t** out) {
+  INS_REQUIRE(G && ps64 && out, "null argument");
+  INS_REQUIRE(ps64->grid == G, "the fp64 solver was created for a different grid");
+  const GridDev& g = G->g;
+  for (int a = 0; a < g.D; ++a)
+    if (g.bc[a][0] == INS_BC_HALO || g.bc[a][1] == INS_BC_HALO) {
+      ins_set_error("ins_poisson_wrap_f32: slab (halo) grids run in fp64 only");
+      return INS_ERR_UNSUPPORTED;
+    }
+  ins_poisson32* ps = new ins_poisson32();
+  ps->grid = G;
+  ps->wrap64 = ps64;
+  for (int a = 0; a < g.D; ++a) ps->np[a] = g.ip_hi[a] - g.ip_lo[a];
+  const bool ok = hipMalloc(&ps->p64, G->ncell * sizeof(double)) == hipSuccess && hipMemset(ps->p64, 0, G->ncell * sizeof(double)) == hipSuccess &&
+                  hipMalloc(&ps->div32, G->ncell * sizeof(float)) == hipSuccess && hipMemset(ps->div32, 0, G->ncell * sizeof(float)) == hipSuccess;
+  if (!ok) {
+    ins_set_error("ins_poisson_wrap_f32: device allocation failed");
+    ins_poisson_destroy_f32(ps);
+    return INS_ERR_HIP;
+  }
+  *out = ps;
   return INS_OK;
 }
 
@@ -402,6 +440,7 @@ extern "C" int ins_project_f32(const ins_grid_t* G, ins_poisson32_t* ps, float* 
   INS_REQUIRE(G && ps && u && p, "null argument");
   INS_REQUIRE(ps->grid == G, "psolver was created for a different grid");
   hipStream_t s = as_stream(stream);
+  if (ps->wrap64) return ins_k32g_project(G, ps->wrap64, ps->p64, u, p, s);
   const Box32 b = box_of(G);
   int rc;
   if (ps->own32) {
@@ -452,6 +491,7 @@ extern "C" int ins_poisson_solve_f32(ins_poisson32_t* ps, float* p, void* stream
   hipStream_t s = as_stream(stream);
   const ins_grid* G = ps->grid;
   const GridDev& g = G->g;
+  if (ps->wrap64) return ins_k32g_solve(G, ps->wrap64, ps->p64, p, s);
   // strip the ghosts (2-D copies), solve, pad
   const size_t w = (size_t)ps->np[0] * sizeof(float);
   hipMemcpy3DParms c = {};
@@ -520,10 +560,15 @@ static int rk32_step(ins_rk32* rk, float visc, float* u, float dt, hipStream_t s
   const ins_grid* G = rk->grid;
   const int ns = rk->nstage, D = G->g.D;
   const long long nvec = G->ncell * D;
-  const bool wide = ins_flux64_supported(G);
+  const bool general = !periodic_uniform(G);  // walls / stretched spacings: the operator kernels of ins_f32g.hip, the reference's sequence stage by stage
+  const bool wide = !general && ins_flux64_supported(G);
   const bool raw_in = chain & 1, raw_out = chain & 2;
   int rc;
-  if (!raw_in && (rc = bc_periodic(G, u, D, s))) return rc;                     // :19
+  if (general && !rk->ps->wrap64) {
+    ins_set_error("ins_rk_step_f32: this grid needs a solver made by ins_poisson_wrap_f32");
+    return INS_ERR_UNSUPPORTED;
+  }
+  if (!raw_in && (rc = general ? ins_k32g_apply_bc_u(G, u, s) : bc_periodic(G, u, D, s))) return rc;  // :19
   // Wide power-of-two boxes: the fp64 path's stage structure in float — stages >= 2 read the previous stage's UNCORRECTED u* and
   // its pressure and apply u = u* - ∇p in registers (CORR = 1), the solve forms Ω·div(u*) from the float field inside its x
   // pass; only the last stage materialises u (padded p, gradient-subtract, ghosts).
@@ -593,6 +638,7 @@ static int rk32_step(ins_rk32* rk, float visc, float* u, float dt, hipStream_t s
       }
       hipLaunchKernelGGL(k32_combine, dim3((unsigned)std::min<long long>((nvec + 255) / 256, 8192)), dim3(256), 0, s, nvec, u, outp, cb);  // :35-38
       INS_LAUNCH_CHECK();
+      if (general && (rc = ins_k32g_apply_bc_u(G, outp, s))) return rc;          // :47
     }
     if (incorr && (i < ns - 1 || raw_out) && own32) {  // solve only, float2 spectra: p lands in the solver's float pI
       ins_poisson32* q = rk->ps;
@@ -605,6 +651,7 @@ static int rk32_step(ins_rk32* rk, float visc, float* u, float dt, hipStream_t s
     } else if ((rc = ins_project_f32(G, rk->ps, outp, rk->p, s))) {             // :48-49 (periodic images: no ghost fill before)
       return rc;
     }
+    if (general && (rc = ins_k32g_apply_bc_u(G, outp, s))) return rc;            // :49
     cur = outp;
   }
   if (ns == 1) INS_HIP_TRY(hipMemcpyAsync(u, rk->ub[0], nvec * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -645,6 +692,17 @@ extern "C" int ins_rk_steps_f32(ins_rk32_t* rk, float visc, float* u, float dt, 
 extern "C" int ins_max_abs_divergence_f32(const ins_grid_t* G, ins_poisson32_t* ps, const float* u, float* out, void* stream) {
   INS_REQUIRE(G && ps && u && out, "null argument");
   hipStream_t s = as_stream(stream);
+  if (ps->wrap64) {  // any grid: divergence! on Ip of a padded scratch (zero elsewhere), maximum on the host
+    int rc = ins_k32g_divergence(G, u, ps->div32, s);
+    if (rc) return rc;
+    std::vector<float> h(G->ncell);
+    INS_HIP_TRY(hipMemcpyAsync(h.data(), ps->div32, G->ncell * sizeof(float), hipMemcpyDeviceToHost, s));
+    INS_HIP_TRY(hipStreamSynchronize(s));
+    float m = 0.f;
+    for (float v : h) m = std::fmax(m, std::fabs(v));
+    *out = m;
+    return INS_OK;
+  }
   const Box32 b = box_of(G);
   if (b.D == 2)
     hipLaunchKernelGGL(k32_div<2>, grid_over(b, false), dim3(64, 4), 0, s, b, u, ps->pI);

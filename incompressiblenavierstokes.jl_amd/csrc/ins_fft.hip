@@ -1184,8 +1184,10 @@ int launch_yz(YzArgs& a, const double2* tw, hipStream_t s) {
     case 256: return CALL(8);               \
     case 512: return CALL(9);               \
     case 1024: return CALL(10);             \
+    case 96: return CALL(32 + 5);           \
     case 192: return CALL(32 + 6);          \
     case 384: return CALL(32 + 7);          \
+    case 160: return CALL(64 + 5);          \
     case 320: return CALL(64 + 6);          \
     case 640: return CALL(64 + 7);          \
   }                                         \
@@ -1204,7 +1206,7 @@ bool ins_ownfft_supported_slab(const int np[3]) {
   if (ins_opt(OPT_INS_DISABLE_OWNFFT)) return false;
   for (int a = 0; a < 2; ++a) {
     const bool pow2 = np[a] >= 16 && np[a] <= 1024 && !(np[a] & (np[a] - 1));
-    const bool r3 = (np[a] == 192 || np[a] == 384 || np[a] == 320 || np[a] == 640) && !ins_opt(OPT_INS_OWNFFT_POW2_ONLY);
+    const bool r3 = (np[a] == 96 || np[a] == 192 || np[a] == 384 || np[a] == 160 || np[a] == 320 || np[a] == 640) && !ins_opt(OPT_INS_OWNFFT_POW2_ONLY);
     if (!pow2 && !r3) return false;
   }
   return np[2] >= 2;
@@ -1214,7 +1216,7 @@ bool ins_ownfft_supported_mixed(const int np[3]) {
   if (ins_opt(OPT_INS_DISABLE_OWNFFT)) return false;
   for (int a = 0; a < 3; ++a) {
     const bool pow2 = np[a] >= 16 && np[a] <= 1024 && !(np[a] & (np[a] - 1));
-    const bool r3 = (np[a] == 192 || np[a] == 384 || np[a] == 320 || np[a] == 640) && !ins_opt(OPT_INS_OWNFFT_POW2_ONLY);  // 3 * 2^m, 5 * 2^m
+    const bool r3 = (np[a] == 96 || np[a] == 192 || np[a] == 384 || np[a] == 160 || np[a] == 320 || np[a] == 640) && !ins_opt(OPT_INS_OWNFFT_POW2_ONLY);  // 3 * 2^m, 5 * 2^m
     if (!pow2 && !r3) return false;
   }
   return ins_zsolve_supported(np[2]);

@@ -371,8 +371,9 @@ __global__ __launch_bounds__(NT) void k_zsolve3(C* __restrict__ data, long long 
   using T = typename zreal<C>::t;
   // size code as in ins_fft.hip: 32 + m stands for 3 * 2^m, 64 + m for 5 * 2^m
   constexpr int N = LOGN >= 64 ? 5 << (LOGN & 31) : (LOGN >= 32 ? 3 << (LOGN & 31) : 1 << LOGN);
-  constexpr int R1 = N / 64, R2 = 8, R3 = 8;  // 256 = 4 x 8 x 8, 512 = 8 x 8 x 8, 192 = 3 x 8 x 8, 384 = 6 x 8 x 8, 320 = 5 x 8 x 8, 640 = 10 x 8 x 8
-  static_assert(R1 == 4 || R1 == 8 || R1 == 3 || R1 == 6 || R1 == 5 || R1 == 10, "nz = 192, 256, 320, 384, 512 or 640");
+  // 256 = 4 x 8 x 8, 512 = 8 x 8 x 8, 192 = 3 x 8 x 8, 384 = 6 x 8 x 8, 320 = 5 x 8 x 8, 640 = 10 x 8 x 8; 96 = 3 x 4 x 8, 160 = 5 x 4 x 8
+  constexpr int R3 = 8, R2 = N % 64 == 0 ? 8 : 4, R1 = N / (R2 * R3);
+  static_assert(R1 * R2 * R3 == N && (R1 == 4 || R1 == 8 || R1 == 3 || R1 == 6 || R1 == 5 || R1 == 10), "nz = 96, 160, 192, 256, 320, 384, 512 or 640");
   constexpr int L2 = N / R1;                  // block length of pass 2 (64)
   extern __shared__ __align__(16) unsigned char lds_raw3[];
   C* buf = reinterpret_cast<C*>(lds_raw3);  // [N][TK], swizzled
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(NT) void k_zsolve3(C* __restrict__ data, long long 
   for (int m = t; m < N; m += NT) tw[m] = tw_g[m];
   constexpr int RPI = NT / TK;  // transforms of one line column started per sweep of the workgroup
   constexpr int B1 = (N / R1 + RPI - 1) / RPI, B2 = (N / R2 + RPI - 1) / RPI, B3 = (N / R3 + RPI - 1) / RPI;  // sweeps per pass
-  constexpr bool G2 = (N / R2) % RPI != 0;  // 192 / 384: the last sweep of passes 2 and 3 is partial
+  constexpr bool G2 = (N / R2) % RPI != 0 || (N / R3) % RPI != 0;  // 3 * 2^m, 5 * 2^m: the last sweep of passes 2 and 3 is partial
   static_assert((N / R1) % RPI == 0 && NT % TK == 0, "tile shape");
   const int c = t % TK;  // NT is a multiple of TK: a work-item keeps its line column in every pass
   auto is_live = [&](long long line) { return line < nl && (int)(line % kxs) < kxn; };  // padding columns of a row (kx >= kxn) hold nothing
@@ -544,7 +545,7 @@ int launch_zsolve(double2* data, long long nl, const double* ax, int kxn, const 
 bool ins_zsolve_supported(int nz) {
   if (ins_opt(OPT_INS_DISABLE_ZSOLVE)) return false;
   // 3 x 8 x 8, 6 x 8 x 8, 5 x 8 x 8 and 10 x 8 x 8 in the three-pass kernel
-  if ((nz == 192 || nz == 384 || nz == 320 || nz == 640) && !ins_opt(OPT_INS_OWNFFT_POW2_ONLY)) return true;
+  if ((nz == 96 || nz == 192 || nz == 384 || nz == 160 || nz == 320 || nz == 640) && !ins_opt(OPT_INS_OWNFFT_POW2_ONLY)) return true;
   return nz >= 16 && nz <= 1024 && (nz & (nz - 1)) == 0;
 }
 
@@ -636,6 +637,8 @@ int ins_k_zsolve(double* data, int nz, long long nl, const double* ax, int kxn, 
     case 128: return launch_zsolve<7, 16>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
     case 192: return launch_zsolve3<32 + 6, 8, 256>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
     case 384: return launch_zsolve3<32 + 7, 8, 256>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+    case 96: return launch_zsolve3<32 + 5, 16, 256>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
+    case 160: return launch_zsolve3<64 + 5, 16, 256>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
     case 320: return launch_zsolve3<64 + 6, 8, 256>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);
     case 640: return launch_zsolve3<64 + 7, 8, 512>(d, nl, ax, kxn, ay, az, w, inv_n, zero_mean, s, kxs);  // 92 KB tile
     case 256:

@@ -1,5 +1,6 @@
-"""Host mirror of the `_f32` entry-point family (include/ins_hip.h; csrc/ins_f32.hip): the reference with `T = Float32`
-(docs/src/manual/precision.md:3-16, examples/DecayingTurbulence3D.jl:16) on all-periodic uniform boxes.
+"""Host mirror of the `_f32` entry-point family (include/ins_hip.h; csrc/ins_f32.hip, csrc/ins_f32g.hip): the reference with `T = Float32`
+(docs/src/manual/precision.md:3-16, examples/DecayingTurbulence3D.jl:16): all-periodic uniform boxes on the spectral solver, every other grid
+(walls, symmetric / pressure sides, stretched spacings; constant boundary data) on `psolver_wrap32` around an fp64 solver.
 
 Fields are torch.float32 tensors in the reference layout; `setup` is the ordinary (fp64-metric) Setup."""
 import ctypes as C
@@ -40,7 +41,13 @@ def _ptr(setup, f, ncomp):
     return C.c_void_p(f.data_ptr())
 
 
+def _constant_bc_only(setup):
+    if setup.needs_bc_planes:
+        raise NotImplementedError("the _f32 family takes constant boundary data (callable DirichletBC values: use the fp64 entry points)")
+
+
 def apply_bc_u32_(u, setup):
+    _constant_bc_only(setup)
     _lib.call("ins_apply_bc_u_f32", setup.handle, _ptr(setup, u, setup.grid.dimension), setup.stream)
     return u
 
@@ -82,6 +89,30 @@ class psolver_spectral32:
                 pass
 
 
+class psolver_wrap32(psolver_spectral32):
+    """psolver_direct(setup) / psolver_cg(setup) / psolver_spectral(setup) with T = Float32 on any grid (pressure.jl:85-154, 209-351): a Float32 solver
+    around the fp64 solver `psolver64` (default: the setup's default_psolver) — right-hand side in double, fp64 solve, pressure rounded once."""
+
+    def __init__(self, setup, psolver64=None):
+        from .pressure import default_psolver
+
+        self.setup = setup
+        self.psolver64 = psolver64 if psolver64 is not None else default_psolver(setup)  # kept alive: the native handle borrows it
+        self._handle = C.c_void_p()
+        _lib.call("ins_poisson_wrap_f32", setup.handle, self.psolver64.handle, C.byref(self._handle))
+
+
+def default_psolver32(setup):
+    """default_psolver(setup) with T = Float32 (pressure.jl:85-98): spectral on all-periodic uniform boxes, direct elsewhere."""
+    from .pressure import default_psolver, psolver_spectral
+
+    ps64 = default_psolver(setup)
+    if isinstance(ps64, psolver_spectral):
+        del ps64
+        return psolver_spectral32(setup)
+    return psolver_wrap32(setup, ps64)
+
+
 def project32_(u, setup, psolver, p):
     """project!(u, setup; psolver, p) with T = Float32 (pressure.jl:69-82)."""
     D = setup.grid.dimension
@@ -104,6 +135,7 @@ class ERKCache32:
         c = np.ascontiguousarray(method.c, dtype=np.float64)
         self._handle = C.c_void_p()
         dp = C.POINTER(C.c_double)
+        _constant_bc_only(setup)
         _lib.call("ins_rk_create_f32", setup.handle, psolver.handle, len(method.b), A.ctypes.data_as(dp), c.ctypes.data_as(dp), C.byref(self._handle))
 
     def __del__(self):

@@ -570,10 +570,11 @@ def test_lmwray3_native_loop_equals_host_driven_loop(ins, oracle, geom, monkeypa
 @pytest.mark.parametrize("n", [(16, 16, 16), (32, 16, 64), (128, 32, 16), (64, 128, 32), (256, 16, 16), (16, 256, 32),
                                (512, 16, 16), (16, 512, 16), (1024, 16, 16), (16, 1024, 16),
                                (192, 16, 16), (16, 192, 32), (16, 16, 192), (384, 16, 16), (16, 384, 16), (32, 16, 384), (192, 384, 192),
-                               (320, 16, 16), (16, 320, 32), (16, 16, 320), (640, 16, 16), (16, 640, 16), (32, 16, 640), (320, 192, 320)])
+                               (320, 16, 16), (16, 320, 32), (16, 16, 320), (640, 16, 16), (16, 640, 16), (32, 16, 640), (320, 192, 320),
+                               (96, 16, 16), (16, 96, 32), (16, 32, 96), (160, 16, 16), (32, 160, 16), (16, 16, 160), (160, 96, 160)])
 def test_own_fft_passes_match_oracle(ins, oracle, n):
     """All-own-kernel spectral solve (csrc/ins_fft.hip: paired-row real x transform, digit-reversed y pass, fused z pass) —
-    every supported length incl. the odd-log2 ones, 192 / 384 (a radix-3 stage in front of the power-of-two stages) and 320 / 640 (a radix-5
+    every supported length incl. the odd-log2 ones, 96 / 192 / 384 (a radix-3 stage in front of the power-of-two stages) and 160 / 320 / 640 (a radix-5
     stage in front), in each direction; both the generic psolver(p) entry and the fused projection (right-hand side formed inside the x pass)."""
     import ctypes
     from ins_amd import _lib
