@@ -118,6 +118,8 @@ void ins_set_error(const char* fmt, ...);
   X(INS_EXT_TEMP_SPLIT)          \
   X(INS_DISABLE_FUSED_RK)        \
   X(INS_DISABLE_STEP_CHAIN)      \
+  X(INS_DISABLE_STEP_GRAPH)      \
+  X(INS_STEP_GRAPH)              \
   X(INS_ZSOLVE_SKEL)             \
   X(INS_ZSOLVE_TK)               \
   X(INS_ZSOLVE_RADIX4)           \
@@ -136,6 +138,7 @@ void ins_set_error(const char* fmt, ...);
 enum InsOptId { INS_OPT_LIST(INS_OPT_ENUM) INS_OPT_COUNT };
 #undef INS_OPT_ENUM
 long long ins_opt(int id);  // current value (0 = off / default)
+long long ins_opt_epoch();  // bumped by every ins_set_option: cached launch plans (step graphs) are rebuilt when it moves
 
 // ------------------------------------------------------------------------------------------------
 // Device view of the grid, passed to kernels by value (lives in the kernarg segment -> SGPR loads).
@@ -254,6 +257,7 @@ struct ins_rk {
   ins_rk_ext* ext = nullptr;
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;  // (start, stop) pairs around momentum launches
+  void* step_graph = nullptr;           // launch-bound boxes: one step of ins_rk_steps_f64 captured as a hipGraph (ins_rk.hip)
 };
 
 // Metric records of the flux-form stage kernels on stretched / masked grids (ins_fast3d_flux.hip builds them per viscosity: ins_flux3d_prepare;

@@ -20,6 +20,8 @@ struct Opt {
 Opt g_opts[INS_OPT_COUNT] = {INS_OPT_LIST(INS_OPT_ROW)};
 #undef INS_OPT_ROW
 
+std::atomic<long long> g_epoch{0};
+
 long long from_env(const char* name) {
   const char* v = getenv(name);
   if (!v) return 0;
@@ -43,6 +45,8 @@ long long ins_opt(int id) {
   return o.value.load(std::memory_order_relaxed);
 }
 
+long long ins_opt_epoch() { return g_epoch.load(std::memory_order_relaxed); }
+
 static int find(const char* name) {
   if (!name) return -1;
   for (int i = 0; i < INS_OPT_COUNT; ++i)
@@ -58,6 +62,7 @@ extern "C" int ins_set_option(const char* name, int64_t value) {
   }
   g_opts[id].value.store(value, std::memory_order_relaxed);
   g_opts[id].state.store(1, std::memory_order_release);
+  g_epoch.fetch_add(1, std::memory_order_relaxed);
   return INS_OK;
 }
 

@@ -81,6 +81,9 @@ static int combine_n(long long nvec, const double* base, double* out, int nterms
   return INS_OK;
 }
 
+static void step_graph_free(ins_rk* rk);
+bool ins_k_spectral_own3d(const ins_poisson* ps);  // every pass of the solver is one of the library's own kernels (ins_poisson.hip)
+
 extern "C" int ins_rk_create(const ins_grid_t* G, ins_poisson_t* ps, int nstage, const double* A, const double* c, ins_rk_t** out) {
   INS_REQUIRE(G && ps && A && c && out, "null argument");
   INS_REQUIRE(ps->grid == G, "psolver was created for a different grid");
@@ -120,6 +123,7 @@ extern "C" int ins_rk_destroy(ins_rk_t* rk) {
     if (b) (void)hipFree(b);
   for (hipEvent_t e : rk->prof_events) (void)hipEventDestroy(e);
   ins_rk_ext_free(rk->ext);
+  step_graph_free(rk);
   delete rk;
   return INS_OK;
 }
@@ -338,6 +342,87 @@ static int rk_step_fused_periodic_2d(ins_rk* rk, double visc, double* u, double 
   return INS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ a step as a hipGraph (opt-in: INS_STEP_GRAPH=1)
+// A 32^3 .. 64^3 box (or a 2-D grid) runs ~24 dependent launches of a few microseconds each per RK44 step.  With INS_STEP_GRAPH=1 ins_rk_steps_f64 captures
+// the launches of ONE step of its loop into a hipGraph the first time it sees (u, Δt, ν) and replays it for the following steps — the same kernels with the
+// same arguments in the same order, so results are bitwise those of the plain loop (tests/test_gpu_step_graph.py).
+// Measured (profiles/r03_step_graph_lab.txt, RK44): the HOST time to issue a step drops 0.09 -> 0.02 ms, but the device span GROWS — 32^3: 0.137 -> 0.168
+// ms/step, 128^2: 0.113 -> 0.140 — because these steps are bound by the device's dependent-dispatch latency (~5.7 us per kernel), not by the host's issue
+// rate, and a graph node costs ~1.2 us more than a stream launch on this runtime.  So the graph is NOT the default: it is for callers whose host thread has
+// other work to do while the steps run (the reference's processors / a training loop), and the lever for small boxes is fewer launches per stage.
+//   * all-periodic boxes on the spectral solver's own FFT passes only (no rocFFT / rocBLAS call, no host read inside the step);
+//   * the caller's stream may be the legacy null stream, which cannot be captured: capture and replay run on a stream of the cache, ordered against
+//     the caller's stream by events on both sides;
+//   * the first step of a call always runs directly (lazy allocations and attribute settings happen there, none during the capture); a capture that fails
+//     for any reason is dropped and the loop continues with direct launches.
+struct StepGraph {
+  hipStream_t gs = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  hipGraphExec_t exec = nullptr;
+  double* u = nullptr;
+  double dt = 0.0, visc = 0.0;
+  const double* force = nullptr;
+  int kind = 0;
+  long long epoch = -1;
+  long long replays = 0;
+  bool broken = false;  // a capture failed on this cache: do not try again
+};
+
+static void step_graph_free(ins_rk* rk) {
+  StepGraph* g = static_cast<StepGraph*>(rk->step_graph);
+  if (!g) return;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->ev_in) (void)hipEventDestroy(g->ev_in);
+  if (g->ev_out) (void)hipEventDestroy(g->ev_out);
+  if (g->gs) (void)hipStreamDestroy(g->gs);
+  delete g;
+  rk->step_graph = nullptr;
+}
+
+// test / lab hook: how many steps this cache has run as graph replays
+extern "C" long long ins_dbg_rk_graph_replays(const ins_rk_t* rk) { return (rk && rk->step_graph) ? static_cast<const StepGraph*>(rk->step_graph)->replays : 0; }
+
+// kind 1: the chained middle step of the fused periodic 3-D loop; 2: a whole fused periodic step (3-D without the chain, or 2-D).  0: no graph.
+static int step_graph_kind(const ins_rk* rk, bool chain_ok) {
+  const ins_grid* G = rk->grid;
+  if (!ins_opt(OPT_INS_STEP_GRAPH) || ins_opt(OPT_INS_DISABLE_STEP_GRAPH) || rk->profiling || rk->ext) return 0;
+  if (ins_opt(OPT_INS_DISABLE_FUSED_RK) || !G->all_periodic || rk->ps->kind != POISSON_SPECTRAL) return 0;
+  if (G->g.D == 3) {
+    if (!(G->all_dof && ins_fast3d_supported(G) && ins_k_spectral_own3d(rk->ps))) return 0;
+    for (int a = 0; a < 3; ++a)
+      if (rk->ps->np[a] < 2) return 0;
+    return chain_ok ? 1 : 2;
+  }
+  return (ins_poisson_own2d(rk->ps) && ins_flux2d_supported(G)) ? 2 : 0;
+}
+
+// Capture `enqueue(gs)` into g->exec.  Nothing executes here.  false: no graph (the cache is marked broken).
+template <typename F>
+static bool step_graph_capture(StepGraph* g, F&& enqueue) {
+  if (g->exec) {
+    (void)hipGraphExecDestroy(g->exec);
+    g->exec = nullptr;
+  }
+  if (!g->gs && hipStreamCreateWithFlags(&g->gs, hipStreamNonBlocking) != hipSuccess) return false;
+  if (!g->ev_in && hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming) != hipSuccess) return false;
+  if (!g->ev_out && hipEventCreateWithFlags(&g->ev_out, hipEventDisableTiming) != hipSuccess) return false;
+  if (hipStreamBeginCapture(g->gs, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  const int rc = enqueue(g->gs);
+  hipGraph_t graph = nullptr;
+  const hipError_t e = hipStreamEndCapture(g->gs, &graph);
+  bool ok = rc == INS_OK && e == hipSuccess && graph != nullptr;
+  if (ok) ok = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+  if (graph) (void)hipGraphDestroy(graph);
+  if (!ok) {
+    (void)hipGetLastError();
+    g->exec = nullptr;
+  }
+  return ok;
+}
+
 // nsteps steps of size dt with the final correction of every step but the last folded into the next step's first stage kernel
 // (same arithmetic per cell; the uncorrected intermediate results never become visible).  Falls back to single steps elsewhere.
 extern "C" int ins_rk_steps_f64(ins_rk_t* rk, double visc, double* u, double t, double dt, int nsteps, void* stream) {
@@ -349,6 +434,42 @@ extern "C" int ins_rk_steps_f64(ins_rk_t* rk, double visc, double* u, double t, 
              no_chain = ins_opt(OPT_INS_DISABLE_STEP_CHAIN) != 0;
   bool ok = !no_fuse && !no_corr && !no_chain && !rk->force && g.D == 3 && G->all_periodic && G->all_dof && rk->ps->kind == POISSON_SPECTRAL && ins_fast3d_supported(G) &&
             ins_flux64_supported(G) && G->uniform_exact && rk->nstage > 1 && g.N[0] >= 8 && g.N[1] >= 8 && g.N[2] >= 8;  // = in-kernel correction runs
+  const int gkind = step_graph_kind(rk, ok && nsteps >= 2);
+  if (gkind && nsteps >= 3) {
+    StepGraph* sg = static_cast<StepGraph*>(rk->step_graph);
+    if (!sg) rk->step_graph = sg = new StepGraph();
+    int rc, done = 0;
+    // first step: direct (kind 1: it leaves its result uncorrected for the chain)
+    if ((rc = gkind == 1 ? rk_step_fused_periodic(rk, visc, u, dt, s, 2) : ins_rk_step_f64(rk, visc, u, t, dt, nullptr, stream))) return rc;
+    done = 1;
+    const int last_direct = gkind == 1 ? 1 : 0;  // kind 1: the last step corrects (chain bit 1 only) and runs directly
+    const int nreplay = nsteps - done - last_direct;
+    const bool same = sg->exec && sg->u == u && sg->dt == dt && sg->visc == visc && sg->force == rk->force && sg->kind == gkind && sg->epoch == ins_opt_epoch();
+    if (!same && !sg->broken) {
+      const bool got = step_graph_capture(sg, [&](hipStream_t gs) {
+        return gkind == 1 ? rk_step_fused_periodic(rk, visc, u, dt, gs, 3) : ins_rk_step_f64(rk, visc, u, t, dt, nullptr, gs);
+      });
+      sg->u = u, sg->dt = dt, sg->visc = visc, sg->force = rk->force, sg->kind = gkind, sg->epoch = ins_opt_epoch();
+      if (!got) sg->broken = true;
+    }
+    if (sg->exec && !sg->broken && nreplay > 0) {
+      INS_HIP_TRY(hipEventRecord(sg->ev_in, s));
+      INS_HIP_TRY(hipStreamWaitEvent(sg->gs, sg->ev_in, 0));
+      for (int n = 0; n < nreplay; ++n) INS_HIP_TRY(hipGraphLaunch(sg->exec, sg->gs));
+      INS_HIP_TRY(hipEventRecord(sg->ev_out, sg->gs));
+      INS_HIP_TRY(hipStreamWaitEvent(s, sg->ev_out, 0));
+      sg->replays += nreplay;
+      done += nreplay;
+    }
+    for (int n = done; n < nsteps; ++n) {  // the last step of a chain, or everything when no graph exists
+      if (gkind == 1)
+        rc = rk_step_fused_periodic(rk, visc, u, dt, s, 1 | (n < nsteps - 1 ? 2 : 0));
+      else
+        rc = ins_rk_step_f64(rk, visc, u, t + n * dt, dt, nullptr, stream);
+      if (rc) return rc;
+    }
+    return INS_OK;
+  }
   if (!ok || nsteps < 2) {
     for (int n = 0; n < nsteps; ++n) {
       int rc = ins_rk_step_f64(rk, visc, u, t + n * dt, dt, nullptr, stream);
