@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void k_yfft(C* __restrict__ data, int kxn, int
 // ------------------------------------------------------------------------------------------------------------
 template <int LOGN, int NP, int SRC, typename C = double2>
 __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restrict__ src, C* __restrict__ out, int n1,
-                                              const C* __restrict__ tw_g, int kxs, int kz0) {
+                                              const C* __restrict__ tw_g, int kxs, int kz0, int skel) {
   using T = real_t<C>;  // (C = float2: `src` points to float data — SRC 0: the float pI; SRC 5: the float velocity field)
   constexpr int N = fft_len(LOGN);
   constexpr int KXN = N / 2 + 1;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
     }
   }
   __syncthreads();
-  fft_dif<LOGN, NP, 1, N, true>(buf, tw, t);
+  if (!skel) fft_dif<LOGN, NP, 1, N, true>(buf, tw, t);  // skel (INS_X_SKEL): timing experiment, loads / LDS scatter / stores only
   // separate the two real rows:  A[k] = (Z[k] + conj Z[N-k]) / 2,   B[k] = (Z[k] - conj Z[N-k]) / (2i)
   for (int idx = t; idx < NP * KXN; idx += 256) {
     const int p = idx / KXN, s = idx - p * KXN;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
 // ------------------------------------------------------------------------------------------------------------
 template <int LOGN, int NP, typename C = double2>
 __global__ __launch_bounds__(256) void k_xinv(const C* __restrict__ in, real_t<C>* __restrict__ pI, int n1,
-                                              const C* __restrict__ tw_g, int kxs) {
+                                              const C* __restrict__ tw_g, int kxs, int skel) {
   using T = real_t<C>;
   constexpr int N = fft_len(LOGN);
   constexpr int KXN = N / 2 + 1;
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void k_xinv(const C* __restrict__ in, real_t<C
     }
   }
   __syncthreads();
-  fft_dit<LOGN, NP, 1, N, true>(buf, tw, t);
+  if (!skel) fft_dit<LOGN, NP, 1, N, true>(buf, tw, t);
   const T* bufd = reinterpret_cast<const T*>(buf);
   for (int idx = t; idx < 2 * NP * N; idx += 256) {
     const int row = idx / N, i = idx - row * N;
@@ -669,17 +669,17 @@ int launch_xfwd(const GridDev& g, const double* src, int from_u, double2* out, i
   constexpr size_t lds = ((size_t)NP * N + N) * sizeof(double2);
   dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
   if (from_u == 5)
-    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 5>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0);
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 5>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0, (int)ins_opt(OPT_INS_X_SKEL));
   else if (from_u == 4)
-    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 4>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0);
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 4>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0, (int)ins_opt(OPT_INS_X_SKEL));
   else if (from_u == 3)
-    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 3>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0);
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 3>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0, (int)ins_opt(OPT_INS_X_SKEL));
   else if (from_u == 2)
-    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 2>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0);
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 2>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0, (int)ins_opt(OPT_INS_X_SKEL));
   else if (from_u)
-    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 1>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0);
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 1>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0, (int)ins_opt(OPT_INS_X_SKEL));
   else
-    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 0>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0);
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 0>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0, (int)ins_opt(OPT_INS_X_SKEL));
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -692,9 +692,9 @@ int launch_xfwd32(const GridDev& g, const float* src, int from_u, float2* out, i
   dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
   const double* srcd = reinterpret_cast<const double*>(src);  // the kernel reads float data behind this pointer (C = float2)
   if (from_u)
-    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 5, float2>), grid, dim3(256), lds, s, g, srcd, out, n1, tw, kxs, 0);
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 5, float2>), grid, dim3(256), lds, s, g, srcd, out, n1, tw, kxs, 0, (int)ins_opt(OPT_INS_X_SKEL));
   else
-    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 0, float2>), grid, dim3(256), lds, s, g, srcd, out, n1, tw, kxs, 0);
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 0, float2>), grid, dim3(256), lds, s, g, srcd, out, n1, tw, kxs, 0, (int)ins_opt(OPT_INS_X_SKEL));
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -705,7 +705,7 @@ int launch_xinv(const C* in, real_t<C>* pI, int n1, int n2, const C* tw, int kxs
   constexpr int NP = fft_r3(LOGN) == 5 ? 640 / N : (fft_r3(LOGN) == 3 ? 768 / N : (N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N)));  // 2 NP N a multiple of 256
   constexpr size_t lds = ((size_t)NP * N + N) * sizeof(C);
   dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
-  hipLaunchKernelGGL((k_xinv<LOGN, NP, C>), grid, dim3(256), lds, s, in, pI, n1, tw, kxs);
+  hipLaunchKernelGGL((k_xinv<LOGN, NP, C>), grid, dim3(256), lds, s, in, pI, n1, tw, kxs, (int)ins_opt(OPT_INS_X_SKEL));
   INS_LAUNCH_CHECK();
   return INS_OK;
 }

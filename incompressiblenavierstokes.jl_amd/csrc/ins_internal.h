@@ -119,6 +119,10 @@ void ins_set_error(const char* fmt, ...);
   X(INS_DISABLE_FUSED_RK)        \
   X(INS_DISABLE_STEP_CHAIN)      \
   X(INS_DISABLE_STEP_GRAPH)      \
+  X(INS_DISABLE_LINE3)           \
+  X(INS_X_SKEL)                  \
+  X(INS_LINE3_TK)                \
+  X(INS_LINE3_WGS)               \
   X(INS_STEP_GRAPH)              \
   X(INS_ZSOLVE_SKEL)             \
   X(INS_ZSOLVE_TK)               \
@@ -219,6 +223,7 @@ struct ins_poisson {
   hipStream_t plan_stream = nullptr;
   bool zfused = false;      // 3-D: batched 2-D (x,y) plans + the fused z kernel (ins_zsolve.hip)
   bool ownfft = false;      // 3-D power-of-two box: all five passes are own LDS kernels (ins_fft.hip), no rocFFT
+  bool y3 = false;          // ownfft, 3-D: the y passes run on the register passes (k_line3, ins_zsolve.hip); ahat[1] is in THEIR storage order
   int kxs = 0;              // ownfft: row stride of phat (kmax[0] rounded up to 8 complex = 128 B)
   double* tw = nullptr;     // z twiddles
   double* tw_x = nullptr;   // x / y twiddles (ownfft)
@@ -252,8 +257,8 @@ struct ins_rk {
   std::vector<double*> ku;
   double* p = nullptr;
   double* ub[2] = {nullptr, nullptr};  // ping-pong stage velocities of the fused path
-  std::vector<double*> vb;
-  const double* force = nullptr;  // steady body force field (caller-owned), ins_rk_set_bodyforce             // all uncorrected stage velocities V_0..V_{s-2} (stage-velocity basis, ins_rk.hip)
+  std::vector<double*> vb;        // all uncorrected stage velocities V_0..V_{s-2} (stage-velocity basis, ins_rk.hip)
+  const double* force = nullptr;  // steady body force field (caller-owned), ins_rk_set_bodyforce
   ins_rk_ext* ext = nullptr;
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;  // (start, stop) pairs around momentum launches
@@ -354,6 +359,10 @@ int ins_k_ownfft_xfwd(const ins_grid* G, const double* src, int from_u, double* 
                       int kxs = 0, int kz0 = 0);
 int ins_k_ownfft_xinv(const double* phat, double* pI, int n0, int n1, int n2, const double* tw, hipStream_t s, int kxs = 0);
 int ins_k_ownfft_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s, int kxs = 0);
+bool ins_line3_supported(int n);
+void ins_line3_permute_symbol(int n, const double* ay, double* out);
+int ins_k_line3_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s, int kxs);
+int ins_k_line3_y_f32(float* phat, int kxn, int n1, int n2, const float* tw, bool inverse, hipStream_t s, int kxs);
 int ins_ownfft_yz_partitions(int kxn, int n1, int n2);
 long long ins_ownfft_yz_scratch(int kxn, int n1, int n2, int P);
 int ins_k_ownfft_yz_solve(double* phat, int kxn, int n1, int n2, int kxs, int P, const double* ax, const double* ay, double c, double scale, const double* tw_y,

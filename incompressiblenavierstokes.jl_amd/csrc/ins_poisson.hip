@@ -833,9 +833,14 @@ extern "C" int ins_poisson_spectral_create(const ins_grid_t* G, ins_poisson_t** 
       const double sn = std::sin(M_PI * ((double)k / ps->np[a]));
       ah[k] = 4 * om * sn * sn / (G->h[a] * G->h[a]);
     }
-    if (ps->ownfft && D == 3 && a == 1) {  // the own y pass leaves ky in digit-reversed order (ins_fft.hip)
+    if (ps->ownfft && D == 3 && a == 1) {  // the own y pass leaves ky in its storage order: digit-reversed (ins_fft.hip) or that of the register passes (k_line3)
+      // the four-pass route (opt-in) rides on the LDS y passes; otherwise the y passes run on the register passes wherever they exist
+      ps->y3 = ins_line3_supported(ps->np[1]) && ins_ownfft_yz_partitions(ps->kmax[0], ps->np[1], ps->np[2]) == 0;
       std::vector<double> perm(ah.size());
-      ins_ownfft_permute_symbol(ps->np[1], ah.data(), perm.data());
+      if (ps->y3)
+        ins_line3_permute_symbol(ps->np[1], ah.data(), perm.data());
+      else
+        ins_ownfft_permute_symbol(ps->np[1], ah.data(), perm.data());
       ah.swap(perm);
     }
     if (hipMalloc(&ps->ahat[a], ah.size() * sizeof(double)) != hipSuccess ||
@@ -897,10 +902,10 @@ static int ownfft_transform(ins_poisson* ps, const double* from_u, hipStream_t s
     if ((rc = ins_k_ownfft_yz_solve(ph, kxn, n1, n2, kxs, ps->yz_P, ps->ahat[0], ps->ahat[1], c, -1.0 / ((double)n0 * n1), ps->tw_y, ps->yz_scratch, s))) return rc;
     return ins_k_ownfft_xinv(ph, ps->pI, n0, n1, n2, ps->tw_x, s, kxs);
   }
-  if ((rc = ins_k_ownfft_y(ph, kxn, n1, n2, ps->tw_y, false, s, kxs))) return rc;
+  if ((rc = ps->y3 ? ins_k_line3_y(ph, kxn, n1, n2, ps->tw_y, false, s, kxs) : ins_k_ownfft_y(ph, kxn, n1, n2, ps->tw_y, false, s, kxs))) return rc;
   const double inv_n = 1.0 / ((double)n0 * n1 * n2);
   if ((rc = ins_k_zsolve(ph, n2, (long long)kxs * n1, ps->ahat[0], kxn, ps->ahat[1], ps->ahat[2], ps->tw, inv_n, true, s, kxs))) return rc;
-  if ((rc = ins_k_ownfft_y(ph, kxn, n1, n2, ps->tw_y, true, s, kxs))) return rc;
+  if ((rc = ps->y3 ? ins_k_line3_y(ph, kxn, n1, n2, ps->tw_y, true, s, kxs) : ins_k_ownfft_y(ph, kxn, n1, n2, ps->tw_y, true, s, kxs))) return rc;
   return ins_k_ownfft_xinv(ph, ps->pI, n0, n1, n2, ps->tw_x, s, kxs);
 }
 
@@ -1523,10 +1528,10 @@ int ins_k_spectral_solve_f32(ins_poisson* ps, const float* u32, float* pI32, flo
   const int n0 = ps->np[0], n1 = ps->np[1], n2 = ps->np[2], kxn = ps->kmax[0];
   int rc;
   if ((rc = ins_k_ownfft_xfwd_f32(ps->grid, u32 ? u32 : pI32, u32 ? 1 : 0, phat32, n0, n1, n2, twx, s, kxs32))) return rc;
-  if ((rc = ins_k_ownfft_y_f32(phat32, kxn, n1, n2, twy, false, s, kxs32))) return rc;
+  if ((rc = ps->y3 ? ins_k_line3_y_f32(phat32, kxn, n1, n2, twy, false, s, kxs32) : ins_k_ownfft_y_f32(phat32, kxn, n1, n2, twy, false, s, kxs32))) return rc;
   const double inv_n = 1.0 / ((double)n0 * n1 * n2);
   if ((rc = ins_k_zsolve_f32(phat32, n2, (long long)kxs32 * n1, ps->ahat[0], kxn, ps->ahat[1], ps->ahat[2], twz, inv_n, true, s, kxs32))) return rc;
-  if ((rc = ins_k_ownfft_y_f32(phat32, kxn, n1, n2, twy, true, s, kxs32))) return rc;
+  if ((rc = ps->y3 ? ins_k_line3_y_f32(phat32, kxn, n1, n2, twy, true, s, kxs32) : ins_k_ownfft_y_f32(phat32, kxn, n1, n2, twy, true, s, kxs32))) return rc;
   return ins_k_ownfft_xinv_f32(phat32, pI32, n0, n1, n2, twx, s, kxs32);
 }
 

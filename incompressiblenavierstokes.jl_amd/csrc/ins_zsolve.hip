@@ -267,7 +267,11 @@ __device__ __forceinline__ void dft5(C& x0, C& x1, C& x2, C& x3, C& x4) {
 template <int R, bool INV, typename C>
 __device__ __forceinline__ void dft(C (&x)[R]) {
   using T = typename zreal<C>::t;
-  if constexpr (R == 4) {
+  if constexpr (R == 2) {
+    const C a = x[0], b = x[1];
+    x[0] = cadd(a, b);
+    x[1] = csub(a, b);
+  } else if constexpr (R == 4) {
     dft4<INV>(x[0], x[1], x[2], x[3]);
   } else if constexpr (R == 3) {
     dft3<INV>(x[0], x[1], x[2]);
@@ -334,8 +338,9 @@ __device__ __forceinline__ void dft(C (&x)[R]) {
 template <int R, bool CONJ, typename C>
 __device__ __forceinline__ void twiddle(C (&x)[R], C w1) {
   if (CONJ) w1.y = -w1.y;
-  const C w2 = cmul(w1, w1), w3 = cmul(w2, w1);
   x[1] = cmul(x[1], w1);
+  if constexpr (R == 2) return;
+  const C w2 = cmul(w1, w1), w3 = cmul(w2, w1);
   x[2] = cmul(x[2], w2);
   if constexpr (R >= 4) x[3] = cmul(x[3], w3);
   if constexpr (R == 5 || R == 10) {
@@ -496,6 +501,175 @@ __global__ __launch_bounds__(NT) void k_zsolve3(C* __restrict__ data, long long 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// One direction of the transform ALONE on the register passes of k_zsolve3 (the y passes of the spectral solve: data[plane][ky][kx], a tile = TK
+// consecutive kx of one plane x all N ky, elements of a line `es` = kxs complex values apart).  The LDS radix-4 kernel of ins_fft.hip (k_yfft) makes
+// ten LDS accesses per element for its 32 B of memory traffic — on spectra that fit the Infinity Cache (256^3: 135 MB) and at 512^3 alike it runs at the
+// rate of its LDS stages, 4.8 TB/s, not of the memory behind it; here an element crosses LDS twice (R1 x 8 x 8 in registers: 4 accesses).
+//   forward: natural ky in; storage position p = q1 R2 R3 + q2 R3 + q3 holds frequency k = q1 + R1 q2 + R1 R2 q3 (ins_line3_permute_symbol)
+//   inverse: that order in, natural ky out; unscaled both ways (the z pass carries the whole 1/N).
+template <int LOGN, int TK, int NT, bool INV, typename C>
+__global__ __launch_bounds__(NT) void k_line3(C* __restrict__ data, long long es, long long pstride, int kxn, int tiles_x, int ntiles,
+                                              const C* __restrict__ tw_g) {
+  constexpr int N = LOGN >= 64 ? 5 << (LOGN & 31) : (LOGN >= 32 ? 3 << (LOGN & 31) : 1 << LOGN);
+  constexpr int R3 = 8, R2 = N % 64 == 0 ? 8 : 4, R1 = N / (R2 * R3);
+  static_assert(R1 * R2 * R3 == N && (R1 == 2 || R1 == 4 || R1 == 8 || R1 == 3 || R1 == 6 || R1 == 5 || R1 == 10), "length");
+  constexpr int L2 = N / R1;
+  extern __shared__ __align__(16) unsigned char lds_raw_l3[];
+  C* buf = reinterpret_cast<C*>(lds_raw_l3);  // [N][TK], swizzled
+  C* tw = buf + N * TK;                        // [N]
+  const int t = threadIdx.x;
+  auto at = [&](int n, int c) -> C& { return buf[(n ^ ((n >> 3) & 1)) * TK + c]; };
+  for (int m = t; m < N; m += NT) tw[m] = tw_g[m];
+  constexpr int RPI = NT / TK;
+  constexpr int B1 = (N / R1 + RPI - 1) / RPI, B2 = (N / R2 + RPI - 1) / RPI, B3 = (N / R3 + RPI - 1) / RPI;
+  constexpr bool G2 = (N / R2) % RPI != 0 || (N / R3) % RPI != 0;
+  static_assert((N / R1) % RPI == 0 && NT % TK == 0, "tile shape");
+  const int c = t % TK, r0 = t / TK;
+  constexpr int PF = INV ? B3 * R3 : B1 * R1;  // values of the next tile held in registers while this one is in LDS
+  C xp[PF];
+  auto tile_base = [&](int tile, bool& live) -> C* {
+    const int plane = tile / tiles_x, kx = (tile - plane * tiles_x) * TK + c;
+    live = kx < kxn;
+    return data + (long long)plane * pstride + kx;
+  };
+  auto prefetch = [&](int tile) {
+    bool live;
+    const C* b = tile_base(tile, live);
+    if constexpr (!INV) {
+#pragma unroll
+      for (int i = 0; i < B1; ++i)
+#pragma unroll
+        for (int q = 0; q < R1; ++q) xp[i * R1 + q] = live ? b[(long long)(r0 + i * RPI + q * (N / R1)) * es] : zmk<C>(0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < B3; ++i) {
+        const int g = r0 + i * RPI;
+#pragma unroll
+        for (int q = 0; q < R3; ++q) xp[i * R3 + q] = (live && (!G2 || g < N / R3)) ? b[(long long)(g * R3 + q) * es] : zmk<C>(0, 0);
+      }
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) prefetch(tile);
+  __syncthreads();  // twiddle table
+  for (; tile < ntiles; tile += gridDim.x) {
+    bool live;
+    C* b = tile_base(tile, live);
+    if constexpr (!INV) {
+      // ---- pass 1: registers -> LDS
+#pragma unroll
+      for (int i = 0; i < B1; ++i) {
+        const int j = r0 + i * RPI;
+        C x[R1];
+#pragma unroll
+        for (int q = 0; q < R1; ++q) x[q] = xp[i * R1 + q];
+        dft<R1, false>(x);
+        twiddle<R1, false>(x, tw[j]);
+#pragma unroll
+        for (int q = 0; q < R1; ++q) at(j + q * (N / R1), c) = x[q];
+      }
+      __syncthreads();
+      if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+      // ---- pass 2 (blocks of L2)
+#pragma unroll
+      for (int i = 0; i < B2; ++i) {
+        const int bb = r0 + i * RPI, g1 = bb / (L2 / R2), j = bb % (L2 / R2);
+        if (G2 && bb >= N / R2) break;
+        C x[R2];
+#pragma unroll
+        for (int q = 0; q < R2; ++q) x[q] = at(g1 * L2 + j + q * (L2 / R2), c);
+        dft<R2, false>(x);
+        twiddle<R2, false>(x, tw[j * R1]);
+#pragma unroll
+        for (int q = 0; q < R2; ++q) at(g1 * L2 + j + q * (L2 / R2), c) = x[q];
+      }
+      __syncthreads();
+      // ---- pass 3 (blocks of 8, unit twiddles): LDS -> registers -> global, in storage order
+#pragma unroll
+      for (int i = 0; i < B3; ++i) {
+        const int g = r0 + i * RPI;
+        if (G2 && g >= N / R3) break;
+        C x[R3];
+#pragma unroll
+        for (int q = 0; q < R3; ++q) x[q] = at(g * R3 + q, c);
+        dft<R3, false>(x);
+        if (live)
+#pragma unroll
+          for (int q = 0; q < R3; ++q) b[(long long)(g * R3 + q) * es] = x[q];
+      }
+    } else {
+      // ---- inverse pass 1: registers -> LDS
+#pragma unroll
+      for (int i = 0; i < B3; ++i) {
+        const int g = r0 + i * RPI;
+        if (G2 && g >= N / R3) break;
+        C x[R3];
+#pragma unroll
+        for (int q = 0; q < R3; ++q) x[q] = xp[i * R3 + q];
+        dft<R3, true>(x);
+#pragma unroll
+        for (int q = 0; q < R3; ++q) at(g * R3 + q, c) = x[q];
+      }
+      __syncthreads();
+      if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+      // ---- inverse pass 2
+#pragma unroll
+      for (int i = 0; i < B2; ++i) {
+        const int bb = r0 + i * RPI, g1 = bb / (L2 / R2), j = bb % (L2 / R2);
+        if (G2 && bb >= N / R2) break;
+        C x[R2];
+#pragma unroll
+        for (int q = 0; q < R2; ++q) x[q] = at(g1 * L2 + j + q * (L2 / R2), c);
+        twiddle<R2, true>(x, tw[j * R1]);
+        dft<R2, true>(x);
+#pragma unroll
+        for (int q = 0; q < R2; ++q) at(g1 * L2 + j + q * (L2 / R2), c) = x[q];
+      }
+      __syncthreads();
+      // ---- inverse pass 3: LDS -> registers -> global, natural order
+#pragma unroll
+      for (int i = 0; i < B1; ++i) {
+        const int j = r0 + i * RPI;
+        C x[R1];
+#pragma unroll
+        for (int q = 0; q < R1; ++q) x[q] = at(j + q * (N / R1), c);
+        twiddle<R1, true>(x, tw[j]);
+        dft<R1, true>(x);
+        if (live)
+#pragma unroll
+          for (int q = 0; q < R1; ++q) b[(long long)(j + q * (N / R1)) * es] = x[q];
+      }
+    }
+    __syncthreads();  // the LDS tile is rewritten by the next tile's first pass
+  }
+}
+
+template <int LOGN, int TK, int NT, typename C>
+int launch_line3(C* data, int kxn, int kxs, int nplanes, const C* tw, bool inverse, hipStream_t s) {
+  constexpr int N = LOGN >= 64 ? 5 << (LOGN & 31) : (LOGN >= 32 ? 3 << (LOGN & 31) : 1 << LOGN);
+  constexpr size_t lds = ((size_t)N * TK + N) * sizeof(C);
+  const int tiles_x = (kxn + TK - 1) / TK;
+  const long long ntiles = (long long)tiles_x * nplanes;
+  static bool attr_set[2] = {false, false};
+  if (lds > 64 * 1024 && !attr_set[inverse]) {
+    if (inverse)
+      INS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line3<LOGN, TK, NT, true, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    else
+      INS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_line3<LOGN, TK, NT, false, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set[inverse] = true;
+  }
+  // one tile per workgroup (measured equal to or better than persistent workgroups at 256^3 and 512^3); INS_LINE3_WGS = workgroups per CU makes them persistent
+  const long long per_cu = ins_opt(OPT_INS_LINE3_WGS) > 0 ? ins_opt(OPT_INS_LINE3_WGS) : (1LL << 20);
+  const unsigned nb = (unsigned)std::min<long long>(ntiles, 256LL * per_cu);
+  if (inverse)
+    hipLaunchKernelGGL((k_line3<LOGN, TK, NT, true, C>), dim3(nb), dim3(NT), lds, s, data, (long long)kxs, (long long)N * kxs, kxn, tiles_x, (int)ntiles, tw);
+  else
+    hipLaunchKernelGGL((k_line3<LOGN, TK, NT, false, C>), dim3(nb), dim3(NT), lds, s, data, (long long)kxs, (long long)N * kxs, kxn, tiles_x, (int)ntiles, tw);
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
 template <int LOGN, int TK, int NT, typename C = double2>
 int launch_zsolve3(C* data, long long nl, const double* ax, int kxn, const double* ay, const double* az, const C* tw,
                    double inv_n, bool zero_mean, hipStream_t s, int kxs) {
@@ -547,6 +721,50 @@ bool ins_zsolve_supported(int nz) {
   // 3 x 8 x 8, 6 x 8 x 8, 5 x 8 x 8 and 10 x 8 x 8 in the three-pass kernel
   if ((nz == 96 || nz == 192 || nz == 384 || nz == 160 || nz == 320 || nz == 640) && !ins_opt(OPT_INS_OWNFFT_POW2_ONLY)) return true;
   return nz >= 16 && nz <= 1024 && (nz & (nz - 1)) == 0;
+}
+
+// The y passes of the single-GPU spectral solve on the register passes (k_line3): lengths the three-pass kernel has, plus 128 = 2 x 8 x 8.
+bool ins_line3_supported(int n) {
+  if (ins_opt(OPT_INS_DISABLE_LINE3)) return false;
+  if (n == 128 || n == 256 || n == 512) return true;
+  return (n == 96 || n == 192 || n == 384 || n == 160 || n == 320 || n == 640) && !ins_opt(OPT_INS_OWNFFT_POW2_ONLY);
+}
+// out[p] = ay[k(p)]: the frequency held at storage position p after the forward pass of k_line3
+void ins_line3_permute_symbol(int n, const double* ay, double* out) {
+  const int R3 = 8, R2 = n % 64 == 0 ? 8 : 4, R1 = n / (R2 * R3);
+  for (int p = 0; p < n; ++p) {
+    const int q1 = p / (R2 * R3), q2 = (p / R3) % R2, q3 = p % R3;
+    out[p] = ay[q1 + R1 * q2 + R1 * R2 * q3];
+  }
+}
+template <typename C>
+static int line3_y(C* d, int kxn, int kxs, int n1, int n2, const C* w, bool inverse, hipStream_t s) {
+  const int tk = (int)ins_opt(OPT_INS_LINE3_TK);
+  switch (n1) {
+    case 96: return launch_line3<32 + 5, 16, 256, C>(d, kxn, kxs, n2, w, inverse, s);
+    case 160: return launch_line3<64 + 5, 16, 256, C>(d, kxn, kxs, n2, w, inverse, s);
+    case 128: return launch_line3<7, 16, 256, C>(d, kxn, kxs, n2, w, inverse, s);
+    case 192: return launch_line3<32 + 6, 8, 256, C>(d, kxn, kxs, n2, w, inverse, s);
+    case 256:
+      // 256^3, one solve: LDS kernel 352-364 us; 8 lines 339, 16 lines 338 (256 work-items) / 341 (512), 32 lines 377 (profiles/r03_line3_lab.txt)
+      if (tk == 8) return launch_line3<8, 8, 256, C>(d, kxn, kxs, n2, w, inverse, s);
+      return launch_line3<8, 16, 256, C>(d, kxn, kxs, n2, w, inverse, s);
+    case 320: return launch_line3<64 + 6, 8, 256, C>(d, kxn, kxs, n2, w, inverse, s);
+    case 384: return launch_line3<32 + 7, 8, 256, C>(d, kxn, kxs, n2, w, inverse, s);
+    case 512:
+      // 512^3, one solve: LDS kernel 3184 us; 8 lines x 512 work-items, one tile per workgroup 3100; 256 work-items 3128; persistent 3194; 16 lines 3168
+      if (tk == 16) return launch_line3<9, 16, 512, C>(d, kxn, kxs, n2, w, inverse, s);
+      return launch_line3<9, 8, 512, C>(d, kxn, kxs, n2, w, inverse, s);
+    case 640: return launch_line3<64 + 7, 8, 512, C>(d, kxn, kxs, n2, w, inverse, s);
+  }
+  ins_set_error("k_line3: unsupported length %d", n1);
+  return INS_ERR_UNSUPPORTED;
+}
+int ins_k_line3_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s, int kxs) {
+  return line3_y<double2>(reinterpret_cast<double2*>(phat), kxn, kxs, n1, n2, reinterpret_cast<const double2*>(tw), inverse, s);
+}
+int ins_k_line3_y_f32(float* phat, int kxn, int n1, int n2, const float* tw, bool inverse, hipStream_t s, int kxs) {
+  return line3_y<float2>(reinterpret_cast<float2*>(phat), kxn, kxs, n1, n2, reinterpret_cast<const float2*>(tw), inverse, s);
 }
 
 // Twiddles W_nz^m = exp(-2πi m / nz), m = 0..nz-1, on the device (caller frees).

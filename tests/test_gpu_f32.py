@@ -163,7 +163,7 @@ def test_f32_spectral_solver_refuses_other_grids(ins, oracle):
 # The family on every other grid of the fp64 family (csrc/ins_f32g.hip): walls, symmetric / pressure sides, stretched spacings, 2-D and 3-D.
 # Checker as above: the oracle in float64 on the float32-rounded inputs; float32 tolerances (a stretched 16-cell tanh grid has spacing
 # ratios ~30, so the momentum sum is judged against max|F|).
-def _lid_setup(o, n=(40, 24, 20)):
+def _lid_setup(o, n=(24, 16, 12)):
     """the shape of examples/LidDrivenCavity3D.jl: cosine x cosine x periodic, moving lid"""
     x = (o.cosine_grid(0.0, 1.0, n[0]), o.cosine_grid(0.0, 1.0, n[1]), np.linspace(-0.2, 0.2, n[2] + 1))
     lid = (o.DirichletBC(), o.DirichletBC((1.0, 0.0, 0.2)))

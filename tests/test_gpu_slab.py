@@ -97,7 +97,7 @@ def _worker(rank, world, port, n, nsteps, out_dir, chunks=1, zsolve="fft", backe
                                                    (4, (64, 32, 32), 1, "fft"), (2, (64, 16, 32), 4, "fft"), (2, (66, 16, 32), 3, "fft"),
                                                    (2, (128, 16, 32), 4, "fft"), (2, (64, 16, 32), 1, "tridiag"), (4, (64, 32, 32), 1, "tridiag"),
                                                    (2, (66, 16, 24), 1, "tridiag"), (3, (128, 18, 24), 1, "tridiag"), (2, (128, 16, 32), 1, "tridiag"), (2, (64, 16, 32), 1, "tridiag-2ranges"),
-                                                   (3, (192, 192, 24), 1, "tridiag"), (2, (64, 192, 48), 1, "fft"), (3, (384, 48 * 4, 18), 1, "tridiag"), (2, (64, 320, 16), 1, "tridiag"), (2, (320, 64, 32), 1, "fft")])
+                                                   (3, (192, 96, 24), 1, "tridiag"), (2, (64, 192, 48), 1, "fft"), (3, (384, 96, 18), 1, "tridiag"), (2, (64, 320, 16), 1, "tridiag"), (2, (320, 64, 32), 1, "fft")])
 def test_multi_rank_slab_on_one_gpu_matches_oracle(tmp_path, oracle, world, n, chunks, zsolve, monkeypatch):
     """(66,16,24): rocFFT x/y + rocFFT z; boxes whose x and y sides are 2^m, 3 * 2^m or 5 * 2^m (round 3: 192, 384, 320, 640): own x/y passes with the digit-reversed ky order
     split across ranks; z: the fused z kernel, a rocFFT z plan (48 planes) or — tridiagonal route — no transform at all."""
@@ -122,7 +122,7 @@ def test_multi_rank_slab_on_one_gpu_matches_oracle(tmp_path, oracle, world, n, c
         assert rell2(got, st["u"][:, :, ks, :]) < 1e-10
         assert float(np.load(tmp_path / f"div_{r}.npy")[0]) < 1e-10
         packed, inkernel, nch = np.load(tmp_path / f"flags_{r}.npy")
-        own = all((v >= 16 and v & (v - 1) == 0) or v in (192, 384, 320, 640) for v in n[:2])
+        own = all((v >= 16 and v & (v - 1) == 0) or v in (96, 192, 384, 160, 320, 640) for v in n[:2])
         assert bool(packed) == own and bool(inkernel) == own and nch == chunks  # the fast slab pipeline really ran
 
 
