@@ -56,7 +56,8 @@ struct PlaneM {
 // stage force, and
 // w_α = u_α · diffusion(u)_α is stored to epi.wout — the diffusive part of every face flux is accumulated a second time on its own.
 template <int R, int XW, int CORR, bool WT = false>
-__global__ __launch_bounds__(256, 2) void k_flux64m(FluxMArgs a) {  // (256, 3) = 168 VGPRs + 284 B scratch measured neutral (cavity 4.27 vs 4.29 ms/step)
+__global__ __launch_bounds__(256, 2) void k_flux64m(FluxMArgs a) {  // (256, 3) = 168 VGPRs + 284 B scratch measured neutral (cavity 4.27 vs 4.29 ms/step); 8 wavefronts (two
+                                                                    // stacked groups of four, barrier per plane) slower: 4.20 vs 4.10 (round 3)
   constexpr unsigned EB = 8;
   constexpr int NW = 4;
   static_assert(R + 2 + (CORR ? 1 : 0) <= 8, "packed halo rows live in 8-lane groups");
