@@ -354,6 +354,9 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
       const int j = min(j0 + row, n1 - 1);
       if (SRC == 0) {
         v[q] = reinterpret_cast<const T*>(src)[i + (long long)N * (j + (long long)n1 * kz)];
+      } else if (SRC == 6) {
+        // one padded scalar array (a velocity component): its interior volumes, ghosts stripped on the fly (observespectrum, ins_spectrum.hip)
+        v[q] = (T)src[(g.ip_lo[0] + i) + (g.ip_lo[1] + j) * g.sx[1] + (g.ip_lo[2] + kz) * g.sx[2]];
       } else if (SRC == 5) {
         // as SRC 1, from a FLOAT velocity field (the `_f32` family solves its pressure equation with these fp64 passes, ins_f32.hip):
         // differences and metrics in double from the float values
@@ -668,7 +671,9 @@ int launch_xfwd(const GridDev& g, const double* src, int from_u, double2* out, i
   constexpr int NP = fft_r3(LOGN) == 5 ? 640 / N : (fft_r3(LOGN) == 3 ? 768 / N : (N >= 1024 ? 2 : (1024 / N > 16 ? 16 : 1024 / N)));  // 2 NP N a multiple of 256
   constexpr size_t lds = ((size_t)NP * N + N) * sizeof(double2);
   dim3 grid((n1 + 2 * NP - 1) / (2 * NP), n2);
-  if (from_u == 5)
+  if (from_u == 6)
+    hipLaunchKernelGGL((k_xfwd<LOGN, NP, 6>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0, (int)ins_opt(OPT_INS_X_SKEL));
+  else if (from_u == 5)
     hipLaunchKernelGGL((k_xfwd<LOGN, NP, 5>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0, (int)ins_opt(OPT_INS_X_SKEL));
   else if (from_u == 4)
     hipLaunchKernelGGL((k_xfwd<LOGN, NP, 4>), grid, dim3(256), lds, s, g, src, out, n1, tw, kxs, kz0, (int)ins_opt(OPT_INS_X_SKEL));

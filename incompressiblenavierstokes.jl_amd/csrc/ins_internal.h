@@ -120,6 +120,7 @@ void ins_set_error(const char* fmt, ...);
   X(INS_DISABLE_STEP_CHAIN)      \
   X(INS_DISABLE_STEP_GRAPH)      \
   X(INS_DISABLE_LINE3)           \
+  X(INS_SPECTRUM_ROCFFT)         \
   X(INS_X_SKEL)                  \
   X(INS_LINE3_TK)                \
   X(INS_LINE3_WGS)               \
@@ -361,6 +362,8 @@ int ins_k_ownfft_xinv(const double* phat, double* pI, int n0, int n1, int n2, co
 int ins_k_ownfft_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s, int kxs = 0);
 bool ins_line3_supported(int n);
 void ins_line3_permute_symbol(int n, const double* ay, double* out);
+int ins_line3_pos_of_freq(int n, int k);
+int ins_k_line3_z(double* phat, int kxn, int n1, int n2, const double* tw, hipStream_t s, int kxs);
 int ins_k_line3_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s, int kxs);
 int ins_k_line3_y_f32(float* phat, int kxn, int n1, int n2, const float* tw, bool inverse, hipStream_t s, int kxs);
 int ins_ownfft_yz_partitions(int kxn, int n1, int n2);

@@ -646,8 +646,12 @@ __global__ __launch_bounds__(NT) void k_line3(C* __restrict__ data, long long es
 }
 
 template <int LOGN, int TK, int NT, typename C>
-int launch_line3(C* data, int kxn, int kxs, int nplanes, const C* tw, bool inverse, hipStream_t s) {
+int launch_line3(C* data, int kxn, int kxs, int nplanes, const C* tw, bool inverse, hipStream_t s, long long es = 0, long long pstride = 0) {
   constexpr int N = LOGN >= 64 ? 5 << (LOGN & 31) : (LOGN >= 32 ? 3 << (LOGN & 31) : 1 << LOGN);
+  if (es == 0) {  // y direction: lines of one plane
+    es = kxs;
+    pstride = (long long)N * kxs;
+  }
   constexpr size_t lds = ((size_t)N * TK + N) * sizeof(C);
   const int tiles_x = (kxn + TK - 1) / TK;
   const long long ntiles = (long long)tiles_x * nplanes;
@@ -663,9 +667,9 @@ int launch_line3(C* data, int kxn, int kxs, int nplanes, const C* tw, bool inver
   const long long per_cu = ins_opt(OPT_INS_LINE3_WGS) > 0 ? ins_opt(OPT_INS_LINE3_WGS) : (1LL << 20);
   const unsigned nb = (unsigned)std::min<long long>(ntiles, 256LL * per_cu);
   if (inverse)
-    hipLaunchKernelGGL((k_line3<LOGN, TK, NT, true, C>), dim3(nb), dim3(NT), lds, s, data, (long long)kxs, (long long)N * kxs, kxn, tiles_x, (int)ntiles, tw);
+    hipLaunchKernelGGL((k_line3<LOGN, TK, NT, true, C>), dim3(nb), dim3(NT), lds, s, data, es, pstride, kxn, tiles_x, (int)ntiles, tw);
   else
-    hipLaunchKernelGGL((k_line3<LOGN, TK, NT, false, C>), dim3(nb), dim3(NT), lds, s, data, (long long)kxs, (long long)N * kxs, kxn, tiles_x, (int)ntiles, tw);
+    hipLaunchKernelGGL((k_line3<LOGN, TK, NT, false, C>), dim3(nb), dim3(NT), lds, s, data, es, pstride, kxn, tiles_x, (int)ntiles, tw);
   INS_LAUNCH_CHECK();
   return INS_OK;
 }
@@ -738,30 +742,43 @@ void ins_line3_permute_symbol(int n, const double* ay, double* out) {
   }
 }
 template <typename C>
-static int line3_y(C* d, int kxn, int kxs, int n1, int n2, const C* w, bool inverse, hipStream_t s) {
+static int line3_y(C* d, int kxn, int kxs, int n1, int n2, const C* w, bool inverse, hipStream_t s, long long es = 0, long long ps = 0) {
   const int tk = (int)ins_opt(OPT_INS_LINE3_TK);
   switch (n1) {
-    case 96: return launch_line3<32 + 5, 16, 256, C>(d, kxn, kxs, n2, w, inverse, s);
-    case 160: return launch_line3<64 + 5, 16, 256, C>(d, kxn, kxs, n2, w, inverse, s);
-    case 128: return launch_line3<7, 16, 256, C>(d, kxn, kxs, n2, w, inverse, s);
-    case 192: return launch_line3<32 + 6, 8, 256, C>(d, kxn, kxs, n2, w, inverse, s);
+    case 96: return launch_line3<32 + 5, 16, 256, C>(d, kxn, kxs, n2, w, inverse, s, es, ps);
+    case 160: return launch_line3<64 + 5, 16, 256, C>(d, kxn, kxs, n2, w, inverse, s, es, ps);
+    case 128: return launch_line3<7, 16, 256, C>(d, kxn, kxs, n2, w, inverse, s, es, ps);
+    case 192: return launch_line3<32 + 6, 8, 256, C>(d, kxn, kxs, n2, w, inverse, s, es, ps);
     case 256:
       // 256^3, one solve: LDS kernel 352-364 us; 8 lines 339, 16 lines 338 (256 work-items) / 341 (512), 32 lines 377 (profiles/r03_line3_lab.txt)
-      if (tk == 8) return launch_line3<8, 8, 256, C>(d, kxn, kxs, n2, w, inverse, s);
-      return launch_line3<8, 16, 256, C>(d, kxn, kxs, n2, w, inverse, s);
-    case 320: return launch_line3<64 + 6, 8, 256, C>(d, kxn, kxs, n2, w, inverse, s);
-    case 384: return launch_line3<32 + 7, 8, 256, C>(d, kxn, kxs, n2, w, inverse, s);
+      if (tk == 8) return launch_line3<8, 8, 256, C>(d, kxn, kxs, n2, w, inverse, s, es, ps);
+      return launch_line3<8, 16, 256, C>(d, kxn, kxs, n2, w, inverse, s, es, ps);
+    case 320: return launch_line3<64 + 6, 8, 256, C>(d, kxn, kxs, n2, w, inverse, s, es, ps);
+    case 384: return launch_line3<32 + 7, 8, 256, C>(d, kxn, kxs, n2, w, inverse, s, es, ps);
     case 512:
       // 512^3, one solve: LDS kernel 3184 us; 8 lines x 512 work-items, one tile per workgroup 3100; 256 work-items 3128; persistent 3194; 16 lines 3168
-      if (tk == 16) return launch_line3<9, 16, 512, C>(d, kxn, kxs, n2, w, inverse, s);
-      return launch_line3<9, 8, 512, C>(d, kxn, kxs, n2, w, inverse, s);
-    case 640: return launch_line3<64 + 7, 8, 512, C>(d, kxn, kxs, n2, w, inverse, s);
+      if (tk == 16) return launch_line3<9, 16, 512, C>(d, kxn, kxs, n2, w, inverse, s, es, ps);
+      return launch_line3<9, 8, 512, C>(d, kxn, kxs, n2, w, inverse, s, es, ps);
+    case 640: return launch_line3<64 + 7, 8, 512, C>(d, kxn, kxs, n2, w, inverse, s, es, ps);
   }
   ins_set_error("k_line3: unsupported length %d", n1);
   return INS_ERR_UNSUPPORTED;
 }
+// storage position of frequency k after the forward pass (the inverse of the map in ins_line3_permute_symbol)
+int ins_line3_pos_of_freq(int n, int k) {
+  const int R3 = 8, R2 = n % 64 == 0 ? 8 : 4, R1 = n / (R2 * R3);
+  const int q1 = k % R1, q2 = (k / R1) % R2, q3 = k / (R1 * R2);
+  return q1 * R2 * R3 + q2 * R3 + q3;
+}
+// forward transform along z of data[kz][ky][kx] (rows of kxs complex values, n1 rows per plane): the "planes" of the kernel are the ky rows, elements of a
+// line are kxs * n1 apart (observespectrum on the library's own passes, ins_spectrum.hip)
+int ins_k_line3_z(double* phat, int kxn, int n1, int n2, const double* tw, hipStream_t s, int kxs);
 int ins_k_line3_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s, int kxs) {
   return line3_y<double2>(reinterpret_cast<double2*>(phat), kxn, kxs, n1, n2, reinterpret_cast<const double2*>(tw), inverse, s);
+}
+int ins_k_line3_z(double* phat, int kxn, int n1, int n2, const double* tw, hipStream_t s, int kxs) {
+  // length n2 along z; n1 "planes" (the ky rows) kxs apart; elements of a line kxs * n1 apart
+  return line3_y<double2>(reinterpret_cast<double2*>(phat), kxn, kxs, n2, n1, reinterpret_cast<const double2*>(tw), false, s, (long long)kxs * n1, (long long)kxs);
 }
 int ins_k_line3_y_f32(float* phat, int kxn, int n1, int n2, const float* tw, bool inverse, hipStream_t s, int kxs) {
   return line3_y<float2>(reinterpret_cast<float2*>(phat), kxn, kxs, n1, n2, reinterpret_cast<const float2*>(tw), inverse, s);

@@ -34,7 +34,9 @@ rows = [
     ("gravity", 24, lambda: ins.gravity_(F, temp, setup)),
     ("smagtensor", 72, lambda: ins.smagtensor_(sig, u, 0.1, setup)),
     ("divoftensor", 72, lambda: ins.divoftensor_(F, sig, setup)),
-    ("spectrum (3 x strip + D2Z + shells)", 3 * (16 + 8), lambda: spec(u)),
+    # priced as round 2 did (per component: the real array in, the half spectrum out); what must move at least is u in: 24 B per cell; as built it is three
+    # passes per component (x incl. the ghost strip 16 B, y 16 B, z 16 B per cell) + the shell gather
+    ("spectrum (3 x [x + y + z pass] + shells)", 3 * (16 + 8), lambda: spec(u)),
 ]
 out = {}
 for name, bpc, fn in rows:
