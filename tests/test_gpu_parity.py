@@ -574,7 +574,7 @@ def test_lmwray3_native_loop_equals_host_driven_loop(ins, oracle, geom, monkeypa
                                (512, 16, 16), (16, 512, 16), (1024, 16, 16), (16, 1024, 16),
                                (192, 16, 16), (16, 192, 32), (16, 16, 192), (384, 16, 16), (16, 384, 16), (32, 16, 384), (192, 384, 192),
                                (320, 16, 16), (16, 320, 32), (16, 16, 320), (640, 16, 16), (16, 640, 16), (32, 16, 640), (320, 192, 320),
-                               (96, 16, 16), (16, 96, 32), (16, 32, 96), (160, 16, 16), (32, 160, 16), (16, 16, 160), (160, 96, 160)])
+                               (96, 16, 16), (16, 96, 32), (16, 32, 96), (160, 16, 16), (32, 160, 16), (16, 16, 160), (160, 96, 160), (32, 16, 256), (16, 256, 256)])
 def test_own_fft_passes_match_oracle(ins, oracle, n):
     """All-own-kernel spectral solve (csrc/ins_fft.hip: paired-row real x transform, digit-reversed y pass, fused z pass) —
     every supported length incl. the odd-log2 ones, 96 / 192 / 384 (a radix-3 stage in front of the power-of-two stages) and 160 / 320 / 640 (a radix-5
