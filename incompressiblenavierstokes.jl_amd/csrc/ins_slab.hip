@@ -29,6 +29,10 @@ struct ins_slab_fft {
   const ins_grid* dummy_grid = nullptr;
   // transpose-free z solve (ins_ztri.hip): every ky in storage order, Ω/Δz², interface values (L_{r-1}, F_{r+1}) per line
   double* ay_full = nullptr;
+  // tridiagonal route: its y passes run on the register passes (k_line3, ins_zsolve.hip) where they exist; ay3 = the full symbol vector in THEIR storage order
+  // (the transposes route keeps the LDS passes: its packed y kernels and the ky ownership of the ranks are tied to the digit-reversed order)
+  bool y3 = false;
+  double* ay3 = nullptr;
   double cz = 0.0;
   double* ztri_bc = nullptr;
   int kxs = 0;  // row stride of `work` on the transpose-free route: kxn rounded up to whole 128-B lines with the own passes
@@ -169,6 +173,13 @@ extern "C" int ins_slab_fft_create(const int32_t np[3], const double h[3], int r
     for (int k = 0; k < S->nyl; ++k) ay[k] = symbol(1, rank * S->nyl + k);
   }
   for (int k = 0; k < np[2]; ++k) az[k] = symbol(2, k);
+  S->y3 = S->ownfft && ins_line3_supported(np[1]);
+  if (S->y3) {
+    std::vector<double> full(np[1]), p3(np[1]);
+    for (int k = 0; k < np[1]; ++k) full[k] = symbol(1, k);
+    ins_line3_permute_symbol(np[1], full.data(), p3.data());
+    if (hipMalloc(&S->ay3, p3.size() * 8) != hipSuccess || hipMemcpy(S->ay3, p3.data(), p3.size() * 8, hipMemcpyHostToDevice) != hipSuccess) S->y3 = false;
+  }
   bool ok = hipMalloc(&S->ax, ax.size() * 8) == hipSuccess && hipMalloc(&S->ay, ay.size() * 8) == hipSuccess &&
             hipMalloc(&S->az, az.size() * 8) == hipSuccess && hipMalloc(&S->ay_full, ayf.size() * 8) == hipSuccess &&
             hipMalloc(&S->ztri_bc, (size_t)4 * S->kxn * np[1] * 8) == hipSuccess;
@@ -236,6 +247,7 @@ extern "C" int ins_slab_fft_destroy(ins_slab_fft_t* S) {
   if (S->ay) (void)hipFree(S->ay);
   if (S->az) (void)hipFree(S->az);
   if (S->ay_full) (void)hipFree(S->ay_full);
+  if (S->ay3) (void)hipFree(S->ay3);
   if (S->ztri_bc) (void)hipFree(S->ztri_bc);
   delete S;
   return INS_OK;
@@ -391,6 +403,12 @@ extern "C" int ins_slab_ztri_edge_elems(const ins_slab_fft_t* S, int64_t* double
   return ins_slab_ztri_chunk(S, 0, 1, nullptr, nullptr, doubles);
 }
 
+// y pass of the tridiagonal route (no transposes: every rank holds all ky of its planes, so only the symbol has to know the storage order)
+static int slab_y(ins_slab_fft_t* S, double* work, bool inverse, hipStream_t s) {
+  if (S->y3) return ins_k_line3_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, inverse, s, S->kxs);
+  return ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, inverse, s, S->kxs);
+}
+
 // (x, y) forward transforms of the local planes into `work` (from_u = 1: Ω·div(u) formed inside the x pass, own passes only; 2: the x
 // pass was done by ins_slab_xfwd_planes; 0: src = pI).
 extern "C" int ins_slab_ztri_transform(ins_slab_fft_t* S, const ins_grid_t* G, const double* src, int from_u, double* work, void* stream) {
@@ -400,17 +418,17 @@ extern "C" int ins_slab_ztri_transform(ins_slab_fft_t* S, const ins_grid_t* G, c
   int rc;
   if (from_u == 2) {  // x pass already done plane range by plane range (ins_slab_xfwd_planes)
     INS_REQUIRE(S->ownfft, "forming the right-hand side inside the x pass needs x and y sides of 2^m or 3 * 2^m");
-    return ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s, S->kxs);
+    return slab_y(S, work, false, s);
   }
   if (from_u) {
     INS_REQUIRE(S->ownfft, "forming the right-hand side inside the x pass needs x and y sides of 2^m or 3 * 2^m");
     INS_REQUIRE(G && G->g.D == 3 && G->g.N[0] == S->np[0] + 2 && G->g.N[1] == S->np[1] + 2 && G->g.N[2] == S->nzl + 2, "grid does not match the slab");
     if ((rc = ins_k_ownfft_xfwd(G, src, 2, work, S->np[0], S->np[1], S->nzl, S->tw_x, s, S->kxs))) return rc;
-    return ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s, S->kxs);
+    return slab_y(S, work, false, s);
   }
   if (S->ownfft) {
     if ((rc = ins_k_ownfft_xfwd(nullptr, src, 0, work, S->np[0], S->np[1], S->nzl, S->tw_x, s, S->kxs))) return rc;
-    return ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, false, s, S->kxs);
+    return slab_y(S, work, false, s);
   }
   return slab_xy_forward(S, const_cast<double*>(src), work, s);
 }
@@ -421,7 +439,7 @@ extern "C" int ins_slab_ztri_sweep_forward(ins_slab_fft_t* S, double* work, doub
   long long lo, cnt;
   ztri_range(S, c, nchunks, &lo, &cnt);
   const double scale = -1.0 / ((double)S->np[0] * S->np[1]);
-  return ins_k_ztri_forward(work, S->kxn, S->kxs, S->np[1], S->nzl, S->nranks, S->rank, S->ax, S->ay_full, S->cz, scale, edge, lo, cnt, as_stream(stream));
+  return ins_k_ztri_forward(work, S->kxn, S->kxs, S->np[1], S->nzl, S->nranks, S->rank, S->ax, S->y3 ? S->ay3 : S->ay_full, S->cz, scale, edge, lo, cnt, as_stream(stream));
 }
 
 // edges_all = the gathered edge buffers of range c (rank-major): interface solve + back substitution of the range
@@ -430,7 +448,7 @@ extern "C" int ins_slab_ztri_sweep_backward(ins_slab_fft_t* S, double* work, con
   long long lo, cnt;
   ztri_range(S, c, nchunks, &lo, &cnt);
   const long long stride = 2 * cnt + (c == 0 ? S->nzl : 0);
-  return ins_k_ztri_finish(work, S->kxn, S->kxs, S->np[1], S->nzl, S->nranks, S->rank, S->ax, S->ay_full, S->cz, edges_all, stride,
+  return ins_k_ztri_finish(work, S->kxn, S->kxs, S->np[1], S->nzl, S->nranks, S->rank, S->ax, S->y3 ? S->ay3 : S->ay_full, S->cz, edges_all, stride,
                            S->ztri_bc + 4 * lo, lo, cnt, as_stream(stream));
 }
 
@@ -439,7 +457,7 @@ extern "C" int ins_slab_ztri_inverse(ins_slab_fft_t* S, double* work, double* pI
   INS_REQUIRE(S && work && pI, "null argument");
   hipStream_t s = as_stream(stream);
   if (!S->ownfft) return slab_xy_inverse(S, work, pI, s);
-  int rc = ins_k_ownfft_y(work, S->kxn, S->np[1], S->nzl, S->tw_y, true, s, S->kxs);
+  int rc = slab_y(S, work, true, s);
   if (rc) return rc;
   return ins_k_ownfft_xinv(work, pI, S->np[0], S->np[1], S->nzl, S->tw_x, s, S->kxs);
 }
