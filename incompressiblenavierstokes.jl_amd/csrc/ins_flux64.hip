@@ -210,6 +210,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
         for (int rr = 0; rr < R; ++rr) gacc[rr] = (T)a.epi.ga2 * ((T)0.5 * (ldb<T>(r0, ocol, orow[rr]) + ldb<T>(r1, ocol + dcol, orow[rr] + drow)));
       }
     }
+    const bool ntl = (a.nt & 8) != 0;  // INS_FLUX64_NT bit 3: non-temporal loads of the epilogue terms (read once; they share L2 with the re-read velocity planes)
     if (a.epi.ustart) {
       const T* b = static_cast<const T*>((const void*)a.epi.ustart) + pk;
       const T c0 = (T)(1.0 + a.epi.c0m1);  // exactly 1 in the k-basis
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
       for (int c = 0; c < 3; ++c) {
         const rsrc_t rs = plane_rsrc(b + c * a.sc, ubytes);
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) sacc[c][rr] = c0 * ldb<T>(rs, ocol, orow[rr]);
+        for (int rr = 0; rr < R; ++rr) sacc[c][rr] = c0 * (ntl ? ldb_aux<2>(rs, ocol, orow[rr], (T)0) : ldb<T>(rs, ocol, orow[rr]));
       }
     } else {
 #pragma unroll
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
         const rsrc_t rs = plane_rsrc(kq + c * a.sc, ubytes);
         T kv[R];
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) kv[rr] = ldb<T>(rs, ocol, orow[rr]);
+        for (int rr = 0; rr < R; ++rr) kv[rr] = ntl ? ldb_aux<2>(rs, ocol, orow[rr], (T)0) : ldb<T>(rs, ocol, orow[rr]);
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) sacc[c][rr] += cq * kv[rr];
       }
@@ -249,15 +250,16 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 2) void k_flux64(FluxArgs a
   // the three components of one result (INS_FLUX64_NT: cache-policy bits on these stores, an experiment)
   auto st3 = [&](T* o, unsigned co, unsigned rowb, T v0, T v1, T v2) {
     const rsrc_t r0 = plane_rsrc(o, ubytes), r1 = plane_rsrc(o + a.sc, ubytes), r2 = plane_rsrc(o + 2 * a.sc, ubytes);
-    if (a.nt == 0) {
+    const int snt = a.nt & 7;
+    if (snt == 0) {
       stb(r0, co, rowb, v0);
       stb(r1, co, rowb, v1);
       stb(r2, co, rowb, v2);
-    } else if (a.nt == 1) {
+    } else if (snt == 1) {
       stb_aux<2>(r0, co, rowb, v0);
       stb_aux<2>(r1, co, rowb, v1);
       stb_aux<2>(r2, co, rowb, v2);
-    } else if (a.nt == 2) {
+    } else if (snt == 2) {
       stb_aux<17>(r0, co, rowb, v0);
       stb_aux<17>(r1, co, rowb, v1);
       stb_aux<17>(r2, co, rowb, v2);
@@ -730,7 +732,13 @@ static int flux64_dispatch(const ins_grid* G, double visc, const T* u, T* F, con
   }
   a.zc = zc;
   a.bar = ins_opt(OPT_INS_FLUX64_NOBAR) ? 0 : 1;
-  a.nt = (int)ins_opt(OPT_INS_FLUX64_NT);
+  // cache-policy bits of the stage kernel's once-only streams: bit 0 = nt on the result stores, bit 3 = nt on the loads of the epilogue terms (ustart, stage terms).
+  // Default: both (256^3 step 2.538 -> 2.518 ms same-box, 512^3 21.09 -> 20.99: the re-read velocity planes keep more of L2); INS_FLUX64_NT=16: plain; 1 / 2 / 3 / 8: the
+  // single experiments (profiles/r03_nt_lab.txt)
+  {
+    const long long o = ins_opt(OPT_INS_FLUX64_NT);
+    a.nt = o == 0 ? ((epi && !F32) ? 9 : 0) : (o == 16 ? 0 : (int)o);  // the plain kernel (no epilogue) lost with nt stores in round 1's experiment: stage kernels only; fp32 not measured
+  }
 #define INS_F64_CASE(RR, FUSE)                                                        \
   if constexpr (!F32 || RR == 2 || RR == 4) {                                         \
     if (rows == RR) {                                                                 \

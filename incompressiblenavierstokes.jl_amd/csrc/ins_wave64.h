@@ -46,6 +46,16 @@ template <>
 __device__ __forceinline__ float ldb<float>(rsrc_t r, unsigned voff, unsigned soff) {
   return __int_as_float((int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+// loads with the cache-policy bits of the instruction (aux 2 = nt): arrays a kernel reads exactly once (the epilogue terms of the stage kernels) — an experiment switch
+template <int AUX>
+__device__ __forceinline__ double ldb_aux(rsrc_t r, unsigned voff, unsigned soff, double) {
+  const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX);
+  return __hiloint2double((int)v.y, (int)v.x);
+}
+template <int AUX>
+__device__ __forceinline__ float ldb_aux(rsrc_t r, unsigned voff, unsigned soff, float) {
+  return __int_as_float((int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
+}
 __device__ __forceinline__ void stb(rsrc_t r, unsigned voff, unsigned soff, double x) {
   v2u v;
   v.x = (unsigned)__double2loint(x);
