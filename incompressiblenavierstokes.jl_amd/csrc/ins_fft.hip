@@ -84,6 +84,20 @@ __host__ __device__ __forceinline__ int pos_of_freq(int k) {
   return p;
 }
 
+// x layout (RFAST, SR == 1): in the radix-4 stages with Q = 4 and Q = 1 the 16 lanes of a quarter wave read 16-B elements 64 B or 256 B apart, and the twiddle
+// reads of the stages with Q <= 16 are 64 B .. 256 B apart as well: four-way bank conflicts — 61-63 % of the LDS cycles of k_xfwd / k_xinv at 256^3
+// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, tools/run_lds_pmc.sh).  So a row (and the twiddle table) is stored with every element ROTATED inside its group
+// of 16 by an amount that depends on the group: bits 4-5 of the index rotate by one element, bits 6-7 by four.  Unit-stride accesses stay conflict-free
+// (a rotation permutes a group); the Q = 1 stage becomes conflict-free as it is; the Q = 4 stage needs its butterflies dealt to the lanes so that a quarter
+// wave spans bits 6-7 instead of bits 4-5 (fft_swz_g).  Lengths whose power-of-two part is a multiple of 256 (256, 512, 1024).
+template <int LOGN>
+constexpr bool fft_swz_on() { return fft_r3(LOGN) == 1 && fft_len(LOGN) % 256 == 0; }
+template <bool ON>
+__host__ __device__ __forceinline__ int fft_swz(int i) {
+  return ON ? ((i & ~15) | ((i + ((i >> 4) & 3) + 4 * ((i >> 6) & 3)) & 15)) : i;
+}
+__device__ __forceinline__ int fft_swz_g(int gg) { return (gg & ~15) | ((gg & 3) << 2) | ((gg >> 2) & 3); }  // 16-element block index: bit pairs 0-1 and 2-3 swapped
+
 // In-place transforms of NC independent lines held in LDS; element (r, c) lives at buf[r*SR + c*SC].
 // RFAST: consecutive work-items take consecutive butterflies of one line (x layout, SR == 1) instead of the
 // same butterfly of consecutive lines (y/z layout, SC == 1) — keeps LDS accesses unit-stride in both layouts.
@@ -149,15 +163,17 @@ __device__ __forceinline__ void fft_dif(C* __restrict__ buf, const C* __restrict
     }
     __syncthreads();
   }
+  constexpr bool SWZ = RFAST && fft_swz_on<LOGN>();  // rows and twiddle table stored rotated (see fft_swz); SR == 1 then
   int L = M;
   if (ODD) {
     for (int w = t; w < (N / 2) * NC; w += NT) {
       const int c = RFAST ? w / (N / 2) : w % NC, jj = RFAST ? w % (N / 2) : w / NC;
       const int sub = jj / (M / 2), j = jj - sub * (M / 2);
       C* x = buf + c * SC + sub * M * SR;
-      const C a0 = x[j * SR], a1 = x[(j + M / 2) * SR];
-      x[j * SR] = cadd(a0, a1);
-      x[(j + M / 2) * SR] = cmul(csub(a0, a1), tw[j * R3]);  // W_M^j = W_N^(R3 j)
+      const int i0 = fft_swz<SWZ>(j) * SR, i1 = fft_swz<SWZ>(j + M / 2) * SR;
+      const C a0 = x[i0], a1 = x[i1];
+      x[i0] = cadd(a0, a1);
+      x[i1] = cmul(csub(a0, a1), tw[fft_swz<SWZ>(j * R3)]);  // W_M^j = W_N^(R3 j)
     }
     L = M / 2;
     __syncthreads();
@@ -168,21 +184,25 @@ __device__ __forceinline__ void fft_dif(C* __restrict__ buf, const C* __restrict
     for (int w = t; w < (N / 4) * NC; w += NT) {
       const int c = RFAST ? w / (N / 4) : w % NC, bb = RFAST ? w % (N / 4) : w / NC;
       const int sub = bb / (M / 4), b = bb - sub * (M / 4);
-      const int g = b / Q, j = b - g * Q;
-      C* x = buf + c * SC + (sub * M + g * L + j) * SR;
-      const C a0 = x[0], a1 = x[Q * SR], a2 = x[2 * Q * SR], a3 = x[3 * Q * SR];
+      int g = b / Q;
+      const int j = b - g * Q;
+      if (SWZ && Q == 4) g = fft_swz_g(g);
+      C* x = buf + c * SC + sub * M * SR;
+      const int e = g * L + j;
+      const int i0 = fft_swz<SWZ>(e) * SR, i1 = fft_swz<SWZ>(e + Q) * SR, i2 = fft_swz<SWZ>(e + 2 * Q) * SR, i3 = fft_swz<SWZ>(e + 3 * Q) * SR;
+      const C a0 = x[i0], a1 = x[i1], a2 = x[i2], a3 = x[i3];
       const C t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
       C y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
       if (L > 4) {
-        const C w1 = tw[j * step], w2 = cmul(w1, w1), w3 = cmul(w2, w1);  // one table read instead of three (LDS-bound stages)
+        const C w1 = tw[fft_swz<SWZ>(j * step)], w2 = cmul(w1, w1), w3 = cmul(w2, w1);  // one table read instead of three (LDS-bound stages)
         y1 = cmul(y1, w1);
         y2 = cmul(y2, w2);
         y3 = cmul(y3, w3);
       }
-      x[0] = cadd(t0, t2);
-      x[Q * SR] = y1;
-      x[2 * Q * SR] = y2;
-      x[3 * Q * SR] = y3;
+      x[i0] = cadd(t0, t2);
+      x[i1] = y1;
+      x[i2] = y2;
+      x[i3] = y3;
     }
     __syncthreads();
   }
@@ -192,26 +212,31 @@ template <int LOGN, int NC, int SR, int SC, bool RFAST, int NT = 256, typename C
 __device__ __forceinline__ void fft_dit(C* __restrict__ buf, const C* __restrict__ tw, int t) {
   constexpr int N = fft_len(LOGN), R3 = fft_r3(LOGN), M = N / R3;
   constexpr bool ODD = fft_lg(LOGN) & 1;
+  constexpr bool SWZ = RFAST && fft_swz_on<LOGN>();
 #pragma unroll 1
   for (int L = 4; L <= (ODD ? M / 2 : M); L <<= 2) {
     const int Q = L / 4, step = N / L;
     for (int w = t; w < (N / 4) * NC; w += NT) {
       const int c = RFAST ? w / (N / 4) : w % NC, bb = RFAST ? w % (N / 4) : w / NC;
       const int sub = bb / (M / 4), b = bb - sub * (M / 4);
-      const int g = b / Q, j = b - g * Q;
-      C* x = buf + c * SC + (sub * M + g * L + j) * SR;
-      C x0 = x[0], x1 = x[Q * SR], x2 = x[2 * Q * SR], x3 = x[3 * Q * SR];
+      int g = b / Q;
+      const int j = b - g * Q;
+      if (SWZ && Q == 4) g = fft_swz_g(g);
+      C* x = buf + c * SC + sub * M * SR;
+      const int e = g * L + j;
+      const int i0 = fft_swz<SWZ>(e) * SR, i1 = fft_swz<SWZ>(e + Q) * SR, i2 = fft_swz<SWZ>(e + 2 * Q) * SR, i3 = fft_swz<SWZ>(e + 3 * Q) * SR;
+      C x0 = x[i0], x1 = x[i1], x2 = x[i2], x3 = x[i3];
       if (L > 4) {
-        const C w1 = tw[j * step], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+        const C w1 = tw[fft_swz<SWZ>(j * step)], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
         x1 = cmulc(x1, w1);
         x2 = cmulc(x2, w2);
         x3 = cmulc(x3, w3);
       }
       const C t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = mul_pi(csub(x1, x3));
-      x[0] = cadd(t0, t2);
-      x[Q * SR] = cadd(t1, t3);
-      x[2 * Q * SR] = csub(t0, t2);
-      x[3 * Q * SR] = csub(t1, t3);
+      x[i0] = cadd(t0, t2);
+      x[i1] = cadd(t1, t3);
+      x[i2] = csub(t0, t2);
+      x[i3] = csub(t1, t3);
     }
     __syncthreads();
   }
@@ -220,9 +245,10 @@ __device__ __forceinline__ void fft_dit(C* __restrict__ buf, const C* __restrict
       const int c = RFAST ? w / (N / 2) : w % NC, jj = RFAST ? w % (N / 2) : w / NC;
       const int sub = jj / (M / 2), j = jj - sub * (M / 2);
       C* x = buf + c * SC + sub * M * SR;
-      const C x0 = x[j * SR], x1 = cmulc(x[(j + M / 2) * SR], tw[j * R3]);
-      x[j * SR] = cadd(x0, x1);
-      x[(j + M / 2) * SR] = csub(x0, x1);
+      const int i0 = fft_swz<SWZ>(j) * SR, i1 = fft_swz<SWZ>(j + M / 2) * SR;
+      const C x0 = x[i0], x1 = cmulc(x[i1], tw[fft_swz<SWZ>(j * R3)]);
+      x[i0] = cadd(x0, x1);
+      x[i1] = csub(x0, x1);
     }
     __syncthreads();
   }
@@ -340,7 +366,8 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
   const int t = threadIdx.x;
   const int kz = kz0 + blockIdx.y;  // interior plane index (kz0: first plane of this launch)
   const int j0 = blockIdx.x * 2 * NP;
-  for (int m = t; m < N; m += 256) tw[m] = tw_g[m];
+  constexpr bool SWZ = fft_swz_on<LOGN>();  // rows and twiddles stored rotated inside groups of 16 (bank conflicts of the late stages: fft_swz)
+  for (int m = t; m < N; m += 256) tw[fft_swz<SWZ>(m)] = tw_g[m];
   T* bufd = reinterpret_cast<T*>(buf);
   // every work-item owns NIT (row, column) points; all their loads are issued (clamped rows, no branches) before the first
   // LDS write, so one round trip to HBM covers the whole tile instead of one per row
@@ -405,7 +432,7 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
     for (int q = 0; q < NIT; ++q) {
       const int idx = t + 256 * q;
       const int row = idx / N, i = idx - row * N;
-      bufd[2 * ((row >> 1) * N + i) + (row & 1)] = (j0 + row < n1) ? v[q] : (T)0;
+      bufd[2 * ((row >> 1) * N + fft_swz<SWZ>(i)) + (row & 1)] = (j0 + row < n1) ? v[q] : (T)0;
     }
   }
   __syncthreads();
@@ -415,8 +442,8 @@ __global__ __launch_bounds__(256) void k_xfwd(GridDev g, const double* __restric
     const int p = idx / KXN, s = idx - p * KXN;
     const int j = j0 + 2 * p;
     if (j >= n1) continue;
-    const C zk = buf[p * N + pos_of_freq<LOGN>(s)];
-    const C zm = buf[p * N + pos_of_freq<LOGN>((N - s) % N)];
+    const C zk = buf[p * N + fft_swz<SWZ>(pos_of_freq<LOGN>(s))];
+    const C zm = buf[p * N + fft_swz<SWZ>(pos_of_freq<LOGN>((N - s) % N))];
     const C a = mkc<C>((T)0.5 * (zk.x + zm.x), (T)0.5 * (zk.y - zm.y));
     const C b = mkc<C>((T)0.5 * (zk.y + zm.y), (T)-0.5 * (zk.x - zm.x));
     const long long o = s + (long long)kxs * (j + (long long)n1 * kz);
@@ -441,7 +468,8 @@ __global__ __launch_bounds__(256) void k_xinv(const C* __restrict__ in, real_t<C
   const int t = threadIdx.x;
   const int kz = blockIdx.y;
   const int j0 = blockIdx.x * 2 * NP;
-  for (int m = t; m < N; m += 256) tw[m] = tw_g[m];
+  constexpr bool SWZ = fft_swz_on<LOGN>();
+  for (int m = t; m < N; m += 256) tw[fft_swz<SWZ>(m)] = tw_g[m];
   constexpr int NIT = (NP * KXN + 255) / 256;  // all loads first (clamped, branch-free), then the LDS scatter
   {
     C av[NIT], bv[NIT];
@@ -465,8 +493,8 @@ __global__ __launch_bounds__(256) void k_xinv(const C* __restrict__ in, real_t<C
         a.y = 0;
         b.y = 0;
       }
-      buf[p * N + pos_of_freq<LOGN>(s)] = mkc<C>(a.x - b.y, a.y + b.x);
-      if (s != 0 && s != N / 2) buf[p * N + pos_of_freq<LOGN>(N - s)] = mkc<C>(a.x + b.y, b.x - a.y);
+      buf[p * N + fft_swz<SWZ>(pos_of_freq<LOGN>(s))] = mkc<C>(a.x - b.y, a.y + b.x);
+      if (s != 0 && s != N / 2) buf[p * N + fft_swz<SWZ>(pos_of_freq<LOGN>(N - s))] = mkc<C>(a.x + b.y, b.x - a.y);
     }
   }
   __syncthreads();
@@ -475,7 +503,7 @@ __global__ __launch_bounds__(256) void k_xinv(const C* __restrict__ in, real_t<C
   for (int idx = t; idx < 2 * NP * N; idx += 256) {
     const int row = idx / N, i = idx - row * N;
     const int j = j0 + row;
-    if (j < n1) pI[i + (long long)N * (j + (long long)n1 * kz)] = bufd[2 * ((row >> 1) * N + i) + (row & 1)];
+    if (j < n1) pI[i + (long long)N * (j + (long long)n1 * kz)] = bufd[2 * ((row >> 1) * N + fft_swz<SWZ>(i)) + (row & 1)];
   }
 }
 
