@@ -98,3 +98,25 @@ def test_rk_tableaux_match_oracle(oracle):
     for name in ("RK44", "Wray3", "SSP33", "FE11"):
         a, b = getattr(ins_amd.RKMethods, name)(), getattr(oracle, name)()
         assert np.allclose(a.A, b.A) and np.allclose(a.c, b.c) and np.allclose(a.b, b.b)
+
+
+def test_every_run_time_option_is_documented():
+    """DESIGN.md §5 lists every switch of csrc/ins_options.hip (name spelled out, or as `_SUFFIX` next to a sibling with the same prefix)."""
+    import ctypes
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = ctypes.CDLL(os.path.join(root, "incompressiblenavierstokes.jl_amd", "libinship.so"))
+    lib.ins_option_name.restype = ctypes.c_char_p
+    names = [lib.ins_option_name(i).decode() for i in range(lib.ins_option_count())]
+    assert len(names) == len(set(names)) and all(n.startswith("INS_") for n in names)
+    doc = open(os.path.join(root, "DESIGN.md"), encoding="utf-8").read()
+    missing = []
+    for n in names:
+        if n in doc:
+            continue
+        prefix, suffix = n.rsplit("_", 1)
+        if not re.search(r"`%s_\w+`(?: / `_\w+`)* / `_%s`" % (re.escape(prefix), re.escape(suffix)), doc):
+            missing.append(n)
+    assert not missing, missing
