@@ -277,3 +277,13 @@ def test_f32_family_refuses_what_it_does_not_cover(ins, oracle):
     sw = ins.Setup(x=x, boundary_conditions=((ins.DirichletBC(), ins.DirichletBC()),) * 2, Re=100.0)
     with pytest.raises(Exception, match="ins_poisson_wrap_f32"):
         f32.psolver_spectral32(sw)
+    # a Float32 solver handle wraps an fp64 solver of the SAME grid only
+    other = ins.Setup(x=tuple(np.linspace(0.0, 1.0, 13) for _ in range(2)), boundary_conditions=((ins.DirichletBC(), ins.DirichletBC()),) * 2, Re=100.0)
+    with pytest.raises(ins.INSHipError, match="different grid"):
+        f32.psolver_wrap32(sw, ins.psolver_direct(other))
+    # and a stepper cache on a wall-bounded grid needs such a handle (there is no spectral float solver to hand it)
+    ps = f32.psolver_wrap32(sw)
+    cache = f32.ERKCache32(ins.RKMethods.RK44(), sw, ps)
+    u = f32.vectorfield32(sw)
+    f32.timestep32_(cache, u, 1e-3)
+    assert bool(torch.isfinite(u).all())
