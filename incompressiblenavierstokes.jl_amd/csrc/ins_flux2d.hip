@@ -22,6 +22,7 @@ __device__ __forceinline__ double from_prev(double v) { return dpp<0x138>(v); } 
 
 struct Flux2dArgs {
   const double* u;
+  const double* p;   // CORR: the unpadded pressure of the projection of `u` (n0 x n1), u = u* - ∇p applied row by row in registers
   double* F;
   int N0, N1;
   long long sc;
@@ -31,7 +32,10 @@ struct Flux2dArgs {
   RkEpi epi;
 };
 
-template <bool FUSE>
+// CORR (the 2-D sibling of the 3-D kernels' in-register pressure correction): `u` is the previous stage's UNCORRECTED u* (interior volumes only) and `p` the
+// unpadded pressure of its projection; every row is corrected as it is loaded, u = u* - ∇p (applypressure!, operators.jl:225-233), rows and columns
+// outside the interior are read through their periodic images.  The stage loop then needs no gradient-subtract / ghost-fill pass between its stages.
+template <bool FUSE, bool CORR = false>
 __global__ __launch_bounds__(256) void k_flux2d(Flux2dArgs a) {
   const int lane = threadIdx.x;
   const int x0 = 1 + (int)blockIdx.x * 62;                       // first output column of this wavefront
@@ -40,16 +44,36 @@ __global__ __launch_bounds__(256) void k_flux2d(Flux2dArgs a) {
   const int j1 = min(j0 + a.yc, a.N1 - 1);
   const int ci = min(x0 - 1 + lane, a.N0 - 1);
   const bool xout = lane >= 1 && lane <= 62 && x0 - 1 + lane <= a.N0 - 2;
-  const double* u0 = a.u + ci;
-  const double* v0 = a.u + a.sc + ci;
+  const int n0 = a.N0 - 2, n1 = a.N1 - 2;
+  auto wrap = [](int q, int n) { return q < 0 ? q + n : (q >= n ? q - n : q); };
+  const int ii = CORR ? wrap(ci - 1, n0) : 0, iip = CORR ? wrap(ii + 1, n0) : 0;  // interior column of this lane and its right neighbour
+  const double* u0 = a.u + (CORR ? ii + 1 : ci);
+  const double* v0 = a.u + a.sc + (CORR ? ii + 1 : ci);
   auto row = [&](int j) { return (long long)j * a.N0; };
-  double um = u0[row(j0 - 1)], vm = v0[row(j0 - 1)];
-  double uc = u0[row(j0)], vc = v0[row(j0)];
+  double pcur = 0.0;  // CORR: p(ii, row being loaded), carried from the previous load
+  // one row of the two components, corrected when CORR (j: padded row index, possibly a ghost row -> its periodic image)
+  auto load_row = [&](int j, double& uu, double& vv, bool first) {
+    if (!CORR) {
+      uu = u0[row(j)];
+      vv = v0[row(j)];
+      return;
+    }
+    const int jj = wrap(j - 1, n1), jjp = wrap(jj + 1, n1);
+    if (first) pcur = a.p[ii + (long long)n0 * jj];
+    const double pnext = a.p[ii + (long long)n0 * jjp], px = a.p[iip + (long long)n0 * jj];
+    uu = u0[row(jj + 1)] - (px - pcur) * a.rx;
+    vv = v0[row(jj + 1)] - (pnext - pcur) * a.ry;
+    pcur = pnext;
+  };
+  double um, vm, uc, vc;
+  load_row(j0 - 1, um, vm, true);
+  load_row(j0, uc, vc, false);
   // y-face fluxes between rows j0-1 and j0
   double gyu = a.vy * (uc - um) - 0.5 * (um + uc) * 0.5 * (vm + from_next(vm));
   double gyv = a.vy * (vc - vm) - 0.25 * (vm + vc) * (vm + vc);
   for (int j = j0; j < j1; ++j) {
-    const double up = u0[row(j + 1)], vp = v0[row(j + 1)];
+    double up, vp;
+    load_row(j + 1, up, vp, false);
     // epilogue operands first: their loads fly during the flux arithmetic
     double su = 0.0, sv = 0.0;
     const long long c = row(j) + ci;
@@ -98,10 +122,11 @@ bool ins_flux2d_supported(const ins_grid* G) {
 }
 
 // epi == nullptr: plain momentum! into F (ghost ring of F untouched: the caller's F has a zero ring or does not read it)
-int ins_k_flux2d(const ins_grid* G, double visc, const double* u, double* F, const RkEpi* epi, hipStream_t s) {
+int ins_k_flux2d(const ins_grid* G, double visc, const double* u, double* F, const RkEpi* epi, hipStream_t s, const double* pI) {
   const GridDev& g = G->g;
   Flux2dArgs a;
   a.u = u;
+  a.p = pI;
   a.F = F;
   a.N0 = g.N[0];
   a.N1 = g.N[1];
@@ -118,7 +143,13 @@ int ins_k_flux2d(const ins_grid* G, double visc, const double* u, double* F, con
   if (epi) a.epi = *epi;
   else memset(&a.epi, 0, sizeof(a.epi));
   dim3 block(64, 4, 1), grid(cdiv(g.N[0] - 2, 62), cdiv(cdiv(n1, a.yc), 4), 1);
-  if (epi)
+  if (pI && !epi) {
+    ins_set_error("ins_k_flux2d: the correcting form exists for the fused stage kernel only");
+    return INS_ERR_INVALID;
+  }
+  if (pI)
+    hipLaunchKernelGGL((k_flux2d<true, true>), grid, block, 0, s, a);
+  else if (epi)
     hipLaunchKernelGGL(k_flux2d<true>, grid, block, 0, s, a);
   else
     hipLaunchKernelGGL(k_flux2d<false>, grid, block, 0, s, a);

@@ -120,6 +120,7 @@ void ins_set_error(const char* fmt, ...);
   X(INS_DISABLE_STEP_CHAIN)      \
   X(INS_DISABLE_STEP_GRAPH)      \
   X(INS_DISABLE_LINE3)           \
+  X(INS_DISABLE_CORR2D)          \
   X(INS_SPECTRUM_ROCFFT)         \
   X(INS_X_SKEL)                  \
   X(INS_LINE3_TK)                \
@@ -327,7 +328,8 @@ int ins_k_laplacian(const ins_grid* grid, const double* p, double* L, hipStream_
 int ins_k_project(const ins_grid* grid, ins_poisson* ps, double* u, double* p, hipStream_t s);
 int ins_k_momentum_rk_fused(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s);
 bool ins_flux2d_supported(const ins_grid* G);
-int ins_k_flux2d(const ins_grid* G, double visc, const double* u, double* F, const RkEpi* epi, hipStream_t s);
+int ins_k_flux2d(const ins_grid* G, double visc, const double* u, double* F, const RkEpi* epi, hipStream_t s, const double* pI = nullptr);
+int ins_k_project_periodic_solve_only_2d(const ins_grid* G, ins_poisson* ps, const double* u, hipStream_t s);
 int ins_k_momentum_rk_fused_generic(const ins_grid* G, double visc, const double* u_in, double* k_out, const RkEpi& epi, hipStream_t s);
 int ins_k_momentum_rk_fused_corr(const ins_grid* G, double visc, const double* ustar_prev, const double* pI, double* k_out, const RkEpi& epi,
                                  hipStream_t s);

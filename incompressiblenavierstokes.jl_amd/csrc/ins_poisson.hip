@@ -1492,6 +1492,16 @@ int ins_k_project_periodic_fused_2d(const ins_grid* G, ins_poisson* ps, double* 
   return INS_OK;
 }
 
+// first half of the 2-D fused projection only: pI <- solution of L p = Ω div(u) (u: interior volumes valid); the next stage kernel corrects in registers
+int ins_k_project_periodic_solve_only_2d(const ins_grid* G, ins_poisson* ps, const double* u, hipStream_t s) {
+  const int n0 = ps->np[0], n1 = ps->np[1], kxn = ps->kmax[0], kxs = ps->kxs;
+  double* ph = reinterpret_cast<double*>(ps->phat);
+  int rc;
+  if ((rc = ins_k_ownfft_xfwd(G, u, 3, ph, n0, n1, 1, ps->tw_x, s, kxs))) return rc;
+  if ((rc = ins_k_zsolve(ph, n1, (long long)kxs, ps->ahat[0], kxn, ps->ahat[2], ps->ahat[1], ps->tw, 1.0 / ((double)n0 * n1), true, s, kxs))) return rc;
+  return ins_k_ownfft_xinv(ph, ps->pI, n0, n1, 1, ps->tw_x, s, kxs);
+}
+
 bool ins_poisson_own2d(const ins_poisson* ps) { return ps->kind == POISSON_SPECTRAL && ps->ownfft && ps->grid->g.D == 2; }
 
 // First half of the fused periodic projection only: pI <- solution of L p = Ω div(u) (u: interior volumes valid).

@@ -1061,3 +1061,39 @@ def test_masked_inkernel_correction_matches_oracle(ins, oracle, geom, method, nx
             outs[key] = ins.to_numpy(u)
         assert rell2(outs[key][mask], want[mask]) < STEP_TOL, key
     assert rell2(outs["corr"][mask], outs["project"][mask]) < 1e-12
+
+
+@pytest.mark.parametrize("n", [(64, 32), (128, 128), (256, 64), (16, 512)])
+@pytest.mark.parametrize("method", ["RK44", "Wray3", "SSP33"])
+def test_fused_2d_stage_loop_with_in_register_correction(ins, oracle, n, method):
+    """2-D periodic power-of-two boxes (the fused path: flux-form stage kernel + own passes): stages >= 2 read the previous stage's uncorrected u* and its
+    unpadded pressure and apply u = u* - ∇p in registers (k_flux2d<…, CORR>, rows and columns through periodic images; 256 columns = five wavefront windows),
+    the projection between two stages only solves.  Against the oracle's step (step_explicit_runge_kutta.jl:4-59) and against the loop with the
+    gradient-subtract pass between the stages (INS_DISABLE_CORR2D)."""
+    from ins_amd import _lib
+
+    o = oracle
+    so = fx.setup_periodic(o, n, D=2, Re=800.0)
+    sp = mirror(ins, so, o)
+    pso, psp = o.psolver_spectral(so), ins.psolver_spectral(sp)
+    u0 = o.random_field(so, kp=3, seed=9)
+    mo = getattr(o, method)()
+    st = dict(setup=so, psolver=pso, u=u0.copy(order="F"), t=0.0, n=0)
+    oc = o.ode_method_cache(mo, so)
+    for _ in range(3):
+        st = o.timestep_(mo, st, 2e-3, oc)
+    m = getattr(ins.RKMethods, method)()
+
+    def run(**opts):
+        with _lib.options(**opts):
+            cache = ins.ode_method_cache(m, sp, psp)
+            s = ins.create_stepper(m, setup=sp, psolver=psp, u=ins.from_numpy(sp, u0), t=0.0)
+            s = ins.timesteps_(m, s, 2e-3, 2, cache=cache)
+            s = ins.timestep_(m, s, 2e-3, cache=cache)
+            return ins.to_numpy(s.u), float(ins.max_abs_divergence(s.u, sp))
+
+    got, div = run()
+    ref, _ = run(INS_DISABLE_CORR2D=1)
+    assert rell2(got, st["u"]) < STEP_TOL
+    assert relmax(got, ref) < 1e-12
+    assert div * (1.0 / max(n)) < 1e-12
