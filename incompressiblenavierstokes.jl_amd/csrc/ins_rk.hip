@@ -287,7 +287,8 @@ static int rk_step_fused_periodic(ins_rk* rk, double visc, double* u, double dt,
 }
 
 // Fused periodic path in 2-D (uniform periodic power-of-two boxes): per stage the flux-form stage kernel (K1 + K6, ins_flux2d.hip) and the
-// four-launch projection above — five launches per stage instead of ten, which is what a 128² .. 512² grid is bound by.
+// four-launch projection above — five launches per stage instead of ten, which is what a 128² .. 512² grid is bound by; with the in-register correction
+// (stages >= 2, ins_flux2d.hip CORR) the projections between two stages only solve: four launches per stage, 17 per RK44 step.
 static int rk_step_fused_periodic_2d(ins_rk* rk, double visc, double* u, double dt, hipStream_t s) {
   const ins_grid* G = rk->grid;
   const int ns = rk->nstage;
