@@ -98,6 +98,10 @@ __global__ __launch_bounds__(256) void k_flux2d(Flux2dArgs a) {
       if (FUSE) {
         a.epi.ustar[c] = su + a.epi.coef_self * fu;
         a.epi.ustar[a.sc + c] = sv + a.epi.coef_self * fv;
+        if (CORR && a.epi.ustart_out) {  // first stage of a chained step: the corrected input is this step's ustart
+          a.epi.ustart_out[c] = uc;
+          a.epi.ustart_out[a.sc + c] = vc;
+        }
       }
       if (!FUSE || a.epi.write_k) {
         a.F[c] = fu;

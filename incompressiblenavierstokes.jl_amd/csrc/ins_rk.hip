@@ -289,7 +289,8 @@ static int rk_step_fused_periodic(ins_rk* rk, double visc, double* u, double dt,
 // Fused periodic path in 2-D (uniform periodic power-of-two boxes): per stage the flux-form stage kernel (K1 + K6, ins_flux2d.hip) and the
 // four-launch projection above — five launches per stage instead of ten, which is what a 128² .. 512² grid is bound by; with the in-register correction
 // (stages >= 2, ins_flux2d.hip CORR) the projections between two stages only solve: four launches per stage, 17 per RK44 step.
-static int rk_step_fused_periodic_2d(ins_rk* rk, double visc, double* u, double dt, hipStream_t s) {
+// chain: as rk_step_fused_periodic (bit 1: `u` holds the previous step's uncorrected result and ps->pI its pressure; bit 2: leave this step's result uncorrected).
+static int rk_step_fused_periodic_2d(ins_rk* rk, double visc, double* u, double dt, hipStream_t s, int chain = 0) {
   const ins_grid* G = rk->grid;
   const int ns = rk->nstage;
   const size_t vbytes = (size_t)G->ncell * 2 * sizeof(double);
@@ -299,8 +300,13 @@ static int rk_step_fused_periodic_2d(ins_rk* rk, double visc, double* u, double 
       INS_HIP_TRY(hipMemsetAsync(rk->ub[b], 0, vbytes, s));
     }
   int rc;
-  if ((rc = ins_k_apply_bc_u(G, u, 0, nullptr, s))) return rc;  // :19 (first stage; later ghosts come with the gradient-subtract)
+  const bool raw_in = chain & 1, raw_out = chain & 2;
+  if (!raw_in && (rc = ins_k_apply_bc_u(G, u, 0, nullptr, s))) return rc;  // :19 (first stage; later ghosts come with the gradient-subtract)
   const bool incorr = ns > 1 && !ins_opt(OPT_INS_DISABLE_INKERNEL_CORR) && !ins_opt(OPT_INS_DISABLE_CORR2D) && G->g.N[0] >= 6 && G->g.N[1] >= 6;
+  if (chain && !incorr) {
+    ins_set_error("chained 2-D steps need the in-register correction");
+    return INS_ERR_INVALID;
+  }
   const double* in = u;
   for (int i = 0; i < ns; ++i) {
     double* out = (i == ns - 1 && ns > 1) ? u : rk->ub[i & 1];
@@ -323,8 +329,9 @@ static int rk_step_fused_periodic_2d(ins_rk* rk, double visc, double* u, double 
     for (int i2 = i + 1; i2 < ns; ++i2)
       if (rk->A[i2 * ns + i] != 0.0) epi.write_k = 1;
     epi.coef_self = dt * rk->A[i * ns + i];
-    epi.ustart = (i == 0) ? nullptr : u;
+    epi.ustart = (i == 0) ? nullptr : (raw_in ? rk->ustart : u);  // raw_in: the corrected start field lives in the cache array
     epi.ustar = out;
+    if (i == 0 && raw_in) epi.ustart_out = rk->ustart;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (rk->profiling) {
       INS_HIP_TRY(hipEventCreate(&e0));
@@ -333,13 +340,13 @@ static int rk_step_fused_periodic_2d(ins_rk* rk, double visc, double* u, double 
     }
     // stages >= 2 read the previous stage's UNCORRECTED u* and its pressure and correct in registers (k_flux2d<…, CORR>): between two stages the projection
     // only solves (three launches instead of four, 48 B per volume less); the last stage's projection materialises u, p and their ghosts
-    if ((rc = ins_k_flux2d(G, visc, in, rk->ku[i], &epi, s, (incorr && i > 0) ? rk->ps->pI : nullptr))) return rc;
+    if ((rc = ins_k_flux2d(G, visc, in, rk->ku[i], &epi, s, (incorr && (i > 0 || raw_in)) ? rk->ps->pI : nullptr))) return rc;
     if (rk->profiling) {
       INS_HIP_TRY(hipEventRecord(e1, s));
       rk->prof_events.push_back(e0);
       rk->prof_events.push_back(e1);
     }
-    rc = (incorr && i < ns - 1) ? ins_k_project_periodic_solve_only_2d(G, rk->ps, out, s) : ins_k_project_periodic_fused_2d(G, rk->ps, out, rk->p, i == ns - 1, s);
+    rc = (incorr && (i < ns - 1 || raw_out)) ? ins_k_project_periodic_solve_only_2d(G, rk->ps, out, s) : ins_k_project_periodic_fused_2d(G, rk->ps, out, rk->p, i == ns - 1, s);
     if (rc) return rc;
     in = out;
   }
@@ -398,7 +405,12 @@ static int step_graph_kind(const ins_rk* rk, bool chain_ok) {
       if (rk->ps->np[a] < 2) return 0;
     return chain_ok ? 1 : 2;
   }
-  return (ins_poisson_own2d(rk->ps) && ins_flux2d_supported(G)) ? 2 : 0;
+  return (ins_poisson_own2d(rk->ps) && ins_flux2d_supported(G)) ? (chain_ok ? 1 : 2) : 0;
+}
+
+// one step of the chained loop (3-D or 2-D fused periodic path)
+static int chain_step(ins_rk* rk, double visc, double* u, double dt, hipStream_t s, int chain) {
+  return rk->grid->g.D == 2 ? rk_step_fused_periodic_2d(rk, visc, u, dt, s, chain) : rk_step_fused_periodic(rk, visc, u, dt, s, chain);
 }
 
 // Capture `enqueue(gs)` into g->exec.  Nothing executes here.  false: no graph (the cache is marked broken).
@@ -439,20 +451,22 @@ extern "C" int ins_rk_steps_f64(ins_rk_t* rk, double visc, double* u, double t, 
              no_chain = ins_opt(OPT_INS_DISABLE_STEP_CHAIN) != 0;
   bool ok = !no_fuse && !no_corr && !no_chain && !rk->force && g.D == 3 && G->all_periodic && G->all_dof && rk->ps->kind == POISSON_SPECTRAL && ins_fast3d_supported(G) &&
             ins_flux64_supported(G) && G->uniform_exact && rk->nstage > 1 && g.N[0] >= 8 && g.N[1] >= 8 && g.N[2] >= 8;  // = in-kernel correction runs
-  const int gkind = step_graph_kind(rk, ok && nsteps >= 2);
+  const bool ok2d = !no_fuse && !no_corr && !no_chain && !ins_opt(OPT_INS_DISABLE_CORR2D) && !rk->force && !rk->ext && g.D == 2 && rk->ps->kind == POISSON_SPECTRAL &&
+                    ins_poisson_own2d(rk->ps) && ins_flux2d_supported(G) && rk->nstage > 1 && g.N[0] >= 6 && g.N[1] >= 6;
+  const int gkind = step_graph_kind(rk, (ok || ok2d) && nsteps >= 2);
   if (gkind && nsteps >= 3) {
     StepGraph* sg = static_cast<StepGraph*>(rk->step_graph);
     if (!sg) rk->step_graph = sg = new StepGraph();
     int rc, done = 0;
     // first step: direct (kind 1: it leaves its result uncorrected for the chain)
-    if ((rc = gkind == 1 ? rk_step_fused_periodic(rk, visc, u, dt, s, 2) : ins_rk_step_f64(rk, visc, u, t, dt, nullptr, stream))) return rc;
+    if ((rc = gkind == 1 ? chain_step(rk, visc, u, dt, s, 2) : ins_rk_step_f64(rk, visc, u, t, dt, nullptr, stream))) return rc;
     done = 1;
     const int last_direct = gkind == 1 ? 1 : 0;  // kind 1: the last step corrects (chain bit 1 only) and runs directly
     const int nreplay = nsteps - done - last_direct;
     const bool same = sg->exec && sg->u == u && sg->dt == dt && sg->visc == visc && sg->force == rk->force && sg->kind == gkind && sg->epoch == ins_opt_epoch();
     if (!same && !sg->broken) {
       const bool got = step_graph_capture(sg, [&](hipStream_t gs) {
-        return gkind == 1 ? rk_step_fused_periodic(rk, visc, u, dt, gs, 3) : ins_rk_step_f64(rk, visc, u, t, dt, nullptr, gs);
+        return gkind == 1 ? chain_step(rk, visc, u, dt, gs, 3) : ins_rk_step_f64(rk, visc, u, t, dt, nullptr, gs);
       });
       sg->u = u, sg->dt = dt, sg->visc = visc, sg->force = rk->force, sg->kind = gkind, sg->epoch = ins_opt_epoch();
       if (!got) sg->broken = true;
@@ -468,9 +482,16 @@ extern "C" int ins_rk_steps_f64(ins_rk_t* rk, double visc, double* u, double t, 
     }
     for (int n = done; n < nsteps; ++n) {  // the last step of a chain, or everything when no graph exists
       if (gkind == 1)
-        rc = rk_step_fused_periodic(rk, visc, u, dt, s, 1 | (n < nsteps - 1 ? 2 : 0));
+        rc = chain_step(rk, visc, u, dt, s, 1 | (n < nsteps - 1 ? 2 : 0));
       else
         rc = ins_rk_step_f64(rk, visc, u, t + n * dt, dt, nullptr, stream);
+      if (rc) return rc;
+    }
+    return INS_OK;
+  }
+  if (ok2d && nsteps >= 2) {  // 2-D fused path: the same chain (the final gradient-subtract / ghost pass of every step but the last goes into the next step's first stage kernel)
+    for (int n = 0; n < nsteps; ++n) {
+      int rc = chain_step(rk, visc, u, dt, s, (n > 0 ? 1 : 0) | (n < nsteps - 1 ? 2 : 0));
       if (rc) return rc;
     }
     return INS_OK;

@@ -50,7 +50,7 @@ def test_graph_replay_is_bitwise_the_plain_loop(ins, n, method):
     assert rb == 0  # not the default
     # chained 3-D loop (here: the 128-column box, which runs the 64-wide stage kernel with the in-register correction): the first and the last step of a call run directly (4 replays per call of
     # 6); whole-step graphs: all but the first (5 per call)
-    chained = len(n) == 3 and n[0] >= 128 and method != "FE11"
+    chained = method != "FE11" and (len(n) == 2 or n[0] >= 128)  # 2-D fused path: chained as well (round 3)
     assert ra == 2 * (4 if chained else 5)
     assert torch.equal(a, b)
     assert bool(torch.isfinite(a).all()) and diva < 1e-9
