@@ -44,9 +44,12 @@ class Observable:
 class Processor:
     """`processor(initialize, finalize)` (processors.jl:40-41) in the protocol `solve_unsteady` drives."""
 
-    def __init__(self, initialize, finalize=None):
+    def __init__(self, initialize, finalize=None, nupdate=1):
         self._initialize, self._finalize = initialize, finalize or (lambda initialized, state: initialized)
         self._obs = None
+        # the processor acts only on states whose step count is a multiple of `nupdate` (the library's own factories say so; a user-made processor sees every
+        # step): `solve_unsteady` runs the steps in between as one native call (chained steps) instead of one call per step
+        self.nupdate = max(1, int(nupdate))
 
     def initialize(self, getter):
         self._obs = Observable(getter())
@@ -59,8 +62,8 @@ class Processor:
         return self._finalize(initialized, getter())
 
 
-def processor(initialize, finalize=None):
-    return Processor(initialize, finalize)
+def processor(initialize, finalize=None, nupdate=1):
+    return Processor(initialize, finalize, nupdate)
 
 
 def timelogger(*, showiter=False, showt=True, showdt=True, showmax=True, showspeed=True, nupdate=1, log=print):
@@ -68,11 +71,12 @@ def timelogger(*, showiter=False, showt=True, showdt=True, showmax=True, showspe
 
     def initialize(state):
         told = [state.value["t"]]
+        nold = [state.value["n"]]
         oldtime = [time.time()]
 
         def step(s):
-            Δt = s["t"] - told[0]
-            told[0] = s["t"]
+            Δt = (s["t"] - told[0]) / max(1, s["n"] - nold[0])  # the last step's size (the state may arrive every `nupdate` steps only)
+            told[0], nold[0] = s["t"], s["n"]
             if s["n"] % nupdate != 0:
                 return
             newtime = time.time()
@@ -94,7 +98,7 @@ def timelogger(*, showiter=False, showt=True, showdt=True, showmax=True, showspe
         state.on(step)
         return None
 
-    return processor(initialize)
+    return processor(initialize, nupdate=nupdate)
 
 
 def fieldsaver(*, setup, nupdate=1):
@@ -111,7 +115,7 @@ def fieldsaver(*, setup, nupdate=1):
         state.on(step)
         return states
 
-    return processor(initialize)
+    return processor(initialize, nupdate=nupdate)
 
 
 def observefield(state, *, setup, fieldname, logtol=np.finfo(np.float64).eps, psolver=None):
@@ -345,4 +349,4 @@ def vtk_writer(*, setup, nupdate=1, dir="output", filename="solution", **kwargs)
             fh.write("</Collection>\n</VTKFile>\n")
         return fn
 
-    return processor(initialize, finalize)
+    return processor(initialize, finalize, nupdate=nupdate)

@@ -1,5 +1,7 @@
 """`solve_unsteady` and the CFL time step (solver.jl)."""
 import ctypes as C
+import math
+import os
 
 from . import _lib
 from .pressure import default_psolver
@@ -60,8 +62,19 @@ def solve_unsteady(*, setup, tlims, ustart, tempstart=None, method=None, psolver
             stepper = timesteps_(method, stepper, Δt, nstep, θ=θ, cache=cache)
             fire()
         else:
-            for _ in range(nstep):
-                stepper = timestep_(method, stepper, Δt, θ=θ, cache=cache)
+            # processors that act every `nupdate` steps only (timelogger, fieldsaver, vtk_writer say so; a user-made processor has nupdate = 1) never look at
+            # the states in between: those steps run as one native call (chained steps), and the state fires at the multiples of gcd(nupdate...) — every
+            # step a processor acts on is among them.  INS_NO_PROCESSOR_BATCH=1: one call and one state update per step, as the reference's loop.
+            g = 0
+            for v in processors.values():
+                g = math.gcd(g, int(getattr(v, "nupdate", 1)))
+            if g <= 1 or os.environ.get("INS_NO_PROCESSOR_BATCH"):
+                g = 1
+            done = 0
+            while done < nstep:
+                k = min(g - (stepper.n % g), nstep - done)
+                stepper = timesteps_(method, stepper, Δt, k, θ=θ, cache=cache) if k > 1 else timestep_(method, stepper, Δt, θ=θ, cache=cache)
+                done += k
                 fire()
     outputs = {k: processors[k].finalize(initialized[k], lambda: state["value"]) for k in processors}
     return (stepper.u, stepper.temp, stepper.t), outputs

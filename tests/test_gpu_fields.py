@@ -686,3 +686,35 @@ def test_sixteen_stages_plus_body_force_reference_order_loop(ins, oracle, geom):
         with _lib.options(**opts):
             (u, _, _), _ = ins.solve_unsteady(setup=sp, tlims=(0.0, 2e-3), ustart=ins.from_numpy(sp, u0), method=m, psolver=ps_d, Δt=2e-3)
         assert rell2(ins.to_numpy(u)[mask], st["u"][mask]) < STEP_TOL, opts
+
+
+def test_solve_unsteady_batches_the_steps_between_processor_updates(ins, monkeypatch):
+    """Processors that act every `nupdate` steps (timelogger, fieldsaver, vtk_writer) do not look at the states in between: solve_unsteady runs those steps as one
+    native call (chained steps) and fires at the multiples of gcd(nupdate...).  Same saved states, same log lines as the one-call-per-step loop."""
+    sp = ins.Setup(x=(np.linspace(0.0, 1.0, 65),) * 2, Re=500.0)
+    ps = ins.psolver_spectral(sp)
+    u0 = ins.random_field(sp, kp=3, seed=4, psolver=ps)
+
+    def run():
+        lines = []
+        calls = []
+        orig = ins.solver.timesteps_
+
+        def counting(method, stepper, dt, k, **kw):
+            calls.append(k)
+            return orig(method, stepper, dt, k, **kw)
+
+        monkeypatch.setattr(ins.solver, "timesteps_", counting)
+        procs = dict(log=ins.timelogger(nupdate=10, showmax=False, showspeed=False, log=lines.append), save=ins.fieldsaver(setup=sp, nupdate=5))
+        (u, _, t), out = ins.solve_unsteady(setup=sp, tlims=(0.0, 0.044), ustart=u0, psolver=ps, Δt=0.002, processors=procs)
+        monkeypatch.setattr(ins.solver, "timesteps_", orig)
+        return ins.to_numpy(u), t, out["save"], lines, calls
+
+    ua, ta, sa, la, ca = run()
+    monkeypatch.setenv("INS_NO_PROCESSOR_BATCH", "1")
+    ub, tb, sb, lb, cb = run()
+    assert ca == [5, 5, 5, 5, 2] and cb == []  # 22 steps: four batches of gcd(10, 5) = 5 and the remainder; without batching only single steps
+    assert ta == pytest.approx(tb) and rell2(ua, ub) < 1e-12
+    assert [s["n"] for s in sa] == [s["n"] for s in sb] == [5, 10, 15, 20]
+    assert all(rell2(x["u"], y["u"]) < 1e-12 and x["t"] == pytest.approx(y["t"]) for x, y in zip(sa, sb))
+    assert len(la) == len(lb) == 2 and all("Δt = 0.002" in line for line in la + lb)
