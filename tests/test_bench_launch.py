@@ -49,3 +49,17 @@ def test_bench_refuses_mismatched_world():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=ROOT,
                        env=_env(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
+
+
+def test_bench_gpus8_self_launch_runs_eight_ranks():
+    """The N = 8 shape of the driver's scaling run (BASELINE configs[3]: 512^3 over 8 z-slabs) on the same launch path with eight gloo ranks and tiny grids:
+    the weak box of GLOBAL_GRIDS[8] scaled by --n, the strong leg with two planes per rank."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--n", "8", "--no-cpu-baseline"],
+                       cwd=ROOT, env=_env(INS_BENCH_STRONG_GRID="16x16x16"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["grid"] == [16, 16, 16] and out["check"]["finite"] and out["check"]["max_abs_div_times_dx"] < 1e-10
+    s = out["strong_512"]
+    assert s["n_gpus"] == 8 and s["grid"] == [16, 16, 16] and s["planes_per_rank"] == 2 and s["finite"] and s["max_abs_div_times_dx"] < 1e-10
