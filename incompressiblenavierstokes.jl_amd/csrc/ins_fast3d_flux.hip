@@ -313,6 +313,11 @@ __global__ __launch_bounds__(256, 2) void k_momentum_flux(GridDev g, const Rec* 
             su = Uc;
             sv = Vc;
             sw = Wc;
+            if (CORR && epi.ustart_out) {  // first stage of a chained step: the corrected stencil input is this step's ustart (ins_rk_steps_f64)
+              epi.ustart_out[c] = Uc;
+              epi.ustart_out[c + g.sc] = Vc;
+              epi.ustart_out[c + 2 * g.sc] = Wc;
+            }
           }
           for (int q = 0; q < epi.n; ++q) {
             const double* kq = epi.k[q];

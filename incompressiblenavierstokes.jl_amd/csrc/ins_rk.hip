@@ -449,8 +449,9 @@ extern "C" int ins_rk_steps_f64(ins_rk_t* rk, double visc, double* u, double t, 
   const GridDev& g = G->g;
   const bool no_fuse = ins_opt(OPT_INS_DISABLE_FUSED_RK) != 0, no_corr = ins_opt(OPT_INS_DISABLE_INKERNEL_CORR) != 0,
              no_chain = ins_opt(OPT_INS_DISABLE_STEP_CHAIN) != 0;
+  // (boxes too narrow for the 64-wide stage kernel chain on the 62-wide one: it stores the corrected start field too — round 3)
   bool ok = !no_fuse && !no_corr && !no_chain && !rk->force && g.D == 3 && G->all_periodic && G->all_dof && rk->ps->kind == POISSON_SPECTRAL && ins_fast3d_supported(G) &&
-            ins_flux64_supported(G) && G->uniform_exact && rk->nstage > 1 && g.N[0] >= 8 && g.N[1] >= 8 && g.N[2] >= 8;  // = in-kernel correction runs
+            G->uniform_exact && rk->nstage > 1 && g.N[0] >= 8 && g.N[1] >= 8 && g.N[2] >= 8;  // = in-kernel correction runs
   const bool ok2d = !no_fuse && !no_corr && !no_chain && !ins_opt(OPT_INS_DISABLE_CORR2D) && !rk->force && !rk->ext && g.D == 2 && rk->ps->kind == POISSON_SPECTRAL &&
                     ins_poisson_own2d(rk->ps) && ins_flux2d_supported(G) && rk->nstage > 1 && g.N[0] >= 6 && g.N[1] >= 6;
   const int gkind = step_graph_kind(rk, (ok || ok2d) && nsteps >= 2);

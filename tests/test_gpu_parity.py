@@ -711,8 +711,8 @@ def test_flux64_rk_steps_match_oracle(ins, oracle, n, method):
 @pytest.mark.parametrize("n", [(128, 16, 12), (96, 10, 8), (66, 10, 4), (32, 32, 32)])
 def test_chained_steps_equal_single_steps(ins, oracle, n):
     """`timesteps_` (ins_rk_steps_f64): on wide exact boxes the final correction of every step but the last is folded into the next
-    step's first stage kernel; the result must be what step-by-step `timestep_` gives (and the oracle); the last two boxes (too thin for
-    the in-kernel correction / too narrow for the 64-wide kernel) take the plain loop."""
+    step's first stage kernel; the result must be what step-by-step `timestep_` gives (and the oracle); (66, 10, 4) is too thin for the in-kernel
+    correction and takes the plain loop, (32, 32, 32) chains on the 62-wide stage kernel (round 3)."""
     o = oracle
     so = exact_box(o, n)
     sp = mirror(ins, so, o)

@@ -48,9 +48,8 @@ def test_graph_replay_is_bitwise_the_plain_loop(ins, n, method):
     a, ra, diva = _run(ins, n, method, 6, 2, INS_STEP_GRAPH=1)
     b, rb, _ = _run(ins, n, method, 6, 2)
     assert rb == 0  # not the default
-    # chained 3-D loop (here: the 128-column box, which runs the 64-wide stage kernel with the in-register correction): the first and the last step of a call run directly (4 replays per call of
-    # 6); whole-step graphs: all but the first (5 per call)
-    chained = method != "FE11" and (len(n) == 2 or n[0] >= 128)  # 2-D fused path: chained as well (round 3)
+    # chained loops: the first and the last step of a call run directly (4 replays per call of 6); whole-step graphs (FE11): all but the first (5 per call)
+    chained = method != "FE11"  # every fused periodic path chains its steps (64-wide, 62-wide and 2-D stage kernels); one-stage methods have nothing to fold
     assert ra == 2 * (4 if chained else 5)
     assert torch.equal(a, b)
     assert bool(torch.isfinite(a).all()) and diva < 1e-9
@@ -76,4 +75,4 @@ def test_graph_is_rebuilt_when_the_step_size_changes_and_off_switch_wins(ins):
 
     a, ra = run(INS_STEP_GRAPH=1)
     b, rb = run(INS_STEP_GRAPH=1, INS_DISABLE_STEP_GRAPH=1)
-    assert ra == 8 and rb == 0 and torch.equal(a, b)  # 32 columns: whole-step graphs, 4 replays in each call of 5
+    assert ra == 6 and rb == 0 and torch.equal(a, b)  # chained: 3 replays in each call of 5 (first and last step direct), none in the call of 2
