@@ -1206,6 +1206,125 @@ int launch_yz(YzArgs& a, const double2* tw, hipStream_t s) {
   return INS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Small planes (n0, n1 <= 64): the x and the y pass of one kz-plane in ONE kernel.  A 64 x 64 plane is 32 KB as row pairs and 33 KB as half
+// spectrum, so a workgroup holds the whole plane in LDS: x forward (paired-row real transform) -> split of the pairs into spec[ky][kx] -> y forward
+// (same storage order of ky as k_yfft) -> global; and back.  Boxes of 16^3 .. 64^3 are bound by the latency of their dependent launches (~5.7 us
+// each): this makes a stage four launches (stage kernel, xy forward, z solve, xy inverse) instead of six.
+//   SRC 0: rows from pI; SRC 1: rows = Ω·div(u) with periodic wrap (as k_xfwd).
+// ------------------------------------------------------------------------------------------------------------
+template <int LX, int LY, int SRC, int NT>
+__global__ __launch_bounds__(NT) void k_xyfwd(GridDev g, const double* __restrict__ src, double2* __restrict__ out, const double2* __restrict__ twx_g,
+                                               const double2* __restrict__ twy_g, int kxs) {
+  using C = double2;
+  constexpr int N0 = 1 << LX, N1 = 1 << LY, KXN = N0 / 2 + 1, NP = N1 / 2, KP = KXN;
+  extern __shared__ __align__(16) unsigned char lds_raw_xy[];
+  C* bufx = reinterpret_cast<C*>(lds_raw_xy);  // [NP][N0]: row pairs (real part = row 2p, imaginary part = row 2p + 1)
+  C* spec = bufx + NP * N0;                      // [N1][KP]
+  C* twx = spec + N1 * KP;                       // [N0]
+  C* twy = twx + N0;                             // [N1]
+  const int t = threadIdx.x, kz = blockIdx.x;
+  for (int m = t; m < N0; m += NT) twx[m] = twx_g[m];
+  for (int m = t; m < N1; m += NT) twy[m] = twy_g[m];
+  double* bufd = reinterpret_cast<double*>(bufx);
+  for (int idx = t; idx < N1 * N0; idx += NT) {
+    const int j = idx / N0, i = idx - j * N0;
+    double v;
+    if (SRC == 0) {
+      v = src[i + (long long)N0 * (j + (long long)N1 * kz)];
+    } else {
+      const int I0 = i + 1, I1 = j + 1, I2 = kz + 1;
+      const long long c = I0 + I1 * g.sx[1] + I2 * g.sx[2];
+      const long long cx = I0 == 1 ? c + (long long)(g.N[0] - 3) : c - 1;
+      const long long cy = I1 == 1 ? c + (long long)(g.N[1] - 3) * g.sx[1] : c - g.sx[1];
+      const long long cz = I2 == 1 ? c + (long long)(g.N[2] - 3) * g.sx[2] : c - g.sx[2];
+      double d = (src[c] - src[cx]) * g.rdx[0][I0];
+      d += (src[g.sc + c] - src[g.sc + cy]) * g.rdx[1][I1];
+      d += (src[2 * g.sc + c] - src[2 * g.sc + cz]) * g.rdx[2][I2];
+      v = d * (g.dx[0][I0] * g.dx[1][I1] * g.dx[2][I2]);
+    }
+    bufd[2 * ((j >> 1) * N0 + i) + (j & 1)] = v;
+  }
+  __syncthreads();
+  fft_dif<LX, NP, 1, N0, true, NT>(bufx, twx, t);
+  // separate the two real rows of every pair: A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / (2i)
+  for (int idx = t; idx < NP * KXN; idx += NT) {
+    const int p = idx / KXN, s = idx - p * KXN;
+    const C zk = bufx[p * N0 + pos_of_freq<LX>(s)];
+    const C zm = bufx[p * N0 + pos_of_freq<LX>((N0 - s) % N0)];
+    spec[(2 * p) * KP + s] = mkc<C>(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+    spec[(2 * p + 1) * KP + s] = mkc<C>(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+  }
+  __syncthreads();
+  fft_dif<LY, KXN, KP, 1, false, NT>(spec, twy, t);  // lines = kx (unit stride), elements = ky (KP apart); ky stays in digit-reversed storage order
+  C* o = out + (long long)kz * N1 * kxs;
+  for (int idx = t; idx < N1 * KXN; idx += NT) {
+    const int j = idx / KXN, s = idx - j * KXN;
+    o[(long long)j * kxs + s] = spec[j * KP + s];
+  }
+}
+
+template <int LX, int LY, int NT>
+__global__ __launch_bounds__(NT) void k_xyinv(const double2* __restrict__ in, double* __restrict__ pI, const double2* __restrict__ twx_g,
+                                               const double2* __restrict__ twy_g, int kxs) {
+  using C = double2;
+  constexpr int N0 = 1 << LX, N1 = 1 << LY, KXN = N0 / 2 + 1, NP = N1 / 2, KP = KXN;
+  extern __shared__ __align__(16) unsigned char lds_raw_xy[];
+  C* bufx = reinterpret_cast<C*>(lds_raw_xy);
+  C* spec = bufx + NP * N0;
+  C* twx = spec + N1 * KP;
+  C* twy = twx + N0;
+  const int t = threadIdx.x, kz = blockIdx.x;
+  for (int m = t; m < N0; m += NT) twx[m] = twx_g[m];
+  for (int m = t; m < N1; m += NT) twy[m] = twy_g[m];
+  const C* ip = in + (long long)kz * N1 * kxs;
+  for (int idx = t; idx < N1 * KXN; idx += NT) {
+    const int j = idx / KXN, s = idx - j * KXN;
+    spec[j * KP + s] = ip[(long long)j * kxs + s];
+  }
+  __syncthreads();
+  fft_dit<LY, KXN, KP, 1, false, NT>(spec, twy, t);  // back to natural ky
+  // Z[k] = A[k] + i B[k], Z[N-k] = conj A[k] + i conj B[k] into the storage order the x DIT expects
+  for (int idx = t; idx < NP * KXN; idx += NT) {
+    const int p = idx / KXN, s = idx - p * KXN;
+    C a = spec[(2 * p) * KP + s], b = spec[(2 * p + 1) * KP + s];
+    if (s == 0 || s == N0 / 2) {  // C2R semantics: DC and Nyquist bins are real
+      a.y = 0;
+      b.y = 0;
+    }
+    bufx[p * N0 + pos_of_freq<LX>(s)] = mkc<C>(a.x - b.y, a.y + b.x);
+    if (s != 0 && s != N0 / 2) bufx[p * N0 + pos_of_freq<LX>(N0 - s)] = mkc<C>(a.x + b.y, b.x - a.y);
+  }
+  __syncthreads();
+  fft_dit<LX, NP, 1, N0, true, NT>(bufx, twx, t);
+  const double* bufd = reinterpret_cast<const double*>(bufx);
+  for (int idx = t; idx < N1 * N0; idx += NT) {
+    const int j = idx / N0, i = idx - j * N0;
+    pI[i + (long long)N0 * (j + (long long)N1 * kz)] = bufd[2 * ((j >> 1) * N0 + i) + (j & 1)];
+  }
+}
+
+template <int LX, int LY>
+int launch_xy(const GridDev& g, const double* src, int from_u, double2* spec, double* pI, int n2, const double2* twx, const double2* twy, int kxs,
+              bool inverse, hipStream_t s) {
+  constexpr int N0 = 1 << LX, N1 = 1 << LY, KXN = N0 / 2 + 1;
+  constexpr int NT = N0 * N1 >= 2048 ? 1024 : 256;  // a plane is one workgroup's serial work: 1024 work-items from 64 x 32 volumes on
+  constexpr size_t lds = ((size_t)(N1 / 2) * N0 + (size_t)N1 * KXN + N0 + N1) * sizeof(double2);
+  int rc;
+  if (inverse) {
+    if ((rc = set_lds(&k_xyinv<LX, LY, NT>, lds))) return rc;
+    hipLaunchKernelGGL((k_xyinv<LX, LY, NT>), dim3(n2), dim3(NT), lds, s, spec, pI, twx, twy, kxs);
+  } else if (from_u) {
+    if ((rc = set_lds(&k_xyfwd<LX, LY, 1, NT>, lds))) return rc;
+    hipLaunchKernelGGL((k_xyfwd<LX, LY, 1, NT>), dim3(n2), dim3(NT), lds, s, g, src, spec, twx, twy, kxs);
+  } else {
+    if ((rc = set_lds(&k_xyfwd<LX, LY, 0, NT>, lds))) return rc;
+    hipLaunchKernelGGL((k_xyfwd<LX, LY, 0, NT>), dim3(n2), dim3(NT), lds, s, g, src, spec, twx, twy, kxs);
+  }
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
 }  // namespace
 
 #define INS_POW2_SWITCH(n, CALL)            \
@@ -1278,6 +1397,26 @@ void ins_ownfft_permute_symbol(int n, const double* ay, double* out) {
     }
     out[p] = ay[k];
   }
+}
+
+bool ins_ownfft_xy_supported(int n0, int n1) {
+  auto small = [](int n) { return n == 16 || n == 32 || n == 64; };
+  return !ins_opt(OPT_INS_DISABLE_XYFUSED) && small(n0) && small(n1);
+}
+// from_u: 0 = rows from pI, 1 = Ω·div(u) formed on the fly (periodic wrap); inverse: spectrum -> pI
+int ins_k_ownfft_xy(const ins_grid* G, const double* src, int from_u, double* phat, double* pI, int n0, int n1, int n2, const double* twx, const double* twy,
+                    bool inverse, hipStream_t s, int kxs) {
+  static const GridDev no_grid{};
+  const GridDev& g = G ? G->g : no_grid;
+  double2* sp = reinterpret_cast<double2*>(phat);
+  const double2 *wx = reinterpret_cast<const double2*>(twx), *wy = reinterpret_cast<const double2*>(twy);
+  auto lg = [](int n) { return n == 16 ? 4 : (n == 32 ? 5 : 6); };
+#define INS_XY(A, B) \
+  if (lg(n0) == A && lg(n1) == B) return launch_xy<A, B>(g, src, from_u, sp, pI, n2, wx, wy, kxs, inverse, s);
+  INS_XY(4, 4) INS_XY(4, 5) INS_XY(4, 6) INS_XY(5, 4) INS_XY(5, 5) INS_XY(5, 6) INS_XY(6, 4) INS_XY(6, 5) INS_XY(6, 6)
+#undef INS_XY
+  ins_set_error("ins_k_ownfft_xy: unsupported plane %d x %d", n0, n1);
+  return INS_ERR_UNSUPPORTED;
 }
 
 int ins_k_ownfft_xfwd(const ins_grid* G, const double* src, int from_u, double* phat, int n0, int n1, int n2, const double* tw,

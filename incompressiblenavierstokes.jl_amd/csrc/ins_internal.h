@@ -120,6 +120,7 @@ void ins_set_error(const char* fmt, ...);
   X(INS_DISABLE_STEP_CHAIN)      \
   X(INS_DISABLE_STEP_GRAPH)      \
   X(INS_DISABLE_LINE3)           \
+  X(INS_DISABLE_XYFUSED)         \
   X(INS_DISABLE_CORR2D)          \
   X(INS_SPECTRUM_ROCFFT)         \
   X(INS_X_SKEL)                  \
@@ -362,6 +363,9 @@ int ins_k_ownfft_xfwd(const ins_grid* G, const double* src, int from_u, double* 
                       int kxs = 0, int kz0 = 0);
 int ins_k_ownfft_xinv(const double* phat, double* pI, int n0, int n1, int n2, const double* tw, hipStream_t s, int kxs = 0);
 int ins_k_ownfft_y(double* phat, int kxn, int n1, int n2, const double* tw, bool inverse, hipStream_t s, int kxs = 0);
+bool ins_ownfft_xy_supported(int n0, int n1);
+int ins_k_ownfft_xy(const ins_grid* G, const double* src, int from_u, double* phat, double* pI, int n0, int n1, int n2, const double* twx, const double* twy,
+                    bool inverse, hipStream_t s, int kxs);
 bool ins_line3_supported(int n);
 void ins_line3_permute_symbol(int n, const double* ay, double* out);
 int ins_line3_pos_of_freq(int n, int k);

@@ -895,6 +895,13 @@ static int ownfft_transform(ins_poisson* ps, const double* from_u, hipStream_t s
     if ((rc = ins_k_zsolve(ph, n1, (long long)kxs, ps->ahat[0], kxn, ps->ahat[2], ps->ahat[1], ps->tw, 1.0 / ((double)n0 * n1), true, s, kxs))) return rc;
     return ins_k_ownfft_xinv(ph, ps->pI, n0, n1, 1, ps->tw_x, s, kxs);
   }
+  // small planes (16 .. 64 on both sides): the x and the y pass of a plane as one kernel each way — four launches per solve... three: xy forward, z, xy inverse
+  if (!ps->y3 && !ps->yz_P && (src_code == 1 || !from_u) && ins_ownfft_xy_supported(n0, n1)) {
+    if ((rc = ins_k_ownfft_xy(ps->grid, from_u ? from_u : ps->pI, from_u ? 1 : 0, ph, nullptr, n0, n1, n2, ps->tw_x, ps->tw_y, false, s, kxs))) return rc;
+    const double inv_n = 1.0 / ((double)n0 * n1 * n2);
+    if ((rc = ins_k_zsolve(ph, n2, (long long)kxs * n1, ps->ahat[0], kxn, ps->ahat[1], ps->ahat[2], ps->tw, inv_n, true, s, kxs))) return rc;
+    return ins_k_ownfft_xy(nullptr, nullptr, 0, ph, ps->pI, n0, n1, n2, ps->tw_x, ps->tw_y, true, s, kxs);
+  }
   if ((rc = ins_k_ownfft_xfwd(ps->grid, from_u ? from_u : ps->pI, from_u ? src_code : 0, ph, n0, n1, n2, ps->tw_x, s, kxs))) return rc;
   if (ps->yz_P && !ins_opt(OPT_INS_DISABLE_YZ_FUSED)) {
     const ins_grid* G = ps->grid;

@@ -10,7 +10,7 @@ from ins_amd import _lib
 D = 2 if os.environ.get("LAB_2D") else 3
 K = 50
 for n in [int(a) for a in sys.argv[1:]]:
-    for label, opts in (("graph", {"INS_STEP_GRAPH": 1}), ("plain", {"INS_DISABLE_STEP_GRAPH": 1})):
+    for label, opts in (("warm-up", {}), ("plain", {"INS_DISABLE_STEP_GRAPH": 1}), ("separate x / y passes", {"INS_DISABLE_XYFUSED": 1}), ("graph", {"INS_STEP_GRAPH": 1})):
         with _lib.options(**opts):
             sp = ins.Setup(x=(np.linspace(0, 1, n + 1),) * D, Re=1000.0)
             ps = ins.psolver_spectral(sp)
