@@ -1304,6 +1304,95 @@ __global__ __launch_bounds__(NT) void k_xyinv(const double2* __restrict__ in, do
   }
 }
 
+// 2-D grids of up to 64 x 64 volumes: the WHOLE spectral solve (x forward with the divergence formed inside, y forward, symbol, y inverse, x inverse) as one
+// workgroup — one launch instead of three; such a grid is 4096 volumes, and its step is nothing but launch latency.  SRC 0: rows from pI; SRC 3: Ω·div(u), 2-D, periodic wrap.
+template <int LX, int LY, int SRC, int NT>
+__global__ __launch_bounds__(NT) void k_xysolve2d(GridDev g, const double* __restrict__ src, double* __restrict__ pI, const double2* __restrict__ twx_g,
+                                                  const double2* __restrict__ twy_g, const double* __restrict__ ax, const double* __restrict__ ay, double inv_n) {
+  using C = double2;
+  constexpr int N0 = 1 << LX, N1 = 1 << LY, KXN = N0 / 2 + 1, NP = N1 / 2, KP = KXN;
+  extern __shared__ __align__(16) unsigned char lds_raw_xy[];
+  C* bufx = reinterpret_cast<C*>(lds_raw_xy);
+  C* spec = bufx + NP * N0;
+  C* twx = spec + N1 * KP;
+  C* twy = twx + N0;
+  const int t = threadIdx.x;
+  for (int m = t; m < N0; m += NT) twx[m] = twx_g[m];
+  for (int m = t; m < N1; m += NT) twy[m] = twy_g[m];
+  double* bufd = reinterpret_cast<double*>(bufx);
+  for (int idx = t; idx < N1 * N0; idx += NT) {
+    const int j = idx / N0, i = idx - j * N0;
+    double v;
+    if (SRC == 0) {
+      v = src[i + (long long)N0 * j];
+    } else {
+      const int I0 = i + 1, I1 = j + 1;
+      const long long c = I0 + I1 * g.sx[1];
+      const long long cx = I0 == 1 ? c + (long long)(g.N[0] - 3) : c - 1;
+      const long long cy = I1 == 1 ? c + (long long)(g.N[1] - 3) * g.sx[1] : c - g.sx[1];
+      const double d = (src[c] - src[cx]) * g.rdx[0][I0] + (src[g.sc + c] - src[g.sc + cy]) * g.rdx[1][I1];
+      v = d * (g.dx[0][I0] * g.dx[1][I1]);
+    }
+    bufd[2 * ((j >> 1) * N0 + i) + (j & 1)] = v;
+  }
+  __syncthreads();
+  fft_dif<LX, NP, 1, N0, true, NT>(bufx, twx, t);
+  for (int idx = t; idx < NP * KXN; idx += NT) {
+    const int p = idx / KXN, s = idx - p * KXN;
+    const C zk = bufx[p * N0 + pos_of_freq<LX>(s)];
+    const C zm = bufx[p * N0 + pos_of_freq<LX>((N0 - s) % N0)];
+    spec[(2 * p) * KP + s] = mkc<C>(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+    spec[(2 * p + 1) * KP + s] = mkc<C>(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+  }
+  __syncthreads();
+  fft_dif<LY, KXN, KP, 1, false, NT>(spec, twy, t);
+  // phat = -phat / (âx + ây) / prod(Np), phat[0, 0] = 0 (pressure.jl:326-341); frequency ky sits at storage position pos_of_freq(ky)
+  for (int idx = t; idx < N1 * KXN; idx += NT) {
+    const int k = idx / KXN, s = idx - k * KXN;
+    const double sc = (k == 0 && s == 0) ? 0.0 : -inv_n / (ax[s] + ay[k]);
+    C& z = spec[pos_of_freq<LY>(k) * KP + s];
+    z.x *= sc;
+    z.y *= sc;
+  }
+  __syncthreads();
+  fft_dit<LY, KXN, KP, 1, false, NT>(spec, twy, t);
+  for (int idx = t; idx < NP * KXN; idx += NT) {
+    const int p = idx / KXN, s = idx - p * KXN;
+    C a = spec[(2 * p) * KP + s], b = spec[(2 * p + 1) * KP + s];
+    if (s == 0 || s == N0 / 2) {
+      a.y = 0;
+      b.y = 0;
+    }
+    bufx[p * N0 + pos_of_freq<LX>(s)] = mkc<C>(a.x - b.y, a.y + b.x);
+    if (s != 0 && s != N0 / 2) bufx[p * N0 + pos_of_freq<LX>(N0 - s)] = mkc<C>(a.x + b.y, b.x - a.y);
+  }
+  __syncthreads();
+  fft_dit<LX, NP, 1, N0, true, NT>(bufx, twx, t);
+  for (int idx = t; idx < N1 * N0; idx += NT) {
+    const int j = idx / N0, i = idx - j * N0;
+    pI[i + (long long)N0 * j] = bufd[2 * ((j >> 1) * N0 + i) + (j & 1)];
+  }
+}
+
+template <int LX, int LY>
+int launch_xysolve2d(const GridDev& g, const double* src, int from_u, double* pI, const double2* twx, const double2* twy, const double* ax, const double* ay,
+                     hipStream_t s) {
+  constexpr int N0 = 1 << LX, N1 = 1 << LY, KXN = N0 / 2 + 1;
+  constexpr int NT = N0 * N1 >= 2048 ? 1024 : 256;
+  constexpr size_t lds = ((size_t)(N1 / 2) * N0 + (size_t)N1 * KXN + N0 + N1) * sizeof(double2);
+  const double inv_n = 1.0 / ((double)N0 * N1);
+  int rc;
+  if (from_u) {
+    if ((rc = set_lds(&k_xysolve2d<LX, LY, 3, NT>, lds))) return rc;
+    hipLaunchKernelGGL((k_xysolve2d<LX, LY, 3, NT>), dim3(1), dim3(NT), lds, s, g, src, pI, twx, twy, ax, ay, inv_n);
+  } else {
+    if ((rc = set_lds(&k_xysolve2d<LX, LY, 0, NT>, lds))) return rc;
+    hipLaunchKernelGGL((k_xysolve2d<LX, LY, 0, NT>), dim3(1), dim3(NT), lds, s, g, src, pI, twx, twy, ax, ay, inv_n);
+  }
+  INS_LAUNCH_CHECK();
+  return INS_OK;
+}
+
 template <int LX, int LY>
 int launch_xy(const GridDev& g, const double* src, int from_u, double2* spec, double* pI, int n2, const double2* twx, const double2* twy, int kxs,
               bool inverse, hipStream_t s) {
@@ -1416,6 +1505,21 @@ int ins_k_ownfft_xy(const ins_grid* G, const double* src, int from_u, double* ph
   INS_XY(4, 4) INS_XY(4, 5) INS_XY(4, 6) INS_XY(5, 4) INS_XY(5, 5) INS_XY(5, 6) INS_XY(6, 4) INS_XY(6, 5) INS_XY(6, 6)
 #undef INS_XY
   ins_set_error("ins_k_ownfft_xy: unsupported plane %d x %d", n0, n1);
+  return INS_ERR_UNSUPPORTED;
+}
+
+// the whole 2-D solve of a grid of up to 64 x 64 volumes as one launch: pI <- solution of L p = (from_u ? Ω·div(u) : pI)
+int ins_k_ownfft_xysolve2d(const ins_grid* G, const double* src, int from_u, double* pI, int n0, int n1, const double* twx, const double* twy, const double* ax,
+                           const double* ay, hipStream_t s) {
+  static const GridDev no_grid{};
+  const GridDev& g = G ? G->g : no_grid;
+  const double2 *wx = reinterpret_cast<const double2*>(twx), *wy = reinterpret_cast<const double2*>(twy);
+  auto lg = [](int n) { return n == 16 ? 4 : (n == 32 ? 5 : 6); };
+#define INS_XY(A, B) \
+  if (lg(n0) == A && lg(n1) == B) return launch_xysolve2d<A, B>(g, src, from_u, pI, wx, wy, ax, ay, s);
+  INS_XY(4, 4) INS_XY(4, 5) INS_XY(4, 6) INS_XY(5, 4) INS_XY(5, 5) INS_XY(5, 6) INS_XY(6, 4) INS_XY(6, 5) INS_XY(6, 6)
+#undef INS_XY
+  ins_set_error("ins_k_ownfft_xysolve2d: unsupported grid %d x %d", n0, n1);
   return INS_ERR_UNSUPPORTED;
 }
 

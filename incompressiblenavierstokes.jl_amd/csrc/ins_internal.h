@@ -366,6 +366,8 @@ int ins_k_ownfft_y(double* phat, int kxn, int n1, int n2, const double* tw, bool
 bool ins_ownfft_xy_supported(int n0, int n1);
 int ins_k_ownfft_xy(const ins_grid* G, const double* src, int from_u, double* phat, double* pI, int n0, int n1, int n2, const double* twx, const double* twy,
                     bool inverse, hipStream_t s, int kxs);
+int ins_k_ownfft_xysolve2d(const ins_grid* G, const double* src, int from_u, double* pI, int n0, int n1, const double* twx, const double* twy, const double* ax,
+                           const double* ay, hipStream_t s);
 bool ins_line3_supported(int n);
 void ins_line3_permute_symbol(int n, const double* ay, double* out);
 int ins_line3_pos_of_freq(int n, int k);

@@ -891,6 +891,8 @@ static int ownfft_transform(ins_poisson* ps, const double* from_u, hipStream_t s
   double* ph = reinterpret_cast<double*>(ps->phat);
   int rc;
   if (ps->grid->g.D == 2) {  // x forward, fused solve along y (lines = kx, "planes" = ky), x inverse
+    if (ins_ownfft_xy_supported(n0, n1))  // up to 64 x 64 volumes: the whole solve as one launch
+      return ins_k_ownfft_xysolve2d(ps->grid, ps->pI, 0, ps->pI, n0, n1, ps->tw_x, ps->tw, ps->ahat[0], ps->ahat[1], s);
     if ((rc = ins_k_ownfft_xfwd(ps->grid, ps->pI, false, ph, n0, n1, 1, ps->tw_x, s, kxs))) return rc;
     if ((rc = ins_k_zsolve(ph, n1, (long long)kxs, ps->ahat[0], kxn, ps->ahat[2], ps->ahat[1], ps->tw, 1.0 / ((double)n0 * n1), true, s, kxs))) return rc;
     return ins_k_ownfft_xinv(ph, ps->pI, n0, n1, 1, ps->tw_x, s, kxs);
@@ -1487,9 +1489,13 @@ int ins_k_project_periodic_fused_2d(const ins_grid* G, ins_poisson* ps, double* 
   const int n0 = ps->np[0], n1 = ps->np[1], kxn = ps->kmax[0], kxs = ps->kxs;
   double* ph = reinterpret_cast<double*>(ps->phat);
   int rc;
-  if ((rc = ins_k_ownfft_xfwd(G, u, 3, ph, n0, n1, 1, ps->tw_x, s, kxs))) return rc;
-  if ((rc = ins_k_zsolve(ph, n1, (long long)kxs, ps->ahat[0], kxn, ps->ahat[2], ps->ahat[1], ps->tw, 1.0 / ((double)n0 * n1), true, s, kxs))) return rc;
-  if ((rc = ins_k_ownfft_xinv(ph, ps->pI, n0, n1, 1, ps->tw_x, s, kxs))) return rc;
+  if (ins_ownfft_xy_supported(n0, n1)) {
+    if ((rc = ins_k_ownfft_xysolve2d(G, u, 1, ps->pI, n0, n1, ps->tw_x, ps->tw, ps->ahat[0], ps->ahat[1], s))) return rc;
+  } else {
+    if ((rc = ins_k_ownfft_xfwd(G, u, 3, ph, n0, n1, 1, ps->tw_x, s, kxs))) return rc;
+    if ((rc = ins_k_zsolve(ph, n1, (long long)kxs, ps->ahat[0], kxn, ps->ahat[2], ps->ahat[1], ps->tw, 1.0 / ((double)n0 * n1), true, s, kxs))) return rc;
+    if ((rc = ins_k_ownfft_xinv(ph, ps->pI, n0, n1, 1, ps->tw_x, s, kxs))) return rc;
+  }
   dim3 block(64, 4, 1), grid(cdiv(n0, 64), cdiv(n1, 4), 1);
   if (keep_p)
     hipLaunchKernelGGL((k_grad_ghost<2, true>), grid, block, 0, s, g, u, p, ps->pI, n0, n1, 1);
@@ -1504,6 +1510,7 @@ int ins_k_project_periodic_solve_only_2d(const ins_grid* G, ins_poisson* ps, con
   const int n0 = ps->np[0], n1 = ps->np[1], kxn = ps->kmax[0], kxs = ps->kxs;
   double* ph = reinterpret_cast<double*>(ps->phat);
   int rc;
+  if (ins_ownfft_xy_supported(n0, n1)) return ins_k_ownfft_xysolve2d(G, u, 1, ps->pI, n0, n1, ps->tw_x, ps->tw, ps->ahat[0], ps->ahat[1], s);
   if ((rc = ins_k_ownfft_xfwd(G, u, 3, ph, n0, n1, 1, ps->tw_x, s, kxs))) return rc;
   if ((rc = ins_k_zsolve(ph, n1, (long long)kxs, ps->ahat[0], kxn, ps->ahat[2], ps->ahat[1], ps->tw, 1.0 / ((double)n0 * n1), true, s, kxs))) return rc;
   return ins_k_ownfft_xinv(ph, ps->pI, n0, n1, 1, ps->tw_x, s, kxs);

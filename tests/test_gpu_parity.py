@@ -796,7 +796,7 @@ def test_handles_release_their_device_memory(ins):
     assert free0 - free1 < 32 * 2**20, f"{(free0 - free1) / 2**20:.1f} MiB not returned after 6 create/destroy cycles"
 
 
-@pytest.mark.parametrize("n", [(32, 32), (64, 16), (1024, 32), (16, 256)])
+@pytest.mark.parametrize("n", [(32, 32), (64, 16), (1024, 32), (16, 256), (64, 64), (16, 32), (32, 64)])  # up to 64 x 64: the whole solve is one launch (k_xysolve2d)
 def test_own_fft_2d_poisson_matches_oracle_and_rocfft(ins, oracle, n, monkeypatch):
     """2-D power-of-two boxes: own x passes + the fused solve kernel along y, against the oracle and against the rocFFT route
     (INS_DISABLE_OWNFFT, read when the solver is created)."""
@@ -1063,7 +1063,7 @@ def test_masked_inkernel_correction_matches_oracle(ins, oracle, geom, method, nx
     assert rell2(outs["corr"][mask], outs["project"][mask]) < 1e-12
 
 
-@pytest.mark.parametrize("n", [(64, 32), (128, 128), (256, 64), (16, 512)])
+@pytest.mark.parametrize("n", [(64, 32), (128, 128), (256, 64), (16, 512), (64, 64), (32, 16)])  # the last two and the first: one-launch solves
 @pytest.mark.parametrize("method", ["RK44", "Wray3", "SSP33"])
 def test_fused_2d_stage_loop_with_in_register_correction(ins, oracle, n, method):
     """2-D periodic power-of-two boxes (the fused path: flux-form stage kernel + own passes): stages >= 2 read the previous stage's uncorrected u* and its
